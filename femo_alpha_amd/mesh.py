@@ -1,0 +1,249 @@
+"""Shell surface mesh container and DOF numbering for the CG2 x CG1 RM shell space.
+
+The reference hands a ``dolfinx.mesh.Mesh`` (tdim 2, gdim 3) to ``RMShellModel``
+(reference femo_alpha/rm_shell/rm_shell_model.py:31-81) and lets dolfinx build the
+mixed space ``[Lagrange-2]^3 x [Lagrange-1]^3`` (reference
+femo_alpha/rm_shell/linear_shell_fenicsx/linear_shell_model.py:60-65).  This module is
+the build's substitute for both: it takes the same raw data
+``reconstructFEAMesh(filename, nodes, connectivity)`` accepts (reference
+femo_alpha/fea/utils_dolfinx.py:652-668), i.e. ``nodes (nn,3)`` and a
+counter-clockwise ``connectivity (nel,4)`` (quads) or ``(nel,3)`` (triangles), and
+derives the P2 node set, the state-vector layout and the facet sets the penalty /
+strong Dirichlet conditions need.
+
+State-vector layout (solver-internal, opaque to callers exactly as in the reference,
+SURVEY.md section 8a row N)::
+
+    w = [ u(P2 node 0) xyz, u(P2 node 1) xyz, ...,  theta(vertex 0) xyz, ... ]
+    P2 node ids:  vertices 0..nV-1 | edge midpoints nV..nV+nE-1 | cell centres (quads)
+
+so ``ndof = 3*(nV+nE+nC) + 3*nV`` on quads (``3*(nV+nE) + 3*nV`` on triangles).
+Caller node order is kept: no hidden renumbering, hence the reference's
+``input_global_indices`` / ``original_cell_index`` permutations
+(rm_shell_model.py:398-438) are identities here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["ShellMesh", "plate_mesh", "wing_skin_mesh", "quads_to_triangles"]
+
+
+class ShellMesh:
+    """Linear-geometry surface mesh of quads (4 CCW vertices) or triangles in R^3."""
+
+    def __init__(self, nodes, cells):
+        nodes = np.ascontiguousarray(np.asarray(nodes, dtype=np.float64))
+        cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int32))
+        if nodes.ndim != 2 or nodes.shape[1] not in (2, 3):
+            raise ValueError("nodes must be (nn,2) or (nn,3)")
+        if nodes.shape[1] == 2:
+            nodes = np.hstack([nodes, np.zeros((nodes.shape[0], 1))])
+        if cells.ndim != 2 or cells.shape[1] not in (3, 4):
+            raise ValueError("Invalid cell shape--should be either triangular or quadrilateral")
+        if cells.size and (cells.min() < 0 or cells.max() >= nodes.shape[0]):
+            raise ValueError("connectivity refers to a node that does not exist")
+        self.nodes = nodes
+        self.cells = cells
+        self.nn = nodes.shape[0]
+        self.nel = cells.shape[0]
+        self.nvc = cells.shape[1]            # vertices per cell (4 quad, 3 triangle)
+        self.is_quad = self.nvc == 4
+        self._build_edges()
+        self._build_p2()
+
+    # ------------------------------------------------------------------ topology
+    def _build_edges(self):
+        nvc = self.nvc
+        a = self.cells
+        b = np.roll(self.cells, -1, axis=1)          # edge k: vertex k -> vertex (k+1)%nvc
+        lo = np.minimum(a, b).astype(np.int64)
+        hi = np.maximum(a, b).astype(np.int64)
+        key = (lo * self.nn + hi).ravel()
+        ukey, inv = np.unique(key, return_inverse=True)
+        self.nE = ukey.size
+        self.edges = np.stack([ukey // self.nn, ukey % self.nn], axis=1).astype(np.int32)
+        self.cell_edges = inv.reshape(self.nel, nvc).astype(np.int32)
+        # edge -> (cell, local edge) for up to two cells
+        order = np.argsort(inv, kind="stable")
+        counts = np.bincount(inv, minlength=self.nE)
+        if counts.max(initial=0) > 2:
+            raise ValueError("non-manifold mesh: an edge is shared by more than two cells")
+        start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        flat_cell = (order // nvc).astype(np.int32)
+        flat_loc = (order % nvc).astype(np.int32)
+        self.edge_cells = -np.ones((self.nE, 2), dtype=np.int32)
+        self.edge_local = -np.ones((self.nE, 2), dtype=np.int32)
+        self.edge_cells[:, 0] = flat_cell[start]
+        self.edge_local[:, 0] = flat_loc[start]
+        two = counts == 2
+        self.edge_cells[two, 1] = flat_cell[start[two] + 1]
+        self.edge_local[two, 1] = flat_loc[start[two] + 1]
+        self.boundary_edges = np.nonzero(counts == 1)[0].astype(np.int32)
+
+    def _build_p2(self):
+        nV, nE, nC = self.nn, self.nE, (self.nel if self.is_quad else 0)
+        self.nV, self.nC = nV, nC
+        self.nP2 = nV + nE + nC
+        cols = [self.cells, nV + self.cell_edges]
+        if self.is_quad:
+            cols.append((nV + nE + np.arange(self.nel, dtype=np.int32))[:, None])
+        # (nel, 9) quads: 4 vertices, 4 edge midpoints, centre; (nel, 6) triangles
+        self.cell_p2 = np.ascontiguousarray(np.hstack(cols).astype(np.int32))
+        self.npc = self.cell_p2.shape[1]
+        self.ndof_u = 3 * self.nP2
+        self.ndof_t = 3 * nV
+        self.ndof = self.ndof_u + self.ndof_t
+        self.ldof = 3 * self.npc + 3 * self.nvc      # 39 (quad) / 27 (triangle)
+
+    @property
+    def p2_coords(self):
+        """Coordinates of the P2 nodes under the (bi)linear geometry map."""
+        x = self.nodes
+        parts = [x, 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])]
+        if self.is_quad:
+            parts.append(x[self.cells].mean(axis=1))
+        return np.vstack(parts)
+
+    def cell_dofs(self):
+        """(nel, ldof) global DOF numbers, element-local order [u_a xyz ..., theta_b xyz ...]."""
+        u = (3 * self.cell_p2[:, :, None] + np.arange(3)[None, None, :]).reshape(self.nel, -1)
+        t = (self.ndof_u + 3 * self.cells[:, :, None] + np.arange(3)[None, None, :]).reshape(self.nel, -1)
+        return np.hstack([u, t]).astype(np.int32)
+
+    def cell_diameters(self):
+        """UFL ``CellDiameter``: largest distance between two vertices of the cell
+        (used at linear_shell_model.py:285,325,339)."""
+        x = self.nodes[self.cells]
+        d = np.zeros(self.nel)
+        for i in range(self.nvc):
+            for j in range(i + 1, self.nvc):
+                d = np.maximum(d, np.linalg.norm(x[:, i] - x[:, j], axis=1))
+        return d
+
+    # ------------------------------------------------------------------ Dirichlet sets
+    @staticmethod
+    def _eval_marker(func, pts):
+        """Call a dolfinx-style marker ``func(x)`` with ``x`` of shape (3, npts)."""
+        out = np.asarray(func(np.ascontiguousarray(pts.T)))
+        if out.shape != (pts.shape[0],):
+            out = np.broadcast_to(out, (pts.shape[0],))
+        return out.astype(bool)
+
+    def locate_facets(self, func, boundary_only):
+        """Facets (edges) all of whose vertices satisfy ``func`` -- the semantics of
+        ``dolfinx.mesh.locate_entities_boundary`` / ``locate_entities`` used by
+        ``createCustomMeasure`` (reference femo_alpha/fea/utils_dolfinx.py:555-565)."""
+        mark = self._eval_marker(func, self.nodes)
+        ok = mark[self.edges[:, 0]] & mark[self.edges[:, 1]]
+        interior = self.edge_cells[:, 1] >= 0
+        ok &= ~interior if boundary_only else np.ones_like(ok)
+        return np.nonzero(ok)[0].astype(np.int32)
+
+    def penalty_facets(self, func):
+        """(cell, local_edge) pairs the penalty residual integrates over:
+        tagged exterior facets once (``ds(100)``) and tagged interior facets from both
+        sides (``dS(100)``, '+' and '-' restrictions) -- reference
+        linear_shell_model.py:323-333 with measures from rm_shell_model.py:88-95."""
+        ext = self.locate_facets(func, boundary_only=True)
+        allf = self.locate_facets(func, boundary_only=False)
+        inte = allf[self.edge_cells[allf, 1] >= 0]
+        cells = np.concatenate([self.edge_cells[ext, 0], self.edge_cells[inte, 0], self.edge_cells[inte, 1]])
+        locs = np.concatenate([self.edge_local[ext, 0], self.edge_local[inte, 0], self.edge_local[inte, 1]])
+        return np.stack([cells, locs], axis=1).astype(np.int32)
+
+    def locate_dofs_geometrical(self, func):
+        """Strong-BC DOF set: ``locate_dofs_geometrical`` on both sub-spaces
+        (reference rm_shell_model.py:168-180): every P2 node (u) and every vertex
+        (theta) whose coordinates satisfy ``func``."""
+        m2 = self._eval_marker(func, self.p2_coords)
+        mv = m2[: self.nV]
+        un = np.nonzero(m2)[0]
+        tn = np.nonzero(mv)[0]
+        ud = (3 * un[:, None] + np.arange(3)[None, :]).ravel()
+        td = (self.ndof_u + 3 * tn[:, None] + np.arange(3)[None, :]).ravel()
+        return np.concatenate([ud, td]).astype(np.int32)
+
+    # ------------------------------------------------------------------ partitioning
+    def partition_cells(self, nparts):
+        """Deterministic recursive coordinate bisection of cell centroids into
+        ``nparts`` (a power of two) element sets -- SURVEY.md section 8e."""
+        if nparts < 1 or nparts & (nparts - 1):
+            raise ValueError("nparts must be a power of two")
+        cent = self.nodes[self.cells].mean(axis=1)
+        part = np.zeros(self.nel, dtype=np.int32)
+
+        def split(idx, lo, n):
+            if n == 1:
+                part[idx] = lo
+                return
+            c = cent[idx]
+            ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+            order = idx[np.argsort(c[:, ax], kind="stable")]
+            half = order.size // 2
+            split(order[:half], lo, n // 2)
+            split(order[half:], lo + n // 2, n // 2)
+
+        split(np.arange(self.nel), 0, nparts)
+        return part
+
+
+# ---------------------------------------------------------------------- generators
+def plate_mesh(width=2.0, length=10.0, nw=4, nl=20):
+    """Flat rectangular plate, ``nl`` quads along x in [0,length], ``nw`` along y in
+    [0,width]; the regenerable stand-in for the reference's LFS-only
+    ``plate_2_10_quad_{nw}_{nl}`` meshes (ex_simple_shell_opt.py:27-30,42-43), clamped
+    at ``x[0] <= 0`` there (:52-53)."""
+    xs = np.linspace(0.0, length, nl + 1)
+    ys = np.linspace(0.0, width, nw + 1)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    nodes = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size)], axis=1)
+    idx = np.arange((nl + 1) * (nw + 1)).reshape(nl + 1, nw + 1)
+    cells = np.stack([idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(),
+                      idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()], axis=1)
+    return ShellMesh(nodes, cells)
+
+
+def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True,
+                   seed_jitter=1, seed_perm=2):
+    """Synthetic 'wing-skin' surface: an ``nc x ns``
+    quad grid mapped to a cambered, tapered, twisted surface z = c(x,y), interior
+    vertices jittered by ``jitter * h_cell * U(-1,1)``, then cells and nodes randomly
+    renumbered so that no structured locality survives.  Root edge is y = 0."""
+    s = np.linspace(0.0, 1.0, nc + 1)          # chordwise
+    t = np.linspace(0.0, 1.0, ns + 1)          # spanwise
+    S, T = np.meshgrid(s, t, indexing="ij")
+    if jitter > 0:
+        rng = np.random.default_rng(seed_jitter)
+        dS = jitter / nc * rng.uniform(-1, 1, S.shape)
+        dT = jitter / ns * rng.uniform(-1, 1, T.shape)
+        dS[[0, -1], :] = 0; dS[:, [0, -1]] = 0
+        dT[[0, -1], :] = 0; dT[:, [0, -1]] = 0
+        S, T = S + dS, T + dT
+    taper = 1.0 - 0.55 * T
+    sweep = 0.35 * span * T * 0.25
+    xloc = (S - 0.25) * chord * taper
+    camber = 0.06 * chord * taper * 4.0 * S * (1.0 - S)
+    twist = np.deg2rad(-4.0) * T
+    x = sweep + xloc * np.cos(twist) + camber * np.sin(twist)
+    z = -xloc * np.sin(twist) + camber * np.cos(twist) + 0.03 * span * T ** 2
+    y = span * T
+    nodes = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    idx = np.arange((nc + 1) * (ns + 1)).reshape(nc + 1, ns + 1)
+    cells = np.stack([idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(),
+                      idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()], axis=1)
+    if shuffle:
+        rng = np.random.default_rng(seed_perm)
+        pn = rng.permutation(nodes.shape[0])       # new id of old node i
+        inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+        nodes = nodes[inv]
+        cells = pn[cells]
+        cells = cells[rng.permutation(cells.shape[0])]
+    return ShellMesh(nodes, cells)
+
+
+def quads_to_triangles(mesh: ShellMesh):
+    """Split every quad along its 0-2 diagonal (triangle variant of a config)."""
+    c = mesh.cells
+    tri = np.vstack([c[:, [0, 1, 2]], c[:, [0, 2, 3]]])
+    return ShellMesh(mesh.nodes, tri)

@@ -1,0 +1,531 @@
+"""CPU ORACLE -- test infrastructure only, never the product path.
+
+A float64 numpy/scipy restatement of the reference's Reissner-Mindlin shell forward +
+adjoint algorithm (femo_alpha's ``RMShellPDE`` / ``ElasticModelShapeOpt`` / ``FEA``
+path), written from the formulas, element by element, with explicit strain-displacement
+matrices, dense 39x39 element matrices, scipy CSR assembly and SuperLU (``splu``) as the
+stand-in for PETSc + MUMPS.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.
+
+PARITY STATUS: **parity unpinned by the reference's own tests** -- femo_alpha's
+``tests/`` directory is an unmodified project template (reference
+tests/test_pytest.py:5-86) and FEniCSx/PETSc are not installable here, so no reference
+output exists to compare with.  The restatement is pinned instead by (tests/test_oracle*.py):
+analytic Euler-Bernoulli cantilever limit printed by the reference example
+(examples/advanced_examples/simple_shell_opt/ex_simple_shell_opt.py:100-105), rigid-body
+/ symmetry / patch identities, the reference's own finite-difference-vs-adjoint method
+(ex_simple_shell_opt.py:109-111), and an independent sympy derivation of the element
+energy committed as golden vectors (tests/golden/).
+
+What each piece follows (all paths relative to /root/reference/femo_alpha):
+  * function space CG2 x CG1 ............ rm_shell/linear_shell_fenicsx/linear_shell_model.py:60-65
+  * single-layer CLT A, B=0, D, A_s ...... linear_shell_model.py:136-157  (k = 0.833)
+  * local basis E0,E1,E2, T .............. linear_shell_fenicsx/kinematics.py:54-91
+  * F = I + grad(uhat), gradx, J ......... kinematics.py:12-44
+  * strains eps, kappa, gamma ............ linear_shell_model.py:232-258
+  * energies (J only on shear+drilling) .. linear_shell_model.py:275-306
+  * residual, load, penalty .............. linear_shell_model.py:308-333
+  * compliance, regularisation, mass ..... rm_shell/rm_shell_pde.py:64-110
+  * Newton + LU solve semantics .......... fea/utils_dolfinx.py:438-468
+  * adjoint operator protocol ............ csdl_alpha_opt/state_operation.py:174-220
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+SHEAR_CORRECTION = 0.833     # linear_shell_model.py:146
+PENALTY_BETA = 1.0e15        # linear_shell_model.py:324
+REG_ALPHA1 = 1.0e-2          # rm_shell_pde.py:67
+
+
+# ----------------------------------------------------------------------------- tables
+def gauss_legendre(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return x, w
+
+
+def _lag2(t):
+    """1-D quadratic Lagrange on nodes (-1, 0, 1): values and derivatives."""
+    v = np.stack([0.5 * t * (t - 1.0), 1.0 - t * t, 0.5 * t * (t + 1.0)], axis=-1)
+    d = np.stack([t - 0.5, -2.0 * t, t + 0.5], axis=-1)
+    return v, d
+
+
+def _lag1(t):
+    v = np.stack([0.5 * (1.0 - t), 0.5 * (1.0 + t)], axis=-1)
+    d = np.stack([-0.5 * np.ones_like(t), 0.5 * np.ones_like(t)], axis=-1)
+    return v, d
+
+
+# local node -> (i_xi, i_eta) index into the 1-D node sets; CCW vertices, then edge
+# midpoints (edge k joins vertex k and k+1), then the centre
+_Q2_IJ = [(0, 0), (2, 0), (2, 2), (0, 2), (1, 0), (2, 1), (1, 2), (0, 1), (1, 1)]
+_Q1_IJ = [(0, 0), (1, 0), (1, 1), (0, 1)]
+
+
+def quad_tables(pts):
+    """Shape tables of the biquadratic (9) and bilinear (4) Lagrange bases at reference
+    points ``pts`` (npts,2) in [-1,1]^2.  Returns N2,dN2,N1,dN1."""
+    xi, et = pts[:, 0], pts[:, 1]
+    a, da = _lag2(xi); b, db = _lag2(et)
+    N2 = np.stack([a[:, i] * b[:, j] for i, j in _Q2_IJ], axis=1)
+    dN2 = np.stack([np.stack([da[:, i] * b[:, j], a[:, i] * db[:, j]], axis=-1) for i, j in _Q2_IJ], axis=1)
+    c, dc = _lag1(xi); d, dd = _lag1(et)
+    N1 = np.stack([c[:, i] * d[:, j] for i, j in _Q1_IJ], axis=1)
+    dN1 = np.stack([np.stack([dc[:, i] * d[:, j], c[:, i] * dd[:, j]], axis=-1) for i, j in _Q1_IJ], axis=1)
+    return N2, dN2, N1, dN1
+
+
+def quad_rule(n):
+    x, w = gauss_legendre(n)
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    W = np.outer(w, w)
+    return np.stack([X.ravel(), Y.ravel()], axis=1), W.ravel()
+
+
+# Dunavant-type symmetric rule, degree 6, 12 points, on the unit triangle (area 1/2)
+def tri_rule():
+    a1, b1, w1 = 0.063089014491502, 0.873821971016996, 0.050844906370207
+    a2, b2, w2 = 0.249286745170910, 0.501426509658179, 0.116786275726379
+    a3, b3, c3, w3 = 0.053145049844817, 0.310352451033784, 0.636502499121399, 0.082851075618374
+    pts, wts = [], []
+    for a, b, w in ((a1, b1, w1), (a2, b2, w2)):
+        pts += [(a, a), (b, a), (a, b)]; wts += [w] * 3
+    for p in ((a3, b3), (b3, a3), (a3, c3), (c3, a3), (b3, c3), (c3, b3)):
+        pts.append(p); wts.append(w3)
+    return np.array(pts), 0.5 * np.array(wts)
+
+
+def tri_tables(pts):
+    """P2 (6: 3 vertices, midpoints of edges 0-1, 1-2, 2-0) and P1 tables on the unit triangle."""
+    x, y = pts[:, 0], pts[:, 1]
+    L = np.stack([1 - x - y, x, y], axis=1)
+    dL = np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]])
+    N1 = L
+    dN1 = np.broadcast_to(dL, (pts.shape[0], 3, 2)).copy()
+    N2 = np.zeros((pts.shape[0], 6)); dN2 = np.zeros((pts.shape[0], 6, 2))
+    for i in range(3):
+        N2[:, i] = L[:, i] * (2 * L[:, i] - 1)
+        dN2[:, i] = (4 * L[:, i] - 1)[:, None] * dL[i]
+    for k, (i, j) in enumerate([(0, 1), (1, 2), (2, 0)]):
+        N2[:, 3 + k] = 4 * L[:, i] * L[:, j]
+        dN2[:, 3 + k] = 4 * (L[:, i][:, None] * dL[j] + L[:, j][:, None] * dL[i])
+    return N2, dN2, N1, dN1
+
+
+def _cross(a, b):
+    return np.cross(a, b)
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+class ShellOracle:
+    """Float64 CPU restatement of the reference shell path on a ``ShellMesh``-like object
+    (attributes nodes, cells, cell_p2, nV, nP2, ndof, ndof_u, is_quad)."""
+
+    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False,
+                 nquad=4, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None):
+        self.mesh = mesh
+        self.ewm = bool(element_wise_material)
+        self.ewp = bool(elementwise_pressure)
+        self.beta = float(beta)
+        self.penalty_facets = (np.zeros((0, 2), np.int32) if penalty_facets is None
+                               else np.asarray(penalty_facets, np.int32).reshape(-1, 2))
+        self.strong_dofs = (np.zeros(0, np.int32) if strong_dofs is None
+                            else np.unique(np.asarray(strong_dofs, np.int32)))
+        if mesh.is_quad:
+            self.pts, self.wts = quad_rule(nquad) if rule is None else rule
+            self.N2, self.dN2, self.N1, self.dN1 = quad_tables(self.pts)
+        else:
+            self.pts, self.wts = tri_rule() if rule is None else rule
+            self.N2, self.dN2, self.N1, self.dN1 = tri_tables(self.pts)
+        self.nq = self.pts.shape[0]
+        self.npc = mesh.cell_p2.shape[1]
+        self.nvc = mesh.cells.shape[1]
+        self.ldof = 3 * self.npc + 3 * self.nvc
+        self.hK = mesh.cell_diameters()
+        self.dofs = mesh.cell_dofs()
+        nT = mesh.nel if self.ewm else mesh.nn
+        nF = mesh.nel if self.ewp else mesh.nn
+        # defaults follow FEA.add_input init values, rm_shell_model.py:209-214
+        self.h = np.full(nT, 1e-3); self.E = np.ones(nT); self.nu = np.ones(nT) * 0.3
+        self.rho = np.ones(nT); self.f = np.ones((nF, 3)); self.uhat = np.zeros((mesh.nn, 3))
+
+    # ------------------------------------------------------------------ fields
+    def set_fields(self, h=None, E=None, nu=None, rho=None, f=None, uhat=None):
+        def bc(v, n):
+            v = np.asarray(v, dtype=np.float64).ravel()
+            return np.full(n, v[0]) if v.size == 1 else v.copy()   # utils_dolfinx.py:327-330
+        nT = self.h.size
+        if h is not None: self.h = bc(h, nT)
+        if E is not None: self.E = bc(E, nT)
+        if nu is not None: self.nu = bc(nu, nT)
+        if rho is not None: self.rho = bc(rho, nT)
+        if f is not None: self.f = np.asarray(f, np.float64).reshape(-1, 3).copy()
+        if uhat is not None: self.uhat = np.asarray(uhat, np.float64).reshape(-1, 3).copy()
+
+    def _at_qp(self, field, sl):
+        """VT-field (CG1 nodal or DG0) at the quadrature points of cells ``sl``: (ne,nq)."""
+        if self.ewm:
+            return np.repeat(field[sl][:, None], self.nq, axis=1)
+        return np.einsum("qb,eb->eq", self.N1, field[self.mesh.cells[sl]])
+
+    # ------------------------------------------------------------------ geometry at points
+    def _geometry(self, sl, N1, dN1):
+        """Geometry of cells ``sl`` at reference points with tables N1,dN1 (np,nvc[,2])."""
+        X = self.mesh.nodes[self.mesh.cells[sl]]                       # (ne,nvc,3)
+        Jg = np.einsum("ebi,qbk->eqik", X, dN1)                        # (ne,nq,3,2)
+        a = _cross(Jg[..., 0], Jg[..., 1])
+        det = np.linalg.norm(a, axis=-1)
+        E2 = a / det[..., None]
+        E0 = _unit(Jg[..., 0])
+        E1 = _cross(E2, E0)
+        G = np.einsum("eqik,eqil->eqkl", Jg, Jg)
+        Kinv = np.einsum("eqkl,eqil->eqki", np.linalg.inv(G), Jg)     # (ne,nq,2,3) pseudo-inverse
+        # derivative of the unit normal along x_j (non-zero only on warped quads)
+        W = np.zeros(Jg.shape[:2] + (3, 3))
+        if self.mesh.is_quad:
+            c = 0.25 * (X[:, 0] - X[:, 1] + X[:, 2] - X[:, 3])         # d2x / dxi deta
+            c = np.broadcast_to(c[:, None, :], a.shape)
+            da = np.stack([_cross(Jg[..., 0], c), _cross(c, Jg[..., 1])], axis=-1)   # (ne,nq,3,2)
+            dn = (da - E2[..., None] * np.einsum("eqi,eqik->eqk", E2, da)[..., None, :]) / det[..., None, None]
+            W = np.einsum("eqik,eqkj->eqij", dn, Kinv)
+        # mesh-motion map
+        U = self.uhat[self.mesh.cells[sl]]
+        gradM = np.einsum("eqki,qbk->eqbi", Kinv, dN1)                 # (ne,nq,nvc,3) surface gradient of M_b
+        Gu = np.einsum("ebi,eqbj->eqij", U, gradM)
+        F = np.eye(3) + Gu
+        Finv = np.linalg.inv(F)
+        Ju = np.linalg.det(F)
+        return dict(X=X, Jg=Jg, det=det, E0=E0, E1=E1, E2=E2, Kinv=Kinv, W=W, Finv=Finv, Ju=Ju,
+                    gradM=gradM, F=F)
+
+    def _B(self, sl):
+        """Strain-displacement matrices (ne,nq,9,ldof) and geometry at the cell quadrature points.
+        Rows: eps00, eps11, 2eps01, kap00, kap11, 2kap01, gam0, gam1, omega."""
+        g = self._geometry(sl, self.N1, self.dN1)
+        ne, nq, npc, nvc = g["det"].shape[0], self.nq, self.npc, self.nvc
+        E0, E1, E2, Finv = g["E0"], g["E1"], g["E2"], g["Finv"]
+        gradN = np.einsum("eqki,qak->eqai", g["Kinv"], self.dN2)        # (ne,nq,npc,3)
+        gxN = np.einsum("eqak,eqkj->eqaj", gradN, Finv)
+        gxM = np.einsum("eqbk,eqkj->eqbj", g["gradM"], Finv)
+        d = np.stack([np.einsum("eqj,eqaj->eqa", E0, gxN), np.einsum("eqj,eqaj->eqa", E1, gxN)], axis=-1)
+        m = np.stack([np.einsum("eqj,eqbj->eqb", E0, gxM), np.einsum("eqj,eqbj->eqb", E1, gxM)], axis=-1)
+        Wp = np.einsum("eqik,eqkj->eqij", g["W"], Finv)
+        wl = [np.einsum("eqj,eqij->eqi", E0, Wp), np.einsum("eqj,eqij->eqi", E1, Wp)]   # w_J
+        B = np.zeros((ne, nq, 9, self.ldof))
+        Bu = B[..., : 3 * npc].reshape(ne, nq, 9, npc, 3)
+        Bt = B[..., 3 * npc:].reshape(ne, nq, 9, nvc, 3)
+        e0, e1, e2 = E0[:, :, None, :], E1[:, :, None, :], E2[:, :, None, :]
+        d0, d1 = d[..., 0][..., None], d[..., 1][..., None]
+        Bu[:, :, 0] = e0 * d0
+        Bu[:, :, 1] = e1 * d1
+        Bu[:, :, 2] = e0 * d1 + e1 * d0
+        Bu[:, :, 6] = e2 * d0
+        Bu[:, :, 7] = e2 * d1
+        Bu[:, :, 8] = 0.5 * (e0 * d1 - e1 * d0)
+        M = self.N1[None, :, :, None]                                   # (1,nq,nvc,1)
+        m0, m1 = m[..., 0][..., None], m[..., 1][..., None]
+        c00 = -e1 * m0 + M * _cross(E0, wl[0])[:, :, None, :]
+        c01 = -e1 * m1 + M * _cross(E0, wl[1])[:, :, None, :]
+        c10 = e0 * m0 + M * _cross(E1, wl[0])[:, :, None, :]
+        c11 = e0 * m1 + M * _cross(E1, wl[1])[:, :, None, :]
+        Bt[:, :, 3] = c00
+        Bt[:, :, 4] = c11
+        Bt[:, :, 5] = c01 + c10
+        Bt[:, :, 6] = M * e1
+        Bt[:, :, 7] = -M * e0
+        Bt[:, :, 8] = M * e2
+        return B, g
+
+    def _C(self, sl, g, deriv=None):
+        """Constitutive blocks x measure weights, (ne,nq,9,9); ``deriv`` in {None,'h','E','nu'}
+        returns the derivative with respect to the (point value of the) field."""
+        h, E, nu = self._at_qp(self.h, sl), self._at_qp(self.E, sl), self._at_qp(self.nu, sl)
+        wdet = self.wts[None, :] * g["det"]
+        Ju = g["Ju"]
+        hK2 = (self.hK[sl] ** 2)[:, None]
+        k = SHEAR_CORRECTION
+        one, zero = np.ones_like(nu), np.zeros_like(nu)
+        P = np.stack([np.stack([one, nu, zero], -1), np.stack([nu, one, zero], -1),
+                      np.stack([zero, zero, 0.5 * (1 - nu)], -1)], -2)
+        dP = np.stack([np.stack([zero, one, zero], -1), np.stack([one, zero, zero], -1),
+                       np.stack([zero, zero, -0.5 * one], -1)], -2)
+        c = E / (1 - nu ** 2)
+        G = E / 2 / (1 + nu)
+        if deriv is None:
+            Cm = (c * h)[..., None, None] * P
+            Cb = (c * h ** 3 / 12)[..., None, None] * P
+            cs = k * G * h
+            cd = E * h ** 3 / hK2
+        elif deriv == "h":
+            Cm = c[..., None, None] * P
+            Cb = (c * h ** 2 / 4)[..., None, None] * P
+            cs = k * G
+            cd = 3 * E * h ** 2 / hK2
+        elif deriv == "E":
+            Cm = (h / (1 - nu ** 2))[..., None, None] * P
+            Cb = (h ** 3 / 12 / (1 - nu ** 2))[..., None, None] * P
+            cs = k * h / 2 / (1 + nu)
+            cd = h ** 3 / hK2
+        elif deriv == "nu":
+            dc = E * 2 * nu / (1 - nu ** 2) ** 2
+            Cm = h[..., None, None] * (dc[..., None, None] * P + c[..., None, None] * dP)
+            Cb = (h ** 3 / 12)[..., None, None] * (dc[..., None, None] * P + c[..., None, None] * dP)
+            cs = -k * h * E / 2 / (1 + nu) ** 2
+            cd = zero
+        else:
+            raise ValueError(deriv)
+        C = np.zeros(wdet.shape + (9, 9))
+        C[..., 0:3, 0:3] = Cm * wdet[..., None, None]          # membrane: no J(uhat)  (:278-279)
+        C[..., 3:6, 3:6] = Cb * wdet[..., None, None]          # bending : no J(uhat)  (:281-282)
+        sw = cs * Ju * wdet
+        C[..., 6, 6] = sw; C[..., 7, 7] = sw                   # shear   : J(uhat)     (:275-276)
+        C[..., 8, 8] = cd * Ju * wdet                          # drilling: J(uhat)     (:284-296)
+        return C
+
+    def _chunks(self, size=2048):
+        for s in range(0, self.mesh.nel, size):
+            yield slice(s, min(s + size, self.mesh.nel))
+
+    # ------------------------------------------------------------------ element & global operators
+    def element_matrices(self, sl=slice(None)):
+        """K_e (ne,ldof,ldof) of the elastic energy (no penalty)."""
+        B, g = self._B(sl)
+        C = self._C(sl, g)
+        return np.einsum("eqik,eqij,eqjl->ekl", B, C, B, optimize=True)
+
+    def _penalty_blocks(self):
+        """Edge penalty matrices: list of (dofs (n,), block (n,n)) -- linear_shell_model.py:323-333."""
+        out = []
+        if self.penalty_facets.shape[0] == 0:
+            return out
+        x, w = gauss_legendre(3)                                # degree 4 measure, utils_dolfinx.py:556
+        L2, _ = _lag2(x); L1, _ = _lag1(x)
+        mesh = self.mesh
+        for cell, k in self.penalty_facets:
+            nv = self.nvc
+            va, vb = mesh.cells[cell, k], mesh.cells[cell, (k + 1) % nv]
+            pa, pb, pm = mesh.cell_p2[cell, k], mesh.cell_p2[cell, (k + 1) % nv], mesh.cell_p2[cell, nv + k]
+            length = np.linalg.norm(mesh.nodes[vb] - mesh.nodes[va])
+            nanson = self._nanson(cell, k, x)
+            wq = w * 0.5 * length * nanson * self.beta / self.hK[cell]
+            M2 = np.einsum("q,qi,qj->ij", wq, L2, L2)           # nodes (a, mid, b)
+            M1 = np.einsum("q,qi,qj->ij", wq, L1, L1)           # nodes (a, b)
+            for c in range(3):
+                out.append((np.array([3 * pa + c, 3 * pm + c, 3 * pb + c]), M2))
+                out.append((mesh.ndof_u + np.array([3 * va + c, 3 * vb + c]), M1))
+        return out
+
+    def _nanson(self, cell, k, s):
+        """|| J F^-T N || at edge parameter s in [-1,1] (1 when uhat = 0)."""
+        if not np.any(self.uhat[self.mesh.cells[cell]]):
+            return np.ones_like(s)
+        if self.mesh.is_quad:
+            pts = [np.stack([s, -np.ones_like(s)], 1), np.stack([np.ones_like(s), s], 1),
+                   np.stack([-s, np.ones_like(s)], 1), np.stack([-np.ones_like(s), -s], 1)][k]
+            _, _, N1, dN1 = quad_tables(pts)
+        else:
+            t = 0.5 * (s + 1)
+            pts = [np.stack([t, 0 * t], 1), np.stack([1 - t, t], 1), np.stack([0 * t, 1 - t], 1)][k]
+            _, _, N1, dN1 = tri_tables(pts)
+        g = self._geometry(slice(cell, cell + 1), N1, dN1)
+        nv = self.nvc
+        tvec = _unit(self.mesh.nodes[self.mesh.cells[cell, (k + 1) % nv]] - self.mesh.nodes[self.mesh.cells[cell, k]])
+        Nf = _cross(np.broadcast_to(tvec, g["E2"][0].shape), g["E2"][0])
+        v = g["Ju"][0][:, None] * np.einsum("qji,qj->qi", g["Finv"][0], Nf)
+        return np.linalg.norm(v, axis=-1)
+
+    def assemble_K(self, with_penalty=True, with_strong=True):
+        n = self.mesh.ndof
+        rows, cols, vals = [], [], []
+        for sl in self._chunks():
+            Ke = self.element_matrices(sl)
+            d = self.dofs[sl]
+            rows.append(np.repeat(d, self.ldof, axis=1).ravel())
+            cols.append(np.tile(d, (1, self.ldof)).ravel())
+            vals.append(Ke.ravel())
+        if with_penalty:
+            for d, blk in self._penalty_blocks():
+                rows.append(np.repeat(d, d.size)); cols.append(np.tile(d, d.size)); vals.append(blk.ravel())
+        K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+        if with_strong and self.strong_dofs.size:
+            K = self._apply_strong(K)
+        return K
+
+    def _apply_strong(self, K):
+        """Zero BC rows/columns, unit diagonal -- dolfinx assemble_matrix(bcs) semantics
+        reached from assembleSystem (utils_dolfinx.py:208-221)."""
+        keep = np.ones(K.shape[0]); keep[self.strong_dofs] = 0.0
+        D = sp.diags(keep)
+        return (D @ K @ D + sp.diags(1.0 - keep)).tocsr()
+
+    def load_vector(self):
+        """F_a = int f . N_a J dx (linear_shell_model.py:320)."""
+        Fv = np.zeros(self.mesh.ndof)
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            wj = self.wts[None, :] * g["det"] * g["Ju"]
+            if self.ewp:
+                fq = np.repeat(self.f[sl][:, None, :], self.nq, axis=1)
+            else:
+                fq = np.einsum("qb,ebc->eqc", self.N1, self.f[self.mesh.cells[sl]])
+            Fe = np.einsum("eq,qa,eqc->eac", wj, self.N2, fq).reshape(fq.shape[0], -1)
+            np.add.at(Fv, self.dofs[sl][:, : 3 * self.npc].ravel(), Fe.ravel())
+        if self.strong_dofs.size:
+            Fv[self.strong_dofs] = 0.0
+        return Fv
+
+    def apply_K(self, x, with_penalty=True):
+        """y = K x element by element (no global matrix)."""
+        y = np.zeros(self.mesh.ndof)
+        for sl in self._chunks():
+            Ke = self.element_matrices(sl)
+            ye = np.einsum("eij,ej->ei", Ke, x[self.dofs[sl]])
+            np.add.at(y, self.dofs[sl].ravel(), ye.ravel())
+        if with_penalty:
+            for d, blk in self._penalty_blocks():
+                y[d] += blk @ x[d]
+        return y
+
+    def residual(self, w):
+        """R(w) = K w + penalty(w) - F   (linear_shell_model.py:317-321)."""
+        return self.apply_K(w) - self.load_vector()
+
+    def factorize(self):
+        self._K = self.assemble_K()
+        self._lu = spla.splu(self._K.tocsc())
+        return self._lu
+
+    def solve(self):
+        """Forward solve: Newton on a linear residual == one LU solve (the reference's
+        remaining two Newton iterations are refinement no-ops, utils_dolfinx.py:438-468)."""
+        lu = self.factorize()
+        b = self.load_vector()
+        w = lu.solve(b)
+        w += lu.solve(b - self._K @ w)          # what Newton iteration 2 does
+        return w
+
+    def solve_adjoint(self, rhs):
+        """lambda = A^-1 rhs with the stored factorisation, BC rows zeroed
+        (state_operation.py:211-218; A symmetric so A == A^T, quirk Q3)."""
+        rhs = np.array(rhs, dtype=np.float64)
+        lam = self._lu.solve(rhs)
+        lam += self._lu.solve(rhs - self._K @ lam)
+        if self.strong_dofs.size:
+            lam[self.strong_dofs] = 0.0
+        return lam
+
+    # ------------------------------------------------------------------ outputs
+    def _u_at_qp(self, w, sl):
+        ue = w[self.dofs[sl][:, : 3 * self.npc]].reshape(-1, self.npc, 3)
+        return np.einsum("qa,eac->eqc", self.N2, ue)
+
+    def regularization(self):
+        val = 0.0
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            wd = self.wts[None, :] * g["det"]
+            if self.ewm:
+                val += 0.5 * REG_ALPHA1 * np.sum(self.h[sl] ** 2 * wd.sum(axis=1))
+            else:
+                gh = np.einsum("eqbi,eb->eqi", g["gradM"], self.h[self.mesh.cells[sl]])
+                val += 0.5 * REG_ALPHA1 * np.sum(wd * np.einsum("eqi,eqi->eq", gh, gh))
+        return val
+
+    def compliance(self, w):
+        """int u.u J dx + regularisation(h)  (rm_shell_pde.py:85-89)."""
+        val = 0.0
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            u = self._u_at_qp(w, sl)
+            val += np.sum(self.wts[None, :] * g["det"] * g["Ju"] * np.einsum("eqc,eqc->eq", u, u))
+        return val + self.regularization()
+
+    def mass(self):
+        """int rho h J dx (rm_shell_pde.py:101-102)."""
+        val = 0.0
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            val += np.sum(self.wts[None, :] * g["det"] * g["Ju"] * self._at_qp(self.rho, sl) * self._at_qp(self.h, sl))
+        return val
+
+    def elastic_energy(self, w):
+        return 0.5 * float(w @ self.apply_K(w, with_penalty=False))
+
+    def dcompliance_du(self, w):
+        out = np.zeros(self.mesh.ndof)
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            u = self._u_at_qp(w, sl)
+            ge = 2.0 * np.einsum("eq,qa,eqc->eac", self.wts[None, :] * g["det"] * g["Ju"], self.N2, u)
+            np.add.at(out, self.dofs[sl][:, : 3 * self.npc].ravel(), ge.ravel())
+        return out
+
+    def dcompliance_dh(self, w=None):
+        out = np.zeros(self.h.size)
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            wd = self.wts[None, :] * g["det"]
+            if self.ewm:
+                out[sl] += REG_ALPHA1 * self.h[sl] * wd.sum(axis=1)
+            else:
+                gh = np.einsum("eqbi,eb->eqi", g["gradM"], self.h[self.mesh.cells[sl]])
+                ge = REG_ALPHA1 * np.einsum("eq,eqbi,eqi->eb", wd, g["gradM"], gh)
+                np.add.at(out, self.mesh.cells[sl].ravel(), ge.ravel())
+        return out
+
+    def dmass_dh(self):
+        out = np.zeros(self.h.size)
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            wj = self.wts[None, :] * g["det"] * g["Ju"] * self._at_qp(self.rho, sl)
+            if self.ewm:
+                out[sl] += wj.sum(axis=1)
+            else:
+                np.add.at(out, self.mesh.cells[sl].ravel(), np.einsum("eq,qb->eb", wj, self.N1).ravel())
+        return out
+
+    # ------------------------------------------------------------------ (dR/d arg)^T lambda
+    def dRdfield_T(self, name, w, lam):
+        """(dR/d field)^T lam for field in {'h','E','nu'} -- what
+        ``computeMatVecProductBwd(dRdf, lambda)`` returns (state_operation.py:180-184)."""
+        out = np.zeros(self.h.size)
+        for sl in self._chunks():
+            B, g = self._B(sl)
+            dC = self._C(sl, g, deriv=name)
+            sw = np.einsum("eqij,ej->eqi", B, w[self.dofs[sl]])
+            sl_ = np.einsum("eqij,ej->eqi", B, lam[self.dofs[sl]])
+            dens = np.einsum("eqi,eqij,eqj->eq", sl_, dC, sw)
+            if self.ewm:
+                out[sl] += dens.sum(axis=1)
+            else:
+                np.add.at(out, self.mesh.cells[sl].ravel(), np.einsum("eq,qb->eb", dens, self.N1).ravel())
+        return out
+
+    def dRdf_T(self, lam):
+        """(dR/df)^T lam = - int M_b (lam_u) J dx, node-major xyz like ``F_solid``."""
+        out = np.zeros_like(self.f)
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            wj = self.wts[None, :] * g["det"] * g["Ju"]
+            lu = self._u_at_qp(lam, sl)
+            if self.ewp:
+                out[sl] -= np.einsum("eq,eqc->ec", wj, lu)
+            else:
+                ge = -np.einsum("eq,qb,eqc->ebc", wj, self.N1, lu)
+                np.add.at(out, self.mesh.cells[sl].ravel(), ge.reshape(-1, 3))
+        return out.ravel()
+
+    # ------------------------------------------------------------------ the parity triple
+    def forward_adjoint(self):
+        """displacement, compliance, d compliance / d thickness (total derivative)."""
+        w = self.solve()
+        J = self.compliance(w)
+        lam = self.solve_adjoint(self.dcompliance_du(w))
+        dJdh = self.dcompliance_dh(w) - self.dRdfield_T("h", w, lam)
+        return w, J, dJdh

@@ -1,0 +1,247 @@
+"""Pins for the CPU oracle (oracle/rm_shell_oracle.py).
+
+The reference's own tests pin nothing on this path (reference tests/test_pytest.py:5-86 is
+a project template), so the oracle is pinned by: the independent sympy derivation in
+tests/golden/sympy_element.npz, structural identities, the Euler-Bernoulli limit the
+reference example prints (ex_simple_shell_opt.py:100-105; ex_simple_shell.py:38-44,61), and
+the reference's own adjoint-vs-finite-difference method (ex_simple_shell_opt.py:109-111).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from femo_alpha_amd.mesh import ShellMesh, plate_mesh, quads_to_triangles
+from oracle.rm_shell_oracle import ShellOracle
+
+CLAMP = lambda x: np.less(x[0], 3e-16)          # ex_simple_shell_opt.py:51-53
+
+
+def _single_quad(X):
+    return ShellMesh(np.asarray(X, float), np.array([[0, 1, 2, 3]]))
+
+
+def test_golden_affine_element(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sympy_element.npz"))
+    m = _single_quad(g["A_X"])
+    o = ShellOracle(m)
+    o.set_fields(h=g["A_h"], E=g["A_E"], nu=g["A_nu"], f=g["A_f"])
+    Ke = o.element_matrices()[0]
+    d = m.cell_dofs()[0]                     # element-local -> global numbering
+    scale = np.abs(g["A_Ke"]).max()
+    assert np.abs(Ke - g["A_Ke"]).max() / scale < 1e-13
+    Fe = o.load_vector()[d[:27]]
+    assert np.abs(Fe - g["A_Fe"]).max() / np.abs(g["A_Fe"]).max() < 1e-13
+
+
+def test_golden_warped_pointwise(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sympy_element.npz"))
+    m = _single_quad(g["B_X"])
+    for ip in range(g["B_pts"].shape[0]):
+        o = ShellOracle(m, rule=(g["B_pts"][ip:ip + 1], np.ones(1)))
+        o.set_fields(h=g["B_h"], E=g["B_E"], nu=g["B_nu"], f=g["B_f"], uhat=g["B_uhat"])
+        B, geo = o._B(slice(None))
+        assert np.allclose(geo["det"][0, 0], g["B_detJu"][ip, 0], rtol=1e-13)
+        assert np.allclose(geo["Ju"][0, 0], g["B_detJu"][ip, 1], rtol=1e-13)
+        assert np.abs(B[0, 0] - g["B_Bq"][ip]).max() / np.abs(g["B_Bq"][ip]).max() < 1e-12
+        Kq = o.element_matrices()[0]
+        assert np.abs(Kq - g["B_Kq"][ip]).max() / np.abs(g["B_Kq"][ip]).max() < 1e-12
+        Fq = o.load_vector()[m.cell_dofs()[0][:27]]
+        assert np.abs(Fq - g["B_Fq"][ip]).max() / np.abs(g["B_Fq"][ip]).max() < 1e-12
+
+
+def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
+    m = plate_mesh(2.0, 10.0, nw, nl)
+    rng = np.random.default_rng(seed)
+    x = m.nodes.copy()
+    hx, hy = 10.0 / nl, 2.0 / nw
+    inner = (x[:, 0] > 1e-9) & (x[:, 0] < 10 - 1e-9) & (x[:, 1] > 1e-9) & (x[:, 1] < 2 - 1e-9)
+    x[inner, 0] += amp * hx * rng.uniform(-1, 1, inner.sum())
+    x[inner, 1] += amp * hy * rng.uniform(-1, 1, inner.sum())
+    if tilt:   # rigid rotation of the flat plate into a general plane
+        a, b = 0.4, -0.7
+        Ra = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Rb = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        x = x @ (Ra @ Rb).T
+    return ShellMesh(x, m.cells)
+
+
+@pytest.mark.parametrize("tri", [False, True])
+def test_symmetry_and_rigid_body_modes(tri):
+    m = _jittered_plate(3, 6)
+    if tri:
+        m = quads_to_triangles(m)
+    o = ShellOracle(m)
+    rng = np.random.default_rng(3)
+    o.set_fields(h=0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)), E=2e7 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)),
+                 nu=0.3 + 0.05 * rng.uniform(-1, 1, m.nn))
+    K = o.assemble_K().toarray()
+    assert np.abs(K - K.T).max() / np.abs(K).max() < 1e-14
+    X = m.p2_coords
+    scale = np.abs(K).max()
+    for k in range(3):
+        w = np.zeros(m.ndof)
+        w[k:m.ndof_u:3] = 1.0                                  # translation
+        assert np.abs(K @ w).max() / scale < 1e-12
+        om = np.zeros(3); om[k] = 1.0
+        w = np.zeros(m.ndof)
+        w[:m.ndof_u] = np.cross(om, X).ravel()                 # u = omega x X
+        w[m.ndof_u:] = np.tile(om, m.nV)                       # theta = omega
+        assert np.abs(K @ w).max() / (scale * np.abs(w).max()) < 1e-12
+    ev = np.linalg.eigvalsh(K)
+    assert (ev > 1e-9 * ev[-1]).sum() == m.ndof - 6            # exactly six zero-energy modes
+
+
+def test_membrane_patch_distorted_quads():
+    m = _jittered_plate(4, 8, tilt=False)
+    o = ShellOracle(m)
+    o.set_fields(h=0.1, E=1e6, nu=0.3)
+    X = m.p2_coords
+    w = np.zeros(m.ndof)
+    a, b, d = 1e-3, 4e-4, -7e-4                                 # symmetric displacement gradient
+    w[0:m.ndof_u:3] = a * X[:, 0] + b * X[:, 1]
+    w[1:m.ndof_u:3] = b * X[:, 0] + d * X[:, 1]
+    r = o.apply_K(w)
+    onb = (np.abs(X[:, 0]) < 1e-9) | (np.abs(X[:, 0] - 10) < 1e-9) | (np.abs(X[:, 1]) < 1e-9) | (np.abs(X[:, 1] - 2) < 1e-9)
+    ru = r[:m.ndof_u].reshape(-1, 3)
+    assert np.abs(ru[~onb]).max() < 1e-10 * np.abs(ru[onb]).max()
+    assert np.abs(r[m.ndof_u:]).max() < 1e-10 * np.abs(ru[onb]).max()
+
+
+def test_bending_patch_affine_quads():
+    m0 = plate_mesh(2.0, 10.0, 3, 7)
+    x = m0.nodes.copy(); x[:, 0] += 0.3 * x[:, 1]                # parallelograms
+    m = ShellMesh(x, m0.cells)
+    o = ShellOracle(m)
+    o.set_fields(h=0.1, E=1e6, nu=0.0)
+    X = m.p2_coords
+    kap = 2e-3
+    w = np.zeros(m.ndof)
+    w[2:m.ndof_u:3] = 0.5 * kap * X[:, 0] ** 2                    # w = kappa x^2 / 2
+    w[m.ndof_u + 1::3] = -kap * m.nodes[:, 0]                     # theta_y = -dw/dx  (gamma = 0)
+    r = o.apply_K(w)
+    onb = np.zeros(m.nP2, bool)
+    onb[m.edges[m.boundary_edges].ravel()] = True
+    onb[m.nV + m.boundary_edges] = True
+    ru = r[:m.ndof_u].reshape(-1, 3); rt = r[m.ndof_u:].reshape(-1, 3)
+    big = max(np.abs(ru).max(), np.abs(rt).max())
+    assert np.abs(ru[~onb]).max() < 1e-9 * big
+    assert np.abs(rt[~onb[:m.nV]]).max() < 1e-9 * big
+    # energy = 1/2 D kappa^2 area
+    D = 1e6 * 0.1 ** 3 / 12
+    assert np.isclose(o.elastic_energy(w), 0.5 * D * kap ** 2 * 20.0, rtol=1e-10)
+
+
+def test_euler_bernoulli_limit():
+    """nu = 0 cantilever plate under uniform pressure: tip deflection -> q b L^4 / (8 E I)
+    (+ shear term), parameter set of reference ex_simple_shell.py:38-44 (8.68e-3, :61)."""
+    E, h, q, b, L = 4.32e8, 0.2, 2.0, 2.0, 10.0
+    m = plate_mesh(b, L, 4, 20)
+    o = ShellOracle(m, penalty_facets=m.penalty_facets(CLAMP))
+    o.set_fields(h=h, E=E, nu=0.0, f=np.tile([0, 0, q], (m.nn, 1)))
+    w = o.solve()
+    tip = np.abs(w[2:m.ndof_u:3]).max()
+    I = b * h ** 3 / 12
+    eb = q * b * L ** 4 / (8 * E * I)
+    shear = q * b * L ** 2 / (2 * 0.833 * (E / 2) * b * h)
+    assert abs(eb - 8.68e-3) < 1e-5
+    assert abs(tip - (eb + shear)) / eb < 2e-3           # 4x20 mesh; 8.3e-4 measured
+    # clamped edge held by the 1e15 penalty
+    root = np.abs(m.p2_coords[:, 0]) < 1e-12
+    assert np.abs(w[:m.ndof_u].reshape(-1, 3)[root]).max() < 1e-10 * tip   # reaction * h_K / beta ~ 1.4e-14
+
+
+def test_penalty_vs_strong_bc():
+    m = plate_mesh(2.0, 10.0, 4, 20)
+    f = np.tile([0, 0, 5.0], (m.nn, 1))
+    op = ShellOracle(m, penalty_facets=m.penalty_facets(CLAMP))
+    os_ = ShellOracle(m, strong_dofs=m.locate_dofs_geometrical(CLAMP))
+    for o in (op, os_):
+        o.set_fields(h=0.1, E=1e8, nu=0.3, f=f)
+    wp, ws = op.solve(), os_.solve()
+    assert np.abs(wp - ws).max() / np.abs(ws).max() < 1e-9
+    assert np.isclose(op.mass() / 1.0, 1.0 * 0.1 * 20.0)          # rho defaults to 1
+
+
+@pytest.mark.parametrize("ewm", [False, True])
+def test_adjoint_vs_finite_difference(ewm):
+    m = _jittered_plate(3, 9, tilt=True)
+    rng = np.random.default_rng(0)
+    n_h = m.nel if ewm else m.nn
+    h0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, n_h))
+    # clamp: the tilted plate's root edge is the image of x = 0
+    root_nodes = np.nonzero(np.abs(plate_mesh(2.0, 10.0, 3, 9).nodes[:, 0]) < 1e-12)[0]
+    mark = np.zeros(m.nn, bool); mark[root_nodes] = True
+    ok = mark[m.edges[:, 0]] & mark[m.edges[:, 1]] & (m.edge_cells[:, 1] < 0)
+    ed = np.nonzero(ok)[0]
+    pf = np.stack([m.edge_cells[ed, 0], m.edge_local[ed, 0]], axis=1)
+    # beta = 1e9 instead of 1e15: the same discrete problem family, but the LU round-off
+    # (~1e-16 * cond) stays far below the finite-difference increments
+    o = ShellOracle(m, element_wise_material=ewm, penalty_facets=pf, beta=1e9)
+    f = rng.uniform(-1, 1, (m.nn, 3)) * 5
+    o.set_fields(h=h0, E=1e8, nu=0.3, f=f)
+    w, J, dJ = o.forward_adjoint()
+
+    def Jof(h):
+        o.set_fields(h=h)
+        return o.compliance(o.solve())
+
+    for i in rng.choice(n_h, 5, replace=False):
+        step = 1e-3 * h0[i]          # truncation ~1e-6 rel; LU round-off noise rules out tiny steps
+        hp, hm = h0.copy(), h0.copy()
+        hp[i] += step; hm[i] -= step
+        fd = (Jof(hp) - Jof(hm)) / (2 * step)
+        assert abs(fd - dJ[i]) <= 1e-5 * max(abs(dJ).max(), 1e-30), (i, fd, dJ[i])
+
+
+def test_partials_vs_finite_difference():
+    """(dR/d field)^T lam for h, E, nu, f against central differences of R."""
+    m = _jittered_plate(2, 4, tilt=True)
+    rng = np.random.default_rng(5)
+    o = ShellOracle(m)
+    base = dict(h=0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=1e6 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)),
+                nu=0.3 + 0.05 * rng.uniform(-1, 1, m.nn), f=rng.uniform(-1, 1, (m.nn, 3)))
+    o.set_fields(**base)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-3
+    lam = rng.uniform(-1, 1, m.ndof)
+    for name in ("h", "E", "nu"):
+        g = o.dRdfield_T(name, w, lam)
+        for i in rng.choice(m.nn, 3, replace=False):
+            v = base[name].copy(); step = 1e-6 * v[i]
+            v[i] += step; o.set_fields(**{name: v}); rp = o.residual(w)
+            v[i] -= 2 * step; o.set_fields(**{name: v}); rm = o.residual(w)
+            o.set_fields(**{name: base[name]})
+            fd = lam @ (rp - rm) / (2 * step)
+            assert abs(fd - g[i]) <= 1e-6 * np.abs(g).max()
+    g = o.dRdf_T(lam).reshape(-1, 3)
+    for i in (0, 5):
+        for c in range(3):
+            v = base["f"].copy(); v[i, c] += 1.0; o.set_fields(f=v); rp = o.residual(w)
+            o.set_fields(f=base["f"])
+            assert abs(lam @ (rp - o.residual(w)) - g[i, c]) <= 1e-10 * np.abs(g).max()
+
+
+def test_uhat_is_a_rigid_translation_invariant():
+    """uhat = constant moves the mesh rigidly: F = I, J = 1, nothing changes."""
+    m = _jittered_plate(2, 5)
+    o = ShellOracle(m)
+    o.set_fields(h=0.1, E=1e6, nu=0.3)
+    K0 = o.assemble_K()
+    o.set_fields(uhat=np.tile([0.3, -0.2, 0.1], (m.nn, 1)))
+    K1 = o.assemble_K()
+    assert abs(K0 - K1).max() / abs(K0).max() < 1e-13
+
+
+def test_uhat_scaling_of_flat_plate():
+    """uhat = s*x in-plane stretches a flat plate by (1+s): compare with the oracle on the
+    stretched mesh.  Shear/drilling carry J, membrane/bending do not (quirk Q4), so the two
+    agree only after the reference's own J convention is applied term by term."""
+    s = 0.1
+    m = plate_mesh(2.0, 10.0, 2, 4)
+    ms = ShellMesh(m.nodes * (1 + s), m.cells)
+    w = np.random.default_rng(1).uniform(-1, 1, m.ndof) * 1e-3
+    o = ShellOracle(m); o.set_fields(h=0.1, E=1e6, nu=0.3, uhat=s * m.nodes)
+    os_ = ShellOracle(ms); os_.set_fields(h=0.1, E=1e6, nu=0.3)
+    # compliance has the J factor: int u.u J dx on the reference mesh == int u.u dx on the stretched one
+    assert np.isclose(o.compliance(w) - o.regularization(), os_.compliance(w) - os_.regularization(), rtol=1e-12)
+    assert np.isclose(o.mass(), os_.mass(), rtol=1e-12)
