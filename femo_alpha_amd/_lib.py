@@ -1,0 +1,82 @@
+"""ctypes binding of libfemo_hip.so (include/femo_hip.h).  Fails loudly when the HIP
+library is missing -- there is deliberately no CPU fallback behind this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import LIB
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int32_p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); kept in the same order as include/femo_hip.h
+SIGNATURES = {
+    "femo_version": (C.c_int, []),
+    "femo_device_count": (C.c_int, []),
+    "femo_last_error": (C.c_char_p, [C.c_void_p]),
+    "femo_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                              _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int]),
+    "femo_destroy": (None, [C.c_void_p]),
+    "femo_ndof": (C.c_int64, [C.c_void_p]),
+    "femo_field_size": (C.c_int64, [C.c_void_p, C.c_char_p]),
+    "femo_set_penalty_facets": (C.c_int, [C.c_void_p, C.c_int32, _c_int32_p, C.c_double]),
+    "femo_set_strong_dofs": (C.c_int, [C.c_void_p, C.c_int32, _c_int32_p]),
+    "femo_set_field": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_int64]),
+    "femo_get_field": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_int64]),
+    "femo_set_state": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_get_state": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_apply_K": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
+    "femo_residual": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
+    "femo_load_vector": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_diagonal": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_element_matrices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p]),
+    "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
+    "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
+    "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_functional": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p]),
+    "femo_dfunctional": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, _c_double_p, C.c_int64]),
+    "femo_dRdarg_T": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, _c_double_p, C.c_int64]),
+    "femo_total_gradient": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, _c_double_p, C.c_int64, _c_int32_p,
+                                      _c_double_p]),
+    "femo_last_timing": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_bench_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _c_double_p]),
+    "femo_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+}
+
+_lib = None
+
+
+class FemoHipError(RuntimeError):
+    """A libfemo_hip call returned a non-zero status."""
+
+
+def load():
+    """Load libfemo_hip.so and bind every symbol of the header; raises if the library or a
+    symbol is missing (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise FemoHipError(
+            f"{LIB} is missing: build it with `python -m femo_alpha_amd._build` (hipcc, gfx950). "
+            "femo_alpha_amd has no CPU fallback.")
+    lib = C.CDLL(LIB)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_c_double_p)
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_c_int32_p)

@@ -1,0 +1,170 @@
+"""``ShellContext``: one mesh resident on one MI355X, a thin object wrapper over the C ABI
+(include/femo_hip.h).  All arithmetic happens in libfemo_hip.so; this class only converts
+numpy arrays to pointers and status codes to exceptions."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FemoHipError, dptr, iptr
+from .mesh import ShellMesh
+
+PENALTY_BETA = 1.0e15      # reference linear_shell_model.py:324
+
+
+class ShellContext:
+    def __init__(self, mesh: ShellMesh, element_wise_material=False, elementwise_pressure=False,
+                 nquad=4, device=0):
+        self.lib = _lib.load()
+        self.mesh = mesh
+        self.element_wise_material = bool(element_wise_material)
+        self.elementwise_pressure = bool(elementwise_pressure)
+        h = C.c_void_p()
+        xyz = np.ascontiguousarray(mesh.nodes, dtype=np.float64)
+        cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
+        cp2 = np.ascontiguousarray(mesh.cell_p2, dtype=np.int32)
+        rc = self.lib.femo_create(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
+                                  dptr(xyz), iptr(cells), iptr(cp2),
+                                  int(self.element_wise_material), int(self.elementwise_pressure), int(nquad))
+        if rc:
+            raise FemoHipError(f"femo_create failed ({rc}): {self.lib.femo_last_error(None).decode()}")
+        self._h = h
+        self.ndof = int(self.lib.femo_ndof(h))
+        assert self.ndof == mesh.ndof
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, rc):
+        if rc:
+            raise FemoHipError(self.lib.femo_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.femo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _vec(a):
+        return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+
+    # ------------------------------------------------------------------ data in
+    def field_size(self, name):
+        n = int(self.lib.femo_field_size(self._h, name.encode()))
+        if n < 0:
+            raise FemoHipError(f"unknown field '{name}'")
+        return n
+
+    def set_field(self, name, values):
+        v = self._vec(values)
+        self._chk(self.lib.femo_set_field(self._h, name.encode(), dptr(v), v.size))
+
+    def get_field(self, name):
+        out = np.empty(self.field_size(name))
+        self._chk(self.lib.femo_get_field(self._h, name.encode(), dptr(out), out.size))
+        return out
+
+    def set_penalty_facets(self, facets, beta=PENALTY_BETA):
+        f = np.ascontiguousarray(np.asarray(facets, dtype=np.int32).reshape(-1, 2))
+        self._chk(self.lib.femo_set_penalty_facets(self._h, f.shape[0], iptr(f), float(beta)))
+
+    def set_strong_dofs(self, dofs):
+        d = np.ascontiguousarray(np.asarray(dofs, dtype=np.int32).ravel())
+        self._chk(self.lib.femo_set_strong_dofs(self._h, d.size, iptr(d)))
+
+    def set_state(self, w):
+        w = self._vec(w)
+        if w.size != self.ndof:
+            raise ValueError("state has the wrong length")
+        self._chk(self.lib.femo_set_state(self._h, dptr(w)))
+
+    def get_state(self):
+        w = np.empty(self.ndof)
+        self._chk(self.lib.femo_get_state(self._h, dptr(w)))
+        return w
+
+    # ------------------------------------------------------------------ operators
+    def apply_K(self, x):
+        x = self._vec(x); y = np.empty(self.ndof)
+        self._chk(self.lib.femo_apply_K(self._h, dptr(x), dptr(y)))
+        return y
+
+    def residual(self, w=None):
+        r = np.empty(self.ndof)
+        wp = None if w is None else dptr(self._vec(w))
+        self._chk(self.lib.femo_residual(self._h, wp, dptr(r)))
+        return r
+
+    def load_vector(self):
+        F = np.empty(self.ndof)
+        self._chk(self.lib.femo_load_vector(self._h, dptr(F)))
+        return F
+
+    def diagonal(self):
+        d = np.empty(self.ndof)
+        self._chk(self.lib.femo_diagonal(self._h, dptr(d)))
+        return d
+
+    def element_matrices(self, first=0, count=None):
+        count = self.mesh.nel - first if count is None else count
+        ld = self.mesh.ldof
+        Ke = np.empty((count, ld, ld))
+        self._chk(self.lib.femo_element_matrices(self._h, first, count, dptr(Ke)))
+        return Ke
+
+    # ------------------------------------------------------------------ solves
+    def set_solver(self, preconditioner=0, rtol=1e-10, maxit=200000, check_every=50):
+        self._chk(self.lib.femo_set_solver(self._h, preconditioner, rtol, maxit, check_every))
+
+    def solve_state(self, zero_guess=True):
+        it = C.c_int32(); rr = C.c_double()
+        self._chk(self.lib.femo_solve_state(self._h, int(zero_guess), C.byref(it), C.byref(rr)))
+        return it.value, rr.value
+
+    def solve_linear(self, rhs):
+        rhs = self._vec(rhs); x = np.empty(self.ndof)
+        it = C.c_int32(); rr = C.c_double()
+        self._chk(self.lib.femo_solve_linear(self._h, dptr(rhs), dptr(x), C.byref(it), C.byref(rr)))
+        return x, it.value, rr.value
+
+    # ------------------------------------------------------------------ outputs
+    def functional(self, name):
+        v = C.c_double()
+        self._chk(self.lib.femo_functional(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def arg_size(self, wrt):
+        return self.ndof if wrt == "disp_solid" else self.field_size(wrt)
+
+    def dfunctional(self, name, wrt):
+        out = np.empty(self.arg_size(wrt))
+        self._chk(self.lib.femo_dfunctional(self._h, name.encode(), wrt.encode(), dptr(out), out.size))
+        return out
+
+    def dRdarg_T(self, arg, lam):
+        lam = self._vec(lam); out = np.empty(self.field_size(arg))
+        self._chk(self.lib.femo_dRdarg_T(self._h, arg.encode(), dptr(lam), dptr(out), out.size))
+        return out
+
+    def total_gradient(self, functional, arg):
+        out = np.empty(self.field_size(arg))
+        it = C.c_int32(); rr = C.c_double()
+        self._chk(self.lib.femo_total_gradient(self._h, functional.encode(), arg.encode(), dptr(out), out.size,
+                                               C.byref(it), C.byref(rr)))
+        return out, it.value, rr.value
+
+    def last_timing(self):
+        t = np.zeros(5)
+        self._chk(self.lib.femo_last_timing(self._h, dptr(t)))
+        return dict(setup_ms=t[0], krylov_ms=t[1], total_ms=t[2], operator_launches=int(t[4]))
+
+    def bench_kernel(self, name, reps=50):
+        v = C.c_double()
+        self._chk(self.lib.femo_bench_kernel(self._h, name.encode(), reps, C.byref(v)))
+        return v.value

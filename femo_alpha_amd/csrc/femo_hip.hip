@@ -1,0 +1,831 @@
+// libfemo_hip.so: C ABI (include/femo_hip.h) over the gfx950 shell kernels.
+// One context = one mesh on one GPU with every buffer resident in HBM.
+#include "../../include/femo_hip.h"
+#include "shell_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace femo;
+
+#define FEMO_VERSION 100
+
+static std::string g_create_error;
+
+struct femo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;
+    bool quad = true, ewm = false, ewp = false, has_uhat = false;
+    int64_t nT = 0, nF = 0;
+    // mesh
+    double* xyz = nullptr;
+    int* cells = nullptr;
+    int* cellp2 = nullptr;
+    double* hK = nullptr;
+    Tables* tab = nullptr;
+    // fields
+    double *h = nullptr, *E = nullptr, *nu = nullptr, *rho = nullptr, *f = nullptr, *uhat = nullptr;
+    // dirichlet
+    int nf = 0;
+    int *fcell = nullptr, *fledge = nullptr, *funode = nullptr, *fvnode = nullptr;
+    double *fM2 = nullptr, *fM1 = nullptr;
+    double beta = 1e15;
+    bool penalty_dirty = true;
+    unsigned char* mask = nullptr;
+    bool has_mask = false;
+    // vectors
+    double *w = nullptr, *lam = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *Ap = nullptr, *dinv = nullptr,
+           *b = nullptr, *tmp = nullptr;
+    double* scal = nullptr;        // device, 8 slots
+    double* scal_host = nullptr;   // pinned, 8 slots
+    bool diag_dirty = true;
+    // solver
+    int precond = 0;
+    double rtol = 1e-10;
+    int maxit = 200000, check_every = 50;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double timing[5] = {0, 0, 0, 0, 0};
+    std::string err;
+};
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            char buf_[512];                                                                      \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = buf_;                                                                   \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+static int fail(femo_ctx* c, const std::string& msg) {
+    c->err = msg;
+    return 2;
+}
+
+// ------------------------------------------------------------------------------------------ tables
+static void gauss_legendre(int n, double* x, double* w) {
+    // Newton on Legendre polynomials
+    for (int i = 0; i < n; ++i) {
+        double t = cos(M_PI * (i + 0.75) / (n + 0.5));
+        for (int it = 0; it < 100; ++it) {
+            double p0 = 1.0, p1 = t;
+            for (int k = 2; k <= n; ++k) {
+                const double p2 = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+                p0 = p1;
+                p1 = p2;
+            }
+            const double dp = n * (t * p1 - p0) / (t * t - 1.0);
+            const double dt = p1 / dp;
+            t -= dt;
+            if (fabs(dt) < 1e-16) break;
+        }
+        double p0 = 1.0, p1 = t;
+        for (int k = 2; k <= n; ++k) {
+            const double p2 = ((2 * k - 1) * t * p1 - (k - 1) * p0) / k;
+            p0 = p1;
+            p1 = p2;
+        }
+        const double dp = n * (t * p1 - p0) / (t * t - 1.0);
+        x[n - 1 - i] = t;
+        w[n - 1 - i] = 2.0 / ((1.0 - t * t) * dp * dp);
+    }
+}
+
+static void lag2(double t, double* v, double* d) {
+    v[0] = 0.5 * t * (t - 1.0); v[1] = 1.0 - t * t; v[2] = 0.5 * t * (t + 1.0);
+    d[0] = t - 0.5; d[1] = -2.0 * t; d[2] = t + 0.5;
+}
+static void lag1(double t, double* v, double* d) {
+    v[0] = 0.5 * (1.0 - t); v[1] = 0.5 * (1.0 + t);
+    d[0] = -0.5; d[1] = 0.5;
+}
+
+static void build_tables(bool quad, int nquad, Tables& T) {
+    memset(&T, 0, sizeof T);
+    if (quad) {
+        static const int Q2I[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
+        static const int Q1I[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+        double gx[8], gw[8];
+        gauss_legendre(nquad, gx, gw);
+        T.nq = nquad * nquad;
+        for (int i = 0; i < nquad; ++i)
+            for (int j = 0; j < nquad; ++j) {
+                const int q = i * nquad + j;
+                const double xi = gx[i], eta = gx[j];
+                T.w[q] = gw[i] * gw[j];
+                double a[3], da[3], b[3], db[3], c[2], dc[2], d[2], dd[2];
+                lag2(xi, a, da); lag2(eta, b, db); lag1(xi, c, dc); lag1(eta, d, dd);
+                for (int n = 0; n < 9; ++n) {
+                    const int ii = Q2I[n][0], jj = Q2I[n][1];
+                    T.N2[q][n] = a[ii] * b[jj];
+                    T.dN2[q][n][0] = da[ii] * b[jj];
+                    T.dN2[q][n][1] = a[ii] * db[jj];
+                }
+                for (int n = 0; n < 4; ++n) {
+                    const int ii = Q1I[n][0], jj = Q1I[n][1];
+                    T.N1[q][n] = c[ii] * d[jj];
+                    T.dN1[q][n][0] = dc[ii] * d[jj];
+                    T.dN1[q][n][1] = c[ii] * dd[jj];
+                }
+            }
+    } else {
+        // degree-6, 12-point symmetric rule on the unit triangle
+        const double a1 = 0.063089014491502, b1 = 0.873821971016996, w1 = 0.050844906370207;
+        const double a2 = 0.249286745170910, b2 = 0.501426509658179, w2 = 0.116786275726379;
+        const double a3 = 0.053145049844817, b3 = 0.310352451033784, c3 = 0.636502499121399, w3 = 0.082851075618374;
+        const double P[12][3] = {{a1, a1, w1}, {b1, a1, w1}, {a1, b1, w1}, {a2, a2, w2}, {b2, a2, w2}, {a2, b2, w2},
+                                 {a3, b3, w3}, {b3, a3, w3}, {a3, c3, w3}, {c3, a3, w3}, {b3, c3, w3}, {c3, b3, w3}};
+        const double dL[3][2] = {{-1, -1}, {1, 0}, {0, 1}};
+        static const int ED[3][2] = {{0, 1}, {1, 2}, {2, 0}};
+        T.nq = 12;
+        for (int q = 0; q < 12; ++q) {
+            const double x = P[q][0], y = P[q][1];
+            T.w[q] = 0.5 * P[q][2];
+            const double L[3] = {1 - x - y, x, y};
+            for (int i = 0; i < 3; ++i) {
+                T.N1[q][i] = L[i];
+                T.dN1[q][i][0] = dL[i][0];
+                T.dN1[q][i][1] = dL[i][1];
+                T.N2[q][i] = L[i] * (2 * L[i] - 1);
+                T.dN2[q][i][0] = (4 * L[i] - 1) * dL[i][0];
+                T.dN2[q][i][1] = (4 * L[i] - 1) * dL[i][1];
+            }
+            for (int k = 0; k < 3; ++k) {
+                const int i = ED[k][0], j = ED[k][1];
+                T.N2[q][3 + k] = 4 * L[i] * L[j];
+                T.dN2[q][3 + k][0] = 4 * (L[i] * dL[j][0] + L[j] * dL[i][0]);
+                T.dN2[q][3 + k][1] = 4 * (L[i] * dL[j][1] + L[j] * dL[i][1]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
+static inline int vec_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+
+static MeshDev mesh_dev(const femo_ctx* c) {
+    MeshDev m;
+    m.nn = c->nn; m.nel = c->nel; m.nP2 = c->nP2; m.ndof_u = c->ndof_u; m.ndof = c->ndof;
+    m.xyz = c->xyz; m.cells = c->cells; m.cellp2 = c->cellp2; m.hK = c->hK;
+    return m;
+}
+static FieldsDev fields_dev(const femo_ctx* c) {
+    FieldsDev f;
+    f.h = c->h; f.E = c->E; f.nu = c->nu; f.rho = c->rho; f.f = c->f; f.uhat = c->uhat;
+    f.ewm = c->ewm; f.ewp = c->ewp;
+    return f;
+}
+static FacetDev facet_dev(const femo_ctx* c) {
+    FacetDev fd;
+    fd.nf = c->nf; fd.cell = c->fcell; fd.ledge = c->fledge; fd.unode = c->funode; fd.vnode = c->fvnode;
+    fd.M2 = c->fM2; fd.M1 = c->fM1;
+    return fd;
+}
+
+// KERNEL is a template <NPC,NVC,QUAD,UHAT>; EXTRA may carry more template args (leading comma)
+#define ELEM_LAUNCH(c, KERNEL, EXTRA, grid, block, ...)                                                       \
+    do {                                                                                                      \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+    } while (0)
+#define NOEXTRA
+#define COMMA_H , DERIV_H
+#define COMMA_E , DERIV_E
+#define COMMA_NU , DERIV_NU
+
+static const int EB = 128;   // element kernels: threads per block (one element per thread)
+
+static int refresh_penalty(femo_ctx* c) {
+    if (c->nf == 0 || !c->penalty_dirty) return 0;
+    ELEM_LAUNCH(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
+    HIPCHK(c, hipGetLastError());
+    c->penalty_dirty = false;
+    return 0;
+}
+
+// y += K_elastic x (+ penalty); y must hold the values to accumulate onto (usually zeros)
+static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, double* za, double* zb, bool with_penalty) {
+    ELEM_LAUNCH(c, k_apply, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, x, y, dotslot, za, zb);
+    if (with_penalty && c->nf > 0) {
+        if (refresh_penalty(c)) return 1;
+        hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 0, x, y,
+                           dotslot);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int refresh_diag(femo_ctx* c) {
+    if (!c->diag_dirty) return 0;
+    const int64_t n = c->ndof;
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv, 0.0, n);
+    ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
+    if (c->nf > 0) {
+        if (refresh_penalty(c)) return 1;
+        hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 1,
+                           (const double*)nullptr, c->dinv, (double*)nullptr);
+    }
+    hipLaunchKernelGGL(k_invert_diag, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv,
+                       c->has_mask ? c->mask : (const unsigned char*)nullptr, n);
+    HIPCHK(c, hipGetLastError());
+    c->diag_dirty = false;
+    return 0;
+}
+
+static int load_vector_dev(femo_ctx* c, double* F) {
+    const int64_t n = c->ndof;
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, 0.0, n);
+    ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, F, 1.0);
+    if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, c->mask, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Jacobi-preconditioned CG on the device; b is overwritten only on masked rows (set to zero)
+static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (refresh_diag(c)) return 1;
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+    if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
+    hipLaunchKernelGGL(k_dot, dim3(vg), dim3(256), 0, c->stream, b, b, n, c->scal + 6);
+    hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
+    if (zero_guess) {
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
+    } else {
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, x, mask, n);
+        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+    }
+    hipLaunchKernelGGL(k_pcg_init, dim3(vg), dim3(256), 0, c->stream, b, c->Ap, c->dinv, mask, c->r, c->z, c->p, n, c->scal,
+                       zero_guess ? 0 : 1);
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double bb = c->scal_host[6];
+    double rr = c->scal_host[4];
+    int k = 0;
+    int napply = 0;
+    if (bb == 0.0) {
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
+        rr = 0.0;
+    } else {
+        const double target = c->rtol * c->rtol * bb;
+        while (rr > target && k < c->maxit) {
+            const int chunk = std::min(c->check_every, c->maxit - k);
+            for (int j = 0; j < chunk; ++j, ++k) {
+                const int s = k & 1;
+                // K1 also clears the rz/rr slots the update kernel of this iteration accumulates into
+                if (op_apply(c, c->p, c->Ap, c->scal + s, c->scal + 2 + (1 - s), c->scal + 4 + (1 - s), true)) return 1;
+                hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, x, c->r, c->z, c->p, c->Ap, c->dinv, mask, n,
+                                   c->scal, s);
+                hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, s);
+                ++napply;
+            }
+            HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rr = c->scal_host[4 + (k & 1)];   // after iteration k-1 (s = (k-1)&1) the fresh value sits in slot 1-s = k&1
+            if (!(rr == rr)) return fail(c, "PCG broke down (NaN residual)");
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float t_setup = 0, t_loop = 0;
+    hipEventElapsedTime(&t_setup, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
+    c->timing[0] = t_setup; c->timing[1] = t_loop; c->timing[2] = t_setup + t_loop; c->timing[4] = napply;
+    if (iters) *iters = k;
+    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int femo_version(void) { return FEMO_VERSION; }
+
+int femo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* femo_last_error(const femo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static int alloc_d(femo_ctx* c, double** p, int64_t n) {
+    HIPCHK(c, hipMalloc((void**)p, std::max<int64_t>(n, 1) * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(*p, 0, std::max<int64_t>(n, 1) * sizeof(double), c->stream));
+    return 0;
+}
+
+static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, const int32_t* cell_p2, int nquad) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamCreate(&c->stream));
+    for (int i = 0; i < 4; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    const int nel = c->nel, nvc = c->nvc, npc = c->npc;
+    // SoA connectivity
+    std::vector<int> soa_c((size_t)nvc * nel), soa_p((size_t)npc * nel);
+    std::vector<double> hK(nel);
+    for (int e = 0; e < nel; ++e) {
+        for (int b = 0; b < nvc; ++b) soa_c[(size_t)b * nel + e] = cells[(size_t)e * nvc + b];
+        for (int a = 0; a < npc; ++a) soa_p[(size_t)a * nel + e] = cell_p2[(size_t)e * npc + a];
+        double d = 0.0;
+        for (int i = 0; i < nvc; ++i)
+            for (int j = i + 1; j < nvc; ++j) {
+                const double* xi = xyz + 3 * (size_t)cells[(size_t)e * nvc + i];
+                const double* xj = xyz + 3 * (size_t)cells[(size_t)e * nvc + j];
+                const double dd = sqrt((xi[0] - xj[0]) * (xi[0] - xj[0]) + (xi[1] - xj[1]) * (xi[1] - xj[1]) +
+                                       (xi[2] - xj[2]) * (xi[2] - xj[2]));
+                d = std::max(d, dd);
+            }
+        hK[e] = d;
+    }
+    HIPCHK(c, hipMalloc((void**)&c->xyz, (size_t)c->nn * 3 * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->xyz, xyz, (size_t)c->nn * 3 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->cells, soa_c.size() * sizeof(int)));
+    HIPCHK(c, hipMemcpy(c->cells, soa_c.data(), soa_c.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->cellp2, soa_p.size() * sizeof(int)));
+    HIPCHK(c, hipMemcpy(c->cellp2, soa_p.data(), soa_p.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&c->hK, (size_t)nel * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
+    Tables T;
+    build_tables(c->quad, nquad, T);
+    HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
+    HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    c->nT = c->ewm ? nel : c->nn;
+    c->nF = c->ewp ? nel : c->nn;
+    if (alloc_d(c, &c->h, c->nT) || alloc_d(c, &c->E, c->nT) || alloc_d(c, &c->nu, c->nT) || alloc_d(c, &c->rho, c->nT) ||
+        alloc_d(c, &c->f, 3 * c->nF) || alloc_d(c, &c->uhat, 3 * (int64_t)c->nn))
+        return 1;
+    double** vecs[] = {&c->w, &c->lam, &c->r, &c->z, &c->p, &c->Ap, &c->dinv, &c->b, &c->tmp};
+    for (auto v : vecs)
+        if (alloc_d(c, v, c->ndof)) return 1;
+    HIPCHK(c, hipMalloc((void**)&c->scal, 8 * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void**)&c->scal_host, 8 * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->mask, (size_t)c->ndof));
+    HIPCHK(c, hipMemset(c->mask, 0, (size_t)c->ndof));
+    // FEA.add_input initial values (rm_shell_model.py:209-214): thickness 1e-3, others 1, uhat 0
+    const int vgT = vec_grid(c->nT);
+    hipLaunchKernelGGL(k_fill, dim3(vgT), dim3(256), 0, c->stream, c->h, 1e-3, c->nT);
+    hipLaunchKernelGGL(k_fill, dim3(vgT), dim3(256), 0, c->stream, c->E, 1.0, c->nT);
+    hipLaunchKernelGGL(k_fill, dim3(vgT), dim3(256), 0, c->stream, c->nu, 1.0, c->nT);
+    hipLaunchKernelGGL(k_fill, dim3(vgT), dim3(256), 0, c->stream, c->rho, 1.0, c->nT);
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(3 * c->nF)), dim3(256), 0, c->stream, c->f, 1.0, 3 * c->nF);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2, const double* xyz,
+                const int32_t* cells, const int32_t* cell_p2, int elementwise_material, int elementwise_pressure, int nquad) {
+    if (!out) return 2;
+    *out = nullptr;
+    if (nvc != 3 && nvc != 4) { g_create_error = "nvc must be 3 (triangles) or 4 (quads)"; return 2; }
+    if (nn <= 0 || nel <= 0 || !xyz || !cells || !cell_p2) { g_create_error = "empty mesh or null pointer"; return 2; }
+    if (nvc == 4 && (nquad < 2 || nquad > 5)) { g_create_error = "nquad must be in 2..5"; return 2; }
+    const int npc = nvc == 4 ? 9 : 6;
+    for (int64_t i = 0; i < (int64_t)nel * nvc; ++i)
+        if (cells[i] < 0 || cells[i] >= nn) { g_create_error = "cells refers to a vertex outside 0..nn-1"; return 2; }
+    for (int64_t i = 0; i < (int64_t)nel * npc; ++i)
+        if (cell_p2[i] < 0 || cell_p2[i] >= nP2) { g_create_error = "cell_p2 refers to a node outside 0..nP2-1"; return 2; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libfemo_hip needs an MI355X; there is no CPU fallback)"; return 3; }
+    if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return 2; }
+    femo_ctx* c = new femo_ctx();
+    c->device = device;
+    c->nn = nn; c->nel = nel; c->nvc = nvc; c->npc = npc; c->nP2 = nP2;
+    c->quad = nvc == 4;
+    c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * nn; c->ld = 3 * npc + 3 * nvc;
+    c->ewm = elementwise_material != 0; c->ewp = elementwise_pressure != 0;
+    if (create_impl(c, xyz, cells, cell_p2, nquad)) {
+        g_create_error = c->err;
+        femo_destroy(c);
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+void femo_destroy(femo_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->hK, c->tab, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+                    c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
+                    c->scal};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (c->scal_host) hipHostFree(c->scal_host);
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int64_t femo_ndof(const femo_ctx* c) { return c ? c->ndof : -1; }
+
+static double* field_ptr(const femo_ctx* c, const char* name, int64_t* n) {
+    const std::string s(name ? name : "");
+    if (s == "thickness") { *n = c->nT; return c->h; }
+    if (s == "E") { *n = c->nT; return c->E; }
+    if (s == "nu") { *n = c->nT; return c->nu; }
+    if (s == "density") { *n = c->nT; return c->rho; }
+    if (s == "F_solid") { *n = 3 * c->nF; return c->f; }
+    if (s == "uhat") { *n = 3 * (int64_t)c->nn; return c->uhat; }
+    *n = -1;
+    return nullptr;
+}
+
+int64_t femo_field_size(const femo_ctx* c, const char* name) {
+    int64_t n;
+    field_ptr(c, name, &n);
+    return n;
+}
+
+int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double beta) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nf < 0 || (nf > 0 && !cl)) return fail(c, "bad facet list");
+    void* old[] = {c->fcell, c->fledge, c->funode, c->fvnode, c->fM2, c->fM1};
+    for (void* p : old)
+        if (p) hipFree(p);
+    c->fcell = c->fledge = c->funode = c->fvnode = nullptr;
+    c->fM2 = c->fM1 = nullptr;
+    c->nf = 0;
+    c->beta = beta;
+    c->penalty_dirty = c->diag_dirty = true;
+    if (nf == 0) return 0;
+    std::vector<int> hc((size_t)c->nvc * c->nel), hp((size_t)c->npc * c->nel);
+    HIPCHK(c, hipMemcpy(hc.data(), c->cells, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hp.data(), c->cellp2, hp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> cell(nf), le(nf), un(3 * (size_t)nf), vn(2 * (size_t)nf);
+    for (int i = 0; i < nf; ++i) {
+        const int e = cl[2 * i], k = cl[2 * i + 1];
+        if (e < 0 || e >= c->nel || k < 0 || k >= c->nvc) return fail(c, "facet (cell, local edge) out of range");
+        cell[i] = e; le[i] = k;
+        const int kb = (k + 1) % c->nvc;
+        un[3 * i] = hp[(size_t)k * c->nel + e];
+        un[3 * i + 1] = hp[(size_t)(c->nvc + k) * c->nel + e];
+        un[3 * i + 2] = hp[(size_t)kb * c->nel + e];
+        vn[2 * i] = hc[(size_t)k * c->nel + e];
+        vn[2 * i + 1] = hc[(size_t)kb * c->nel + e];
+    }
+    HIPCHK(c, hipMalloc((void**)&c->fcell, nf * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->fledge, nf * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->funode, 3 * (size_t)nf * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->fvnode, 2 * (size_t)nf * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->fM2, 9 * (size_t)nf * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->fM1, 4 * (size_t)nf * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->fcell, cell.data(), nf * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->fledge, le.data(), nf * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->funode, un.data(), un.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->fvnode, vn.data(), vn.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->nf = nf;
+    return 0;
+}
+
+int femo_set_strong_dofs(femo_ctx* c, int32_t n, const int32_t* dofs) {
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned char> m((size_t)c->ndof, 0);
+    for (int i = 0; i < n; ++i) {
+        if (dofs[i] < 0 || dofs[i] >= c->ndof) return fail(c, "strong-BC dof out of range");
+        m[dofs[i]] = 1;
+    }
+    HIPCHK(c, hipMemcpy(c->mask, m.data(), m.size(), hipMemcpyHostToDevice));
+    c->has_mask = n > 0;
+    c->diag_dirty = true;
+    return 0;
+}
+
+int femo_set_field(femo_ctx* c, const char* name, const double* v, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t len;
+    double* d = field_ptr(c, name, &len);
+    if (!d) return fail(c, std::string("unknown field '") + (name ? name : "") + "'");
+    if (!v) return fail(c, "null values");
+    if (n == 1 && len != 1) {   // update(): a length-1 array broadcasts (fea/utils_dolfinx.py:327-330)
+        hipLaunchKernelGGL(k_fill, dim3(vec_grid(len)), dim3(256), 0, c->stream, d, v[0], len);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else if (n == len) {
+        HIPCHK(c, hipMemcpy(d, v, (size_t)len * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        char buf[160];
+        snprintf(buf, sizeof buf, "field '%s' has length %lld, got %lld", name, (long long)len, (long long)n);
+        return fail(c, buf);
+    }
+    if (d == c->uhat) {
+        bool any = false;
+        for (int64_t i = 0; i < n; ++i)
+            if (v[i] != 0.0) { any = true; break; }
+        c->has_uhat = any;
+        c->penalty_dirty = true;
+    }
+    if (d != c->f && d != c->rho) c->diag_dirty = true;
+    return 0;
+}
+
+int femo_get_field(femo_ctx* c, const char* name, double* v, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t len;
+    double* d = field_ptr(c, name, &len);
+    if (!d) return fail(c, "unknown field");
+    if (n != len) return fail(c, "length mismatch");
+    HIPCHK(c, hipMemcpy(v, d, (size_t)len * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int femo_set_state(femo_ctx* c, const double* w) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->w, w, (size_t)c->ndof * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int femo_get_state(femo_ctx* c, double* w) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(w, c->w, (size_t)c->ndof * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// y = A x on device vectors (x is modified on masked rows only through a copy in tmp)
+static int full_apply_dev(femo_ctx* c, const double* x, double* y) {
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, y, 0.0, n);
+    const double* xin = x;
+    if (c->has_mask) {
+        HIPCHK(c, hipMemcpyAsync(c->tmp, x, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->tmp, c->mask, n);
+        xin = c->tmp;
+    }
+    if (op_apply(c, xin, y, nullptr, nullptr, nullptr, true)) return 1;
+    if (c->has_mask) hipLaunchKernelGGL(k_mask_identity, dim3(vg), dim3(256), 0, c->stream, y, x, c->mask, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int femo_apply_K(femo_ctx* c, const double* x, double* y) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->ndof * sizeof(double);
+    HIPCHK(c, hipMemcpy(c->z, x, bytes, hipMemcpyHostToDevice));
+    if (full_apply_dev(c, c->z, c->r)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(y, c->r, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int femo_load_vector(femo_ctx* c, double* F) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (load_vector_dev(c, c->b)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(F, c->b, (size_t)c->ndof * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int femo_residual(femo_ctx* c, const double* w, double* r) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->ndof;
+    const double* wd = c->w;
+    if (w) {
+        HIPCHK(c, hipMemcpy(c->z, w, n * sizeof(double), hipMemcpyHostToDevice));
+        wd = c->z;
+    }
+    if (full_apply_dev(c, wd, c->r)) return 1;
+    if (load_vector_dev(c, c->b)) return 1;
+    hipLaunchKernelGGL(k_axpby, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->r, -1.0, c->b, 1.0, n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(r, c->r, n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int femo_diagonal(femo_ctx* c, double* d) {
+    HIPCHK(c, hipSetDevice(c->device));
+    c->diag_dirty = true;
+    if (refresh_diag(c)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> inv((size_t)c->ndof);
+    HIPCHK(c, hipMemcpy(inv.data(), c->dinv, inv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < inv.size(); ++i) d[i] = 1.0 / inv[i];
+    return 0;
+}
+
+int femo_element_matrices(femo_ctx* c, int32_t first, int32_t count, double* Ke) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (first < 0 || count < 0 || first + count > c->nel) return fail(c, "element range out of bounds");
+    if (count == 0) return 0;
+    double* d = nullptr;
+    const size_t bytes = (size_t)count * c->ld * c->ld * sizeof(double);
+    HIPCHK(c, hipMalloc((void**)&d, bytes));
+    ELEM_LAUNCH(c, k_element_matrices, NOEXTRA, count, 64, mesh_dev(c), fields_dev(c), c->tab, first, count, d);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(Ke, d, bytes, hipMemcpyDeviceToHost);
+    hipFree(d);
+    HIPCHK(c, e);
+    return 0;
+}
+
+int femo_set_solver(femo_ctx* c, int preconditioner, double rtol, int32_t maxit, int32_t check_every) {
+    if (preconditioner != 0) return fail(c, "only preconditioner 0 (Jacobi) is available in this build");
+    if (!(rtol > 0) || maxit < 1 || check_every < 1) return fail(c, "bad solver parameters");
+    c->precond = preconditioner; c->rtol = rtol; c->maxit = maxit; c->check_every = check_every;
+    return 0;
+}
+
+int femo_solve_state(femo_ctx* c, int zero_guess, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (load_vector_dev(c, c->b)) return 1;
+    return pcg(c, c->b, c->w, zero_guess != 0, iters, relres);
+}
+
+int femo_solve_linear(femo_ctx* c, const double* rhs, double* x, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->ndof * sizeof(double);
+    HIPCHK(c, hipMemcpy(c->b, rhs, bytes, hipMemcpyHostToDevice));
+    if (int rc = pcg(c, c->b, c->lam, true, iters, relres)) return rc;
+    HIPCHK(c, hipMemcpy(x, c->lam, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int functionals_dev(femo_ctx* c, double out3[3]) {
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+    ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, c->scal);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) out3[i] = c->scal_host[i];
+    return 0;
+}
+
+int femo_functional(femo_ctx* c, const char* name, double* value) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const std::string s(name ? name : "");
+    if (s == "compliance" || s == "mass") {
+        double v[3];
+        if (functionals_dev(c, v)) return 1;
+        *value = s == "mass" ? v[2] : v[0] + v[1];
+        return 0;
+    }
+    if (s == "elastic_energy") {
+        const int64_t n = c->ndof;
+        HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->r, 0.0, n);
+        if (op_apply(c, c->w, c->r, c->scal + 7, nullptr, nullptr, false)) return 1;
+        HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *value = 0.5 * c->scal_host[7];
+        return 0;
+    }
+    return fail(c, "unknown functional '" + s + "'");
+}
+
+// gradient of a functional into a device buffer `out` (length n, zero-filled here)
+static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string& wrt, double* out, int64_t n) {
+    int64_t len;
+    if (wrt == "disp_solid") len = c->ndof;
+    else if (!field_ptr(c, wrt.c_str(), &len)) return fail(c, "unknown argument '" + wrt + "'");
+    if (len != n) return fail(c, "gradient buffer has the wrong length for '" + wrt + "'");
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n);
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int g = nblk(c->nel, EB);
+    if (wrt == "uhat") return fail(c, "derivatives with respect to 'uhat' are not implemented in this build");
+    if (fn == "compliance") {
+        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out);
+        else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+    } else if (fn == "mass") {
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
+        else if (wrt == "density") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
+    } else if (fn == "elastic_energy") {
+        if (wrt == "disp_solid") { if (op_apply(c, c->w, out, nullptr, nullptr, nullptr, false)) return 1; }
+        else if (wrt == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+    } else {
+        return fail(c, "unknown functional '" + fn + "'");
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int dRdarg_T_dev(femo_ctx* c, const std::string& arg, const double* lam, double scale, double* out, int64_t n) {
+    int64_t len;
+    if (!field_ptr(c, arg.c_str(), &len)) return fail(c, "unknown argument '" + arg + "'");
+    if (len != n) return fail(c, "buffer has the wrong length for '" + arg + "'");
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int g = nblk(c->nel, EB);
+    if (arg == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "F_solid") ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
+    else if (arg == "density") { /* R does not depend on density */ }
+    else return fail(c, "(dR/d" + arg + ")^T is not implemented in this build");
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int femo_dfunctional(femo_ctx* c, const char* name, const char* wrt, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, std::max<int64_t>(n, 1) * sizeof(double)));
+    int rc = dfunctional_dev(c, name ? name : "", wrt ? wrt : "", d, n);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    hipFree(d);
+    return rc;
+}
+
+int femo_dRdarg_T(femo_ctx* c, const char* arg, const double* lambda, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, std::max<int64_t>(n, 1) * sizeof(double)));
+    hipMemsetAsync(d, 0, std::max<int64_t>(n, 1) * sizeof(double), c->stream);
+    hipMemcpyAsync(c->lam, lambda, (size_t)c->ndof * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    int rc = dRdarg_T_dev(c, arg ? arg : "", c->lam, 1.0, d, n);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    hipFree(d);
+    return rc;
+}
+
+int femo_total_gradient(femo_ctx* c, const char* functional, const char* arg, double* out, int64_t n, int32_t* iters,
+                        double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const std::string fn(functional ? functional : ""), a(arg ? arg : "");
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, std::max<int64_t>(n, 1) * sizeof(double)));
+    int rc = dfunctional_dev(c, fn, "disp_solid", c->b, c->ndof);          // dJ/dw
+    if (!rc) rc = pcg(c, c->b, c->lam, true, iters, relres);                // lambda = K^-1 dJ/dw
+    if (!rc) rc = dfunctional_dev(c, fn, a, d, n);                          // dJ/d arg (zero-fills d)
+    if (!rc) rc = dRdarg_T_dev(c, a, c->lam, -1.0, d, n);                   // - (dR/d arg)^T lambda
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    hipFree(d);
+    return rc;
+}
+
+int femo_last_timing(const femo_ctx* c, double* out5) {
+    for (int i = 0; i < 5; ++i) out5[i] = c->timing[i];
+    return 0;
+}
+
+// average duration (ms) of `reps` back-to-back launches of a named kernel, HIP events on the
+// context's stream: "apply" (element operator, y += K p), "pcg_update", "pcg_direction", "diag"
+int femo_bench_kernel(femo_ctx* c, const char* name, int32_t reps, double* avg_ms) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const std::string s(name ? name : "");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    if (reps < 1) return fail(c, "reps must be >= 1");
+    if (refresh_diag(c)) return 1;
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->scal, 1.0, 8);
+    auto launch = [&]() -> int {
+        if (s == "apply") return op_apply(c, c->p, c->Ap, c->scal + 7, nullptr, nullptr, false);
+        if (s == "pcg_update") { hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, c->tmp, c->r, c->z, c->p, c->Ap, c->dinv, (const unsigned char*)nullptr, n, c->scal, 0); return 0; }
+        if (s == "pcg_direction") { hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, 0); return 0; }
+        if (s == "diag") { ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
+        return fail(c, "unknown kernel '" + s + "'");
+    };
+    for (int i = 0; i < 3; ++i)
+        if (int rc = launch()) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    *avg_ms = ms / reps;
+    return 0;
+}
+
+void* femo_device_ptr(femo_ctx* c, const char* name) {
+    const std::string s(name ? name : "");
+    if (s == "state") return c->w;
+    if (s == "adjoint") return c->lam;
+    int64_t n;
+    return field_ptr(c, name, &n);
+}
+
+}  // extern "C"

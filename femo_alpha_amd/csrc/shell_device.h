@@ -1,0 +1,1083 @@
+// Device-side element mathematics of the CG2 x CG1 Reissner-Mindlin shell (gfx950, fp64).
+//
+// What is computed follows the reference's UFL definitions (paths relative to
+// /root/reference/femo_alpha/rm_shell/linear_shell_fenicsx):
+//   local basis E0,E1,E2 ............ kinematics.py:54-91
+//   F = I + grad(uhat), gradx, J .... kinematics.py:12-44
+//   CLT matrices A, D, A_s .......... linear_shell_model.py:136-157
+//   eps, kappa, gamma, drilling ..... linear_shell_model.py:232-258, 284-296
+//   energies / residual ............. linear_shell_model.py:275-321
+// How it is computed is this build's own: no B matrix and no element matrix is formed for the
+// operator; each quadrature point maps reference derivatives to local "gradx" derivatives with one
+// 2x2 matrix Q = Jloc^-1 (T F^-1 T^T), reduces the nodal values to six 3-vectors
+// (G0,G1 | theta,Th0,Th1), evaluates nine generalised strains and scatters the nine stresses back
+// through the same six vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace femo {
+
+constexpr int MAXQ = 25;
+constexpr double K_SHEAR = 0.833;       // linear_shell_model.py:146
+constexpr double REG_ALPHA1 = 1.0e-2;   // rm_shell_pde.py:67
+
+struct Tables {
+    int nq;
+    int pad;
+    double w[MAXQ];
+    double N2[MAXQ][9];
+    double dN2[MAXQ][9][2];
+    double N1[MAXQ][4];
+    double dN1[MAXQ][4][2];
+};
+
+struct MeshDev {
+    int nn, nel, nP2, ndof_u, ndof;
+    const double* xyz;    // nn*3
+    const int* cells;     // SoA [nvc][nel]
+    const int* cellp2;    // SoA [npc][nel]
+    const double* hK;     // nel, UFL CellDiameter
+};
+
+struct FieldsDev {
+    const double* h;
+    const double* E;
+    const double* nu;
+    const double* rho;
+    const double* f;
+    const double* uhat;
+    int ewm, ewp;
+};
+
+// ------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// one atomic per block into *slot (slot may be null)
+__device__ __forceinline__ void block_accumulate(double v, double* slot) {
+    __shared__ double s_part[16];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) s_part[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0 && slot) {
+        double t = 0.0;
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) t += s_part[i];
+        atomicAdd(slot, t);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ element
+template <int NPC, int NVC>
+struct Elem {
+    int vid[NVC];
+    int pid[NPC];
+    double X[NVC][3];
+    double Uh[NVC][3];
+    double hn[NVC], En[NVC], nun[NVC];
+    double hK;
+};
+
+template <int NPC, int NVC, bool UHAT>
+__device__ __forceinline__ void load_elem(const MeshDev& m, const FieldsDev& f, int e, Elem<NPC, NVC>& el) {
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        const int v = m.cells[b * m.nel + e];
+        el.vid[b] = v;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) el.X[b][c] = m.xyz[3 * v + c];
+        if (UHAT) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) el.Uh[b][c] = f.uhat[3 * v + c];
+        }
+        const int t = f.ewm ? e : v;
+        el.hn[b] = f.h[t];
+        el.En[b] = f.E[t];
+        el.nun[b] = f.nu[t];
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a) el.pid[a] = m.cellp2[a * m.nel + e];
+    el.hK = m.hK[e];
+}
+
+// geometry of one quadrature point
+struct QPG {
+    double E0[3], E1[3], E2[3];
+    double Q[2][2];    // reference derivative -> local gradx derivative: d_J = dN_0 Q[0][J] + dN_1 Q[1][J]
+    double Q0[2][2];   // the same without mesh motion (plain surface gradient)
+    double w0[3], w1[3];  // derivative of the unit normal along local gradx directions 0, 1
+    double det;        // |J0 x J1|
+    double Ju;         // det F(uhat)
+};
+
+template <int NVC, bool QUAD, bool UHAT>
+__device__ __forceinline__ void qp_geometry(const double (*X)[3], const double (*Uh)[3], const double* M,
+                                            const double (*dM)[2], QPG& g) {
+    double J0[3] = {0, 0, 0}, J1[3] = {0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            J0[c] += X[b][c] * dM[b][0];
+            J1[c] += X[b][c] * dM[b][1];
+        }
+    double a[3];
+    cross3(J0, J1, a);
+    g.det = sqrt(dot3(a, a));
+    const double idet = 1.0 / g.det;
+    const double l0 = sqrt(dot3(J0, J0));
+    const double il0 = 1.0 / l0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g.E2[c] = a[c] * idet;
+        g.E0[c] = J0[c] * il0;
+    }
+    cross3(g.E2, g.E0, g.E1);
+    const double j01 = dot3(g.E0, J1), j11 = dot3(g.E1, J1);
+    // Jloc = [[l0, j01], [0, j11]]  ->  Jloc^-1
+    g.Q0[0][0] = il0;
+    g.Q0[0][1] = -j01 * il0 / j11;
+    g.Q0[1][0] = 0.0;
+    g.Q0[1][1] = 1.0 / j11;
+    g.Ju = 1.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g.Q[i][j] = g.Q0[i][j];
+    if (UHAT) {
+        // F = I + sum_b Uh_b (x) gradM_b, gradM_b = (dM_b^T Q0)_0 E0 + (dM_b^T Q0)_1 E1
+        double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) {
+            const double d0 = dM[b][0] * g.Q0[0][0] + dM[b][1] * g.Q0[1][0];
+            const double d1 = dM[b][0] * g.Q0[0][1] + dM[b][1] * g.Q0[1][1];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double gm = d0 * g.E0[j] + d1 * g.E1[j];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) F[i][j] += Uh[b][i] * gm;
+            }
+        }
+        double C[3][3];   // cofactors
+        C[0][0] = F[1][1] * F[2][2] - F[1][2] * F[2][1];
+        C[0][1] = F[1][2] * F[2][0] - F[1][0] * F[2][2];
+        C[0][2] = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+        C[1][0] = F[0][2] * F[2][1] - F[0][1] * F[2][2];
+        C[1][1] = F[0][0] * F[2][2] - F[0][2] * F[2][0];
+        C[1][2] = F[0][1] * F[2][0] - F[0][0] * F[2][1];
+        C[2][0] = F[0][1] * F[1][2] - F[0][2] * F[1][1];
+        C[2][1] = F[0][2] * F[1][0] - F[0][0] * F[1][2];
+        C[2][2] = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+        g.Ju = F[0][0] * C[0][0] + F[0][1] * C[0][1] + F[0][2] * C[0][2];
+        const double iJ = 1.0 / g.Ju;
+        // Finv[k][j] = C[j][k] / Ju ;  S[b][a] = E_b . Finv E_a
+        double FE0[3], FE1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            FE0[k] = (C[0][k] * g.E0[0] + C[1][k] * g.E0[1] + C[2][k] * g.E0[2]) * iJ;
+            FE1[k] = (C[0][k] * g.E1[0] + C[1][k] * g.E1[1] + C[2][k] * g.E1[2]) * iJ;
+        }
+        const double S00 = dot3(g.E0, FE0), S01 = dot3(g.E0, FE1);
+        const double S10 = dot3(g.E1, FE0), S11 = dot3(g.E1, FE1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            g.Q[i][0] = g.Q0[i][0] * S00 + g.Q0[i][1] * S10;
+            g.Q[i][1] = g.Q0[i][0] * S01 + g.Q0[i][1] * S11;
+        }
+    }
+    if (QUAD) {
+        // d2x/dxi deta of the bilinear map, then d(normal)/dxi_m
+        double tw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tw[c] = 0.25 * (X[0][c] - X[1][c] + X[2][c] - X[3][c]);
+        double da0[3], da1[3];
+        cross3(J0, tw, da0);
+        cross3(tw, J1, da1);
+        const double p0 = dot3(g.E2, da0), p1 = dot3(g.E2, da1);
+        double dn0[3], dn1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dn0[c] = (da0[c] - g.E2[c] * p0) * idet;
+            dn1[c] = (da1[c] - g.E2[c] * p1) * idet;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g.w0[c] = dn0[c] * g.Q[0][0] + dn1[c] * g.Q[1][0];
+            g.w1[c] = dn0[c] * g.Q[0][1] + dn1[c] * g.Q[1][1];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g.w0[c] = g.w1[c] = 0.0;
+    }
+}
+
+// nine generalised strains / the nine conjugate stresses
+struct Gen {
+    double e00, e11, g01, k00, k11, k01, ga0, ga1, om;
+};
+
+struct Mat {
+    double cm, cb, cs, cd, nu;   // membrane, bending, shear, drilling coefficients (measure included)
+};
+
+enum { DERIV_NONE = 0, DERIV_H = 1, DERIV_E = 2, DERIV_NU = 3 };
+
+// constitutive coefficients at a point; which = derivative selector
+template <int WHICH>
+__device__ __forceinline__ void material(double h, double E, double nu, double hK, double wdet, double Ju, Mat& m,
+                                         Mat& dm_dnu_extra) {
+    const double om = 1.0 - nu * nu;
+    const double c = E / om;
+    const double G2 = 1.0 / (2.0 * (1.0 + nu));
+    const double ihk2 = 1.0 / (hK * hK);
+    m.nu = nu;
+    if (WHICH == DERIV_NONE) {
+        m.cm = c * h * wdet;
+        m.cb = c * h * h * h / 12.0 * wdet;
+        m.cs = K_SHEAR * E * G2 * h * Ju * wdet;
+        m.cd = E * h * h * h * ihk2 * Ju * wdet;
+    } else if (WHICH == DERIV_H) {
+        m.cm = c * wdet;
+        m.cb = c * h * h / 4.0 * wdet;
+        m.cs = K_SHEAR * E * G2 * Ju * wdet;
+        m.cd = 3.0 * E * h * h * ihk2 * Ju * wdet;
+    } else if (WHICH == DERIV_E) {
+        m.cm = h / om * wdet;
+        m.cb = h * h * h / 12.0 / om * wdet;
+        m.cs = K_SHEAR * G2 * h * Ju * wdet;
+        m.cd = h * h * h * ihk2 * Ju * wdet;
+    } else {   // d/dnu: C' = c' P + c P',  c' = 2 nu E / (1-nu^2)^2
+        const double dc = 2.0 * nu * E / (om * om);
+        m.cm = dc * h * wdet;
+        m.cb = dc * h * h * h / 12.0 * wdet;
+        m.cs = -K_SHEAR * E * h * 2.0 * G2 * G2 * Ju * wdet;
+        m.cd = 0.0;
+        dm_dnu_extra.cm = c * h * wdet;                  // multiplies P' = [[0,1,0],[1,0,0],[0,0,-1/2]]
+        dm_dnu_extra.cb = c * h * h * h / 12.0 * wdet;
+    }
+}
+
+__device__ __forceinline__ Gen stress_of(const Gen& s, const Mat& m) {
+    Gen t;
+    const double sh = 0.5 * (1.0 - m.nu);
+    t.e00 = m.cm * (s.e00 + m.nu * s.e11);
+    t.e11 = m.cm * (m.nu * s.e00 + s.e11);
+    t.g01 = m.cm * sh * s.g01;
+    t.k00 = m.cb * (s.k00 + m.nu * s.k11);
+    t.k11 = m.cb * (m.nu * s.k00 + s.k11);
+    t.k01 = m.cb * sh * s.k01;
+    t.ga0 = m.cs * s.ga0;
+    t.ga1 = m.cs * s.ga1;
+    t.om = m.cd * s.om;
+    return t;
+}
+
+// extra term of d/dnu: c P' strain
+__device__ __forceinline__ void stress_add_dnu(const Gen& s, const Mat& x, Gen& t) {
+    t.e00 += x.cm * s.e11;
+    t.e11 += x.cm * s.e00;
+    t.g01 += -0.5 * x.cm * s.g01;
+    t.k00 += x.cb * s.k11;
+    t.k11 += x.cb * s.k00;
+    t.k01 += -0.5 * x.cb * s.k01;
+}
+
+__device__ __forceinline__ double gen_dot(const Gen& a, const Gen& b) {
+    return a.e00 * b.e00 + a.e11 * b.e11 + a.g01 * b.g01 + a.k00 * b.k00 + a.k11 * b.k11 + a.k01 * b.k01 +
+           a.ga0 * b.ga0 + a.ga1 * b.ga1 + a.om * b.om;
+}
+
+template <int NPC, int NVC>
+__device__ __forceinline__ void local_derivs(const Tables& t, int q, const double Q[2][2], double (*d)[2], double (*m)[2]) {
+#pragma unroll
+    for (int a = 0; a < NPC; ++a) {
+        const double r0 = t.dN2[q][a][0], r1 = t.dN2[q][a][1];
+        d[a][0] = r0 * Q[0][0] + r1 * Q[1][0];
+        d[a][1] = r0 * Q[0][1] + r1 * Q[1][1];
+    }
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        m[b][0] = r0 * Q[0][0] + r1 * Q[1][0];
+        m[b][1] = r0 * Q[0][1] + r1 * Q[1][1];
+    }
+}
+
+// strains of the element vector xe = [u_a xyz ..., theta_b xyz ...]
+template <int NPC, int NVC>
+__device__ __forceinline__ Gen strains(const QPG& g, const double (*d)[2], const double (*m)[2], const double* M,
+                                       const double* xe) {
+    double G0[3] = {0, 0, 0}, G1[3] = {0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            G0[c] += xe[3 * a + c] * d[a][0];
+            G1[c] += xe[3 * a + c] * d[a][1];
+        }
+    double th[3] = {0, 0, 0}, T0[3] = {0, 0, 0}, T1[3] = {0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = xe[3 * NPC + 3 * b + c];
+            th[c] += M[b] * v;
+            T0[c] += m[b][0] * v;
+            T1[c] += m[b][1] * v;
+        }
+    Gen s;
+    const double t00 = dot3(g.E0, G0), t01 = dot3(g.E0, G1), t10 = dot3(g.E1, G0), t11 = dot3(g.E1, G1);
+    s.e00 = t00;
+    s.e11 = t11;
+    s.g01 = t01 + t10;
+    s.om = 0.5 * (t01 - t10) + dot3(th, g.E2);
+    s.ga0 = dot3(th, g.E1) + dot3(g.E2, G0);
+    s.ga1 = -dot3(th, g.E0) + dot3(g.E2, G1);
+    double x00[3], x01[3], x10[3], x11[3];
+    cross3(g.E0, g.w0, x00);
+    cross3(g.E0, g.w1, x01);
+    cross3(g.E1, g.w0, x10);
+    cross3(g.E1, g.w1, x11);
+    const double b00 = -dot3(g.E1, T0) + dot3(th, x00);
+    const double b01 = -dot3(g.E1, T1) + dot3(th, x01);
+    const double b10 = dot3(g.E0, T0) + dot3(th, x10);
+    const double b11 = dot3(g.E0, T1) + dot3(th, x11);
+    s.k00 = b00;
+    s.k11 = b11;
+    s.k01 = b01 + b10;
+    return s;
+}
+
+// ye += B^T t  (transpose of `strains`)
+template <int NPC, int NVC>
+__device__ __forceinline__ void strains_T(const QPG& g, const double (*d)[2], const double (*m)[2], const double* M,
+                                          const Gen& t, double* ye) {
+    double H0[3], H1[3];
+    const double a10 = t.g01 - 0.5 * t.om, a01 = t.g01 + 0.5 * t.om;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        H0[c] = t.e00 * g.E0[c] + a10 * g.E1[c] + t.ga0 * g.E2[c];
+        H1[c] = a01 * g.E0[c] + t.e11 * g.E1[c] + t.ga1 * g.E2[c];
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * a + c] += d[a][0] * H0[c] + d[a][1] * H1[c];
+    double x00[3], x01[3], x10[3], x11[3];
+    cross3(g.E0, g.w0, x00);
+    cross3(g.E0, g.w1, x01);
+    cross3(g.E1, g.w0, x10);
+    cross3(g.E1, g.w1, x11);
+    double Tq[3], C0[3], C1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Tq[c] = t.ga0 * g.E1[c] - t.ga1 * g.E0[c] + t.om * g.E2[c] + t.k00 * x00[c] + t.k11 * x11[c] +
+                t.k01 * (x01[c] + x10[c]);
+        C0[c] = -t.k00 * g.E1[c] + t.k01 * g.E0[c];
+        C1[c] = -t.k01 * g.E1[c] + t.k11 * g.E0[c];
+    }
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += M[b] * Tq[c] + m[b][0] * C0[c] + m[b][1] * C1[c];
+}
+
+template <int NVC>
+__device__ __forceinline__ double interp(const double* M, const double* v) {
+    double r = 0.0;
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) r += M[b] * v[b];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+// y += K_elastic x (element by element, matrix-free); *dotslot += x . K_elastic x
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_apply(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ x, double* __restrict__ y,
+        double* dotslot, double* zero_a, double* zero_b) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zero_a) *zero_a = 0.0;
+        if (zero_b) *zero_b = 0.0;
+    }
+    double local = 0.0;
+    if (e < m.nel) {
+        Elem<NPC, NVC> el;
+        load_elem<NPC, NVC, UHAT>(m, f, e, el);
+        double xe[LD], ye[LD];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xe[3 * a + c] = x[3 * el.pid[a] + c];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = x[m.ndof_u + 3 * el.vid[b] + c];
+#pragma unroll
+        for (int i = 0; i < LD; ++i) ye[i] = 0.0;
+        const int nq = tab->nq;
+        for (int q = 0; q < nq; ++q) {
+            QPG g;
+            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+            double d[NPC][2], mm[NVC][2];
+            local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
+            Mat mat, ex;
+            material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
+                                 interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+            const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
+            const Gen t = stress_of(s, mat);
+            strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) local += xe[i] * ye[i];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&y[3 * el.pid[a] + c], ye[3 * a + c]);
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&y[m.ndof_u + 3 * el.vid[b] + c], ye[3 * NPC + 3 * b + c]);
+    }
+    if (dotslot) block_accumulate(local, dotslot);
+}
+
+// diag += diag(K_elastic)
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_diag(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restrict__ diag) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double de[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) de[i] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        double d[NPC][2], mm[NVC][2];
+        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
+        Mat mat, ex;
+        material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+        const double sh = 0.5 * (1.0 - mat.nu);
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double b0 = g.E0[c] * d[a][0], b1 = g.E1[c] * d[a][1];
+                const double b2 = g.E0[c] * d[a][1] + g.E1[c] * d[a][0];
+                const double b6 = g.E2[c] * d[a][0], b7 = g.E2[c] * d[a][1];
+                const double b8 = 0.5 * (g.E0[c] * d[a][1] - g.E1[c] * d[a][0]);
+                de[3 * a + c] += mat.cm * (b0 * b0 + 2.0 * mat.nu * b0 * b1 + b1 * b1 + sh * b2 * b2) +
+                                 mat.cs * (b6 * b6 + b7 * b7) + mat.cd * b8 * b8;
+            }
+        double x00[3], x01[3], x10[3], x11[3];
+        cross3(g.E0, g.w0, x00);
+        cross3(g.E0, g.w1, x01);
+        cross3(g.E1, g.w0, x10);
+        cross3(g.E1, g.w1, x11);
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) {
+            const double Mb = tab->N1[q][b];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double k00 = -g.E1[c] * mm[b][0] + Mb * x00[c];
+                const double k11 = g.E0[c] * mm[b][1] + Mb * x11[c];
+                const double k01 = -g.E1[c] * mm[b][1] + Mb * x01[c] + g.E0[c] * mm[b][0] + Mb * x10[c];
+                const double g0 = Mb * g.E1[c], g1 = -Mb * g.E0[c], om = Mb * g.E2[c];
+                de[3 * NPC + 3 * b + c] += mat.cb * (k00 * k00 + 2.0 * mat.nu * k00 * k11 + k11 * k11 + sh * k01 * k01) +
+                                           mat.cs * (g0 * g0 + g1 * g1) + mat.cd * om * om;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&diag[3 * el.pid[a] + c], de[3 * a + c]);
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&diag[m.ndof_u + 3 * el.vid[b] + c], de[3 * NPC + 3 * b + c]);
+}
+
+// F += int N_a f J dx   (sign: the residual subtracts it)
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_load(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restrict__ F, double scale) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double fn[NVC][3];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fn[b][c] = f.f[3 * (f.ewp ? e : el.vid[b]) + c];
+    double Fe[3 * NPC];
+#pragma unroll
+    for (int i = 0; i < 3 * NPC; ++i) Fe[i] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        const double wj = tab->w[q] * g.det * g.Ju;
+        double fq[3] = {0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fq[c] += tab->N1[q][b] * fn[b][c];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Fe[3 * a + c] += wj * tab->N2[q][a] * fq[c];
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&F[3 * el.pid[a] + c], scale * Fe[3 * a + c]);
+}
+
+// scalar functionals: slot[0] += int u.u J dx ; slot[1] += regularisation ; slot[2] += mass
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double* slots) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double uu = 0.0, reg = 0.0, mass = 0.0;
+    if (e < m.nel) {
+        Elem<NPC, NVC> el;
+        load_elem<NPC, NVC, UHAT>(m, f, e, el);
+        double ue[3 * NPC];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ue[3 * a + c] = w[3 * el.pid[a] + c];
+        double rhon[NVC];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) rhon[b] = f.rho[f.ewm ? e : el.vid[b]];
+        const int nq = tab->nq;
+        for (int q = 0; q < nq; ++q) {
+            QPG g;
+            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+            const double wd = tab->w[q] * g.det;
+            double uq[3] = {0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < NPC; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) uq[c] += tab->N2[q][a] * ue[3 * a + c];
+            uu += wd * g.Ju * dot3(uq, uq);
+            const double hq = interp<NVC>(tab->N1[q], el.hn);
+            mass += wd * g.Ju * hq * interp<NVC>(tab->N1[q], rhon);
+            if (f.ewm) {
+                reg += 0.5 * REG_ALPHA1 * wd * hq * hq;                    // L2, rm_shell_pde.py:79-81
+            } else {
+                double g0 = 0.0, g1 = 0.0;                                  // H1, rm_shell_pde.py:72-74
+#pragma unroll
+                for (int b = 0; b < NVC; ++b) {
+                    g0 += el.hn[b] * (tab->dN1[q][b][0] * g.Q0[0][0] + tab->dN1[q][b][1] * g.Q0[1][0]);
+                    g1 += el.hn[b] * (tab->dN1[q][b][0] * g.Q0[0][1] + tab->dN1[q][b][1] * g.Q0[1][1]);
+                }
+                reg += 0.5 * REG_ALPHA1 * wd * (g0 * g0 + g1 * g1);
+            }
+        }
+    }
+    block_accumulate(uu, slots + 0);
+    block_accumulate(reg, slots + 1);
+    block_accumulate(mass, slots + 2);
+}
+
+// out_u += 2 int N_a u J dx  (d compliance / d w)
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_dcompliance_du(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w,
+                 double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double ue[3 * NPC], ge[3 * NPC];
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ue[3 * a + c] = w[3 * el.pid[a] + c];
+            ge[3 * a + c] = 0.0;
+        }
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        const double wj = 2.0 * tab->w[q] * g.det * g.Ju;
+        double uq[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) uq[c] += tab->N2[q][a] * ue[3 * a + c];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ge[3 * a + c] += wj * tab->N2[q][a] * uq[c];
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&out[3 * el.pid[a] + c], ge[3 * a + c]);
+}
+
+// field-space gradients that need no state:  mode 0: d reg / d h ; 1: d mass / d h ; 2: d mass / d rho
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_field_grad(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double rhon[NVC], ge[NVC];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        rhon[b] = f.rho[f.ewm ? e : el.vid[b]];
+        ge[b] = 0.0;
+    }
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        const double wd = tab->w[q] * g.det;
+        if (mode == 0) {
+            if (f.ewm) {
+                ge[0] += REG_ALPHA1 * wd * el.hn[0];
+            } else {
+                double g0 = 0.0, g1 = 0.0, d0[NVC], d1[NVC];
+#pragma unroll
+                for (int b = 0; b < NVC; ++b) {
+                    d0[b] = tab->dN1[q][b][0] * g.Q0[0][0] + tab->dN1[q][b][1] * g.Q0[1][0];
+                    d1[b] = tab->dN1[q][b][0] * g.Q0[0][1] + tab->dN1[q][b][1] * g.Q0[1][1];
+                    g0 += el.hn[b] * d0[b];
+                    g1 += el.hn[b] * d1[b];
+                }
+#pragma unroll
+                for (int b = 0; b < NVC; ++b) ge[b] += REG_ALPHA1 * wd * (d0[b] * g0 + d1[b] * g1);
+            }
+        } else {
+            const double other = (mode == 1) ? interp<NVC>(tab->N1[q], rhon) : interp<NVC>(tab->N1[q], el.hn);
+            if (f.ewm) {
+                ge[0] += wd * g.Ju * other;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NVC; ++b) ge[b] += wd * g.Ju * other * tab->N1[q][b];
+            }
+        }
+    }
+    if (f.ewm) {
+        out[e] += ge[0];
+    } else {
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) atomicAdd(&out[el.vid[b]], ge[b]);
+    }
+}
+
+// out += scale * lam^T (dK/d field) w  per field DOF  (field = h, E or nu)
+template <int NPC, int NVC, bool QUAD, bool UHAT, int WHICH>
+__global__ void __launch_bounds__(128)
+k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w,
+             const double* __restrict__ lam, double scale, double* __restrict__ out) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double we[LD], le[LD];
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            we[3 * a + c] = w[3 * el.pid[a] + c];
+            le[3 * a + c] = lam[3 * el.pid[a] + c];
+        }
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            we[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
+            le[3 * NPC + 3 * b + c] = lam[m.ndof_u + 3 * el.vid[b] + c];
+        }
+    double ge[NVC];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) ge[b] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        double d[NPC][2], mm[NVC][2];
+        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
+        Mat mat, ex;
+        material<WHICH>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
+                        interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+        const Gen sw = strains<NPC, NVC>(g, d, mm, tab->N1[q], we);
+        const Gen sl = strains<NPC, NVC>(g, d, mm, tab->N1[q], le);
+        Gen t = stress_of(sw, mat);
+        if (WHICH == DERIV_NU) stress_add_dnu(sw, ex, t);
+        const double dens = gen_dot(t, sl);
+        if (f.ewm) {
+            ge[0] += dens;
+        } else {
+#pragma unroll
+            for (int b = 0; b < NVC; ++b) ge[b] += dens * tab->N1[q][b];
+        }
+    }
+    if (f.ewm) {
+        out[e] += scale * ge[0];
+    } else {
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) atomicAdd(&out[el.vid[b]], scale * ge[b]);
+    }
+}
+
+// out += scale * int M_b lam_u J dx    ((dR/df)^T lam uses scale = -1)
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_dRdf_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ lam, double scale,
+         double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double le[3 * NPC];
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) le[3 * a + c] = lam[3 * el.pid[a] + c];
+    double ge[NVC][3];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ge[b][c] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        const double wj = tab->w[q] * g.det * g.Ju;
+        double lq[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < NPC; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) lq[c] += tab->N2[q][a] * le[3 * a + c];
+        if (f.ewp) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ge[0][c] += wj * lq[c];
+        } else {
+#pragma unroll
+            for (int b = 0; b < NVC; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ge[b][c] += wj * tab->N1[q][b] * lq[c];
+        }
+    }
+    if (f.ewp) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * e + c] += scale * ge[0][c];
+    } else {
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&out[3 * el.vid[b] + c], scale * ge[b][c]);
+    }
+}
+
+// dense element matrices, one wave per element: K_e[i][j] = sum_q B_i^T C B_j
+// Column j of K_e is the operator applied to the unit vector e_j, so lanes own columns.
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(64)
+k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int first, int count, double* __restrict__ Ke) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int le = blockIdx.x;
+    if (le >= count) return;
+    const int e = first + le;
+    const int j = threadIdx.x;
+    if (j >= LD) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double xe[LD], ye[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        xe[i] = (i == j) ? 1.0 : 0.0;
+        ye[i] = 0.0;
+    }
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        double d[NPC][2], mm[NVC][2];
+        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
+        Mat mat, ex;
+        material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+        const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
+        const Gen t = stress_of(s, mat);
+        strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+    }
+    double* out = Ke + (size_t)le * LD * LD;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) out[i * LD + j] = ye[i];
+}
+
+// ------------------------------------------------------------------------------------------ penalty facets
+struct FacetDev {
+    int nf;
+    const int* cell;     // nf
+    const int* ledge;    // nf
+    const int* unode;    // nf*3  P2 nodes (a, mid, b)
+    const int* vnode;    // nf*2  vertices (a, b)
+    double* M2;          // nf*9  beta/h_K * int N2_i N2_j |J F^-T N| ds
+    double* M1;          // nf*4
+};
+
+__device__ __forceinline__ void edge_ref_point(bool quad, int k, double s, double& xi, double& eta) {
+    if (quad) {
+        switch (k) {
+            case 0: xi = s; eta = -1.0; break;
+            case 1: xi = 1.0; eta = s; break;
+            case 2: xi = -s; eta = 1.0; break;
+            default: xi = -1.0; eta = -s; break;
+        }
+    } else {
+        const double t = 0.5 * (s + 1.0);
+        switch (k) {
+            case 0: xi = t; eta = 0.0; break;
+            case 1: xi = 1.0 - t; eta = t; break;
+            default: xi = 0.0; eta = 1.0 - t; break;
+        }
+    }
+}
+
+template <int NVC, bool QUAD>
+__device__ __forceinline__ void p1_shape(double xi, double eta, double* M, double (*dM)[2]) {
+    if (QUAD) {
+        const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            M[b] = 0.25 * (1 + sx[b] * xi) * (1 + sy[b] * eta);
+            dM[b][0] = 0.25 * sx[b] * (1 + sy[b] * eta);
+            dM[b][1] = 0.25 * sy[b] * (1 + sx[b] * xi);
+        }
+    } else {
+        M[0] = 1 - xi - eta; M[1] = xi; M[2] = eta;
+        dM[0][0] = -1; dM[0][1] = -1; dM[1][0] = 1; dM[1][1] = 0; dM[2][0] = 0; dM[2][1] = 1;
+    }
+}
+
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void k_penalty_setup(MeshDev m, FieldsDev f, FacetDev fd, double beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fd.nf) return;
+    const int e = fd.cell[i], k = fd.ledge[i];
+    double X[NVC][3], Uh[NVC][3];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        const int v = m.cells[b * m.nel + e];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            X[b][c] = m.xyz[3 * v + c];
+            Uh[b][c] = UHAT ? f.uhat[3 * v + c] : 0.0;
+        }
+    }
+    const int ka = k, kb = (k + 1) % NVC;
+    double tv[3], len = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        tv[c] = X[kb][c] - X[ka][c];
+        len += tv[c] * tv[c];
+    }
+    len = sqrt(len);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tv[c] /= len;
+    const double gs[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};
+    const double gw[3] = {0.5555555555555556, 0.8888888888888888, 0.5555555555555556};
+    double M2[9] = {0}, M1[4] = {0};
+    for (int q = 0; q < 3; ++q) {
+        const double s = gs[q];
+        double nanson = 1.0;
+        if (UHAT) {
+            double xi, eta, M[NVC], dM[NVC][2];
+            edge_ref_point(QUAD, k, s, xi, eta);
+            p1_shape<NVC, QUAD>(xi, eta, M, dM);
+            QPG g;
+            qp_geometry<NVC, QUAD, true>(X, Uh, M, dM, g);
+            // F again (qp_geometry keeps only Q and Ju): v = Ju F^-T N,  N = t x n
+            double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+            for (int b = 0; b < NVC; ++b) {
+                const double d0 = dM[b][0] * g.Q0[0][0] + dM[b][1] * g.Q0[1][0];
+                const double d1 = dM[b][0] * g.Q0[0][1] + dM[b][1] * g.Q0[1][1];
+                for (int jj = 0; jj < 3; ++jj) {
+                    const double gm = d0 * g.E0[jj] + d1 * g.E1[jj];
+                    for (int ii = 0; ii < 3; ++ii) F[ii][jj] += Uh[b][ii] * gm;
+                }
+            }
+            double Nf[3];
+            cross3(tv, g.E2, Nf);
+            // Ju F^-T N = cof(F) N
+            double C[3][3];
+            C[0][0] = F[1][1] * F[2][2] - F[1][2] * F[2][1];
+            C[0][1] = F[1][2] * F[2][0] - F[1][0] * F[2][2];
+            C[0][2] = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+            C[1][0] = F[0][2] * F[2][1] - F[0][1] * F[2][2];
+            C[1][1] = F[0][0] * F[2][2] - F[0][2] * F[2][0];
+            C[1][2] = F[0][1] * F[2][0] - F[0][0] * F[2][1];
+            C[2][0] = F[0][1] * F[1][2] - F[0][2] * F[1][1];
+            C[2][1] = F[0][2] * F[1][0] - F[0][0] * F[1][2];
+            C[2][2] = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+            double v[3];
+            for (int ii = 0; ii < 3; ++ii) v[ii] = C[ii][0] * Nf[0] + C[ii][1] * Nf[1] + C[ii][2] * Nf[2];
+            nanson = sqrt(dot3(v, v));
+        }
+        const double wq = gw[q] * 0.5 * len * nanson * beta / m.hK[e];
+        const double L2[3] = {0.5 * s * (s - 1.0), 1.0 - s * s, 0.5 * s * (s + 1.0)};
+        const double L1[2] = {0.5 * (1.0 - s), 0.5 * (1.0 + s)};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) M2[3 * a + b] += wq * L2[a] * L2[b];
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) M1[2 * a + b] += wq * L1[a] * L1[b];
+    }
+    for (int a = 0; a < 9; ++a) fd.M2[9 * i + a] = M2[a];
+    for (int a = 0; a < 4; ++a) fd.M1[4 * i + a] = M1[a];
+}
+
+// y += P x (mode 0) or diag += diag(P) (mode 1); *dotslot += x.Px
+__global__ void k_penalty_apply(FacetDev fd, int ndof_u, int mode, const double* __restrict__ x, double* __restrict__ y,
+                                double* dotslot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double local = 0.0;
+    if (i < fd.nf) {
+        const int u0 = fd.unode[3 * i], u1 = fd.unode[3 * i + 1], u2 = fd.unode[3 * i + 2];
+        const int v0 = fd.vnode[2 * i], v1 = fd.vnode[2 * i + 1];
+        const double* A = fd.M2 + 9 * i;
+        const double* B = fd.M1 + 4 * i;
+        const int un[3] = {u0, u1, u2};
+        const int vn[2] = {v0, v1};
+        for (int c = 0; c < 3; ++c) {
+            if (mode == 1) {
+                for (int a = 0; a < 3; ++a) atomicAdd(&y[3 * un[a] + c], A[4 * a]);
+                for (int a = 0; a < 2; ++a) atomicAdd(&y[ndof_u + 3 * vn[a] + c], B[3 * a]);
+            } else {
+                double xu[3], xv[2];
+                for (int a = 0; a < 3; ++a) xu[a] = x[3 * un[a] + c];
+                for (int a = 0; a < 2; ++a) xv[a] = x[ndof_u + 3 * vn[a] + c];
+                for (int a = 0; a < 3; ++a) {
+                    const double r = A[3 * a] * xu[0] + A[3 * a + 1] * xu[1] + A[3 * a + 2] * xu[2];
+                    local += r * xu[a];
+                    atomicAdd(&y[3 * un[a] + c], r);
+                }
+                for (int a = 0; a < 2; ++a) {
+                    const double r = B[2 * a] * xv[0] + B[2 * a + 1] * xv[1];
+                    local += r * xv[a];
+                    atomicAdd(&y[ndof_u + 3 * vn[a] + c], r);
+                }
+            }
+        }
+    }
+    if (dotslot) block_accumulate(local, dotslot);
+}
+
+// ------------------------------------------------------------------------------------------ vector kernels (PCG)
+// scalar slots: [0,1] pAp, [2,3] rz, [4,5] rr, [6] bb, [7] spare
+__global__ void k_fill(double* __restrict__ a, double v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = v;
+}
+
+__global__ void k_mask_zero(double* __restrict__ a, const unsigned char* __restrict__ mask, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (mask[i]) a[i] = 0.0;
+}
+
+// strong-BC rows of the operator: y_i = x_i
+__global__ void k_mask_identity(double* __restrict__ y, const double* __restrict__ x, const unsigned char* __restrict__ mask,
+                                int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (mask[i]) y[i] = x[i];
+}
+
+__global__ void k_invert_diag(double* __restrict__ d, const unsigned char* __restrict__ mask, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = (mask && mask[i]) ? 1.0 : 1.0 / d[i];
+}
+
+__global__ void k_axpby(double* __restrict__ y, double a, const double* __restrict__ x, double b, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + b * y[i];
+}
+
+__global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* slot) {
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += a[i] * b[i];
+    block_accumulate(s, slot);
+}
+
+// r = b - Ap (or r = b when Ap == null); masked rows zero; z = dinv r; p = z; Ap = 0; rz[0] += r.z; rr[0] += r.r
+__global__ void k_pcg_init(const double* __restrict__ b, double* __restrict__ Ap, const double* __restrict__ dinv,
+                           const unsigned char* __restrict__ mask, double* __restrict__ r, double* __restrict__ z,
+                           double* __restrict__ p, int64_t n, double* scal, int have_Ap) {
+    double rz = 0.0, rr = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double ri = have_Ap ? b[i] - Ap[i] : b[i];
+        if (mask && mask[i]) ri = 0.0;
+        const double zi = dinv[i] * ri;
+        r[i] = ri;
+        z[i] = zi;
+        p[i] = zi;
+        Ap[i] = 0.0;
+        rz += ri * zi;
+        rr += ri * ri;
+    }
+    block_accumulate(rz, scal + 2);
+    block_accumulate(rr, scal + 4);
+}
+
+// alpha = rz[s]/pAp[s]; x += alpha p; r -= alpha Ap; z = dinv r; rz[1-s] += r.z; rr[1-s] += r.r
+__global__ void k_pcg_update(double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+                             const double* __restrict__ p, const double* __restrict__ Ap, const double* __restrict__ dinv,
+                             const unsigned char* __restrict__ mask, int64_t n, double* scal, int s) {
+    const double alpha = scal[2 + s] / scal[0 + s];
+    double rz = 0.0, rr = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        double ri = r[i] - alpha * Ap[i];
+        if (mask && mask[i]) ri = 0.0;
+        const double zi = dinv[i] * ri;
+        r[i] = ri;
+        z[i] = zi;
+        rz += ri * zi;
+        rr += ri * ri;
+    }
+    block_accumulate(rz, scal + 2 + (1 - s));
+    block_accumulate(rr, scal + 4 + (1 - s));
+}
+
+// beta = rz[1-s]/rz[s]; p = z + beta p; Ap = 0; slot pAp[1-s] = 0
+__global__ void k_pcg_direction(double* __restrict__ p, const double* __restrict__ z, double* __restrict__ Ap, int64_t n,
+                                double* scal, int s) {
+    const double beta = scal[2 + (1 - s)] / scal[2 + s];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        p[i] = z[i] + beta * p[i];
+        Ap[i] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0 + (1 - s)] = 0.0;
+}
+
+}  // namespace femo

@@ -1,0 +1,141 @@
+/* libfemo_hip.so -- C ABI of the MI355X-native Reissner-Mindlin shell forward + adjoint path.
+ *
+ * The reference (LSDOlab/femo_alpha) has no FFI seam of its own: its hot path is Python that
+ * calls dolfinx / PETSc through pybind11.  This ABI sits *beneath* the
+ * Python operator classes the reference exposes, one entry point per dolfinx/PETSc service the
+ * reference's operators consume.  Each declaration cites the reference call it replaces
+ * (paths relative to /root/reference/femo_alpha).
+ *
+ * Conventions: every call returns 0 on success, non-zero on failure with a message available
+ * from femo_last_error(); all host buffers are owned by the caller, float64 / int32, 1-D;
+ * the context owns every device buffer; one context per GPU; not thread-safe; calls are
+ * synchronous on return unless stated otherwise.
+ *
+ * State vector layout (opaque to callers of the reference as well, rm_shell_model.py:505-527):
+ *   w = [ u(P2 node 0) xyz ... u(P2 node nP2-1) xyz | theta(vertex 0) xyz ... ]   ndof = 3 nP2 + 3 nn
+ */
+#ifndef FEMO_HIP_H
+#define FEMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct femo_ctx femo_ctx;
+
+/* Library / device probing ------------------------------------------------------------------ */
+int femo_version(void);
+int femo_device_count(void);
+/* Message of the last failed call on ctx (ctx == NULL: last failed femo_create). */
+const char* femo_last_error(const femo_ctx* ctx);
+
+/* Context = mesh + CG2xCG1 numbering on one GPU.
+ * Replaces RMShellPDE.__init__ / ShellElement.setUpFunctionSpace (rm_shell/rm_shell_pde.py:25-47,
+ * linear_shell_fenicsx/linear_shell_model.py:47-86).
+ *   nvc            4 (quads, CCW) or 3 (triangles)
+ *   xyz            nn*3 vertex coordinates
+ *   cells          nel*nvc vertex ids
+ *   cell_p2        nel*npc P2 node ids (npc = 9 quads / 6 triangles: vertices, edge midpoints, centre)
+ *   elementwise_material / elementwise_pressure   DG0 instead of CG1 for VT / VF (rm_shell_pde.py:37-44)
+ *   nquad          Gauss points per direction on quads (2..5); ignored on triangles (12-point rule) */
+int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
+                const double* xyz, const int32_t* cells, const int32_t* cell_p2,
+                int elementwise_material, int elementwise_pressure, int nquad);
+void femo_destroy(femo_ctx* ctx);
+
+int64_t femo_ndof(const femo_ctx* ctx);
+/* Length of an input field: "thickness","E","nu","density" (nn or nel), "F_solid" (3*nn or 3*nel), "uhat" (3*nn). */
+int64_t femo_field_size(const femo_ctx* ctx, const char* name);
+
+/* Dirichlet data.
+ * Penalty form: beta/h_K * ||J F^-T N|| * (w - 0).v on the listed (cell, local edge) pairs,
+ * replaces ElasticModelShapeOpt.penaltyResidual (linear_shell_model.py:323-333) with the
+ * ds(100)/dS(100) measures of rm_shell_model.py:88-95.
+ * Strong form: zero values on the listed DOFs, replaces dirichletbc/locate_dofs_geometrical
+ * (rm_shell_model.py:168-180) as consumed by assembleSystem (fea/utils_dolfinx.py:208-221). */
+int femo_set_penalty_facets(femo_ctx* ctx, int32_t nfacets, const int32_t* cell_and_local_edge, double beta);
+int femo_set_strong_dofs(femo_ctx* ctx, int32_t n, const int32_t* dofs);
+
+/* Copy an input field into the context (a length-1 array broadcasts) --
+ * replaces update(Function, ndarray) (fea/utils_dolfinx.py:319-330). */
+int femo_set_field(femo_ctx* ctx, const char* name, const double* values, int64_t n);
+int femo_get_field(femo_ctx* ctx, const char* name, double* values, int64_t n);
+
+/* State access -- replaces getFuncArray / setFuncArray on the state Function
+ * (fea/utils_dolfinx.py:174-186). */
+int femo_set_state(femo_ctx* ctx, const double* w);
+int femo_get_state(femo_ctx* ctx, double* w);
+
+/* y = (dR/dw) x, matrix-free, element by element (elastic energy Hessian + penalty, strong-BC rows
+ * replaced by identity) -- replaces assembleMatrix(dR_du) followed by a mat-vec
+ * (csdl_alpha_opt/state_operation.py:289; fea/utils_dolfinx.py:275-283). */
+int femo_apply_K(femo_ctx* ctx, const double* x, double* y);
+/* r = R(w) for the current fields (w == NULL: the stored state) -- replaces
+ * assemble_vector(form(residual_form)) (fea/utils_dolfinx.py:194-198; linear_shell_model.py:308-321). */
+int femo_residual(femo_ctx* ctx, const double* w, double* r);
+/* F = int f . v J dx, the load part of the residual (linear_shell_model.py:320). */
+int femo_load_vector(femo_ctx* ctx, double* F);
+/* Diagonal of the operator femo_apply_K applies (the Jacobi preconditioner). */
+int femo_diagonal(femo_ctx* ctx, double* d);
+/* Dense element matrices K_e, nel*ldof*ldof, element-local order [u_a xyz ..., theta_b xyz ...]
+ * (what FFCx's tabulate_tensor produces for derivative(residual, w)). */
+int femo_element_matrices(femo_ctx* ctx, int32_t first, int32_t count, double* Ke);
+
+/* Solver configuration. preconditioner: 0 = Jacobi, 1 = node-block Jacobi.
+ * check_every: convergence is polled on the host every this many PCG iterations. */
+int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxit, int32_t check_every);
+
+/* Forward solve R(w) = 0 for the current fields, result kept on the device as the state.
+ * Replaces FEA.solve -> solveNonlinear -> NewtonSolver + MUMPS LU (fea/fea_dolfinx.py:159-170,
+ * fea/utils_dolfinx.py:338-352,438-468): the residual is linear in w, so one PCG solve of
+ * K w = F reproduces what the reference's three Newton iterations converge to.
+ * zero_guess != 0 starts from w = 0, otherwise from the stored state (the reference keeps the
+ * previous solution as initial guess, fea_dolfinx.py:45,165). */
+int femo_solve_state(femo_ctx* ctx, int zero_guess, int32_t* iters, double* relres);
+/* x = K^-1 rhs with BC rows of x zeroed afterwards -- replaces FEA.solveLinearBwd / solveLinearFwd
+ * (fea/fea_dolfinx.py:173-203) and the BC zeroing of state_operation.py:216-218.  K is symmetric, so
+ * the same call serves both modes (reference quirk Q3). */
+int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iters, double* relres);
+
+/* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy" --
+ * replaces assemble_scalar(form(c)) (csdl_alpha_opt/output_operation.py:51-56; forms at
+ * rm_shell/rm_shell_pde.py:64-110). */
+int femo_functional(femo_ctx* ctx, const char* name, double* value);
+/* Gradient vector of a scalar output with respect to "disp_solid", "thickness", "density", "E", "nu",
+ * "F_solid" or "uhat" (zeros where the form does not depend on the argument; "uhat" not yet
+ * implemented -> error) -- replaces assemble(derivative(form, arg), dim=1)
+ * (csdl_alpha_opt/output_operation.py:58-69). n must equal the argument's length. */
+int femo_dfunctional(femo_ctx* ctx, const char* name, const char* wrt, double* out, int64_t n);
+/* out = (dR/d arg)^T lambda at the stored state, arg in "thickness","E","nu","F_solid" --
+ * replaces assembleMatrix(dR/d arg) + computeMatVecProductBwd
+ * (csdl_alpha_opt/state_operation.py:174-184,283-286; fea/utils_dolfinx.py:294-306). */
+int femo_dRdarg_T(femo_ctx* ctx, const char* arg, const double* lambda, double* out, int64_t n);
+
+/* The whole adjoint chain on the device, no host round trips:
+ *   lambda = K^-1 dJ/dw ;  out = dJ/d arg - (dR/d arg)^T lambda      (total derivative)
+ * for J = "compliance" | "elastic_energy" | "mass" and arg = "thickness" | "E" | "nu" | "F_solid".
+ * This is what CSDL's compute_totals assembles from OutputOperation.compute_derivatives,
+ * StateOperation.apply_inverse_jacobian('rev') and compute_jacvec_product('rev')
+ * (SURVEY.md section 3.3). */
+int femo_total_gradient(femo_ctx* ctx, const char* functional, const char* arg, double* out, int64_t n,
+                        int32_t* iters, double* relres);
+
+/* Timing of the most recent solve, measured with HIP events on the context's stream (ms):
+ * [0] setup (diagonal / preconditioner), [1] Krylov loop, [2] total, [3] element-operator kernel
+ * average launch duration (ms), [4] number of element-operator launches. */
+int femo_last_timing(const femo_ctx* ctx, double* out5);
+
+/* Average duration (ms) of `reps` back-to-back launches of one kernel, timed with HIP events on
+ * the context's stream: "apply" (matrix-free element operator), "pcg_update", "pcg_direction", "diag". */
+int femo_bench_kernel(femo_ctx* ctx, const char* name, int32_t reps, double* avg_ms);
+
+/* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")
+ * for zero-copy wrapping by the caller (e.g. torch.from_dlpack-free ctypes views). */
+void* femo_device_ptr(femo_ctx* ctx, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEMO_HIP_H */
