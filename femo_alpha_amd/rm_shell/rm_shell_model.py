@@ -1,0 +1,162 @@
+"""``RMShellModel``: the model facade example scripts call.
+
+Constructor and ``evaluate`` follow femo_alpha/rm_shell/rm_shell_model.py:31-81,364-490; the
+``mesh`` argument is a ``femo_alpha_amd.mesh.ShellMesh`` (nodes + connectivity, the data
+``reconstructFEAMesh`` takes) instead of a dolfinx mesh.  Outputs registered in this build:
+``disp_solid`` (state), ``compliance``, ``mass``, ``elastic_energy``, ``disp_extracted``; the
+stress outputs (``pnorm_stress``, ``stress``, ``aggregated_stress``) are a 'next' row
+ and are absent from the returned group until they land.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import csdl
+from ..csdl_alpha_opt.fea_model import FEAModel
+from ..fea.fea_hip import FEA, DirichletBC, Function
+from ..mesh import ShellMesh
+from .rm_shell_pde import FacetSet, RMShellPDE
+
+
+def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: int):
+    """Tagged facet measure (femo_alpha/fea/utils_dolfinx.py:555-565): 'ds' = boundary facets whose
+    vertices all satisfy the marker, 'dS' = interior facets, integrated from both sides."""
+    if dim != 1:
+        raise ValueError("shell facets have dimension 1")
+    if measure == "ds":
+        ed = mesh.locate_facets(SubdomainFunc, boundary_only=True)
+        pairs = np.stack([mesh.edge_cells[ed, 0], mesh.edge_local[ed, 0]], axis=1)
+    else:
+        ed = mesh.locate_facets(SubdomainFunc, boundary_only=False)
+        ed = ed[mesh.edge_cells[ed, 1] >= 0]
+        pairs = np.vstack([np.stack([mesh.edge_cells[ed, s], mesh.edge_local[ed, s]], axis=1) for s in (0, 1)])
+    sets = {tag: FacetSet(pairs)}
+    return lambda t: sets.get(t, FacetSet(np.zeros((0, 2), np.int32)))
+
+
+class RMShellModel:
+    def __init__(self, mesh: ShellMesh, shell_bc_func: callable = None, element_wise_material=False, rho=100,
+                 PENALTY_BC=True, additional_outputs=None, mesh_tags=None, record=True, elementwise_pressure=False,
+                 device=0):
+        self.mesh = mesh
+        self.mesh_tags = mesh_tags
+        self.additional_outputs = additional_outputs
+        self.shell_bc_func = shell_bc_func
+        self.element_wise_material = element_wise_material
+        self.record = record
+        self.m, self.rho = 1e-6, rho
+        self.PENALTY_BC = PENALTY_BC
+        self.nel, self.nn = mesh.nel, mesh.nn
+        self.elementwise_pressure = elementwise_pressure
+        self.device = device
+        if mesh_tags is not None:
+            raise NotImplementedError("per-tag sub-domain outputs are out of scope (SURVEY.md section 2.1 row 3)")
+        if shell_bc_func is None:
+            raise ValueError("Please provide the shell bc location function.\n"
+                             " Example:\n def ClampedBoundary(x):\n    return np.less(x[1], 0.0)")
+        self.set_up_bcs(shell_bc_func, PENALTY_BC)
+        self.set_up_fea()
+
+    def set_up_bcs(self, bc_locs_func, PENALTY_BC):
+        if PENALTY_BC:
+            self.dss = createCustomMeasure(self.mesh, 1, bc_locs_func, measure="ds", tag=100)(100)
+            self.dSS = createCustomMeasure(self.mesh, 1, bc_locs_func, measure="dS", tag=100)(100)
+        else:
+            self.dss = self.dSS = None
+
+    def set_up_fea(self):
+        mesh = self.mesh
+        shell_pde = self.shell_pde = RMShellPDE(mesh, element_wise_material=self.element_wise_material,
+                                                elementwise_pressure=self.elementwise_pressure, device=self.device)
+        fea = FEA(mesh)
+        fea.PDE_SOLVER = "Newton"
+        fea.REPORT = False
+        fea.record = False                    # XDMF recording is out of scope; the flag is accepted and ignored
+        fea.linear_problem = True
+        h, f = Function(shell_pde.VT), Function(shell_pde.VF)
+        E, nu, density = Function(shell_pde.VT), Function(shell_pde.VT), Function(shell_pde.VT)
+        uhat = Function(shell_pde.VU)
+        w = Function(shell_pde.W)
+        if not self.PENALTY_BC:
+            dofs = mesh.locate_dofs_geometrical(self.shell_bc_func)
+            shell_pde.ctx.set_strong_dofs(dofs)
+            fea.bc = [DirichletBC(dofs)]
+        g = Function(shell_pde.W)
+        residual_form = shell_pde.pdeRes(h=h, w=w, uhat=uhat, f=f, E=E, nu=nu, penalty=self.PENALTY_BC,
+                                         dss=self.dss, dSS=self.dSS, g=g)
+        compliance_form = shell_pde.compliance(w, uhat, h, f)
+        mass_form = shell_pde.mass(uhat, h, density)
+        elastic_energy_form = shell_pde.elastic_energy(w, uhat, h, E)
+        fea.add_input("thickness", h, init_val=0.001)
+        fea.add_input("F_solid", f, init_val=1.0)
+        fea.add_input("E", E, init_val=1.0)
+        fea.add_input("nu", nu, init_val=1.0)
+        fea.add_input("density", density, init_val=1.0)
+        fea.add_input("uhat", uhat, init_val=0.0)
+        fea.add_state(name="disp_solid", function=w, residual_form=residual_form,
+                      arguments=["thickness", "F_solid", "E", "nu", "uhat"])
+        fea.add_output(name="compliance", form=compliance_form, arguments=["disp_solid", "F_solid", "thickness", "uhat"])
+        fea.add_output(name="mass", form=mass_form, arguments=["thickness", "density", "uhat"])
+        fea.add_output(name="elastic_energy", form=elastic_energy_form, arguments=["thickness", "disp_solid", "E", "uhat"])
+        self.fea = fea
+
+    def evaluate(self, force_vector, thickness, E, nu, density, node_disp=None, debug_mode=False, is_pressure=True):
+        shell_inputs = csdl.VariableGroup()
+        mesh = self.mesh
+        # caller order == solver order here; the gathers are kept so that a renumbered mesh object
+        # can plug in its permutations exactly where the reference applies them (:398-438)
+        mat_idx = np.arange(mesh.nel if self.element_wise_material else mesh.nn)
+        shell_inputs.thickness = thickness[mat_idx]
+        shell_inputs.E = E[mat_idx]
+        shell_inputs.nu = nu[mat_idx]
+        shell_inputs.density = density[mat_idx]
+        prs_idx = np.arange(mesh.nel if self.elementwise_pressure else mesh.nn)
+        reshaped_force = csdl.reshape(force_vector[prs_idx], (-1,))
+        if not is_pressure:
+            raise NotImplementedError("force -> pressure conversion is a 'next' row (SURVEY.md section 8f, rank 4)")
+        shell_inputs.F_solid = reshaped_force
+        shell_inputs.F_solid.add_name("F_solid")
+        if node_disp is None:
+            node_disp = csdl.Variable(value=0.0, shape=(mesh.nn, 3), name="node_disp")
+        reshaped_node_disp = node_disp[np.arange(mesh.nn)].reshape((-1,))
+        reshaped_node_disp.add_name("uhat")
+        shell_inputs.uhat = reshaped_node_disp
+        for n in ("thickness", "E", "nu", "density"):
+            getattr(shell_inputs, n).add_name(n)
+
+        solid_model = FEAModel(fea=[self.fea], fea_name="rm_shell")
+        shell_outputs = solid_model.evaluate(shell_inputs, debug_mode=debug_mode)
+
+        disp_extracted = DisplacementExtractionModel(shell_pde=self.shell_pde).evaluate(shell_outputs.disp_solid)
+        disp_extracted.add_name("disp_extracted")
+        shell_outputs.disp_extracted = disp_extracted
+        return shell_outputs
+
+
+class AggregatedStressModel:
+    """aggregated_stress = pnorm^(1/rho) / m (rm_shell_model.py:493-503)."""
+
+    def __init__(self, m: float, rho: int):
+        self.m, self.rho = m, rho
+
+    def evaluate(self, pnorm_stress):
+        return 1 / self.m * pnorm_stress ** (1 / self.rho)
+
+
+class DisplacementExtractionModel:
+    """(nn, 3) vertex displacements in caller node order (rm_shell_model.py:505-527)."""
+
+    def __init__(self, shell_pde: RMShellPDE):
+        self.shell_pde = shell_pde
+
+    def evaluate(self, disp_vec):
+        nn = self.shell_pde.mesh.nn
+        return disp_vec[np.arange(3 * nn)].reshape((nn, 3))
+
+
+class ForceReshapingModel:
+    def __init__(self, shell_pde: RMShellPDE):
+        self.shell_pde = shell_pde
+
+    def evaluate(self, nodal_force_mat):
+        return csdl.reshape(nodal_force_mat[np.arange(self.shell_pde.mesh.nn)], (-1,))

@@ -1,0 +1,78 @@
+"""``RMShellPDE``: the shell's spaces, residual and output forms, resident on one MI355X.
+
+Interface of femo_alpha/rm_shell/rm_shell_pde.py:21-110,173-293.  Where the reference builds UFL
+expressions from dolfinx Functions, this class binds ``Function`` handles to the roles they play
+in the residual ('thickness', 'F_solid', 'E', 'nu', 'uhat', state) and returns named forms that
+libfemo_hip evaluates with hand-written kernels (femo_alpha_amd/csrc/shell_device.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from ..backend import PENALTY_BETA, ShellContext
+from ..fea.fea_hip import Form, Function, FunctionSpace, ResidualForm
+
+
+class FacetSet:
+    """What a tagged ``ds(100)`` / ``dS(100)`` measure integrates over: (cell, local edge) pairs."""
+
+    def __init__(self, pairs):
+        self.pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+
+
+class RMShellPDE:
+    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=4, device=0):
+        self.mesh = mesh
+        self.element_wise_material = element_wise_material
+        self.elementwise_pressure = elementwise_pressure
+        self.ctx = ShellContext(mesh, element_wise_material, elementwise_pressure, nquad=nquad, device=device)
+        self.W = FunctionSpace(self.ctx, "W")          # [CG2]^3 x [CG1]^3, linear_shell_model.py:60-65
+        self.VT = FunctionSpace(self.ctx, "VT")        # rm_shell_pde.py:37-40
+        self.VF = FunctionSpace(self.ctx, "VF")        # :41-44
+        self.VU = FunctionSpace(self.ctx, "VU")        # :45
+
+    # ------------------------------------------------------------------ residual
+    def pdeRes(self, h, w, uhat, f, E, nu, penalty=False, dss=None, dSS=None, g=None):
+        """Residual of the elastic energy + penalty - load (rm_shell_pde.py:50-58,
+        linear_shell_model.py:308-333).  ``g`` (the prescribed value) must be zero."""
+        h.bind("thickness"); w.bind("state"); uhat.bind("uhat"); f.bind("F_solid"); E.bind("E"); nu.bind("nu")
+        if g is not None and np.any(g.get()):
+            raise NotImplementedError("non-zero Dirichlet data g is not supported (the reference always passes 0, "
+                                      "rm_shell_model.py:183-185)")
+        if penalty:
+            pairs = [s.pairs for s in (dss, dSS) if s is not None]
+            self.ctx.set_penalty_facets(np.vstack(pairs) if pairs else np.zeros((0, 2), np.int32), PENALTY_BETA)
+        return ResidualForm(self.ctx)
+
+    # ------------------------------------------------------------------ outputs
+    def compliance(self, u_mid, uhat, h, f):
+        """int u.u J dx + regularisation(h) (rm_shell_pde.py:85-89)."""
+        return Form(self.ctx, "compliance")
+
+    def mass(self, uhat, h, rho):
+        rho.bind("density")
+        return Form(self.ctx, "mass")
+
+    def elastic_energy(self, w, uhat, h, E):
+        return Form(self.ctx, "elastic_energy")
+
+    def pnorm_stress(self, *args, **kwargs):
+        raise NotImplementedError("p-norm stress aggregation is a 'next' row (SURVEY.md section 8f, rank 1)")
+
+    def von_Mises_stress(self, *args, **kwargs):
+        raise NotImplementedError("von Mises stress field is a 'next' row (SURVEY.md section 8f, rank 1)")
+
+    # ------------------------------------------------------------------ maps
+    def construct_nodal_disp_map(self):
+        """Sparse (3 nn x ndof) map state -> [ux; uy; uz] at the mesh vertices, the stacking the
+        reference builds from P2 basis evaluations (rm_shell_pde.py:212-221); vertices are P2 nodes
+        here, so every row holds a single 1."""
+        nn, ndof = self.mesh.nn, self.mesh.ndof
+        rows = np.arange(3 * nn)
+        cols = (3 * np.arange(nn)[None, :] + np.arange(3)[:, None]).ravel()
+        return sp.csr_matrix((np.ones(3 * nn), (rows, cols)), shape=(3 * nn, ndof))
+
+    def compute_nodal_disp(self, func: Function):
+        u = func.get()[: 3 * self.mesh.nn].reshape(-1, 3)
+        return u[:, 0].copy(), u[:, 1].copy(), u[:, 2].copy()

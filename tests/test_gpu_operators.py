@@ -1,0 +1,94 @@
+"""The reference's operator protocol, end to end on the GPU, checked against the CPU oracle.
+
+Reads like the reference's example driver (examples/advanced_examples/simple_shell_opt/
+ex_simple_shell_opt.py:39-111): build RMShellModel on a 2x10 plate, evaluate, print-style sanity
+against Euler-Bernoulli, then check_totals of compliance with respect to thickness."""
+import numpy as np
+import pytest
+
+from femo_alpha_amd import csdl
+from femo_alpha_amd.mesh import plate_mesh
+
+pytestmark = pytest.mark.gpu
+
+DOLFIN_EPS = 3e-16
+
+
+def ClampedBoundary(x):
+    return np.less(x[0], 0.0 + DOLFIN_EPS)
+
+
+@pytest.mark.parametrize("element_wise_material,penalty", [(False, True), (True, True), (False, False)])
+def test_rm_shell_model_protocol(element_wise_material, penalty):
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    from oracle.rm_shell_oracle import ShellOracle
+    mesh = plate_mesh(2.0, 10.0, 4, 20)
+    nn, nel = mesh.nn, mesh.nel
+    E_val, nu_val, h_val, rho_val, f_d = 1e8, 0.3, 0.1, 10.0, 5.0
+    n_h = nel if element_wise_material else nn
+    rng = np.random.default_rng(0)
+    h0 = h_val * (1 + 0.2 * rng.uniform(-1, 1, n_h))
+
+    recorder = csdl.Recorder(inline=True)
+    recorder.start()
+    pressure = csdl.Variable(value=np.zeros((nn, 3)), name="force_vector")
+    pressure.value[:, 2] = f_d
+    thickness = csdl.Variable(value=h0, name="thickness")
+    E = csdl.Variable(value=E_val * np.ones(n_h), name="E")
+    nu = csdl.Variable(value=nu_val * np.ones(n_h), name="nu")
+    density = csdl.Variable(value=rho_val * np.ones(n_h), name="density")
+    node_disp = csdl.Variable(value=np.zeros((nn, 3)), name="node_disp")
+    model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, element_wise_material=element_wise_material,
+                         PENALTY_BC=penalty, record=False)
+    model.shell_pde.ctx.set_solver(rtol=1e-12, maxit=400000, check_every=100)
+    out = model.evaluate(pressure, thickness, E, nu, density, node_disp, debug_mode=False, is_pressure=True)
+    recorder.stop()
+
+    # oracle on the same inputs
+    o = ShellOracle(mesh, element_wise_material=element_wise_material,
+                    penalty_facets=mesh.penalty_facets(ClampedBoundary) if penalty else None,
+                    strong_dofs=None if penalty else mesh.locate_dofs_geometrical(ClampedBoundary))
+    o.set_fields(h=h0, E=E_val, nu=nu_val, rho=rho_val, f=pressure.value)
+    w_ref, J_ref, dJ_ref = o.forward_adjoint()
+
+    assert out.disp_solid.shape == (mesh.ndof,)
+    assert np.abs(out.disp_solid.value - w_ref).max() < 1e-7 * np.abs(w_ref).max()
+    assert abs(out.compliance.value[0] - J_ref) < 1e-8 * abs(J_ref)
+    assert abs(out.mass.value[0] - o.mass()) < 1e-11 * o.mass()
+    assert abs(out.elastic_energy.value[0] - o.elastic_energy(w_ref)) < 1e-7 * o.elastic_energy(w_ref)
+    assert out.disp_extracted.shape == (nn, 3)
+    assert np.allclose(out.disp_extracted.value, w_ref[:3 * nn].reshape(nn, 3), rtol=0, atol=1e-7 * np.abs(w_ref).max())
+    # Euler-Bernoulli sanity the reference prints (ex_simple_shell_opt.py:100-105)
+    eb = f_d * 2.0 * 10.0 ** 4 / (8 * E_val * 2.0 * h_val ** 3 / 12)
+    assert 0.8 * eb < np.abs(out.disp_solid.value[:mesh.ndof_u]).max() < 1.2 * eb
+
+    # total derivative through the operator protocol == oracle adjoint
+    dJ = recorder.compute_totals(out.compliance, thickness)
+    assert np.abs(dJ - dJ_ref).max() < 1e-7 * np.abs(dJ_ref).max()
+    dM = recorder.compute_totals(out.mass, thickness)
+    assert np.abs(dM - o.dmass_dh()).max() < 1e-11 * np.abs(o.dmass_dh()).max()
+    # the reference's own verification: check_totals (finite differences through the GPU solve)
+    rows = recorder.check_totals(out.compliance, thickness, step=1e-3, indices=[0, n_h // 3, n_h - 1])
+    for i, ana, fd, err in rows:
+        assert abs(ana - fd) < 2e-5 * np.abs(dJ).max(), (i, ana, fd)
+
+
+def test_operator_error_behaviour():
+    from femo_alpha_amd.csdl_alpha_opt.state_operation import StateOperation
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    mesh = plate_mesh(2.0, 10.0, 2, 4)
+    with pytest.raises(ValueError, match="shell bc location"):
+        RMShellModel(mesh, shell_bc_func=None)
+    model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False)
+    fea = model.fea
+    with pytest.raises(ValueError, match="already been used"):
+        fea.add_input("thickness", fea.inputs_dict["E"]["function"])
+    op = StateOperation(fea=fea, args_name_list=fea.states_dict["disp_solid"]["arguments"], state_name="disp_solid")
+    with pytest.raises(ValueError, match="not found in the FEA model"):
+        op.evaluate(csdl.VariableGroup())
+    with pytest.raises(ValueError, match="mode must be"):
+        op.compute_jacvec_product({}, {}, {}, {}, {}, "sideways")
+    with pytest.raises(ValueError, match="mode must be"):
+        op.apply_inverse_jacobian({}, {}, {}, {}, "sideways")
+    with pytest.raises(TypeError):
+        StateOperation(fea="not an FEA", args_name_list=[], state_name="disp_solid")
