@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the RM-shell forward + adjoint hot path on MI355X.
+
+Contract:  python bench.py --gpus N --steps K --warmup W   (N>1 under torch.distributed.run)
+prints ONE JSON line on rank 0.
+
+A *step* is one pass of the hot path over one synthetic design: a cold-start forward solve
+(operator set-up + PCG solve of K w = F, "assembly+solve") followed by the adjoint gradient
+d compliance / d thickness (dJ/dw, one more solve, (dR/dh)^T lambda, dJ/dh).  Inputs are resident
+in HBM before the timed region; nothing is cached across steps (zero initial guess, thickness
+re-uploaded outside the timed region only when it changes -- it does not).
+
+``value`` = DOF/s of the forward part = ndof * K * N / (time spent in forward solves), the
+BASELINE.json metric "DOF/s (assembly+solve)"; ``adjoint_ms`` is the adjoint-gradient wall-clock
+per step, the second half of that metric.  ``ms_per_step`` covers the whole step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def make_workload(name):
+    from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
+    if name == "plate250k":      # BASELINE.json configs[1]: flat plate, 250k DOF, thickness design variable
+        m = plate_mesh(2.0, 10.0, 58, 290)
+        rng = np.random.default_rng(0)
+        fields = dict(thickness=0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=[1e8], nu=[0.3], density=[10.0],
+                      F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
+        marker = lambda x: np.less(x[0], 3e-16)
+        desc = "flat plate 2x10, 58x290 CG2xCG1 quads, 255438 DOF, nodal thickness 0.1*(1+0.2U), clamped x=0 (penalty 1e15)"
+    elif name == "wing1m":       # BASELINE.json configs[2]
+        m = wing_skin_mesh(116, 580)
+        fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
+                      F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
+        marker = lambda x: np.less(x[1], 1e-9)
+        desc = "synthetic wing skin 116x580 quads (cambered, tapered, twisted, jittered, renumbered), 1015470 DOF"
+    elif name == "plate8k":      # BASELINE.json configs[0] (plumbing size)
+        m = plate_mesh(2.0, 10.0, 10, 50)
+        fields = dict(thickness=[0.1], E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
+        marker = lambda x: np.less(x[0], 3e-16)
+        desc = "flat plate 2x10, 10x50 quads, 8046 DOF"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return m, fields, marker, desc
+
+
+def cpu_baseline(sample_mesh, fields_fn, marker, repeats=1):
+    """The oracle ('port': this repo's float64 restatement of the reference algorithm -- the
+    reference itself needs FEniCSx/PETSc and cannot run here) timed on the host cores on a bounded
+    sample: 1 assembly + 1 sparse LU + solve ("best CPU effort")."""
+    from oracle.rm_shell_oracle import ShellOracle
+    o = ShellOracle(sample_mesh, penalty_facets=sample_mesh.penalty_facets(marker))
+    o.set_fields(**fields_fn(sample_mesh))
+    t0 = time.perf_counter()
+    w = o.solve()
+    t1 = time.perf_counter()
+    lam = o.solve_adjoint(o.dcompliance_du(w))
+    g = o.dcompliance_dh(w) - o.dRdfield_T("h", w, lam)
+    t2 = time.perf_counter()
+    return dict(value=sample_mesh.ndof / (t1 - t0), unit="DOF/s", cores=1, kind="port",
+                sample=f"{sample_mesh.nel}-cell plate, {sample_mesh.ndof} DOF: numpy element assembly + scipy SuperLU "
+                       f"factor + 2 solves = {t1 - t0:.1f} s; adjoint gradient {t2 - t1:.1f} s",
+                adjoint_ms=(t2 - t1) * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "plate250k"))
+    ap.add_argument("--rtol", type=float, default=1e-9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from femo_alpha_amd.backend import ShellContext
+    m, fields, marker, desc = make_workload(args.workload)
+    ctx = ShellContext(m, device=local_rank)
+    for k, v in fields.items():
+        ctx.set_field(k, v)
+    ctx.set_penalty_facets(m.penalty_facets(marker))
+    ctx.set_solver(rtol=args.rtol, maxit=400000, check_every=200)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        t0 = time.perf_counter()
+        it, rr = ctx.solve_state(zero_guess=True)
+        t1 = time.perf_counter()
+        g, it2, rr2 = ctx.total_gradient("compliance", "thickness")
+        t2 = time.perf_counter()
+        return (t1 - t0, t2 - t1, it, rr, it2, rr2)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    rows = [step() for _ in range(args.steps)]
+    barrier()
+    t_total = time.perf_counter() - t_start
+    t_fwd = sum(r[0] for r in rows)
+    t_adj = sum(r[1] for r in rows)
+    if dist is not None:
+        tt = torch.tensor([t_total, t_fwd, t_adj], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_total, t_fwd, t_adj = tt.tolist()
+
+    # dominant kernel: the matrix-free element operator (one launch per PCG iteration)
+    apply_ms = ctx.bench_kernel("apply", 100)
+    alg_bytes = 16.0 * m.ndof + 340.0 * m.nel          # SURVEY.md section 8d, B_spmv,ebe per launch
+    achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("apply_hbm_bytes_per_launch")
+
+    if rank == 0:
+        out = {
+            "metric": "DOF/s (assembly+solve), forward solve of the RM shell; adjoint-gradient wallclock in adjoint_ms",
+            "value": m.ndof * args.steps * world / t_fwd,
+            "unit": "DOF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_total / args.steps * 1e3,
+            "forward_ms": t_fwd / args.steps * 1e3,
+            "adjoint_ms": t_adj / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
+                       "solver": "Jacobi-PCG, matrix-free element-by-element operator", "rtol": args.rtol,
+                       "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
+                       "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],
+                       "parallelism": "replicas" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "k_apply (matrix-free CG2xCG1 shell operator)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": apply_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from femo_alpha_amd.mesh import plate_mesh
+            sample = plate_mesh(2.0, 10.0, 29, 145)
+            def sample_fields(sm):
+                rng = np.random.default_rng(0)
+                return dict(h=0.1 * (1 + 0.2 * rng.uniform(-1, 1, sm.nn)), E=1e8, nu=0.3, rho=10.0,
+                            f=np.tile([0.0, 0.0, 5.0], (sm.nn, 1)))
+            out["cpu_baseline"] = cpu_baseline(sample, sample_fields, lambda x: np.less(x[0], 3e-16))
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

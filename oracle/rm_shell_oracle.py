@@ -398,7 +398,10 @@ class ShellOracle:
 
     def factorize(self):
         self._K = self.assemble_K()
-        self._lu = spla.splu(self._K.tocsc())
+        # symmetric-mode SuperLU with minimum-degree ordering on A+A^T: 3x faster than the COLAMD
+        # default on this matrix -- the 'best CPU effort' baseline of BASELINE.md section 3
+        self._lu = spla.splu(self._K.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
+                             options=dict(SymmetricMode=True))
         return self._lu
 
     def solve(self):
