@@ -33,6 +33,11 @@ SIGNATURES = {
     "femo_load_vector": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_diagonal": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_element_matrices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p]),
+    "femo_set_frontal_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_int32_p, _c_int32_p, C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int64), _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p,
+                                        _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p]),
+    "femo_factorize": (C.c_int, [C.c_void_p]),
+    "femo_frontal_info": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),

@@ -118,6 +118,38 @@ class ShellContext:
         self._chk(self.lib.femo_element_matrices(self._h, first, count, dptr(Ke)))
         return Ke
 
+    # ------------------------------------------------------------------ multifrontal preconditioner
+    def enable_frontal(self, leaf_size=16):
+        """Run the symbolic analysis on the host (mesh only) and upload it; afterwards
+        ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner."""
+        from .solver.symbolic import build_plan
+        plan = self.plan = build_plan(self.mesh, leaf_size)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        level_off = i32(np.concatenate([[0], np.cumsum([len(l) for l in plan.level_nodes])]))
+        level_nodes = i32(np.concatenate(plan.level_nodes))
+        arrs = dict(nf=i32(plan.nf), npiv=i32(plan.npiv), front_off=i64(plan.front_off), dof_off=i64(plan.dof_off),
+                    front_dofs=i32(plan.front_dofs), up_map=i32(plan.up_map), parent=i32(plan.parent), left=i32(plan.left),
+                    right=i32(plan.right), level_off=level_off, level_nodes=level_nodes,
+                    elem_front=i32(plan.elem_front), elem_map=i32(plan.elem_map))
+        p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        self._chk(self.lib.femo_set_frontal_plan(
+            self._h, plan.ntree, plan.nlevels, iptr(arrs["nf"]), iptr(arrs["npiv"]), p64(arrs["front_off"]),
+            p64(arrs["dof_off"]), iptr(arrs["front_dofs"]), iptr(arrs["up_map"]), iptr(arrs["parent"]), iptr(arrs["left"]),
+            iptr(arrs["right"]), iptr(arrs["level_off"]), iptr(arrs["level_nodes"]), iptr(arrs["elem_front"]),
+            iptr(arrs["elem_map"])))
+        return plan
+
+    def factorize(self):
+        self._chk(self.lib.femo_factorize(self._h))
+        return self.frontal_info()
+
+    def frontal_info(self):
+        t = np.zeros(6)
+        self._chk(self.lib.femo_frontal_info(self._h, dptr(t)))
+        return dict(assemble_ms=t[0], factor_ms=t[1], front_GB=t[2], factor_gflop=t[3], pivots_repaired=int(t[4]),
+                    fronts=int(t[5]))
+
     # ------------------------------------------------------------------ solves
     def set_solver(self, preconditioner=0, rtol=1e-10, maxit=200000, check_every=50):
         self._chk(self.lib.femo_set_solver(self._h, preconditioner, rtol, maxit, check_every))

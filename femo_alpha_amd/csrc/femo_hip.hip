@@ -2,6 +2,7 @@
 // One context = one mesh on one GPU with every buffer resident in HBM.
 #include "../../include/femo_hip.h"
 #include "shell_device.h"
+#include "frontal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -53,6 +54,20 @@ struct femo_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double timing[5] = {0, 0, 0, 0, 0};
     std::string err;
+    // multifrontal preconditioner (precond == 2)
+    struct Frontal {
+        bool ready = false, factored = false;
+        int ntree = 0, nlevels = 0;
+        std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes;
+        int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
+            *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
+        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr;
+        double *F = nullptr, *Linv = nullptr;
+        long long f_doubles = 0, linv_doubles = 0;
+        int max_nf = 0;
+        double t_factor_ms = 0, t_assemble_ms = 0;
+        int pivots_fixed = 0;
+    } fr;
 };
 
 #define HIPCHK(ctx, call)                                                                        \
@@ -315,6 +330,171 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------ multifrontal driver
+static FrontDev front_dev(const femo_ctx* c) {
+    FrontDev fd;
+    fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.foff = c->fr.foff; fd.doff = c->fr.doff;
+    fd.dofs = c->fr.dofs; fd.upmap = c->fr.upmap; fd.parent = c->fr.parent; fd.child[0] = c->fr.left; fd.child[1] = c->fr.right;
+    fd.linvoff = c->fr.linvoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv;
+    return fd;
+}
+
+static int frontal_factorize(femo_ctx* c) {
+    auto& fr = c->fr;
+    if (!fr.ready) return fail(c, "no frontal plan: call femo_set_frontal_plan first");
+    const FrontDev fd = front_dev(c);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
+    if (refresh_penalty(c)) return 1;
+    ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask);
+    if (c->nf > 0)
+        hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
+                           fr.elem_map, c->ld, c->npc, c->nvc, mask);
+    if (mask) hipLaunchKernelGGL(k_front_mask_diag, dim3(fr.ntree), dim3(64), 0, c->stream, fd, mask);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    for (int L = 0; L < fr.nlevels; ++L) {
+        const int b = fr.h_level_off[L], e = fr.h_level_off[L + 1];
+        const int cnt = e - b;
+        const int* lev = fr.level_nodes + b;
+        int max_np = 0;
+        for (int i = b; i < e; ++i) max_np = std::max(max_np, fr.h_npiv[fr.h_level_nodes[i]]);
+        if (L > 0) {
+            // children Schur complements into the parents of this level
+            int max_nb = 0;
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i];
+                max_nb = std::max(max_nb, fr.h_nf[t]);     // child boundary <= parent front
+            }
+            const int nt = (max_nb + TS - 1) / TS;
+            const dim3 grid(nt * (nt + 1) / 2, cnt);
+            hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 0);
+            hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 1);
+        }
+        const int npan = (max_np + NB - 1) / NB;
+        for (int k = 0; k < npan; ++k) {
+            int max_rem = 0;
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i];
+                if (fr.h_npiv[t] > k * NB) max_rem = std::max(max_rem, fr.h_nf[t] - k * NB - std::min(NB, fr.h_npiv[t] - k * NB));
+            }
+            hipLaunchKernelGGL(k_chol_diag, dim3(cnt), dim3(64), 0, c->stream, fd, lev, k, fr.info);
+            if (max_rem > 0) {
+                const int nrb = (max_rem + TS - 1) / TS;
+                hipLaunchKernelGGL(k_panel_trsm, dim3(nrb, cnt), dim3(256), 0, c->stream, fd, lev, k);
+                hipLaunchKernelGGL(k_trailing, dim3(nrb * (nrb + 1) / 2, cnt), dim3(256), 0, c->stream, fd, lev, k);
+            }
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    int info = 0;
+    HIPCHK(c, hipMemcpyAsync(&info, fr.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ta = 0, tf = 0;
+    hipEventElapsedTime(&ta, c->ev[2], c->ev[3]);
+    hipEventElapsedTime(&tf, c->ev[3], c->ev[0]);
+    fr.t_assemble_ms = ta; fr.t_factor_ms = tf; fr.pivots_fixed = info;
+    fr.factored = true;
+    return 0;
+}
+
+// v <- (L L^T)^-1 v
+static int frontal_solve(femo_ctx* c, double* v) {
+    auto& fr = c->fr;
+    const FrontDev fd = front_dev(c);
+    const size_t shm = (size_t)(fr.max_nf + NB) * sizeof(double);
+    for (int L = 0; L < fr.nlevels; ++L) {
+        const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
+        hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+    }
+    for (int L = fr.nlevels - 1; L >= 0; --L) {
+        const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
+        hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// PCG preconditioned by the multifrontal factorisation (a handful of iterations)
+static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->diag_dirty || !c->fr.factored) {
+        if (int rc = frontal_factorize(c)) return rc;
+        c->diag_dirty = false;
+        c->fr.factored = true;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    auto dot = [&](const double* a, const double* bb, double* out) -> int {
+        HIPCHK(c, hipMemsetAsync(c->scal + 7, 0, sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_dot, dim3(vg), dim3(256), 0, c->stream, a, bb, n, c->scal + 7);
+        HIPCHK(c, hipMemcpyAsync(c->scal_host + 7, c->scal + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *out = c->scal_host[7];
+        return 0;
+    };
+    if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
+    double bb = 0, rr = 0, rz = 0, rz_new = 0, pAp = 0;
+    if (dot(b, b, &bb)) return 1;
+    // r = b - A x
+    if (zero_guess) {
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
+        HIPCHK(c, hipMemcpyAsync(c->r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, x, mask, n);
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
+        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+        HIPCHK(c, hipMemcpyAsync(c->r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -1.0, c->Ap, 1.0, n);
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->r, mask, n);
+    }
+    if (dot(c->r, c->r, &rr)) return 1;
+    int k = 0, napply = 0;
+    const double target = c->rtol * c->rtol * bb;
+    while (bb > 0 && rr > target && k < c->maxit) {
+        HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (frontal_solve(c, c->z)) return 1;
+        if (dot(c->r, c->z, &rz_new)) return 1;
+        if (k == 0) {
+            HIPCHK(c, hipMemcpyAsync(c->p, c->z, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, c->z, rz_new / rz, n);   // p = z + beta p
+        }
+        rz = rz_new;
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
+        if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+        ++napply;
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->Ap, mask, n);
+        if (dot(c->p, c->Ap, &pAp)) return 1;
+        if (!(pAp > 0)) return fail(c, "PCG broke down: p.Ap <= 0 (preconditioner or operator not positive definite)");
+        const double alpha = rz / pAp;
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, x, alpha, c->p, 1.0, n);
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -alpha, c->Ap, 1.0, n);
+        if (dot(c->r, c->r, &rr)) return 1;
+        if (!(rr == rr)) return fail(c, "PCG broke down (NaN residual)");
+        ++k;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float t_loop = 0;
+    hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
+    c->timing[0] = c->fr.t_assemble_ms + c->fr.t_factor_ms; c->timing[1] = t_loop; c->timing[2] = c->timing[0] + t_loop;
+    c->timing[4] = napply;
+    if (iters) *iters = k;
+    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+    return 0;
+}
+
+static int solve_dispatch(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    return c->precond == 2 ? pcg_frontal(c, b, x, zero_guess, iters, relres) : pcg(c, b, x, zero_guess, iters, relres);
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -428,6 +608,10 @@ void femo_destroy(femo_ctx* c) {
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
+        if (p) hipFree(p);
+    void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
+                     c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv};
+    for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->scal_host) hipHostFree(c->scal_host);
     for (int i = 0; i < 4; ++i)
@@ -637,7 +821,8 @@ int femo_element_matrices(femo_ctx* c, int32_t first, int32_t count, double* Ke)
 }
 
 int femo_set_solver(femo_ctx* c, int preconditioner, double rtol, int32_t maxit, int32_t check_every) {
-    if (preconditioner != 0) return fail(c, "only preconditioner 0 (Jacobi) is available in this build");
+    if (preconditioner != 0 && preconditioner != 2) return fail(c, "preconditioner must be 0 (Jacobi) or 2 (multifrontal Cholesky)");
+    if (preconditioner == 2 && !c->fr.ready) return fail(c, "preconditioner 2 needs femo_set_frontal_plan first");
     if (!(rtol > 0) || maxit < 1 || check_every < 1) return fail(c, "bad solver parameters");
     c->precond = preconditioner; c->rtol = rtol; c->maxit = maxit; c->check_every = check_every;
     return 0;
@@ -646,14 +831,14 @@ int femo_set_solver(femo_ctx* c, int preconditioner, double rtol, int32_t maxit,
 int femo_solve_state(femo_ctx* c, int zero_guess, int32_t* iters, double* relres) {
     HIPCHK(c, hipSetDevice(c->device));
     if (load_vector_dev(c, c->b)) return 1;
-    return pcg(c, c->b, c->w, zero_guess != 0, iters, relres);
+    return solve_dispatch(c, c->b, c->w, zero_guess != 0, iters, relres);
 }
 
 int femo_solve_linear(femo_ctx* c, const double* rhs, double* x, int32_t* iters, double* relres) {
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)c->ndof * sizeof(double);
     HIPCHK(c, hipMemcpy(c->b, rhs, bytes, hipMemcpyHostToDevice));
-    if (int rc = pcg(c, c->b, c->lam, true, iters, relres)) return rc;
+    if (int rc = solve_dispatch(c, c->b, c->lam, true, iters, relres)) return rc;
     HIPCHK(c, hipMemcpy(x, c->lam, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -773,7 +958,7 @@ int femo_total_gradient(femo_ctx* c, const char* functional, const char* arg, do
     double* d = nullptr;
     HIPCHK(c, hipMalloc((void**)&d, std::max<int64_t>(n, 1) * sizeof(double)));
     int rc = dfunctional_dev(c, fn, "disp_solid", c->b, c->ndof);          // dJ/dw
-    if (!rc) rc = pcg(c, c->b, c->lam, true, iters, relres);                // lambda = K^-1 dJ/dw
+    if (!rc) rc = solve_dispatch(c, c->b, c->lam, true, iters, relres);     // lambda = K^-1 dJ/dw
     if (!rc) rc = dfunctional_dev(c, fn, a, d, n);                          // dJ/d arg (zero-fills d)
     if (!rc) rc = dRdarg_T_dev(c, a, c->lam, -1.0, d, n);                   // - (dR/d arg)^T lambda
     if (!rc) {
@@ -783,6 +968,95 @@ int femo_total_gradient(femo_ctx* c, const char* functional, const char* arg, do
     }
     hipFree(d);
     return rc;
+}
+
+
+int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int32_t* nf, const int32_t* npiv,
+                          const int64_t* front_off, const int64_t* dof_off, const int32_t* front_dofs, const int32_t* up_map,
+                          const int32_t* parent, const int32_t* left, const int32_t* right, const int32_t* level_off,
+                          const int32_t* level_nodes, const int32_t* elem_front, const int32_t* elem_map) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (fr.ready) return fail(c, "frontal plan already set for this context");
+    if (ntree < 1 || nlevels < 1) return fail(c, "empty frontal plan");
+    fr.ntree = ntree; fr.nlevels = nlevels;
+    fr.h_nf.assign(nf, nf + ntree); fr.h_npiv.assign(npiv, npiv + ntree);
+    fr.h_level_off.assign(level_off, level_off + nlevels + 1);
+    fr.h_level_nodes.assign(level_nodes, level_nodes + ntree);
+    if (fr.h_level_off[nlevels] != ntree) return fail(c, "level_off does not cover all fronts");
+    long long piv_total = 0;
+    std::vector<long long> linvoff(ntree + 1, 0);
+    fr.max_nf = 0;
+    for (int t = 0; t < ntree; ++t) {
+        if (npiv[t] < 0 || nf[t] < npiv[t] || front_off[t + 1] - front_off[t] != (long long)nf[t] * nf[t] ||
+            dof_off[t + 1] - dof_off[t] != nf[t])
+            return fail(c, "inconsistent frontal plan (sizes / offsets)");
+        piv_total += npiv[t];
+        linvoff[t + 1] = linvoff[t] + (long long)((npiv[t] + NB - 1) / NB) * NB * NB;
+        fr.max_nf = std::max(fr.max_nf, nf[t]);
+    }
+    if (piv_total != c->ndof) return fail(c, "frontal plan does not eliminate every DOF exactly once");
+    if ((size_t)(fr.max_nf + NB) * sizeof(double) > 150 * 1024) return fail(c, "largest front does not fit the LDS solve kernels");
+    const long long ndofs_total = dof_off[ntree];
+    for (long long i = 0; i < ndofs_total; ++i)
+        if (front_dofs[i] < 0 || front_dofs[i] >= c->ndof) return fail(c, "front_dofs out of range");
+    for (int t = 0; t < ntree; ++t) {
+        const int p = parent[t];
+        if (p < -1 || p >= ntree) return fail(c, "parent out of range");
+        for (long long i = dof_off[t] + npiv[t]; i < dof_off[t + 1]; ++i)
+            if (p < 0 || up_map[i] < 0 || up_map[i] >= nf[p]) return fail(c, "up_map out of range");
+    }
+    for (long long e = 0; e < c->nel; ++e) {
+        const int t = elem_front[e];
+        if (t < 0 || t >= ntree) return fail(c, "elem_front out of range");
+        for (int i = 0; i < c->ld; ++i)
+            if (elem_map[e * c->ld + i] < 0 || elem_map[e * c->ld + i] >= nf[t]) return fail(c, "elem_map out of range");
+    }
+    fr.f_doubles = front_off[ntree];
+    fr.linv_doubles = linvoff[ntree];
+#define UPI(dst, src, n) do { HIPCHK(c, hipMalloc((void**)&dst, std::max<size_t>((size_t)(n), 1) * sizeof(*dst))); \
+        HIPCHK(c, hipMemcpy(dst, src, (size_t)(n) * sizeof(*dst), hipMemcpyHostToDevice)); } while (0)
+    UPI(fr.nf, nf, ntree); UPI(fr.npiv, npiv, ntree); UPI(fr.parent, parent, ntree); UPI(fr.left, left, ntree);
+    UPI(fr.right, right, ntree); UPI(fr.level_nodes, level_nodes, ntree); UPI(fr.dofs, front_dofs, ndofs_total);
+    UPI(fr.upmap, up_map, ndofs_total); UPI(fr.elem_front, elem_front, c->nel); UPI(fr.elem_map, elem_map, (size_t)c->nel * c->ld);
+    HIPCHK(c, hipMalloc((void**)&fr.foff, (ntree + 1) * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(fr.foff, front_off, (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&fr.doff, (ntree + 1) * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(fr.doff, dof_off, (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&fr.linvoff, (ntree + 1) * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(fr.linvoff, linvoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
+    if ((size_t)(fr.max_nf + NB) * sizeof(double) > 48 * 1024) {
+        const int bytes = (int)((fr.max_nf + NB) * sizeof(double));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    fr.ready = true;
+    fr.factored = false;
+    return 0;
+}
+
+int femo_factorize(femo_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = frontal_factorize(c)) return rc;
+    c->diag_dirty = (c->precond != 2);
+    return 0;
+}
+
+/* out6: [0] element-matrix assembly into fronts (ms), [1] numeric factorisation (ms), [2] front storage (GB),
+ *       [3] factor flops (GFLOP, from the plan sizes), [4] number of non-positive pivots repaired, [5] fronts */
+int femo_frontal_info(const femo_ctx* c, double* out6) {
+    const auto& fr = c->fr;
+    double fl = 0;
+    for (int t = 0; t < fr.ntree; ++t) {
+        const double p = fr.h_npiv[t], n = fr.h_nf[t];
+        fl += p * n * n - p * p * n + p * p * p / 3.0;
+    }
+    out6[0] = fr.t_assemble_ms; out6[1] = fr.t_factor_ms; out6[2] = fr.f_doubles * 8.0 / 1e9; out6[3] = fl / 1e9;
+    out6[4] = fr.pivots_fixed; out6[5] = fr.ntree;
+    return 0;
 }
 
 int femo_last_timing(const femo_ctx* c, double* out5) {

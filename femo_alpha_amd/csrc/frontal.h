@@ -1,0 +1,381 @@
+// Multifrontal Cholesky of the shell operator on gfx950 (fp64): numeric factorisation and the
+// triangular solves used as the PCG preconditioner.
+//
+// Role in the reference: PETSc KSP 'preonly' + PC 'lu' with MUMPS
+// (reference femo_alpha/fea/utils_dolfinx.py:466,495-531) -- itself a multifrontal method.
+// Here the elimination tree comes from a geometric nested dissection of the elements
+// (femo_alpha_amd/solver/symbolic.py); element matrices are summed straight into the leaf fronts;
+// every level of the tree is factorised by batched, blocked, right-looking partial Cholesky kernels
+// whose grids span all fronts of the level (panel width NB = 32, 64x64 trailing tiles staged in LDS).
+//
+// Storage: front t is a dense column-major nf x nf block at F + foff[t]; only the lower triangle is
+// maintained.  After factorisation its first npiv columns hold [L11; L21]; the trailing block is
+// the Schur complement that the parent consumes.  Linv keeps the inverses of the NB x NB diagonal
+// blocks of L11 so that every triangular solve becomes a small GEMV.
+#pragma once
+#include "shell_device.h"
+
+namespace femo {
+
+constexpr int NB = 32;     // panel width
+constexpr int TS = 64;     // trailing-update tile
+
+struct FrontDev {
+    int ntree;
+    const int* nf;
+    const int* npiv;
+    const long long* foff;      // doubles, [ntree+1]
+    const long long* doff;      // ints, [ntree+1]
+    const int* dofs;            // global DOF of every front row
+    const int* upmap;           // row of the parent front (boundary rows only)
+    const int* parent;
+    const int* child[2];        // left / right
+    const long long* linvoff;   // doubles, [ntree+1]
+    double* F;
+    double* Linv;
+};
+
+// ------------------------------------------------------------------------------------------ assembly
+// one wave per element; lane j evaluates column j of K_e (operator applied to e_j) and adds its
+// lower-triangle entries into the element's leaf front.  Masked (strong-BC) rows/columns are skipped.
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(64)
+k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, FrontDev fd, const int* __restrict__ elem_front,
+                 const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x;
+    const int j = threadIdx.x;
+    if (e >= m.nel || j >= LD) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double xe[LD], ye[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        xe[i] = (i == j) ? 1.0 : 0.0;
+        ye[i] = 0.0;
+    }
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        double d[NPC][2], mm[NVC][2];
+        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
+        Mat mat, ex;
+        material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+        const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
+        const Gen t = stress_of(s, mat);
+        strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+    }
+    const int t = elem_front[e];
+    const int nf = fd.nf[t];
+    double* F = fd.F + fd.foff[t];
+    const int* map = elem_map + (size_t)e * LD;
+    const int* gd = fd.dofs + fd.doff[t];
+    const int pj = map[j];
+    if (mask && mask[gd[pj]]) return;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        const int pi = map[i];
+        if (pi >= pj && !(mask && mask[gd[pi]])) atomicAdd(&F[pi + (size_t)nf * pj], ye[i]);
+    }
+}
+
+// penalty facet blocks into the leaf front of the facet's element
+__global__ void k_front_penalty(FacetDev pf, FrontDev fd, const int* __restrict__ elem_front, const int* __restrict__ elem_map,
+                                int ld, int npc, int nvc, const unsigned char* __restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pf.nf) return;
+    const int e = pf.cell[i], k = pf.ledge[i];
+    const int t = elem_front[e];
+    const int nf = fd.nf[t];
+    double* F = fd.F + fd.foff[t];
+    const int* map = elem_map + (size_t)e * ld;
+    const int* gd = fd.dofs + fd.doff[t];
+    const int kb = (k + 1) % nvc;
+    const int un[3] = {k, nvc + k, kb};          // element-local P2 nodes (a, mid, b)
+    const int vn[2] = {k, kb};                   // element-local vertices
+    for (int c = 0; c < 3; ++c) {
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const int pa = map[3 * un[a] + c], pb = map[3 * un[b] + c];
+                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]]))) atomicAdd(&F[pa + (size_t)nf * pb], pf.M2[9 * i + 3 * a + b]);
+            }
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const int pa = map[3 * npc + 3 * vn[a] + c], pb = map[3 * npc + 3 * vn[b] + c];
+                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]]))) atomicAdd(&F[pa + (size_t)nf * pb], pf.M1[4 * i + 2 * a + b]);
+            }
+    }
+}
+
+// unit diagonal for masked pivots (their rows / columns were skipped during assembly)
+__global__ void k_front_mask_diag(FrontDev fd, const unsigned char* __restrict__ mask) {
+    const int t = blockIdx.x;
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    for (int p = threadIdx.x; p < np; p += blockDim.x)
+        if (mask[gd[p]]) F[p + (size_t)nf * p] = 1.0;
+}
+
+// parent front += child's Schur complement (one child side per launch -> no write conflicts)
+__global__ void __launch_bounds__(256)
+k_extend_add(FrontDev fd, const int* __restrict__ level_nodes, int side) {
+    const int p = level_nodes[blockIdx.y];
+    const int c = fd.child[side][p];
+    if (c < 0) return;
+    const int nfc = fd.nf[c], npc = fd.npiv[c];
+    const int nb = nfc - npc;
+    const int nt = (nb + TS - 1) / TS;
+    // lower-triangle tile (ti >= tj) from the linear index
+    const int lin = blockIdx.x;
+    if (lin >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+    while (ti * (ti + 1) / 2 > lin) --ti;
+    const int tj = lin - ti * (ti + 1) / 2;
+    const int nfp = fd.nf[p];
+    double* Fp = fd.F + fd.foff[p];
+    const double* Fc = fd.F + fd.foff[c];
+    const int* up = fd.upmap + fd.doff[c] + npc;
+    const int r0 = ti * TS, c0 = tj * TS;
+    for (int idx = threadIdx.x; idx < TS * TS; idx += blockDim.x) {
+        const int lr = idx % TS, lc = idx / TS;
+        const int r = r0 + lr, cc = c0 + lc;
+        if (r < nb && cc <= r) {
+            const double v = Fc[(npc + r) + (size_t)nfc * (npc + cc)];
+            int pr = up[r], pc = up[cc];
+            if (pr < pc) { const int tmp = pr; pr = pc; pc = tmp; }
+            Fp[pr + (size_t)nfp * pc] += v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ factorisation
+// P0: Cholesky of the diagonal block of panel k and its inverse; one wave per front.
+__global__ void __launch_bounds__(64)
+k_chol_diag(FrontDev fd, const int* __restrict__ level_nodes, int k, int* __restrict__ info) {
+    const int t = level_nodes[blockIdx.x];
+    const int np = fd.npiv[t];
+    const int c0 = k * NB;
+    if (c0 >= np) return;
+    const int wb = min(NB, np - c0);
+    const int nf = fd.nf[t];
+    double* F = fd.F + fd.foff[t];
+    __shared__ double a[NB][NB + 1];
+    __shared__ double li[NB][NB + 1];
+    const int lane = threadIdx.x;
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+        const int r = idx % NB, c = idx / NB;
+        a[r][c] = (r < wb && c < wb && c <= r) ? F[(c0 + r) + (size_t)nf * (c0 + c)] : (r == c ? 1.0 : 0.0);
+        li[r][c] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < wb; ++j) {
+        double d = a[j][j];
+        if (!(d > 0.0)) {                       // not positive definite in floating point
+            if (lane == 0) atomicAdd(info, 1);
+            d = fabs(d) > 1e-300 ? fabs(d) : 1.0;
+        }
+        d = sqrt(d);
+        __syncthreads();
+        if (lane == 0) a[j][j] = d;
+        for (int r = j + 1 + lane; r < wb; r += 64) a[r][j] /= d;
+        __syncthreads();
+        // trailing update of the block: (r, c) with j < c <= r
+        const int n = wb - j - 1;
+        for (int idx = lane; idx < n * n; idx += 64) {
+            const int r = j + 1 + idx % n, c = j + 1 + idx / n;
+            if (c <= r) a[r][c] -= a[r][j] * a[c][j];
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular block, one column per lane
+    if (lane < wb) {
+        const int c = lane;
+        li[c][c] = 1.0 / a[c][c];
+        for (int r = c + 1; r < wb; ++r) {
+            double s = 0.0;
+            for (int mm = c; mm < r; ++mm) s += a[r][mm] * li[mm][c];
+            li[r][c] = -s / a[r][r];
+        }
+    }
+    __syncthreads();
+    double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+    for (int idx = lane; idx < NB * NB; idx += 64) {
+        const int r = idx % NB, c = idx / NB;
+        if (r < wb && c < wb && c <= r) F[(c0 + r) + (size_t)nf * (c0 + c)] = a[r][c];
+        Li[r + NB * c] = (r < wb && c < wb) ? li[r][c] : 0.0;
+    }
+}
+
+// P1: rows below the diagonal block:  L_ik = A_ik * Linv_kk^T ; 64 rows per workgroup
+__global__ void __launch_bounds__(256)
+k_panel_trsm(FrontDev fd, const int* __restrict__ level_nodes, int k) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t];
+    const int c0 = k * NB;
+    if (c0 >= np) return;
+    const int wb = min(NB, np - c0);
+    const int nf = fd.nf[t];
+    const int r0 = c0 + wb + blockIdx.x * TS;
+    if (r0 >= nf) return;
+    double* F = fd.F + fd.foff[t];
+    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+    __shared__ double sl[NB][NB + 1];
+    __shared__ double sa[NB][TS + 1];     // [col][row]
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) sl[idx % NB][idx / NB] = Li[idx];
+    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
+        const int r = idx % TS, c = idx / TS;
+        sa[c][r] = (r0 + r < nf && c < wb) ? F[(r0 + r) + (size_t)nf * (c0 + c)] : 0.0;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
+        const int r = idx % TS, c = idx / TS;
+        if (r0 + r < nf && c < wb) {
+            double s = 0.0;
+            for (int mm = 0; mm <= c; ++mm) s += sa[mm][r] * sl[c][mm];
+            F[(r0 + r) + (size_t)nf * (c0 + c)] = s;
+        }
+    }
+}
+
+// P2: trailing update  A_ij -= L_ik L_jk^T  on lower-triangle 64x64 tiles, 256 threads, 4x4 per thread
+__global__ void __launch_bounds__(256)
+k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int k) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t];
+    const int c0 = k * NB;
+    if (c0 >= np) return;
+    const int wb = min(NB, np - c0);
+    const int nf = fd.nf[t];
+    const int base = c0 + wb;
+    const int nrem = nf - base;
+    if (nrem <= 0) return;
+    const int nt = (nrem + TS - 1) / TS;
+    const int lin = blockIdx.x;
+    if (lin >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+    while (ti * (ti + 1) / 2 > lin) --ti;
+    const int tj = lin - ti * (ti + 1) / 2;
+    double* F = fd.F + fd.foff[t];
+    const int ri = base + ti * TS, rj = base + tj * TS;
+    __shared__ double si[NB][TS];
+    __shared__ double sj[NB][TS];
+    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
+        const int r = idx % TS, c = idx / TS;
+        si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (c0 + c)] : 0.0;
+        sj[c][r] = (rj + r < nf && c < wb) ? F[(rj + r) + (size_t)nf * (c0 + c)] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;   // rows 4*tx.., cols 4*ty..
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int mm = 0; mm < wb; ++mm) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            av[a] = si[mm][4 * tx + a];
+            bv[a] = sj[mm][4 * ty + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int cc = rj + 4 * ty + b;
+        if (cc >= nf) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int r = ri + 4 * tx + a;
+            if (r < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ solves
+// forward substitution L y = b on one level (children before parents); v is overwritten in place
+__global__ void __launch_bounds__(256)
+k_front_fwd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+    const int t = level_nodes[blockIdx.x];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    extern __shared__ double sh[];
+    double* y = sh;            // np
+    double* yk = sh + np;      // NB
+    for (int p = threadIdx.x; p < np; p += blockDim.x) y[p] = v[gd[p]];
+    __syncthreads();
+    const int npan = (np + NB - 1) / NB;
+    for (int k = 0; k < npan; ++k) {
+        const int c0 = k * NB, wb = min(NB, np - c0);
+        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+        if (threadIdx.x < wb) {
+            const int r = threadIdx.x;
+            double s = 0.0;
+            for (int mm = 0; mm <= r; ++mm) s += Li[r + NB * mm] * y[c0 + mm];
+            yk[r] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < wb) y[c0 + threadIdx.x] = yk[threadIdx.x];
+        for (int r = c0 + wb + threadIdx.x; r < np; r += blockDim.x) {
+            double s = 0.0;
+            for (int mm = 0; mm < wb; ++mm) s += F[r + (size_t)nf * (c0 + mm)] * yk[mm];
+            y[r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int p = threadIdx.x; p < np; p += blockDim.x) v[gd[p]] = y[p];
+    for (int r = np + threadIdx.x; r < nf; r += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < np; ++c) s += F[r + (size_t)nf * c] * y[c];
+        atomicAdd(&v[gd[r]], -s);
+    }
+}
+
+// backward substitution L^T x = y on one level (parents before children)
+__global__ void __launch_bounds__(256)
+k_front_bwd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+    const int t = level_nodes[blockIdx.x];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    extern __shared__ double sh[];
+    double* x = sh;            // nf
+    double* sk = sh + nf;      // NB
+    for (int p = threadIdx.x; p < nf; p += blockDim.x) x[p] = v[gd[p]];
+    __syncthreads();
+    const int npan = (np + NB - 1) / NB;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = npan - 1; k >= 0; --k) {
+        const int c0 = k * NB, wb = min(NB, np - c0);
+        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+        // s_c = y_c - sum_{r >= c0+wb} L[r][c] x[r]
+        for (int c = wid; c < wb; c += nw) {
+            double s = 0.0;
+            const double* col = F + (size_t)nf * (c0 + c);
+            for (int r = c0 + wb + lane; r < nf; r += 64) s += col[r] * x[r];
+            s = wave_sum(s);
+            if (lane == 0) sk[c] = x[c0 + c] - s;
+        }
+        __syncthreads();
+        // x_k = Linv^T s
+        if (threadIdx.x < wb) {
+            const int c = threadIdx.x;
+            double s = 0.0;
+            for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
+            x[c0 + c] = s;
+        }
+        __syncthreads();
+    }
+    for (int p = threadIdx.x; p < np; p += blockDim.x) v[gd[p]] = x[p];
+}
+
+}  // namespace femo

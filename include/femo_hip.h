@@ -83,7 +83,26 @@ int femo_diagonal(femo_ctx* ctx, double* d);
  * (what FFCx's tabulate_tensor produces for derivative(residual, w)). */
 int femo_element_matrices(femo_ctx* ctx, int32_t first, int32_t count, double* Ke);
 
-/* Solver configuration. preconditioner: 0 = Jacobi, 1 = node-block Jacobi.
+/* Multifrontal Cholesky preconditioner: upload the symbolic analysis (elimination tree of a nested
+ * dissection of the elements, fronts, index maps -- femo_alpha_amd/solver/symbolic.py).  Plays the part
+ * of MUMPS' analysis phase behind setUpKSP_MUMPS (fea/utils_dolfinx.py:514-531).  Arrays: per tree node
+ * nf, npiv, parent, left, right; front_off (ntree+1, doubles), dof_off (ntree+1); front_dofs / up_map
+ * (dof_off[ntree] entries); level_off (nlevels+1) into level_nodes (ntree, children before parents);
+ * elem_front (nel) and elem_map (nel*ldof) place every element matrix in its leaf front. */
+int femo_set_frontal_plan(femo_ctx* ctx, int32_t ntree, int32_t nlevels, const int32_t* nf, const int32_t* npiv,
+                          const int64_t* front_off, const int64_t* dof_off, const int32_t* front_dofs,
+                          const int32_t* up_map, const int32_t* parent, const int32_t* left, const int32_t* right,
+                          const int32_t* level_off, const int32_t* level_nodes, const int32_t* elem_front,
+                          const int32_t* elem_map);
+/* Numeric factorisation for the current fields (also run lazily by the solves when preconditioner == 2):
+ * element matrices -> leaf fronts -> batched partial Cholesky level by level.  Replaces ksp.setUp() with
+ * PC 'lu' / MUMPS (fea/utils_dolfinx.py:495-531). */
+int femo_factorize(femo_ctx* ctx);
+/* out6: [0] front assembly ms, [1] factorisation ms, [2] front storage GB, [3] factor GFLOP,
+ *       [4] non-positive pivots repaired, [5] number of fronts. */
+int femo_frontal_info(const femo_ctx* ctx, double* out6);
+
+/* Solver configuration. preconditioner: 0 = Jacobi, 2 = multifrontal Cholesky (needs a frontal plan).
  * check_every: convergence is polled on the host every this many PCG iterations. */
 int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxit, int32_t check_every);
 

@@ -131,3 +131,31 @@ def test_errors_are_loud():
         c.dfunctional("compliance", "uhat")
     c.set_field("thickness", np.array([0.1]))               # broadcast of a length-1 array
     assert np.all(c.get_field("thickness") == 0.1)
+
+
+@pytest.mark.parametrize("kind,ewm,bc,uhat", [("plate", False, "penalty", False), ("warped", True, "strong", False),
+                                              ("warped", False, "penalty", True), ("tri", False, "penalty", False)])
+def test_multifrontal_preconditioner(kind, ewm, bc, uhat):
+    """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
+    the same parity triple as the reference's direct (MUMPS LU) solve."""
+    m, o, c, rng = _pair(kind, ewm=ewm, bc=bc, uhat=uhat)
+    plan = c.enable_frontal(leaf_size=8)
+    assert plan.ntree > 1
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    info = c.factorize()
+    assert info["pivots_repaired"] == 0
+    w_ref, J_ref, dJ_ref = o.forward_adjoint()
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 6 and rr <= 1e-12
+    assert rel(c.get_state(), w_ref) < 1e-8
+    # 1e-8: the oracle's own LU solve of the 1e15-penalised system is only good to ~1e-9
+    assert abs(c.functional("compliance") - J_ref) < 1e-8 * abs(J_ref)
+    dJ, it2, rr2 = c.total_gradient("compliance", "thickness")
+    assert it2 <= 6
+    assert rel(dJ, dJ_ref) < 1e-8
+    # the factorisation is refreshed when a field changes
+    c.set_field("thickness", 1.1 * c.get_field("thickness"))
+    it3, rr3 = c.solve_state(zero_guess=True)
+    assert it3 <= 6 and rr3 <= 1e-12
+    o.set_fields(h=1.1 * o.h)
+    assert rel(c.get_state(), o.solve()) < 1e-8
