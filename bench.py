@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# fp64 peak: the guide lists FP32 vector/matrix = 157.3 TFLOP/s (64 FLOP/clk/SIMD); CDNA4 runs fp64 FMA and
+# v_mfma_f64_16x16x4_f64 at half that rate -> 78.6 TFLOP/s (MI355X datasheet: FP64 vector = FP64 matrix = 78.6)
+FP64_PEAK_TFLOPS = 78.6
 
 
 def make_workload(name):
@@ -67,7 +70,7 @@ def cpu_baseline(sample_mesh, fields_fn, marker, repeats=1):
     g = o.dcompliance_dh(w) - o.dRdfield_T("h", w, lam)
     t2 = time.perf_counter()
     return dict(value=sample_mesh.ndof / (t1 - t0), unit="DOF/s", cores=1, kind="port",
-                sample=f"{sample_mesh.nel}-cell plate, {sample_mesh.ndof} DOF: numpy element assembly + scipy SuperLU "
+                sample=f"{sample_mesh.nel}-cell sample of the workload, {sample_mesh.ndof} DOF: numpy element assembly + scipy SuperLU "
                        f"factor + 2 solves = {t1 - t0:.1f} s; adjoint gradient {t2 - t1:.1f} s",
                 adjoint_ms=(t2 - t1) * 1e3)
 
@@ -77,8 +80,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "plate250k"))
-    ap.add_argument("--rtol", type=float, default=1e-9)
+    ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "wing1m"))
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
+    ap.add_argument("--leaf", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,7 +105,11 @@ def main():
     for k, v in fields.items():
         ctx.set_field(k, v)
     ctx.set_penalty_facets(m.penalty_facets(marker))
-    ctx.set_solver(rtol=args.rtol, maxit=400000, check_every=200)
+    if args.solver == "frontal":
+        ctx.enable_frontal(args.leaf)                       # symbolic analysis: mesh only, outside the timed region
+        ctx.set_solver(preconditioner=2, rtol=args.rtol, maxit=50, check_every=1)
+    else:
+        ctx.set_solver(rtol=args.rtol, maxit=400000, check_every=200)
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,7 +117,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    thickness = ctx.get_field("thickness")
+
     def step():
+        # a new design: the thickness upload marks the operator set-up (factorisation / diagonal) stale
+        ctx.set_field("thickness", thickness)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         it, rr = ctx.solve_state(zero_guess=True)
         t1 = time.perf_counter()
@@ -130,7 +144,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_total, t_fwd, t_adj = tt.tolist()
 
-    # dominant kernel: the matrix-free element operator (one launch per PCG iteration)
+    # the matrix-free element operator (the SpMV of the north star), HIP events around back-to-back launches
     apply_ms = ctx.bench_kernel("apply", 100)
     alg_bytes = 16.0 * m.ndof + 340.0 * m.nel          # SURVEY.md section 8d, B_spmv,ebe per launch
     achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
@@ -138,6 +152,21 @@ def main():
     pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("apply_hbm_bytes_per_launch")
+    roof_spmv = {"bound": "hbm", "kernel": "k_apply (matrix-free CG2xCG1 shell operator)",
+                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms}
+    roof = roof_spmv
+    prof = None
+    if args.solver == "frontal":
+        # dominant kernel of the frontal path: the trailing update of the partial Cholesky (fp64 rank-32 updates);
+        # one instrumented factorisation with a HIP event pair around every launch on the context's stream
+        prof = ctx.factorize_profile()
+        tr = prof["trailing"]
+        tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "k_trailing (fp64 trailing update of the multifrontal Cholesky)",
+                "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
+                "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}
 
     if rank == 0:
         out = {
@@ -156,23 +185,33 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
-                       "solver": "Jacobi-PCG, matrix-free element-by-element operator", "rtol": args.rtol,
+                       "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
+                                  f"(nested dissection, leaf {args.leaf})" if args.solver == "frontal"
+                                  else "Jacobi-PCG, matrix-free element-by-element operator"), "rtol": args.rtol,
                        "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
                        "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],
                        "parallelism": "replicas" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_apply (matrix-free CG2xCG1 shell operator)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": apply_ms},
+            "roofline": roof,
+            "roofline_spmv": roof_spmv,
         }
+        if prof is not None:
+            out["factorisation_profile_ms"] = {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)}
+            out["frontal"] = {k: (float(v) if not isinstance(v, int) else v) for k, v in ctx.frontal_info().items()}
         if not args.no_cpu_baseline and world == 1:
-            from femo_alpha_amd.mesh import plate_mesh
-            sample = plate_mesh(2.0, 10.0, 29, 145)
-            def sample_fields(sm):
-                rng = np.random.default_rng(0)
-                return dict(h=0.1 * (1 + 0.2 * rng.uniform(-1, 1, sm.nn)), E=1e8, nu=0.3, rho=10.0,
-                            f=np.tile([0.0, 0.0, 5.0], (sm.nn, 1)))
-            out["cpu_baseline"] = cpu_baseline(sample, sample_fields, lambda x: np.less(x[0], 3e-16))
+            from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
+            if args.workload == "wing1m":
+                sample = wing_skin_mesh(29, 145)            # same surface, 1/16 of the cells
+                def sample_fields(sm):
+                    return dict(h=1.27e-3, E=73.1e9, nu=0.33, rho=2780.0,
+                                f=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (sm.nn, 1)))
+                out["cpu_baseline"] = cpu_baseline(sample, sample_fields, lambda x: np.less(x[1], 1e-9))
+            else:
+                sample = plate_mesh(2.0, 10.0, 29, 145)
+                def sample_fields(sm):
+                    rng = np.random.default_rng(0)
+                    return dict(h=0.1 * (1 + 0.2 * rng.uniform(-1, 1, sm.nn)), E=1e8, nu=0.3, rho=10.0,
+                                f=np.tile([0.0, 0.0, 5.0], (sm.nn, 1)))
+                out["cpu_baseline"] = cpu_baseline(sample, sample_fields, lambda x: np.less(x[0], 3e-16))
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -37,6 +37,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int64), _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p,
                                         _c_int32_p, _c_int32_p, _c_int32_p, _c_int32_p]),
     "femo_factorize": (C.c_int, [C.c_void_p]),
+    "femo_factorize_profile": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_frontal_info": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),

@@ -144,6 +144,15 @@ class ShellContext:
         self._chk(self.lib.femo_factorize(self._h))
         return self.frontal_info()
 
+    def factorize_profile(self):
+        """One factorisation timed per kernel class with HIP events on the context's stream."""
+        t = np.zeros(13)
+        self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)))
+        names = ["chol_diag", "panel_trsm", "trailing", "extend_add", "front_assemble", "memset"]
+        out = {n: dict(ms=t[i], launches=int(t[6 + i])) for i, n in enumerate(names)}
+        out["trailing_flops"] = t[12]
+        return out
+
     def frontal_info(self):
         t = np.zeros(6)
         self._chk(self.lib.femo_frontal_info(self._h, dptr(t)))

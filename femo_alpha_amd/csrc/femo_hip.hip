@@ -58,7 +58,7 @@ struct femo_ctx {
     struct Frontal {
         bool ready = false, factored = false;
         int ntree = 0, nlevels = 0;
-        std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes;
+        std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
         long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr;
@@ -67,6 +67,10 @@ struct femo_ctx {
         int max_nf = 0;
         double t_factor_ms = 0, t_assemble_ms = 0;
         int pivots_fixed = 0;
+        bool profile = false;                 // time every kernel class with HIP events (slower)
+        double prof_ms[6] = {0, 0, 0, 0, 0, 0};   // chol_diag, panel_trsm, trailing, extend_add, assemble, memset
+        long long prof_calls[6] = {0, 0, 0, 0, 0, 0};
+        std::vector<hipEvent_t> pev;
     } fr;
 };
 
@@ -340,16 +344,33 @@ static FrontDev front_dev(const femo_ctx* c) {
     return fd;
 }
 
+// event pair around one launch group when profiling
+struct ProfScope {
+    femo_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(femo_ctx* c_, int cls_) : c(c_), cls(cls_) {
+        if (!c->fr.profile) return;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!c->fr.profile) return;
+        hipEventRecord(b, c->stream);
+        c->fr.pev.push_back(a); c->fr.pev.push_back(b); c->fr.pev.push_back((hipEvent_t)(intptr_t)cls);
+    }
+};
+
 static int frontal_factorize(femo_ctx* c) {
     auto& fr = c->fr;
     if (!fr.ready) return fail(c, "no frontal plan: call femo_set_frontal_plan first");
+    for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; }
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream));
+    { ProfScope ps(c, 5); HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream)); }
     HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
     if (refresh_penalty(c)) return 1;
-    ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask);
+    { ProfScope ps(c, 4);
+    ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask); }
     if (c->nf > 0)
         hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
                            fr.elem_map, c->ld, c->npc, c->nvc, mask);
@@ -371,8 +392,8 @@ static int frontal_factorize(femo_ctx* c) {
             }
             const int nt = (max_nb + TS - 1) / TS;
             const dim3 grid(nt * (nt + 1) / 2, cnt);
-            hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 0);
-            hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 1);
+            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 0); }
+            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 1); }
         }
         const int npan = (max_np + NB - 1) / NB;
         for (int k = 0; k < npan; ++k) {
@@ -381,11 +402,11 @@ static int frontal_factorize(femo_ctx* c) {
                 const int t = fr.h_level_nodes[i];
                 if (fr.h_npiv[t] > k * NB) max_rem = std::max(max_rem, fr.h_nf[t] - k * NB - std::min(NB, fr.h_npiv[t] - k * NB));
             }
-            hipLaunchKernelGGL(k_chol_diag, dim3(cnt), dim3(64), 0, c->stream, fd, lev, k, fr.info);
+            { ProfScope ps(c, 0); hipLaunchKernelGGL(k_chol_diag, dim3(cnt), dim3(64), 0, c->stream, fd, lev, k, fr.info); }
             if (max_rem > 0) {
                 const int nrb = (max_rem + TS - 1) / TS;
-                hipLaunchKernelGGL(k_panel_trsm, dim3(nrb, cnt), dim3(256), 0, c->stream, fd, lev, k);
-                hipLaunchKernelGGL(k_trailing, dim3(nrb * (nrb + 1) / 2, cnt), dim3(256), 0, c->stream, fd, lev, k);
+                { ProfScope ps(c, 1); hipLaunchKernelGGL(k_panel_trsm, dim3(nrb, cnt), dim3(256), 0, c->stream, fd, lev, k); }
+                { ProfScope ps(c, 2); hipLaunchKernelGGL(k_trailing, dim3(nrb * (nrb + 1) / 2, cnt), dim3(256), 0, c->stream, fd, lev, k); }
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -399,6 +420,14 @@ static int frontal_factorize(femo_ctx* c) {
     hipEventElapsedTime(&tf, c->ev[3], c->ev[0]);
     fr.t_assemble_ms = ta; fr.t_factor_ms = tf; fr.pivots_fixed = info;
     fr.factored = true;
+    for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, fr.pev[i], fr.pev[i + 1]);
+        const int cls = (int)(intptr_t)fr.pev[i + 2];
+        fr.prof_ms[cls] += ms; fr.prof_calls[cls] += 1;
+        hipEventDestroy(fr.pev[i]); hipEventDestroy(fr.pev[i + 1]);
+    }
+    fr.pev.clear();
     return 0;
 }
 
@@ -406,14 +435,21 @@ static int frontal_factorize(femo_ctx* c) {
 static int frontal_solve(femo_ctx* c, double* v) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
-    const size_t shm = (size_t)(fr.max_nf + NB) * sizeof(double);
     for (int L = 0; L < fr.nlevels; ++L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
-        hipLaunchKernelGGL(k_front_fwd, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+        const size_t shm = (size_t)(fr.h_level_maxnp[L] + NB) * sizeof(double);
+        hipLaunchKernelGGL(k_front_fwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+        if (fr.h_level_maxnb[L] > 0)
+            hipLaunchKernelGGL(k_front_fwd_bnd, dim3((fr.h_level_maxnb[L] + 255) / 256, cnt), dim3(256), 0, c->stream, fd,
+                               fr.level_nodes + b, v);
     }
     for (int L = fr.nlevels - 1; L >= 0; --L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
-        hipLaunchKernelGGL(k_front_bwd, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+        const size_t shm = (size_t)(fr.h_level_maxnp[L] + NB) * sizeof(double);
+        if (fr.h_level_maxnb[L] > 0)
+            hipLaunchKernelGGL(k_front_bwd_bnd, dim3((fr.h_level_maxnp[L] + 3) / 4, cnt), dim3(256), 0, c->stream, fd,
+                               fr.level_nodes + b, v);
+        hipLaunchKernelGGL(k_front_bwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1012,6 +1048,14 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         for (int i = 0; i < c->ld; ++i)
             if (elem_map[e * c->ld + i] < 0 || elem_map[e * c->ld + i] >= nf[t]) return fail(c, "elem_map out of range");
     }
+    fr.h_level_maxnp.assign(nlevels, 0); fr.h_level_maxnb.assign(nlevels, 0);
+    for (int L = 0; L < nlevels; ++L)
+        for (int i = level_off[L]; i < level_off[L + 1]; ++i) {
+            const int t = level_nodes[i];
+            if (t < 0 || t >= ntree) return fail(c, "level_nodes out of range");
+            fr.h_level_maxnp[L] = std::max(fr.h_level_maxnp[L], npiv[t]);
+            fr.h_level_maxnb[L] = std::max(fr.h_level_maxnb[L], nf[t] - npiv[t]);
+        }
     fr.f_doubles = front_off[ntree];
     fr.linv_doubles = linvoff[ntree];
 #define UPI(dst, src, n) do { HIPCHK(c, hipMalloc((void**)&dst, std::max<size_t>((size_t)(n), 1) * sizeof(*dst))); \
@@ -1030,8 +1074,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
     if ((size_t)(fr.max_nf + NB) * sizeof(double) > 48 * 1024) {
         const int bytes = (int)((fr.max_nf + NB) * sizeof(double));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_piv, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_piv, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     fr.ready = true;
     fr.factored = false;
@@ -1047,6 +1091,28 @@ int femo_factorize(femo_ctx* c) {
 
 /* out6: [0] element-matrix assembly into fronts (ms), [1] numeric factorisation (ms), [2] front storage (GB),
  *       [3] factor flops (GFLOP, from the plan sizes), [4] number of non-positive pivots repaired, [5] fronts */
+/* Run one factorisation with a HIP event pair around every kernel launch and report, per kernel class
+ * (0 chol_diag, 1 panel_trsm, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
+ * also the algorithmic flop count of the trailing updates (lower triangle only). out13 = ms[6], calls[6], flops. */
+int femo_factorize_profile(femo_ctx* c, double* out13) {
+    HIPCHK(c, hipSetDevice(c->device));
+    c->fr.profile = true;
+    int rc = frontal_factorize(c);
+    c->fr.profile = false;
+    if (rc) return rc;
+    for (int i = 0; i < 6; ++i) { out13[i] = c->fr.prof_ms[i]; out13[6 + i] = (double)c->fr.prof_calls[i]; }
+    double fl = 0;
+    for (int t = 0; t < c->fr.ntree; ++t) {
+        const int np = c->fr.h_npiv[t], nf = c->fr.h_nf[t];
+        for (int c0 = 0; c0 < np; c0 += NB) {
+            const double wb = std::min(NB, np - c0), rem = nf - c0 - wb;
+            fl += wb * rem * (rem + 1.0);
+        }
+    }
+    out13[12] = fl;
+    return 0;
+}
+
 int femo_frontal_info(const femo_ctx* c, double* out6) {
     const auto& fr = c->fr;
     double fl = 0;

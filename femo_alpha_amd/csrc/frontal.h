@@ -301,9 +301,14 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int k) {
 }
 
 // ------------------------------------------------------------------------------------------ solves
-// forward substitution L y = b on one level (children before parents); v is overwritten in place
+// M^-1 = L^-T L^-1 applied level by level.  Each sweep is split per level into a sequential part on
+// the triangular pivot block L11 (one workgroup per front, panels chained through the stored diagonal
+// block inverses) and a wide part on the rectangular block L21 (plain / transposed GEMV spread over
+// many workgroups), which holds most of the factor's bytes.
+
+// forward, part A: y_p = L11^-1 v_p for every front of the level (v overwritten in place)
 __global__ void __launch_bounds__(256)
-k_front_fwd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const double* F = fd.F + fd.foff[t];
@@ -333,40 +338,73 @@ k_front_fwd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict
         __syncthreads();
     }
     for (int p = threadIdx.x; p < np; p += blockDim.x) v[gd[p]] = y[p];
-    for (int r = np + threadIdx.x; r < nf; r += blockDim.x) {
-        double s = 0.0;
-        for (int c = 0; c < np; ++c) s += F[r + (size_t)nf * c] * y[c];
-        atomicAdd(&v[gd[r]], -s);
-    }
 }
 
-// backward substitution L^T x = y on one level (parents before children)
+// forward, part B: v_B -= L21 y_p ; 256 boundary rows per workgroup, y_p staged in LDS in chunks
 __global__ void __launch_bounds__(256)
-k_front_bwd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int r = np + blockIdx.x * 256 + threadIdx.x;
+    if (np + blockIdx.x * 256 >= nf) return;
+    const double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    __shared__ double ys[256];
+    double s = 0.0;
+    for (int c0 = 0; c0 < np; c0 += 256) {
+        const int w = min(256, np - c0);
+        __syncthreads();
+        if (threadIdx.x < w) ys[threadIdx.x] = v[gd[c0 + threadIdx.x]];
+        __syncthreads();
+        if (r < nf) {
+            const double* col = F + r + (size_t)nf * c0;
+            for (int c = 0; c < w; ++c) s += col[(size_t)nf * c] * ys[c];
+        }
+    }
+    if (r < nf) atomicAdd(&v[gd[r]], -s);
+}
+
+// backward, part A: s_c = y_c - sum_{r in boundary} L21[r][c] x[r] ; one wave per pivot column, 4 per workgroup
+__global__ void __launch_bounds__(256)
+k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wid;
+    if (c >= np || nf == np) return;
+    const double* col = fd.F + fd.foff[t] + (size_t)nf * c;
+    const int* gd = fd.dofs + fd.doff[t];
+    double s = 0.0;
+    for (int r = np + lane; r < nf; r += 64) s += col[r] * v[gd[r]];
+    s = wave_sum(s);
+    if (lane == 0) v[gd[c]] -= s;
+}
+
+// backward, part B: x_p = L11^-T s_p
+__global__ void __launch_bounds__(256)
+k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
-    double* x = sh;            // nf
-    double* sk = sh + nf;      // NB
-    for (int p = threadIdx.x; p < nf; p += blockDim.x) x[p] = v[gd[p]];
+    double* x = sh;            // np
+    double* sk = sh + np;      // NB
+    for (int p = threadIdx.x; p < np; p += blockDim.x) x[p] = v[gd[p]];
     __syncthreads();
     const int npan = (np + NB - 1) / NB;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = npan - 1; k >= 0; --k) {
         const int c0 = k * NB, wb = min(NB, np - c0);
         const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-        // s_c = y_c - sum_{r >= c0+wb} L[r][c] x[r]
         for (int c = wid; c < wb; c += nw) {
             double s = 0.0;
             const double* col = F + (size_t)nf * (c0 + c);
-            for (int r = c0 + wb + lane; r < nf; r += 64) s += col[r] * x[r];
+            for (int r = c0 + wb + lane; r < np; r += 64) s += col[r] * x[r];
             s = wave_sum(s);
             if (lane == 0) sk[c] = x[c0 + c] - s;
         }
         __syncthreads();
-        // x_k = Linv^T s
         if (threadIdx.x < wb) {
             const int c = threadIdx.x;
             double s = 0.0;
