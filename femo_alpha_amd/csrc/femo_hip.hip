@@ -431,25 +431,46 @@ static int frontal_factorize(femo_ctx* c) {
     return 0;
 }
 
-// v <- (L L^T)^-1 v
+// v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
+static const int WIDE_NP = 192;    // levels whose largest pivot block exceeds this use the panel-parallel kernels
 static int frontal_solve(femo_ctx* c, double* v) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
+    double* y = c->tmp;
     for (int L = 0; L < fr.nlevels; ++L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
-        const size_t shm = (size_t)(fr.h_level_maxnp[L] + NB) * sizeof(double);
-        hipLaunchKernelGGL(k_front_fwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
-        if (fr.h_level_maxnb[L] > 0)
-            hipLaunchKernelGGL(k_front_fwd_bnd, dim3((fr.h_level_maxnb[L] + 255) / 256, cnt), dim3(256), 0, c->stream, fd,
-                               fr.level_nodes + b, v);
+        const int* lev = fr.level_nodes + b;
+        const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnp > WIDE_NP) {
+            const int npan = (maxnp + NB - 1) / NB;
+            for (int k = 0; k < npan; ++k) {
+                const int rows = maxnp + maxnb - k * NB;          // upper bound of rows below the panel
+                hipLaunchKernelGGL(k_front_fwd_panel, dim3(std::max(1, (rows + 255) / 256), cnt), dim3(256), 0, c->stream, fd, lev,
+                                   k, v, y);
+            }
+        } else {
+            const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
+            hipLaunchKernelGGL(k_front_fwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
+            if (maxnb > 0)
+                hipLaunchKernelGGL(k_front_fwd_bnd, dim3((maxnb + 255) / 256, cnt), dim3(256), 0, c->stream, fd, lev, v, y);
+        }
     }
+    // backward: y is consumed in place (running right-hand side), x lands in v
     for (int L = fr.nlevels - 1; L >= 0; --L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
-        const size_t shm = (size_t)(fr.h_level_maxnp[L] + NB) * sizeof(double);
-        if (fr.h_level_maxnb[L] > 0)
-            hipLaunchKernelGGL(k_front_bwd_bnd, dim3((fr.h_level_maxnp[L] + 3) / 4, cnt), dim3(256), 0, c->stream, fd,
-                               fr.level_nodes + b, v);
-        hipLaunchKernelGGL(k_front_bwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, fr.level_nodes + b, v);
+        const int* lev = fr.level_nodes + b;
+        const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnb > 0)
+            hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + 3) / 4, cnt), dim3(256), 0, c->stream, fd, lev, y, v);
+        if (maxnp > WIDE_NP) {
+            const int npan = (maxnp + NB - 1) / NB;
+            for (int k = npan - 1; k >= 0; --k)
+                hipLaunchKernelGGL(k_front_bwd_panel, dim3(std::max(1, (k * NB + 255) / 256), cnt), dim3(256), 0, c->stream, fd, lev,
+                                   k, y, v);
+        } else {
+            const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
+            hipLaunchKernelGGL(k_front_bwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return 0;

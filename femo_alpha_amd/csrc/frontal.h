@@ -306,9 +306,9 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int k) {
 // block inverses) and a wide part on the rectangular block L21 (plain / transposed GEMV spread over
 // many workgroups), which holds most of the factor's bytes.
 
-// forward, part A: y_p = L11^-1 v_p for every front of the level (v overwritten in place)
+// forward, part A: y_p = L11^-1 v_p for every front of the level; y goes to yv
 __global__ void __launch_bounds__(256)
-k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ v, double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const double* F = fd.F + fd.foff[t];
@@ -337,12 +337,12 @@ k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
         }
         __syncthreads();
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) v[gd[p]] = y[p];
+    for (int p = threadIdx.x; p < np; p += blockDim.x) yv[gd[p]] = y[p];
 }
 
 // forward, part B: v_B -= L21 y_p ; 256 boundary rows per workgroup, y_p staged in LDS in chunks
 __global__ void __launch_bounds__(256)
-k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v, const double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const int r = np + blockIdx.x * 256 + threadIdx.x;
@@ -354,7 +354,7 @@ k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
     for (int c0 = 0; c0 < np; c0 += 256) {
         const int w = min(256, np - c0);
         __syncthreads();
-        if (threadIdx.x < w) ys[threadIdx.x] = v[gd[c0 + threadIdx.x]];
+        if (threadIdx.x < w) ys[threadIdx.x] = yv[gd[c0 + threadIdx.x]];
         __syncthreads();
         if (r < nf) {
             const double* col = F + r + (size_t)nf * c0;
@@ -366,7 +366,7 @@ k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
 
 // backward, part A: s_c = y_c - sum_{r in boundary} L21[r][c] x[r] ; one wave per pivot column, 4 per workgroup
 __global__ void __launch_bounds__(256)
-k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -375,14 +375,14 @@ k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
     const double* col = fd.F + fd.foff[t] + (size_t)nf * c;
     const int* gd = fd.dofs + fd.doff[t];
     double s = 0.0;
-    for (int r = np + lane; r < nf; r += 64) s += col[r] * v[gd[r]];
+    for (int r = np + lane; r < nf; r += 64) s += col[r] * xv[gd[r]];
     s = wave_sum(s);
-    if (lane == 0) v[gd[c]] -= s;
+    if (lane == 0) sv[gd[c]] -= s;
 }
 
 // backward, part B: x_p = L11^-T s_p
 __global__ void __launch_bounds__(256)
-k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v) {
+k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
     const double* F = fd.F + fd.foff[t];
@@ -390,7 +390,7 @@ k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
     extern __shared__ double sh[];
     double* x = sh;            // np
     double* sk = sh + np;      // NB
-    for (int p = threadIdx.x; p < np; p += blockDim.x) x[p] = v[gd[p]];
+    for (int p = threadIdx.x; p < np; p += blockDim.x) x[p] = sv[gd[p]];
     __syncthreads();
     const int npan = (np + NB - 1) / NB;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -413,7 +413,78 @@ k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
         }
         __syncthreads();
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) v[gd[p]] = x[p];
+    for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
 }
 
+// ---- wide variants for the upper tree levels (few, large fronts): the panel loop runs on the host and
+// every launch spreads one panel's update over many workgroups.  Each workgroup recomputes the 32-vector
+// of the panel from the stored diagonal-block inverse (1k flops) instead of waiting for another one.
+
+// forward panel k:  y_k = Linv_kk v_k -> yv ;  v_r -= L[r, panel k] y_k for all rows r below the panel
+__global__ void __launch_bounds__(256)
+k_front_fwd_panel(FrontDev fd, const int* __restrict__ level_nodes, int k, double* __restrict__ v, double* __restrict__ yv) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int c0 = k * NB;
+    if (c0 >= np) return;
+    const int wb = min(NB, np - c0);
+    const int r0 = c0 + wb + blockIdx.x * 256;
+    if (r0 >= nf && blockIdx.x > 0) return;
+    const double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+    __shared__ double bk[NB], yk[NB];
+    if (threadIdx.x < NB) bk[threadIdx.x] = threadIdx.x < wb ? v[gd[c0 + threadIdx.x]] : 0.0;
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        double s = 0.0;
+        for (int mm = 0; mm <= (int)threadIdx.x; ++mm) s += Li[threadIdx.x + NB * mm] * bk[mm];
+        yk[threadIdx.x] = s;
+        if (blockIdx.x == 0 && threadIdx.x < wb) yv[gd[c0 + threadIdx.x]] = s;
+    }
+    __syncthreads();
+    const int r = r0 + threadIdx.x;
+    if (r < nf) {
+        double s = 0.0;
+        const double* row = F + r + (size_t)nf * c0;
+        for (int mm = 0; mm < wb; ++mm) s += row[(size_t)nf * mm] * yk[mm];
+        if (r < np) v[gd[r]] -= s;
+        else atomicAdd(&v[gd[r]], -s);
+    }
+}
+
+// backward panel k (descending):  x_k = Linv_kk^T s_k -> xv ;  s_j -= L[panel k, j]^T x_k for all columns j < c0
+__global__ void __launch_bounds__(256)
+k_front_bwd_panel(FrontDev fd, const int* __restrict__ level_nodes, int k, double* __restrict__ sv, double* __restrict__ xv) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int c0 = k * NB;
+    if (c0 >= np) return;
+    const int wb = min(NB, np - c0);
+    const int j0 = blockIdx.x * 256;
+    if (j0 >= c0 && blockIdx.x > 0) return;
+    const double* F = fd.F + fd.foff[t];
+    const int* gd = fd.dofs + fd.doff[t];
+    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+    __shared__ double sk[NB], xk[NB];
+    if (threadIdx.x < NB) sk[threadIdx.x] = threadIdx.x < wb ? sv[gd[c0 + threadIdx.x]] : 0.0;
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int c = threadIdx.x;
+        double s = 0.0;
+        for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
+        xk[c] = s;
+        if (blockIdx.x == 0 && c < wb) xv[gd[c0 + c]] = s;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j < c0) {
+        const double* col = F + c0 + (size_t)nf * j;
+        double s = 0.0;
+        for (int i = 0; i < wb; ++i) s += col[i] * xk[i];
+        sv[gd[j]] -= s;
+    }
+}
+
+// backward small-level kernel reads s from sv and writes x to xv
 }  // namespace femo

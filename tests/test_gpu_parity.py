@@ -22,6 +22,8 @@ def rel(a, b):
 def _mesh(kind):
     if kind == "plate":
         return plate_mesh(2.0, 10.0, 4, 12)
+    if kind == "plate24":            # wide enough that the top tree levels take the panel-parallel solve kernels
+        return plate_mesh(2.0, 5.0, 24, 60)
     if kind == "warped":
         return wing_skin_mesh(6, 14, shuffle=True)
     if kind == "tri":
@@ -41,7 +43,7 @@ def _pair(kind, ewm=False, ewp=False, uhat=False, bc="penalty", beta=1e15, seed=
                   F_solid=rng.uniform(-1, 1, (nF, 3)))
     if uhat:
         fields["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
-    marker = CLAMP if kind == "plate" else (lambda x: np.less(x[1], 1e-12))
+    marker = CLAMP if kind.startswith("plate") else (lambda x: np.less(x[1], 1e-12))
     pf = m.penalty_facets(marker) if bc == "penalty" else None
     sd = m.locate_dofs_geometrical(marker) if bc == "strong" else None
     o = ShellOracle(m, element_wise_material=ewm, elementwise_pressure=ewp, penalty_facets=pf, strong_dofs=sd, beta=beta)
@@ -134,13 +136,16 @@ def test_errors_are_loud():
 
 
 @pytest.mark.parametrize("kind,ewm,bc,uhat", [("plate", False, "penalty", False), ("warped", True, "strong", False),
-                                              ("warped", False, "penalty", True), ("tri", False, "penalty", False)])
+                                              ("warped", False, "penalty", True), ("tri", False, "penalty", False),
+                                              ("plate24", False, "penalty", False)])
 def test_multifrontal_preconditioner(kind, ewm, bc, uhat):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
     the same parity triple as the reference's direct (MUMPS LU) solve."""
     m, o, c, rng = _pair(kind, ewm=ewm, bc=bc, uhat=uhat)
     plan = c.enable_frontal(leaf_size=8)
     assert plan.ntree > 1
+    if kind == "plate24":
+        assert plan.npiv.max() > 192
     c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
     info = c.factorize()
     assert info["pivots_repaired"] == 0
