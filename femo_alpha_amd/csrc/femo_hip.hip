@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -68,9 +69,10 @@ struct femo_ctx {
         double t_factor_ms = 0, t_assemble_ms = 0;
         int pivots_fixed = 0;
         bool profile = false;                 // time every kernel class with HIP events (slower)
-        double prof_ms[6] = {0, 0, 0, 0, 0, 0};   // chol_diag, panel_trsm, trailing, extend_add, assemble, memset
+        double prof_ms[6] = {0, 0, 0, 0, 0, 0};   // unused, panel, trailing, extend_add, assemble, memset
         long long prof_calls[6] = {0, 0, 0, 0, 0, 0};
         std::vector<hipEvent_t> pev;
+        int cur_level = 0;
     } fr;
 };
 
@@ -355,7 +357,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!c->fr.profile) return;
         hipEventRecord(b, c->stream);
-        c->fr.pev.push_back(a); c->fr.pev.push_back(b); c->fr.pev.push_back((hipEvent_t)(intptr_t)cls);
+        c->fr.pev.push_back(a); c->fr.pev.push_back(b); c->fr.pev.push_back((hipEvent_t)(intptr_t)(cls + 16 * c->fr.cur_level));
     }
 };
 
@@ -378,6 +380,7 @@ static int frontal_factorize(femo_ctx* c) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     for (int L = 0; L < fr.nlevels; ++L) {
+        fr.cur_level = L;
         const int b = fr.h_level_off[L], e = fr.h_level_off[L + 1];
         const int cnt = e - b;
         const int* lev = fr.level_nodes + b;
@@ -395,18 +398,25 @@ static int frontal_factorize(femo_ctx* c) {
             { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 0); }
             { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 1); }
         }
-        const int npan = (max_np + NB - 1) / NB;
-        for (int k = 0; k < npan; ++k) {
-            int max_rem = 0;
-            for (int i = b; i < e; ++i) {
-                const int t = fr.h_level_nodes[i];
-                if (fr.h_npiv[t] > k * NB) max_rem = std::max(max_rem, fr.h_nf[t] - k * NB - std::min(NB, fr.h_npiv[t] - k * NB));
+        int max_nf = 0;
+        for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
+        // two-level blocking: outer panels of NBO columns (one wide trailing update each), inner panels of NB
+        // factorised left-looking inside the outer panel (one launch each)
+        for (int C0 = 0; C0 < max_np; C0 += NBO) {
+            const int WO = std::min(NBO, max_np - C0);
+            for (int c0 = C0; c0 < C0 + WO; c0 += NB) {
+                // few large fronts: one workgroup per 64-row tile; many small fronts: one workgroup per front looping
+                // over its tiles, so that the redundant diagonal-block factorisation is not multiplied
+                const int rows_below = std::max(0, max_nf - c0 - 1);
+                const int tiles = std::max(1, (rows_below + TS - 1) / TS);
+                const int gx = std::max(1, std::min(tiles, 1024 / cnt));
+                ProfScope ps(c, 1);
+                hipLaunchKernelGGL(k_panel, dim3(gx, cnt), dim3(256), 0, c->stream, fd, lev, C0, c0, fr.info);
             }
-            { ProfScope ps(c, 0); hipLaunchKernelGGL(k_chol_diag, dim3(cnt), dim3(64), 0, c->stream, fd, lev, k, fr.info); }
-            if (max_rem > 0) {
-                const int nrb = (max_rem + TS - 1) / TS;
-                { ProfScope ps(c, 1); hipLaunchKernelGGL(k_panel_trsm, dim3(nrb, cnt), dim3(256), 0, c->stream, fd, lev, k); }
-                { ProfScope ps(c, 2); hipLaunchKernelGGL(k_trailing, dim3(nrb * (nrb + 1) / 2, cnt), dim3(256), 0, c->stream, fd, lev, k); }
+            if (max_nf > C0 + 1) {
+                ProfScope ps(c, 2);
+                const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
+                hipLaunchKernelGGL(k_trailing, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -423,8 +433,10 @@ static int frontal_factorize(femo_ctx* c) {
     for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
         float ms = 0;
         hipEventElapsedTime(&ms, fr.pev[i], fr.pev[i + 1]);
-        const int cls = (int)(intptr_t)fr.pev[i + 2];
+        const int tag = (int)(intptr_t)fr.pev[i + 2];
+        const int cls = tag % 16;
         fr.prof_ms[cls] += ms; fr.prof_calls[cls] += 1;
+        if (getenv("FEMO_PROFILE_VERBOSE")) fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
         hipEventDestroy(fr.pev[i]); hipEventDestroy(fr.pev[i + 1]);
     }
     fr.pev.clear();
@@ -1113,7 +1125,7 @@ int femo_factorize(femo_ctx* c) {
 /* out6: [0] element-matrix assembly into fronts (ms), [1] numeric factorisation (ms), [2] front storage (GB),
  *       [3] factor flops (GFLOP, from the plan sizes), [4] number of non-positive pivots repaired, [5] fronts */
 /* Run one factorisation with a HIP event pair around every kernel launch and report, per kernel class
- * (0 chol_diag, 1 panel_trsm, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
+ * (0 unused, 1 panel, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
  * also the algorithmic flop count of the trailing updates (lower triangle only). out13 = ms[6], calls[6], flops. */
 int femo_factorize_profile(femo_ctx* c, double* out13) {
     HIPCHK(c, hipSetDevice(c->device));

@@ -19,6 +19,7 @@ namespace femo {
 
 constexpr int NB = 32;     // panel width
 constexpr int TS = 64;     // trailing-update tile
+constexpr int NBO = 128;   // outer panel: the wide trailing update applies this many factor columns per pass
 
 struct FrontDev {
     int ntree;
@@ -153,145 +154,211 @@ k_extend_add(FrontDev fd, const int* __restrict__ level_nodes, int side) {
 }
 
 // ------------------------------------------------------------------------------------------ factorisation
-// P0: Cholesky of the diagonal block of panel k and its inverse; one wave per front.
-__global__ void __launch_bounds__(64)
-k_chol_diag(FrontDev fd, const int* __restrict__ level_nodes, int k, int* __restrict__ info) {
-    const int t = level_nodes[blockIdx.x];
+// Cholesky of a 32x32 block and the inverse of its factor, in registers of one wave:
+// lane r < 32 owns row r of the block; pivots and multipliers travel by v_readlane (static lane ids).
+// On return lane r holds row r of L in a[] and lane c holds COLUMN c of L^-1 in x[] (x[r] = Linv[r][c]).
+// Returns the number of non-positive pivots that had to be repaired.
+// broadcast of a double from a compile-time lane: two v_readlane_b32 (a 64-wide __shfl here sends hipcc's
+// optimiser into a compile that does not finish within minutes once the loops below are unrolled)
+__device__ __forceinline__ double rl(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int chol32_inverse(double (&a)[NB], double (&x)[NB], int wb, int lane) {
+    int bad = 0;
+    double idiag[NB];                                   // 1 / L[j][j], wave-uniform
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double d = rl(a[j], j);
+        if (j < wb) {
+            if (!(d > 0.0)) { bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+        } else {
+            d = 1.0;
+        }
+        // 1/sqrt(d): hardware estimate + two Newton steps (no fp64 sqrt / divide expansion on the critical path)
+        double y = __builtin_amdgcn_rsq(d);
+        double e = 1.0 - d * y * y;
+        y = y + 0.5 * y * e;
+        e = 1.0 - d * y * y;
+        y = y + 0.5 * y * e;
+        idiag[j] = y;
+        const double l = (lane == j) ? d * y : a[j] * y;     // column j of L for this lane's row (valid for lane >= j)
+        a[j] = l;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            const double lc = rl(l, c);                       // L[c][j]
+            a[c] -= l * lc;                                   // only entries with c <= row are meaningful
+        }
+    }
+    // X = L^-1: X[r][c] = (delta_rc - sum_{m<r} L[r][m] X[m][c]) / L[r][r]; lane c owns column c of X,
+    // rows of L live in other lanes -> broadcast L[r][m] from lane r.
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        double s = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int mm = 0; mm < r; ++mm) s -= rl(a[mm], r) * x[mm];
+        x[r] = s * idiag[r];
+    }
+    return bad;
+}
+
+// P01: inner panel [c0, c0+32) of the outer panel that starts at C0, for every front of the level
+// (left-looking inside the outer panel, so that one launch per inner panel suffices):
+//   1. apply the factor columns [C0, c0) already computed in this outer panel to the 32x32 diagonal block
+//      and to this workgroup's 64 rows below it;
+//   2. factorise the diagonal block and invert its factor in the registers of wave 0 -- every workgroup
+//      does this redundantly, so no workgroup waits for another one;
+//   3. L_ik = A_ik Linv_kk^T for the workgroup's rows.  Workgroup x == 0 stores Linv_kk.
+// The diagonal block of F is left as assembled (nothing reads it afterwards: the solves use Linv_kk),
+// which is what makes the redundant factorisation race-free.
+__global__ void __launch_bounds__(256)
+k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* __restrict__ info) {
+    const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t];
-    const int c0 = k * NB;
     if (c0 >= np) return;
     const int wb = min(NB, np - c0);
     const int nf = fd.nf[t];
+    const int ntiles = (nf - c0 - wb + TS - 1) / TS;          // 64-row tiles below the diagonal block
+    if ((int)blockIdx.x >= max(ntiles, 1)) return;
+    const int k = c0 / NB;
+    const int kprev = c0 - C0;                                 // factor columns of this outer panel already done
     double* F = fd.F + fd.foff[t];
-    __shared__ double a[NB][NB + 1];
-    __shared__ double li[NB][NB + 1];
-    const int lane = threadIdx.x;
-    for (int idx = lane; idx < NB * NB; idx += 64) {
-        const int r = idx % NB, c = idx / NB;
-        a[r][c] = (r < wb && c < wb && c <= r) ? F[(c0 + r) + (size_t)nf * (c0 + c)] : (r == c ? 1.0 : 0.0);
-        li[r][c] = 0.0;
-    }
-    __syncthreads();
-    for (int j = 0; j < wb; ++j) {
-        double d = a[j][j];
-        if (!(d > 0.0)) {                       // not positive definite in floating point
-            if (lane == 0) atomicAdd(info, 1);
-            d = fabs(d) > 1e-300 ? fabs(d) : 1.0;
-        }
-        d = sqrt(d);
-        __syncthreads();
-        if (lane == 0) a[j][j] = d;
-        for (int r = j + 1 + lane; r < wb; r += 64) a[r][j] /= d;
-        __syncthreads();
-        // trailing update of the block: (r, c) with j < c <= r
-        const int n = wb - j - 1;
-        for (int idx = lane; idx < n * n; idx += 64) {
-            const int r = j + 1 + idx % n, c = j + 1 + idx / n;
-            if (c <= r) a[r][c] -= a[r][j] * a[c][j];
-        }
-        __syncthreads();
-    }
-    // inverse of the lower-triangular block, one column per lane
-    if (lane < wb) {
-        const int c = lane;
-        li[c][c] = 1.0 / a[c][c];
-        for (int r = c + 1; r < wb; ++r) {
-            double s = 0.0;
-            for (int mm = c; mm < r; ++mm) s += a[r][mm] * li[mm][c];
-            li[r][c] = -s / a[r][r];
-        }
-    }
-    __syncthreads();
     double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-    for (int idx = lane; idx < NB * NB; idx += 64) {
+    __shared__ double sd[NB][NB + 1];           // diagonal block [row][col]
+    __shared__ double sl[NB][NB + 1];           // Linv_kk [row][col]
+    __shared__ double sa[NB][TS + 1];           // A_ik [col][row]
+    __shared__ double pd[NBO - NB][NB + 1];     // previous columns of the outer panel, diagonal rows [m][row]
+    __shared__ double pr[NB][TS + 1];           // chunk of previous columns, current row tile [m][row]
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
         const int r = idx % NB, c = idx / NB;
-        if (r < wb && c < wb && c <= r) F[(c0 + r) + (size_t)nf * (c0 + c)] = a[r][c];
-        Li[r + NB * c] = (r < wb && c < wb) ? li[r][c] : 0.0;
+        sd[r][c] = (r < wb && c < wb && c <= r) ? F[(c0 + r) + (size_t)nf * (c0 + c)] : (r == c ? 1.0 : 0.0);
     }
-}
-
-// P1: rows below the diagonal block:  L_ik = A_ik * Linv_kk^T ; 64 rows per workgroup
-__global__ void __launch_bounds__(256)
-k_panel_trsm(FrontDev fd, const int* __restrict__ level_nodes, int k) {
-    const int t = level_nodes[blockIdx.y];
-    const int np = fd.npiv[t];
-    const int c0 = k * NB;
-    if (c0 >= np) return;
-    const int wb = min(NB, np - c0);
-    const int nf = fd.nf[t];
-    const int r0 = c0 + wb + blockIdx.x * TS;
-    if (r0 >= nf) return;
-    double* F = fd.F + fd.foff[t];
-    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-    __shared__ double sl[NB][NB + 1];
-    __shared__ double sa[NB][TS + 1];     // [col][row]
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) sl[idx % NB][idx / NB] = Li[idx];
-    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
-        const int r = idx % TS, c = idx / TS;
-        sa[c][r] = (r0 + r < nf && c < wb) ? F[(r0 + r) + (size_t)nf * (c0 + c)] : 0.0;
+    for (int idx = tid; idx < NB * kprev; idx += 256) {
+        const int r = idx % NB, mm = idx / NB;
+        pd[mm][r] = (r < wb) ? F[(c0 + r) + (size_t)nf * (C0 + mm)] : 0.0;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
-        const int r = idx % TS, c = idx / TS;
-        if (r0 + r < nf && c < wb) {
-            double s = 0.0;
-            for (int mm = 0; mm <= c; ++mm) s += sa[mm][r] * sl[c][mm];
-            F[(r0 + r) + (size_t)nf * (c0 + c)] = s;
+    // 1a. left-looking update of the diagonal block with the columns [C0, c0)
+    if (kprev > 0) {
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx % NB, c = idx / NB;
+            if (c <= r) {
+                double s = 0.0;
+                for (int mm = 0; mm < kprev; ++mm) s += pd[mm][r] * pd[mm][c];
+                sd[r][c] -= s;
+            }
+        }
+        __syncthreads();
+    }
+    // 2. Cholesky + inverse of the diagonal block in wave 0
+    if (tid < 64) {
+        const int lane = tid;
+        double a[NB], x[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? sd[lane][c] : 0.0;
+        const int bad = chol32_inverse(a, x, wb, lane);
+        if (lane < NB) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) sl[r][lane] = (lane < wb && r < wb && lane <= r) ? x[r] : 0.0;
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r) Li[r + NB * lane] = (lane < wb && r < wb && lane <= r) ? x[r] : 0.0;
+                if (lane == 0 && bad) atomicAdd(info, bad);
+            }
+        }
+    }
+    // 1b + 3. this workgroup's share of the 64-row tiles below the block
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = c0 + wb + tile * TS;
+        __syncthreads();
+        for (int idx = tid; idx < NB * TS; idx += 256) {
+            const int r = idx % TS, c = idx / TS;
+            sa[c][r] = (r0 + r < nf && c < wb) ? F[(r0 + r) + (size_t)nf * (c0 + c)] : 0.0;
+        }
+        for (int m0 = 0; m0 < kprev; m0 += NB) {
+            __syncthreads();
+            for (int idx = tid; idx < NB * TS; idx += 256) {
+                const int r = idx % TS, mm = idx / TS;
+                pr[mm][r] = (r0 + r < nf) ? F[(r0 + r) + (size_t)nf * (C0 + m0 + mm)] : 0.0;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < NB * TS; idx += 256) {
+                const int r = idx % TS, c = idx / TS;
+                double s = 0.0;
+#pragma unroll 8
+                for (int mm = 0; mm < NB; ++mm) s += pr[mm][r] * pd[m0 + mm][c];
+                sa[c][r] -= s;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NB * TS; idx += 256) {
+            const int r = idx % TS, c = idx / TS;
+            if (r0 + r < nf && c < wb) {
+                double s = 0.0;
+                for (int mm = 0; mm <= c; ++mm) s += sa[mm][r] * sl[c][mm];
+                F[(r0 + r) + (size_t)nf * (c0 + c)] = s;
+            }
         }
     }
 }
 
-// P2: trailing update  A_ij -= L_ik L_jk^T  on lower-triangle 64x64 tiles, 256 threads, 4x4 per thread
+// P2: trailing update behind an outer panel:  A[r][c] -= sum_m L[r][m] L[c][m] over the factor columns
+// m in [C0, C0+kw), kw <= 128, for all columns c >= C0+kw and rows r >= c (lower-triangle 64x64 tiles);
+// the factor columns are staged through LDS 32 at a time, so each tile of A is read and written once
+// per 128 columns instead of once per 32.
 __global__ void __launch_bounds__(256)
-k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int k) {
-    const int t = level_nodes[blockIdx.y];
+k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max) {
+    const int t = level_nodes[blockIdx.z];
     const int np = fd.npiv[t];
-    const int c0 = k * NB;
-    if (c0 >= np) return;
-    const int wb = min(NB, np - c0);
+    if (kc0 >= np) return;
+    const int kw = min(kw_max, np - kc0);
     const int nf = fd.nf[t];
-    const int base = c0 + wb;
-    const int nrem = nf - base;
-    if (nrem <= 0) return;
-    const int nt = (nrem + TS - 1) / TS;
-    const int lin = blockIdx.x;
-    if (lin >= nt * (nt + 1) / 2) return;
-    int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
-    while (ti * (ti + 1) / 2 > lin) --ti;
-    const int tj = lin - ti * (ti + 1) / 2;
+    const int col_lo = kc0 + kw;
+    const int col_hi = nf;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= col_hi) return;
+    const int ri = cj + blockIdx.x * TS;           // row tiles start at the column tile (lower triangle)
+    if (ri >= nf) return;
     double* F = fd.F + fd.foff[t];
-    const int ri = base + ti * TS, rj = base + tj * TS;
     __shared__ double si[NB][TS];
     __shared__ double sj[NB][TS];
-    for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
-        const int r = idx % TS, c = idx / TS;
-        si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (c0 + c)] : 0.0;
-        sj[c][r] = (rj + r < nf && c < wb) ? F[(rj + r) + (size_t)nf * (c0 + c)] : 0.0;
-    }
-    __syncthreads();
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;   // rows 4*tx.., cols 4*ty..
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int mm = 0; mm < wb; ++mm) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            av[a] = si[mm][4 * tx + a];
-            bv[a] = sj[mm][4 * ty + a];
+    for (int k0 = 0; k0 < kw; k0 += NB) {
+        const int wb = min(NB, kw - k0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
+            const int r = idx % TS, c = idx / TS;
+            si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            sj[c][r] = (cj + r < col_hi && c < wb) ? F[(cj + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
         }
+        __syncthreads();
+#pragma unroll 8
+        for (int mm = 0; mm < NB; ++mm) {
+            double av[4], bv[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
+                av[a] = si[mm][4 * tx + a];
+                bv[a] = sj[mm][4 * ty + a];
+            }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+        }
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int cc = rj + 4 * ty + b;
-        if (cc >= nf) continue;
+        const int cc = cj + 4 * ty + b;
+        if (cc >= col_hi) continue;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int r = ri + 4 * tx + a;

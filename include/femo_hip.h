@@ -98,7 +98,7 @@ int femo_set_frontal_plan(femo_ctx* ctx, int32_t ntree, int32_t nlevels, const i
  * element matrices -> leaf fronts -> batched partial Cholesky level by level.  Replaces ksp.setUp() with
  * PC 'lu' / MUMPS (fea/utils_dolfinx.py:495-531). */
 int femo_factorize(femo_ctx* ctx);
-/* One factorisation with a HIP event pair around every launch; per kernel class (0 chol_diag, 1 panel_trsm,
+/* One factorisation with a HIP event pair around every launch; per kernel class (0 unused, 1 panel (diagonal block + rows below),
  * 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): out13[0..5] total ms, out13[6..11] launches;
  * out13[12] algorithmic flops of the trailing updates. */
 int femo_factorize_profile(femo_ctx* ctx, double* out13);
