@@ -19,6 +19,8 @@ SIGNATURES = {
     "femo_last_error": (C.c_char_p, [C.c_void_p]),
     "femo_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                               _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int]),
+    "femo_create_ghost": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int, C.c_int32]),
     "femo_destroy": (None, [C.c_void_p]),
     "femo_ndof": (C.c_int64, [C.c_void_p]),
     "femo_field_size": (C.c_int64, [C.c_void_p, C.c_char_p]),
@@ -49,6 +51,17 @@ SIGNATURES = {
                                       _c_double_p]),
     "femo_last_timing": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_bench_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _c_double_p]),
+    "femo_vec_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "femo_sync": (C.c_int, [C.c_void_p]),
+    "femo_op_apply_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "femo_load_vec": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_factorize_range": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int]),
+    "femo_frontal_sweep": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+    "femo_front_schur_get": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "femo_front_block_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "femo_functionals_partial": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_dfunctional_vec": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "femo_field_gradient_vec": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, _c_double_p, C.c_int64]),
     "femo_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
 }
 

@@ -15,8 +15,10 @@ PENALTY_BETA = 1.0e15      # reference linear_shell_model.py:324
 
 
 class ShellContext:
+    VEC_IDS = {"state": 0, "adjoint": 1, "r": 2, "z": 3, "p": 4, "Ap": 5, "b": 6}
+
     def __init__(self, mesh: ShellMesh, element_wise_material=False, elementwise_pressure=False,
-                 nquad=4, device=0):
+                 nquad=4, device=0, nghost=0):
         self.lib = _lib.load()
         self.mesh = mesh
         self.element_wise_material = bool(element_wise_material)
@@ -25,14 +27,17 @@ class ShellContext:
         xyz = np.ascontiguousarray(mesh.nodes, dtype=np.float64)
         cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
         cp2 = np.ascontiguousarray(mesh.cell_p2, dtype=np.int32)
-        rc = self.lib.femo_create(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
-                                  dptr(xyz), iptr(cells), iptr(cp2),
-                                  int(self.element_wise_material), int(self.elementwise_pressure), int(nquad))
+        rc = self.lib.femo_create_ghost(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
+                                        dptr(xyz), iptr(cells), iptr(cp2),
+                                        int(self.element_wise_material), int(self.elementwise_pressure), int(nquad),
+                                        int(nghost))
         if rc:
             raise FemoHipError(f"femo_create failed ({rc}): {self.lib.femo_last_error(None).decode()}")
         self._h = h
-        self.ndof = int(self.lib.femo_ndof(h))
-        assert self.ndof == mesh.ndof
+        self.device = int(device)
+        self.nghost = int(nghost)
+        self.ndof = int(self.lib.femo_ndof(h))            # vector length: mesh DOFs + ghost entries
+        assert self.ndof == mesh.ndof + self.nghost
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):
@@ -119,11 +124,12 @@ class ShellContext:
         return Ke
 
     # ------------------------------------------------------------------ multifrontal preconditioner
-    def enable_frontal(self, leaf_size=16):
+    def enable_frontal(self, leaf_size=16, plan=None):
         """Run the symbolic analysis on the host (mesh only) and upload it; afterwards
-        ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner."""
+        ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner.
+        ``plan`` may carry a ready-made plan (the multi-GPU driver passes rank-local plans)."""
         from .solver.symbolic import build_plan
-        plan = self.plan = build_plan(self.mesh, leaf_size)
+        plan = self.plan = build_plan(self.mesh, leaf_size) if plan is None else plan
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
         level_off = i32(np.concatenate([[0], np.cumsum([len(l) for l in plan.level_nodes])]))
@@ -199,6 +205,55 @@ class ShellContext:
         self._chk(self.lib.femo_total_gradient(self._h, functional.encode(), arg.encode(), dptr(out), out.size,
                                                C.byref(it), C.byref(rr)))
         return out, it.value, rr.value
+
+    # ------------------------------------------------------------------ building blocks of the multi-GPU driver
+    def vec_tensor(self, name):
+        """Zero-copy torch view (float64, cuda) of one of the context's state-sized device vectors."""
+        import torch
+
+        class _Arr:      # __cuda_array_interface__ carrier
+            pass
+        a = _Arr()
+        ptr = self.lib.femo_vec_ptr(self._h, self.VEC_IDS[name])
+        a.__cuda_array_interface__ = dict(shape=(self.ndof,), typestr="<f8", data=(int(ptr), False), version=2)
+        t = torch.as_tensor(a, device=f"cuda:{self.device}")
+        t._femo_owner = self          # keep the context alive while the view exists
+        return t
+
+    def sync(self):
+        self._chk(self.lib.femo_sync(self._h))
+
+    def op_apply_vec(self, src, dst):
+        self._chk(self.lib.femo_op_apply_vec(self._h, self.VEC_IDS[src], self.VEC_IDS[dst]))
+
+    def load_vec(self, dst):
+        self._chk(self.lib.femo_load_vec(self._h, self.VEC_IDS[dst]))
+
+    def factorize_range(self, l0, l1, assemble):
+        self._chk(self.lib.femo_factorize_range(self._h, l0, l1, int(assemble)))
+
+    def frontal_sweep(self, vec, l0, l1, backward):
+        self._chk(self.lib.femo_frontal_sweep(self._h, self.VEC_IDS[vec], l0, l1, int(backward)))
+
+    def front_schur_get(self, front, dst_tensor):
+        self._chk(self.lib.femo_front_schur_get(self._h, int(front), C.c_void_p(dst_tensor.data_ptr()), dst_tensor.numel()))
+
+    def front_block_set(self, front, src_tensor):
+        self._chk(self.lib.femo_front_block_set(self._h, int(front), C.c_void_p(src_tensor.data_ptr())))
+
+    def functionals_partial(self):
+        t = np.zeros(3)
+        self._chk(self.lib.femo_functionals_partial(self._h, dptr(t)))
+        return t
+
+    def dfunctional_vec(self, name, dst):
+        self._chk(self.lib.femo_dfunctional_vec(self._h, name.encode(), self.VEC_IDS[dst]))
+
+    def field_gradient_vec(self, functional, arg, lam):
+        out = np.empty(self.field_size(arg))
+        self._chk(self.lib.femo_field_gradient_vec(self._h, functional.encode(), arg.encode(), self.VEC_IDS[lam],
+                                                   dptr(out), out.size))
+        return out
 
     def last_timing(self):
         t = np.zeros(5)

@@ -23,7 +23,8 @@ static std::string g_create_error;
 struct femo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;
+    int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
+    int nghost = 0;
     bool quad = true, ewm = false, ewp = false, has_uhat = false;
     int64_t nT = 0, nF = 0;
     // mesh
@@ -361,25 +362,29 @@ struct ProfScope {
     }
 };
 
-static int frontal_factorize(femo_ctx* c) {
+// levels [l0, l1) of the elimination tree; assemble != 0 first zeroes the fronts and sums the element matrices in
+static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     auto& fr = c->fr;
     if (!fr.ready) return fail(c, "no frontal plan: call femo_set_frontal_plan first");
-    for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; }
+    if (l0 < 0 || l1 > fr.nlevels || l0 > l1) return fail(c, "bad level range");
+    if (assemble) for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; }
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    { ProfScope ps(c, 5); HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream)); }
-    HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
-    if (refresh_penalty(c)) return 1;
-    { ProfScope ps(c, 4);
-    ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask); }
-    if (c->nf > 0)
-        hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
-                           fr.elem_map, c->ld, c->npc, c->nvc, mask);
-    if (mask) hipLaunchKernelGGL(k_front_mask_diag, dim3(fr.ntree), dim3(64), 0, c->stream, fd, mask);
-    HIPCHK(c, hipGetLastError());
+    if (assemble) {
+        { ProfScope ps(c, 5); HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream)); }
+        HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
+        if (refresh_penalty(c)) return 1;
+        { ProfScope ps(c, 4);
+        ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask); }
+        if (c->nf > 0)
+            hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
+                               fr.elem_map, c->ld, c->npc, c->nvc, mask);
+        if (mask) hipLaunchKernelGGL(k_front_mask_diag, dim3(fr.ntree), dim3(64), 0, c->stream, fd, mask);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    for (int L = 0; L < fr.nlevels; ++L) {
+    for (int L = l0; L < l1; ++L) {
         fr.cur_level = L;
         const int b = fr.h_level_off[L], e = fr.h_level_off[L + 1];
         const int cnt = e - b;
@@ -428,8 +433,9 @@ static int frontal_factorize(femo_ctx* c) {
     float ta = 0, tf = 0;
     hipEventElapsedTime(&ta, c->ev[2], c->ev[3]);
     hipEventElapsedTime(&tf, c->ev[3], c->ev[0]);
-    fr.t_assemble_ms = ta; fr.t_factor_ms = tf; fr.pivots_fixed = info;
-    fr.factored = true;
+    if (assemble) { fr.t_assemble_ms = ta; fr.t_factor_ms = 0; }
+    fr.t_factor_ms += tf; fr.pivots_fixed = info;
+    fr.factored = (l1 == fr.nlevels);
     for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
         float ms = 0;
         hipEventElapsedTime(&ms, fr.pev[i], fr.pev[i + 1]);
@@ -443,13 +449,15 @@ static int frontal_factorize(femo_ctx* c) {
     return 0;
 }
 
+static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0, c->fr.nlevels, true); }
+
 // v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
 static const int WIDE_NP = 192;    // levels whose largest pivot block exceeds this use the panel-parallel kernels
-static int frontal_solve(femo_ctx* c, double* v) {
+static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
-    for (int L = 0; L < fr.nlevels; ++L) {
+    for (int L = l0; L < l1; ++L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
@@ -467,8 +475,16 @@ static int frontal_solve(femo_ctx* c, double* v) {
                 hipLaunchKernelGGL(k_front_fwd_bnd, dim3((maxnb + 255) / 256, cnt), dim3(256), 0, c->stream, fd, lev, v, y);
         }
     }
-    // backward: y is consumed in place (running right-hand side), x lands in v
-    for (int L = fr.nlevels - 1; L >= 0; --L) {
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// backward over levels l1-1 ... l0: y (in tmp) is consumed in place (running right-hand side), x lands in v
+static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
+    auto& fr = c->fr;
+    const FrontDev fd = front_dev(c);
+    double* y = c->tmp;
+    for (int L = l1 - 1; L >= l0; --L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
@@ -486,6 +502,11 @@ static int frontal_solve(femo_ctx* c, double* v) {
     }
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+
+static int frontal_solve(femo_ctx* c, double* v) {
+    if (int rc = frontal_fwd(c, v, 0, c->fr.nlevels)) return rc;
+    return frontal_bwd(c, v, 0, c->fr.nlevels);
 }
 
 // PCG preconditioned by the multifrontal factorisation (a handful of iterations)
@@ -642,7 +663,15 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
 
 int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2, const double* xyz,
                 const int32_t* cells, const int32_t* cell_p2, int elementwise_material, int elementwise_pressure, int nquad) {
+    return femo_create_ghost(out, device, nn, nel, nvc, nP2, xyz, cells, cell_p2, elementwise_material, elementwise_pressure,
+                             nquad, 0);
+}
+
+int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2, const double* xyz,
+                      const int32_t* cells, const int32_t* cell_p2, int elementwise_material, int elementwise_pressure,
+                      int nquad, int32_t nghost) {
     if (!out) return 2;
+    if (nghost < 0) { g_create_error = "nghost must be >= 0"; return 2; }
     *out = nullptr;
     if (nvc != 3 && nvc != 4) { g_create_error = "nvc must be 3 (triangles) or 4 (quads)"; return 2; }
     if (nn <= 0 || nel <= 0 || !xyz || !cells || !cell_p2) { g_create_error = "empty mesh or null pointer"; return 2; }
@@ -659,7 +688,7 @@ int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc
     c->device = device;
     c->nn = nn; c->nel = nel; c->nvc = nvc; c->npc = npc; c->nP2 = nP2;
     c->quad = nvc == 4;
-    c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * nn; c->ld = 3 * npc + 3 * nvc;
+    c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * nn + nghost; c->nghost = nghost; c->ld = 3 * npc + 3 * nvc;
     c->ewm = elementwise_material != 0; c->ewp = elementwise_pressure != 0;
     if (create_impl(c, xyz, cells, cell_p2, nquad)) {
         g_create_error = c->err;
@@ -1156,6 +1185,122 @@ int femo_frontal_info(const femo_ctx* c, double* out6) {
     out6[0] = fr.t_assemble_ms; out6[1] = fr.t_factor_ms; out6[2] = fr.f_doubles * 8.0 / 1e9; out6[3] = fl / 1e9;
     out6[4] = fr.pivots_fixed; out6[5] = fr.ntree;
     return 0;
+}
+
+
+// ---- building blocks for the element-partitioned (multi-GPU) driver, femo_alpha_amd/parallel.py -------------
+static double* vec_by_id(femo_ctx* c, int id) {
+    double* v[] = {c->w, c->lam, c->r, c->z, c->p, c->Ap, c->b};
+    return (id >= 0 && id < 7) ? v[id] : nullptr;
+}
+
+void* femo_vec_ptr(femo_ctx* c, int32_t id) { return vec_by_id(c, id); }
+
+int femo_sync(femo_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_op_apply_vec(femo_ctx* c, int32_t src, int32_t dst) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double *x = vec_by_id(c, src), *y = vec_by_id(c, dst);
+    if (!x || !y || x == y) return fail(c, "bad vector ids");
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, y, 0.0, (int64_t)c->ndof);
+    if (op_apply(c, x, y, nullptr, nullptr, nullptr, true)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_load_vec(femo_ctx* c, int32_t dst) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* y = vec_by_id(c, dst);
+    if (!y) return fail(c, "bad vector id");
+    if (load_vector_dev(c, y)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_factorize_range(femo_ctx* c, int32_t l0, int32_t l1, int assemble) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = frontal_factorize_range(c, l0, l1, assemble != 0)) return rc;
+    if (l1 == c->fr.nlevels) c->diag_dirty = (c->precond != 2);
+    return 0;
+}
+
+int femo_frontal_sweep(femo_ctx* c, int32_t vec, int32_t l0, int32_t l1, int backward) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* v = vec_by_id(c, vec);
+    if (!v) return fail(c, "bad vector id");
+    if (l0 < 0 || l1 > c->fr.nlevels || l0 > l1) return fail(c, "bad level range");
+    if (int rc = backward ? frontal_bwd(c, v, l0, l1) : frontal_fwd(c, v, l0, l1)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// contiguous copy of the Schur complement (trailing nb x nb block, column-major) of one front
+int femo_front_schur_get(femo_ctx* c, int32_t front, void* dst_dev, int64_t capacity_doubles) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready || front < 0 || front >= fr.ntree) return fail(c, "bad front id");
+    const int nf = fr.h_nf[front], np = fr.h_npiv[front], nb = nf - np;
+    if ((int64_t)nb * nb > capacity_doubles) return fail(c, "destination too small for the Schur complement");
+    if (nb == 0) return 0;
+    std::vector<long long> off(1);
+    HIPCHK(c, hipMemcpy(off.data(), fr.foff + front, sizeof(long long), hipMemcpyDeviceToHost));
+    const double* src = fr.F + off[0] + (size_t)np + (size_t)nf * np;
+    HIPCHK(c, hipMemcpy2DAsync(dst_dev, (size_t)nb * sizeof(double), src, (size_t)nf * sizeof(double), (size_t)nb * sizeof(double), nb,
+                               hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// overwrite the whole dense block of a front without pivots (a remote subtree's Schur complement)
+int femo_front_block_set(femo_ctx* c, int32_t front, const void* src_dev) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready || front < 0 || front >= fr.ntree) return fail(c, "bad front id");
+    if (fr.h_npiv[front] != 0) return fail(c, "only fronts without pivots can be overwritten");
+    const int nf = fr.h_nf[front];
+    std::vector<long long> off(1);
+    HIPCHK(c, hipMemcpy(off.data(), fr.foff + front, sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(fr.F + off[0], src_dev, (size_t)nf * nf * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// local partial sums for the stored state: out3 = { int u.u J dx, regularisation, mass } over this context's cells
+int femo_functionals_partial(femo_ctx* c, double* out3) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return functionals_dev(c, out3);
+}
+
+// gradient pieces on device vectors (no host copies): dst(vector id) = d functional / d disp_solid
+int femo_dfunctional_vec(femo_ctx* c, const char* name, int32_t dst) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* y = vec_by_id(c, dst);
+    if (!y) return fail(c, "bad vector id");
+    if (int rc = dfunctional_dev(c, name ? name : "", "disp_solid", y, c->ndof)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// out (host, field length) = scale * (dR/d arg)^T lambda(vector id) + d functional / d arg, local cells only
+int femo_field_gradient_vec(femo_ctx* c, const char* functional, const char* arg, int32_t lam, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* l = vec_by_id(c, lam);
+    if (!l) return fail(c, "bad vector id");
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, std::max<int64_t>(n, 1) * sizeof(double)));
+    int rc = dfunctional_dev(c, functional ? functional : "", arg ? arg : "", d, n);
+    if (!rc) rc = dRdarg_T_dev(c, arg ? arg : "", l, -1.0, d, n);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    hipFree(d);
+    return rc;
 }
 
 int femo_last_timing(const femo_ctx* c, double* out5) {

@@ -10,12 +10,18 @@ matrices are summed straight into the leaf fronts (the original "frontal" idea),
 sparse matrix is ever built.
 
 Everything here depends on the mesh only; it is computed once per context and uploaded to HBM.
+
+Multi-GPU: the 2^d subtrees at depth d of the same tree are the element
+partition; ``rank_plan`` cuts out, for one rank, its subtree, the replicated top of the tree and
+pivot-free stand-ins for the other ranks' subtree roots, in the numbering of the rank's sub-mesh.
 """
 from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["FrontalPlan", "build_plan"]
+from ..mesh import ShellMesh
+
+__all__ = ["FrontalPlan", "Tree", "analyse", "build_plan", "rank_plan"]
 
 
 class FrontalPlan:
@@ -29,6 +35,11 @@ class FrontalPlan:
                     max_front=int(nf.max()), max_pivots=int(npv.max()),
                     front_doubles=int(self.front_off[-1]), front_GB=float(self.front_off[-1] * 8 / 1e9),
                     factor_doubles=int(np.sum(nf.astype(np.int64) * npv)), factor_gflop=flops / 1e9)
+
+
+class Tree:
+    """Nested-dissection tree over the elements with, per tree node, the P2 nodes it eliminates
+    (``piv_nodes``) and the ancestor-owned P2 nodes its subtree touches (``bnd_nodes``)."""
 
 
 def _node_dofs(nodes, nV, ndof_u):
@@ -45,21 +56,24 @@ def _node_dofs(nodes, nV, ndof_u):
     vn = nodes[is_v]
     for c in range(3):
         out[vb + 3 + c] = ndof_u + 3 * vn + c
-    return out, off
+    return out
 
 
-def build_plan(mesh, leaf_size=16) -> FrontalPlan:
-    nel, nV, nP2, ndof_u = mesh.nel, mesh.nV, mesh.nP2, mesh.ndof_u
+def analyse(mesh, leaf_size=16, min_depth=0) -> Tree:
+    """Bisection tree, node ownership and boundary lists.  ``min_depth`` forces every branch to be
+    split at least that deep (the multi-GPU driver needs 2^d subtrees)."""
+    nel, nP2 = mesh.nel, mesh.nP2
     cent = mesh.nodes[mesh.cells].mean(axis=1)
-    # ---------------------------------------------------------------- 1. bisection tree over elements
     eorder = np.arange(nel)
     lo_l, hi_l, left_l, right_l, parent_l, depth_l = [0], [nel], [-1], [-1], [-1], [0]
     stack = [0]
     while stack:
         t = stack.pop()
         lo, hi = lo_l[t], hi_l[t]
-        if hi - lo <= leaf_size:
+        if hi - lo <= leaf_size and depth_l[t] >= min_depth:
             continue
+        if hi - lo < 2:
+            raise ValueError("mesh too small for the requested number of partitions")
         idx = eorder[lo:hi]
         c = cent[idx]
         ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
@@ -70,13 +84,17 @@ def build_plan(mesh, leaf_size=16) -> FrontalPlan:
             parent_l.append(t); depth_l.append(depth_l[t] + 1)
             store[t] = len(lo_l) - 1
             stack.append(len(lo_l) - 1)
-    t_lo, t_hi = np.array(lo_l), np.array(hi_l)
-    t_left, t_right, t_parent = np.array(left_l), np.array(right_l), np.array(parent_l)
-    ntree = t_lo.size
-    is_leaf = t_left < 0
+    T = Tree()
+    T.lo, T.hi = np.array(lo_l), np.array(hi_l)
+    T.left, T.right, T.parent = np.array(left_l), np.array(right_l), np.array(parent_l)
+    T.depth = np.array(depth_l)
+    T.ntree = T.lo.size
+    T.eorder = eorder
+    is_leaf = T.left < 0
     epos = np.empty(nel, dtype=np.int64)
     epos[eorder] = np.arange(nel)
-    # ---------------------------------------------------------------- 2. owner of every P2 node
+    T.epos = epos
+    # owner of every P2 node: the deepest tree node whose element interval holds all its elements
     amin = np.full(nP2, nel, dtype=np.int64)
     amax = np.full(nP2, -1, dtype=np.int64)
     pe = np.repeat(epos, mesh.cell_p2.shape[1])
@@ -87,86 +105,202 @@ def build_plan(mesh, leaf_size=16) -> FrontalPlan:
     while active.any():
         ids = np.nonzero(active)[0]
         t = owner[ids]
-        L, R = t_left[t], t_right[t]
+        L, R = T.left[t], T.right[t]
         leaf = L < 0
-        mid = np.where(leaf, 0, t_lo[np.where(leaf, 0, R)])
+        mid = np.where(leaf, 0, T.lo[np.where(leaf, 0, R)])
         go_l = ~leaf & (amax[ids] < mid)
         go_r = ~leaf & (amin[ids] >= mid)
         owner[ids[go_l]] = L[go_l]
         owner[ids[go_r]] = R[go_r]
         active[ids[~(go_l | go_r)]] = False
-    # ---------------------------------------------------------------- 3. heights / levels (children before parents)
-    height = np.zeros(ntree, dtype=np.int64)
-    order_bu = np.argsort(-np.array(depth_l), kind="stable")          # deepest first
+    T.owner = owner
+    height = np.zeros(T.ntree, dtype=np.int64)
+    order_bu = np.argsort(-T.depth, kind="stable")          # deepest first
     for t in order_bu:
         if not is_leaf[t]:
-            height[t] = 1 + max(height[t_left[t]], height[t_right[t]])
-    nlevels = int(height.max()) + 1
-    # ---------------------------------------------------------------- 4. pivot / boundary node lists
-    piv_nodes = [None] * ntree
+            height[t] = 1 + max(height[T.left[t]], height[T.right[t]])
+    T.height = height
     ord_owner = np.argsort(owner, kind="stable")
-    cnt = np.bincount(owner, minlength=ntree)
+    cnt = np.bincount(owner, minlength=T.ntree)
     st = np.concatenate([[0], np.cumsum(cnt)])
-    for t in range(ntree):
-        piv_nodes[t] = ord_owner[st[t]:st[t + 1]]
-    bnd_nodes = [None] * ntree
+    T.piv_nodes = [ord_owner[st[t]:st[t + 1]] for t in range(T.ntree)]
+    bnd = [None] * T.ntree
     for t in order_bu:
         if is_leaf[t]:
-            touched = np.unique(mesh.cell_p2[eorder[t_lo[t]:t_hi[t]]])
-            bnd_nodes[t] = touched[owner[touched] != t]
+            touched = np.unique(mesh.cell_p2[eorder[T.lo[t]:T.hi[t]]])
+            bnd[t] = touched[owner[touched] != t]
         else:
-            u = np.union1d(bnd_nodes[t_left[t]], bnd_nodes[t_right[t]])
-            bnd_nodes[t] = u[owner[u] != t]
-    # ---------------------------------------------------------------- 5. fronts in DOF space
+            u = np.union1d(bnd[T.left[t]], bnd[T.right[t]])
+            bnd[t] = u[owner[u] != t]
+    T.bnd_nodes = bnd
+    return T
+
+
+def _assemble_plan(dof_lists, npiv, parent, left, right, level_of, elem_front, elem_dofs):
+    """FrontalPlan from per-front DOF lists (pivots first) in one consistent DOF numbering."""
+    ntree = len(dof_lists)
     plan = FrontalPlan()
-    plan.ntree, plan.nlevels, plan.nleaves = ntree, nlevels, int(is_leaf.sum())
-    plan.eorder = eorder.astype(np.int32)
-    plan.parent = t_parent.astype(np.int32)
-    plan.left, plan.right = t_left.astype(np.int32), t_right.astype(np.int32)
-    plan.height = height.astype(np.int32)
-    npiv = np.zeros(ntree, dtype=np.int32)
-    nf = np.zeros(ntree, dtype=np.int32)
-    dof_lists = [None] * ntree
-    pos_in_front = [None] * ntree          # dict-free lookup: sorted dofs + positions
-    for t in range(ntree):
-        pd, _ = _node_dofs(piv_nodes[t], nV, ndof_u)
-        bd, _ = _node_dofs(bnd_nodes[t], nV, ndof_u)
-        npiv[t] = pd.size
-        nf[t] = pd.size + bd.size
-        dof_lists[t] = np.concatenate([pd, bd])
-    plan.npiv, plan.nf = npiv, nf
-    plan.dof_off = np.concatenate([[0], np.cumsum(nf.astype(np.int64))])
-    plan.front_dofs = np.concatenate(dof_lists).astype(np.int32)
-    plan.front_off = np.concatenate([[0], np.cumsum(nf.astype(np.int64) ** 2)])
+    plan.ntree = ntree
+    plan.npiv = np.asarray(npiv, dtype=np.int32)
+    plan.nf = np.array([len(d) for d in dof_lists], dtype=np.int32)
+    plan.parent = np.asarray(parent, dtype=np.int32)
+    plan.left, plan.right = np.asarray(left, dtype=np.int32), np.asarray(right, dtype=np.int32)
+    plan.nleaves = int(np.sum(plan.left < 0))
+    plan.dof_off = np.concatenate([[0], np.cumsum(plan.nf.astype(np.int64))])
+    plan.front_dofs = (np.concatenate(dof_lists) if ntree else np.zeros(0)).astype(np.int32)
+    plan.front_off = np.concatenate([[0], np.cumsum(plan.nf.astype(np.int64) ** 2)])
+    sorters = {}
 
     def positions(t, dofs):
-        """positions of global DOFs inside front t (every DOF must be present)."""
-        fd = dof_lists[t]
-        o = np.argsort(fd, kind="stable")
-        k = np.searchsorted(fd[o], dofs)
-        assert np.all(fd[o][k] == dofs)
+        if t not in sorters:
+            fd = np.asarray(dof_lists[t])
+            o = np.argsort(fd, kind="stable")
+            sorters[t] = (fd[o], o)
+        fs, o = sorters[t]
+        k = np.searchsorted(fs, dofs)
+        if np.any(k >= fs.size) or np.any(fs[np.minimum(k, fs.size - 1)] != dofs):
+            raise AssertionError("a boundary DOF is missing from the parent front")
         return o[k]
 
-    # child boundary -> parent front positions, stored at dof_off[child] + npiv[child] ...
     up_map = np.full(plan.front_dofs.size, -1, dtype=np.int32)
     for t in range(ntree):
-        p = t_parent[t]
-        if p >= 0 and nf[t] > npiv[t]:
-            up_map[plan.dof_off[t] + npiv[t]: plan.dof_off[t + 1]] = positions(p, dof_lists[t][npiv[t]:])
+        p = plan.parent[t]
+        if p >= 0 and plan.nf[t] > plan.npiv[t]:
+            up_map[plan.dof_off[t] + plan.npiv[t]: plan.dof_off[t + 1]] = positions(p, np.asarray(dof_lists[t])[plan.npiv[t]:])
     plan.up_map = up_map
-    # element -> leaf front positions
-    leaf_of_pos = np.zeros(nel, dtype=np.int64)
-    for t in np.nonzero(is_leaf)[0]:
-        leaf_of_pos[t_lo[t]:t_hi[t]] = t
-    elem_front = leaf_of_pos[epos].astype(np.int32)
-    cd = mesh.cell_dofs()
-    elem_map = np.empty(cd.shape, dtype=np.int32)
-    for t in np.nonzero(is_leaf)[0]:
-        es = eorder[t_lo[t]:t_hi[t]]
-        elem_map[es] = positions(t, cd[es].ravel()).reshape(es.size, -1)
-    plan.elem_front, plan.elem_map = elem_front, elem_map
-    # level lists (by height), sorted by front size so that a level's launches are load balanced
-    lev_nodes = [np.nonzero(height == h)[0] for h in range(nlevels)]
-    plan.level_nodes = [ln[np.argsort(-nf[ln], kind="stable")].astype(np.int32) for ln in lev_nodes]
-    plan.owner_of_dof = None
+    plan.elem_front = np.asarray(elem_front, dtype=np.int32)
+    elem_map = np.empty(elem_dofs.shape, dtype=np.int32)
+    order = np.argsort(plan.elem_front, kind="stable")
+    bounds = np.searchsorted(plan.elem_front[order], np.arange(ntree + 1))
+    for t in range(ntree):
+        es = order[bounds[t]:bounds[t + 1]]
+        if es.size:
+            elem_map[es] = positions(t, elem_dofs[es].ravel()).reshape(es.size, -1)
+    plan.elem_map = elem_map
+    level_of = np.asarray(level_of)
+    plan.nlevels = int(level_of.max()) + 1
+    plan.height = level_of.astype(np.int32)
+    lev_nodes = [np.nonzero(level_of == h)[0] for h in range(plan.nlevels)]
+    plan.level_nodes = [ln[np.argsort(-plan.nf[ln], kind="stable")].astype(np.int32) for ln in lev_nodes]
     return plan
+
+
+def build_plan(mesh, leaf_size=16) -> FrontalPlan:
+    """Single-GPU plan: every tree node is a front, levels by height."""
+    T = analyse(mesh, leaf_size)
+    nV, ndof_u = mesh.nV, mesh.ndof_u
+    dof_lists, npiv = [], []
+    for t in range(T.ntree):
+        pd = _node_dofs(T.piv_nodes[t], nV, ndof_u)
+        bd = _node_dofs(T.bnd_nodes[t], nV, ndof_u)
+        dof_lists.append(np.concatenate([pd, bd]))
+        npiv.append(pd.size)
+    leaf_of_pos = np.zeros(mesh.nel, dtype=np.int64)
+    for t in np.nonzero(T.left < 0)[0]:
+        leaf_of_pos[T.lo[t]:T.hi[t]] = t
+    plan = _assemble_plan(dof_lists, npiv, T.parent, T.left, T.right, T.height, leaf_of_pos[T.epos], mesh.cell_dofs())
+    plan.eorder = T.eorder.astype(np.int32)
+    return plan
+
+
+def rank_plan(mesh, T: Tree, rank, nranks):
+    """Cut the plan of one rank out of the global tree ``T`` (``analyse(mesh, leaf, min_depth=log2 nranks)``).
+
+    Returns ``(sub, plan, info)``: the rank's sub-mesh (its elements, own numbering), the plan in the
+    sub-mesh's DOF numbering extended by ghost entries for the replicated separator DOFs the rank's
+    elements do not touch, and a dict with
+      ``cells``       global ids of the rank's elements (sub-mesh cell order)
+      ``vertices``    global vertex ids of the sub-mesh vertices
+      ``nghost``      number of ghost entries
+      ``top_local``   local vector indices of all replicated (top) DOFs in a canonical global order
+      ``n_local_levels``  levels [0, n) are the rank's own subtree, [n, nlevels) the replicated top
+      ``root_front``  local front id of the rank's subtree root
+      ``stub_fronts`` local front ids standing for the subtree roots of ranks 0..nranks-1 (own entry = root_front)
+      ``schur_sizes`` boundary sizes of all subtree roots (for the padded all-gather)
+      ``l2g_dof``     global DOF of every local vector entry
+    """
+    d = int(np.log2(nranks))
+    if 2 ** d != nranks:
+        raise ValueError("number of ranks must be a power of two")
+    roots = np.nonzero(T.depth == d)[0]
+    roots = roots[np.argsort(T.lo[roots], kind="stable")]
+    if roots.size != nranks or np.any(T.depth[T.left < 0] < d):
+        raise ValueError("tree is not deep enough for this many ranks")
+    root = int(roots[rank])
+    nVg, ndof_ug = mesh.nV, mesh.ndof_u
+    # ---- sub-mesh
+    cells_g = np.sort(T.eorder[T.lo[root]:T.hi[root]])
+    verts_g = np.unique(mesh.cells[cells_g])
+    g2l_v = -np.ones(mesh.nn, dtype=np.int64)
+    g2l_v[verts_g] = np.arange(verts_g.size)
+    sub = ShellMesh(mesh.nodes[verts_g], g2l_v[mesh.cells[cells_g]])
+    l2g_p2 = np.empty(sub.nP2, dtype=np.int64)
+    l2g_p2[sub.cell_p2.ravel()] = mesh.cell_p2[cells_g].ravel()
+    l2g_dof = np.empty(sub.ndof, dtype=np.int64)
+    for c in range(3):
+        l2g_dof[3 * np.arange(sub.nP2) + c] = 3 * l2g_p2 + c
+        l2g_dof[sub.ndof_u + 3 * np.arange(sub.nV) + c] = ndof_ug + 3 * verts_g + c
+    # ---- which tree nodes become fronts here
+    top = np.nonzero(T.depth < d)[0]
+    in_sub = np.zeros(T.ntree, dtype=bool)
+    stack = [root]
+    while stack:
+        t = stack.pop()
+        in_sub[t] = True
+        if T.left[t] >= 0:
+            stack += [T.left[t], T.right[t]]
+    local = np.nonzero(in_sub)[0]
+    stubs = np.array([r for r in roots if r != root], dtype=np.int64)
+    order = np.concatenate([local, stubs, top]).astype(np.int64)
+    new_id = -np.ones(T.ntree, dtype=np.int64)
+    new_id[order] = np.arange(order.size)
+    # ---- replicated DOFs and ghosts
+    top_dofs_g = np.sort(np.concatenate([_node_dofs(T.piv_nodes[t], nVg, ndof_ug) for t in top])) if top.size else np.zeros(0, np.int64)
+    srt = np.argsort(l2g_dof, kind="stable")
+    lg_sorted = l2g_dof[srt]
+    k = np.searchsorted(lg_sorted, top_dofs_g)
+    k_c = np.minimum(k, max(lg_sorted.size - 1, 0))
+    present = (k < lg_sorted.size) & (lg_sorted[k_c] == top_dofs_g)
+    top_local = np.empty(top_dofs_g.size, dtype=np.int64)
+    top_local[present] = srt[k_c[present]]
+    nghost = int((~present).sum())
+    top_local[~present] = sub.ndof + np.arange(nghost)
+    l2g_full = np.concatenate([l2g_dof, top_dofs_g[~present]])
+    srt_f = np.argsort(l2g_full, kind="stable")
+    lgf_sorted = l2g_full[srt_f]
+
+    def g2l(dofs_g):
+        kk = np.searchsorted(lgf_sorted, dofs_g)
+        assert np.all(lgf_sorted[kk] == dofs_g), "a front DOF is neither local nor replicated"
+        return srt_f[kk]
+
+    # ---- fronts
+    dof_lists, npiv, level_of = [], [], []
+    h_root = int(T.height[root])
+    for t in order:
+        pd = _node_dofs(T.piv_nodes[t], nVg, ndof_ug)
+        bd = _node_dofs(T.bnd_nodes[t], nVg, ndof_ug)
+        if in_sub[t]:
+            dof_lists.append(g2l(np.concatenate([pd, bd]))); npiv.append(pd.size)
+            level_of.append(int(T.height[t]))
+        elif T.depth[t] == d:                        # another rank's subtree root: Schur complement only
+            dof_lists.append(g2l(bd)); npiv.append(0)
+            level_of.append(0)
+        else:                                        # replicated top of the tree
+            dof_lists.append(g2l(np.concatenate([pd, bd]))); npiv.append(pd.size)
+            level_of.append(h_root + (d - int(T.depth[t])))
+    parent = [new_id[T.parent[t]] if T.parent[t] >= 0 else -1 for t in order]
+    left = [new_id[T.left[t]] if (T.left[t] >= 0 and (in_sub[t] or T.depth[t] < d)) else -1 for t in order]
+    right = [new_id[T.right[t]] if (T.right[t] >= 0 and (in_sub[t] or T.depth[t] < d)) else -1 for t in order]
+    # ---- elements (sub-mesh cell order) -> leaf fronts
+    leaf_of_pos = np.zeros(mesh.nel, dtype=np.int64)
+    for t in local[T.left[local] < 0]:
+        leaf_of_pos[T.lo[t]:T.hi[t]] = t
+    elem_front = new_id[leaf_of_pos[T.epos[cells_g]]]
+    plan = _assemble_plan(dof_lists, npiv, parent, left, right, level_of, elem_front, sub.cell_dofs())
+    info = dict(cells=cells_g, vertices=verts_g, nghost=nghost, top_local=top_local.astype(np.int64),
+                n_local_levels=h_root + 1, root_front=int(new_id[root]),
+                stub_fronts=[int(new_id[r]) for r in roots],
+                schur_sizes=[int(_node_dofs(T.bnd_nodes[r], nVg, ndof_ug).size) for r in roots],
+                l2g_dof=l2g_full, l2g_p2=l2g_p2, n_top=int(top_dofs_g.size))
+    return sub, plan, info

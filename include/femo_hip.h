@@ -43,6 +43,12 @@ const char* femo_last_error(const femo_ctx* ctx);
 int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                 const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                 int elementwise_material, int elementwise_pressure, int nquad);
+/* The same with nghost extra entries appended to every state-sized vector: DOFs that exist on other
+ * element partitions only (replicated separator DOFs of the multi-GPU driver).  femo_ndof then returns
+ * mesh DOFs + nghost.  No element kernel touches the extra entries. */
+int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
+                      const double* xyz, const int32_t* cells, const int32_t* cell_p2,
+                      int elementwise_material, int elementwise_pressure, int nquad, int32_t nghost);
 void femo_destroy(femo_ctx* ctx);
 
 int64_t femo_ndof(const femo_ctx* ctx);
@@ -153,6 +159,22 @@ int femo_last_timing(const femo_ctx* ctx, double* out5);
 /* Average duration (ms) of `reps` back-to-back launches of one kernel, timed with HIP events on
  * the context's stream: "apply" (matrix-free element operator), "pcg_update", "pcg_direction", "diag". */
 int femo_bench_kernel(femo_ctx* ctx, const char* name, int32_t reps, double* avg_ms);
+
+/* ---- Building blocks of the element-partitioned multi-GPU driver (femo_alpha_amd/parallel.py).  The
+ * reference has no multi-rank path (its meshes live on MPI.COMM_SELF, fea/utils_dolfinx.py:41); these
+ * calls expose the local pieces between which the driver places its collectives.
+ * Vector ids: 0 state, 1 adjoint, 2 r, 3 z, 4 p, 5 Ap, 6 b. */
+void* femo_vec_ptr(femo_ctx* ctx, int32_t id);                 /* device pointer, femo_ndof doubles */
+int femo_sync(femo_ctx* ctx);                                  /* wait for the context's stream */
+int femo_op_apply_vec(femo_ctx* ctx, int32_t src, int32_t dst);   /* dst = K_local src (no Dirichlet mask) */
+int femo_load_vec(femo_ctx* ctx, int32_t dst);                 /* dst = local load vector */
+int femo_factorize_range(femo_ctx* ctx, int32_t l0, int32_t l1, int assemble);   /* tree levels [l0, l1) */
+int femo_frontal_sweep(femo_ctx* ctx, int32_t vec, int32_t l0, int32_t l1, int backward);
+int femo_front_schur_get(femo_ctx* ctx, int32_t front, void* dst_dev, int64_t capacity_doubles);
+int femo_front_block_set(femo_ctx* ctx, int32_t front, const void* src_dev);
+int femo_functionals_partial(femo_ctx* ctx, double* out3);     /* { int u.u J dx, regularisation, mass } */
+int femo_dfunctional_vec(femo_ctx* ctx, const char* name, int32_t dst);
+int femo_field_gradient_vec(femo_ctx* ctx, const char* functional, const char* arg, int32_t lam, double* out, int64_t n);
 
 /* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")
  * for zero-copy wrapping by the caller (e.g. torch.from_dlpack-free ctypes views). */
