@@ -84,9 +84,12 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
         raise SystemExit("the element partition needs a power-of-two number of GPUs")
     if args.workload != "wing1m":
         raise SystemExit("the multi-GPU bench runs the wing-skin workload")
-    m = wing_skin_mesh(116, 580 * world, span=6.0 * world)
+    ns = int(os.environ.get("FEMO_BENCH_NS", "580"))               # spanwise cells per GPU (580 = the 1M-DOF config)
+    m = wing_skin_mesh(116, ns * world, span=6.0 * world * ns / 580.0)
     marker = lambda x: np.less(x[1], 1e-9)
-    ds = DistributedShell(m, Comm(dist), bc_marker=marker, leaf_size=args.leaf, device=local_rank)
+    comm = Comm(dist)
+    shared_gpu = torch.cuda.device_count() < world                 # rehearsal: several ranks on one card
+    ds = DistributedShell(m, comm, bc_marker=marker, leaf_size=args.leaf, device=0 if shared_gpu else local_rank)
     ds.rtol = args.rtol
     fields = dict(thickness=np.array([1.27e-3]), E=np.array([73.1e9]), nu=np.array([0.33]), density=np.array([2780.0]),
                   F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
@@ -117,7 +120,7 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
     barrier()
     t_total = time.perf_counter() - t_start
     tt = torch.tensor([t_total, sum(r[0] for r in rows), sum(r[1] for r in rows)], device="cuda", dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    comm.allreduce_(tt, op="max")
     t_total, t_fwd, t_adj = tt.tolist()
     apply_ms = ds.eng.ctx.bench_kernel("apply", 50)
     alg_bytes = 16.0 * ds.sub.ndof + 340.0 * ds.sub.nel
@@ -129,7 +132,7 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
             "ms_per_step": t_total / args.steps * 1e3, "forward_ms": t_fwd / args.steps * 1e3,
             "adjoint_ms": t_adj / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"wing1m x{world}: synthetic wing skin 116x{580 * world} quads (span x{world}), {m.ndof} DOF, "
+            "config": {"workload": f"wing1m x{world}: synthetic wing skin 116x{ns * world} quads (span x{world}), {m.ndof} DOF, "
                                    f"one element partition of {ds.sub.nel} cells per GPU",
                        "ndof": m.ndof, "cells": m.nel, "ndof_per_gpu": ds.sub.ndof,
                        "replicated_separator_dofs": ds.info["n_top"],
@@ -165,8 +168,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank if torch.cuda.device_count() > local_rank else 0)
+        backend = os.environ.get("FEMO_BENCH_BACKEND", "nccl")     # "gloo" only to rehearse ranks that share one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 

@@ -38,16 +38,17 @@ class Comm:
         self.size = self.dist.get_world_size() if self.dist else 1
         self._stage = self.dist is not None and self.dist.get_backend() == "gloo"
 
-    def allreduce_(self, t):
-        """In-place sum over ranks (device tensors are staged through the host under gloo)."""
+    def allreduce_(self, t, op="sum"):
+        """In-place sum (or max) over ranks; device tensors are staged through the host under gloo."""
         if self.dist is None:
             return t
+        rop = self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM
         if self._stage and t.is_cuda:
             h = t.cpu()
-            self.dist.all_reduce(h)
+            self.dist.all_reduce(h, op=rop)
             t.copy_(h)
         else:
-            self.dist.all_reduce(t)
+            self.dist.all_reduce(t, op=rop)
         return t
 
     def allgather(self, t):
