@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace femo;
@@ -31,6 +32,9 @@ struct femo_ctx {
     double* xyz = nullptr;
     int* cells = nullptr;
     int* cellp2 = nullptr;
+    int* eorder = nullptr;      // elements along a Morton curve of their centroids (locality of gathers)
+    int *n2e_off = nullptr, *n2e_ent = nullptr;   // inverted connectivity: P2 node -> (slot in Morton order) * npc + local node
+    double* ybuf = nullptr;     // element results of the operator, YSTRIDE doubles per slot
     double* hK = nullptr;
     Tables* tab = nullptr;
     // fields
@@ -240,9 +244,19 @@ static int refresh_penalty(femo_ctx* c) {
     return 0;
 }
 
-// y += K_elastic x (+ penalty); y must hold the values to accumulate onto (usually zeros)
+// y = K_elastic x (+ penalty): element pass into ybuf, then one gather-sum per node (no atomics, fixed order)
 static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, double* za, double* zb, bool with_penalty) {
-    ELEM_LAUNCH(c, k_apply, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, x, y, dotslot, za, zb);
+    {
+        const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
+        ELEM_LAUNCH(c, k_apply4, NOEXTRA, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, x, c->ybuf, dotslot, za, zb);
+        const int nthreads = c->nP2 + c->nghost;
+        if (c->quad)
+            hipLaunchKernelGGL((k_gather_sum<9, 4>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,
+                               c->n2e_off, c->n2e_ent, c->ybuf, y);
+        else
+            hipLaunchKernelGGL((k_gather_sum<6, 3>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,
+                               c->n2e_off, c->n2e_ent, c->ybuf, y);
+    }
     if (with_penalty && c->nf > 0) {
         if (refresh_penalty(c)) return 1;
         hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 0, x, y,
@@ -632,6 +646,52 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipMemcpy(c->cells, soa_c.data(), soa_c.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&c->cellp2, soa_p.size() * sizeof(int)));
     HIPCHK(c, hipMemcpy(c->cellp2, soa_p.data(), soa_p.size() * sizeof(int), hipMemcpyHostToDevice));
+    {   // Morton order of the element centroids (30 bits per axis on the bounding box)
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        std::vector<double> cen((size_t)nel * 3, 0.0);
+        for (int e = 0; e < nel; ++e)
+            for (int k = 0; k < 3; ++k) {
+                double s = 0.0;
+                for (int b = 0; b < nvc; ++b) s += xyz[3 * (size_t)cells[(size_t)e * nvc + b] + k];
+                s /= nvc;
+                cen[3 * (size_t)e + k] = s;
+                lo[k] = std::min(lo[k], s); hi[k] = std::max(hi[k], s);
+            }
+        std::vector<std::pair<unsigned long long, int>> key(nel);
+        auto spread = [](unsigned long long v) {
+            unsigned long long r = 0;
+            for (int b = 0; b < 21; ++b) r |= ((v >> b) & 1ull) << (3 * b);
+            return r;
+        };
+        for (int e = 0; e < nel; ++e) {
+            unsigned long long code = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double ext = hi[k] - lo[k];
+                const unsigned long long q = ext > 0 ? (unsigned long long)((cen[3 * (size_t)e + k] - lo[k]) / ext * 2097151.0) : 0ull;
+                code |= spread(q) << k;
+            }
+            key[e] = {code, e};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int> eo(nel);
+        for (int e = 0; e < nel; ++e) eo[e] = key[e].second;
+        HIPCHK(c, hipMalloc((void**)&c->eorder, (size_t)nel * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->eorder, eo.data(), (size_t)nel * sizeof(int), hipMemcpyHostToDevice));
+        // inverted connectivity in slot order
+        std::vector<int> off(c->nP2 + 1, 0), ent((size_t)nel * npc);
+        for (size_t i = 0; i < (size_t)nel * npc; ++i) off[cell_p2[i] + 1]++;
+        for (int p = 0; p < c->nP2; ++p) off[p + 1] += off[p];
+        std::vector<int> cur(off.begin(), off.end() - 1);
+        for (int slot = 0; slot < nel; ++slot) {
+            const int e = eo[slot];
+            for (int a = 0; a < npc; ++a) ent[cur[cell_p2[(size_t)e * npc + a]]++] = slot * npc + a;
+        }
+        HIPCHK(c, hipMalloc((void**)&c->n2e_off, off.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->n2e_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->n2e_ent, ent.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->n2e_ent, ent.data(), ent.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->ybuf, (size_t)nel * YSTRIDE * sizeof(double)));
+    }
     HIPCHK(c, hipMalloc((void**)&c->hK, (size_t)nel * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
     Tables T;
@@ -702,7 +762,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->hK, c->tab, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)

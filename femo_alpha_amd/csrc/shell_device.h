@@ -457,6 +457,222 @@ k_apply(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __
     if (dotslot) block_accumulate(local, dotslot);
 }
 
+// register-lean variants for the production operator: local derivatives are recomputed from the
+// (scalar-cached) tables where they are used instead of being kept in 26 register pairs
+template <int NPC, int NVC>
+__device__ __forceinline__ Gen strains_q(const Tables& t, int q, const QPG& g, const double* xe) {
+    double G0[3] = {0, 0, 0}, G1[3] = {0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < NPC; ++a) {
+        const double r0 = t.dN2[q][a][0], r1 = t.dN2[q][a][1];
+        const double d0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], d1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            G0[c] += xe[3 * a + c] * d0;
+            G1[c] += xe[3 * a + c] * d1;
+        }
+    }
+    double th[3] = {0, 0, 0}, T0[3] = {0, 0, 0}, T1[3] = {0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double m0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], m1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double Mb = t.N1[q][b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = xe[3 * NPC + 3 * b + c];
+            th[c] += Mb * v;
+            T0[c] += m0 * v;
+            T1[c] += m1 * v;
+        }
+    }
+    Gen s;
+    const double t00 = dot3(g.E0, G0), t01 = dot3(g.E0, G1), t10 = dot3(g.E1, G0), t11 = dot3(g.E1, G1);
+    s.e00 = t00;
+    s.e11 = t11;
+    s.g01 = t01 + t10;
+    s.om = 0.5 * (t01 - t10) + dot3(th, g.E2);
+    s.ga0 = dot3(th, g.E1) + dot3(g.E2, G0);
+    s.ga1 = -dot3(th, g.E0) + dot3(g.E2, G1);
+    double x00[3], x01[3], x10[3], x11[3];
+    cross3(g.E0, g.w0, x00);
+    cross3(g.E0, g.w1, x01);
+    cross3(g.E1, g.w0, x10);
+    cross3(g.E1, g.w1, x11);
+    s.k00 = -dot3(g.E1, T0) + dot3(th, x00);
+    s.k11 = dot3(g.E0, T1) + dot3(th, x11);
+    s.k01 = -dot3(g.E1, T1) + dot3(th, x01) + dot3(g.E0, T0) + dot3(th, x10);
+    return s;
+}
+
+template <int NPC, int NVC>
+__device__ __forceinline__ void strains_T_q(const Tables& t, int q, const QPG& g, const Gen& tt, double* ye) {
+    double H0[3], H1[3];
+    const double a10 = tt.g01 - 0.5 * tt.om, a01 = tt.g01 + 0.5 * tt.om;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        H0[c] = tt.e00 * g.E0[c] + a10 * g.E1[c] + tt.ga0 * g.E2[c];
+        H1[c] = a01 * g.E0[c] + tt.e11 * g.E1[c] + tt.ga1 * g.E2[c];
+    }
+#pragma unroll
+    for (int a = 0; a < NPC; ++a) {
+        const double r0 = t.dN2[q][a][0], r1 = t.dN2[q][a][1];
+        const double d0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], d1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * a + c] += d0 * H0[c] + d1 * H1[c];
+    }
+    double x00[3], x01[3], x10[3], x11[3];
+    cross3(g.E0, g.w0, x00);
+    cross3(g.E0, g.w1, x01);
+    cross3(g.E1, g.w0, x10);
+    cross3(g.E1, g.w1, x11);
+    double Tq[3], C0[3], C1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Tq[c] = tt.ga0 * g.E1[c] - tt.ga1 * g.E0[c] + tt.om * g.E2[c] + tt.k00 * x00[c] + tt.k11 * x11[c] +
+                tt.k01 * (x01[c] + x10[c]);
+        C0[c] = -tt.k00 * g.E1[c] + tt.k01 * g.E0[c];
+        C1[c] = -tt.k01 * g.E1[c] + tt.k11 * g.E0[c];
+    }
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double m0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], m1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double Mb = t.N1[q][b];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += Mb * Tq[c] + m0 * C0[c] + m1 * C1[c];
+    }
+}
+
+// ---- the production element operator: 4 lanes per element (each lane a quarter of the quadrature points),
+// nodal values staged in LDS, partial results combined inside the quad with DPP, XCD-aware block order.
+__device__ __forceinline__ double quad_xor_sum(double v) {
+    // v + lanes xor 1 + xor 2 + xor 3 within each group of 4 lanes (DPP quad_perm, no LDS)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int lo1 = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    int hi1 = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    v += __hiloint2double(hi1, lo1);
+    lo = __double2loint(v); hi = __double2hiint(v);
+    lo1 = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    hi1 = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+    return v + __hiloint2double(hi1, lo1);
+}
+
+constexpr int YSTRIDE = 40;     // doubles per element slot of the element-result buffer (39 or 27 used)
+
+// second pass of the element operator: y(node) = sum of the contributions of the elements around the node,
+// read through the inverted connectivity (n2e_off / n2e_ent = slot * NPC + local node); also clears ghosts
+template <int NPC, int NVC>
+__global__ void __launch_bounds__(256)
+k_gather_sum(int nP2, int nV, int ndof_u, int ndof, const int* __restrict__ n2e_off, const int* __restrict__ n2e_ent,
+             const double* __restrict__ ybuf, double* __restrict__ y) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nP2) {
+        double s0 = 0, s1 = 0, s2 = 0, t0 = 0, t1 = 0, t2 = 0;
+        const int b = n2e_off[p], e = n2e_off[p + 1];
+        for (int k = b; k < e; ++k) {
+            const int ent = n2e_ent[k];
+            const int slot = ent / NPC, a = ent - slot * NPC;
+            const double* src = ybuf + (size_t)slot * YSTRIDE;
+            s0 += src[3 * a]; s1 += src[3 * a + 1]; s2 += src[3 * a + 2];
+            if (a < NVC) {
+                t0 += src[3 * NPC + 3 * a]; t1 += src[3 * NPC + 3 * a + 1]; t2 += src[3 * NPC + 3 * a + 2];
+            }
+        }
+        y[3 * p] = s0; y[3 * p + 1] = s1; y[3 * p + 2] = s2;
+        if (p < nV) {
+            y[ndof_u + 3 * p] = t0; y[ndof_u + 3 * p + 1] = t1; y[ndof_u + 3 * p + 2] = t2;
+        }
+    } else {
+        const int g = ndof_u + 3 * nV + (p - nP2);      // ghost entries: no element touches them
+        if (g < ndof) y[g] = 0.0;
+    }
+}
+
+// blocks that share an XCD (blockIdx % 8, observed round-robin placement -- a speed hint only) work on a
+// contiguous range of the element order, so that their gathers hit the same L2
+__device__ __forceinline__ int xcd_block(int b, int nb) {
+    const int per = (nb + 7) / 8;
+    const int lb = (b & 7) * per + (b >> 3);
+    return lb;
+}
+
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(256, 2)
+k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __restrict__ eorder,
+         const double* __restrict__ x, double* __restrict__ ybuf, double* dotslot, double* zero_a, double* zero_b) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    constexpr int EPB = 64;                     // elements per block (256 threads / 4 lanes)
+    __shared__ double sx[EPB][LD + 1];
+    // the lanes of a quad work on different quadrature points, so the tables are indexed per lane: keep
+    // them in LDS (a per-lane global/scalar load would park ~40 doubles of table data in VGPRs)
+    __shared__ Tables stab;
+    {
+        const double* src = reinterpret_cast<const double*>(tab);
+        double* dst = reinterpret_cast<double*>(&stab);
+        for (int i = threadIdx.x; i < (int)(sizeof(Tables) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zero_a) *zero_a = 0.0;
+        if (zero_b) *zero_b = 0.0;
+    }
+    const int lb = xcd_block(blockIdx.x, gridDim.x);
+    const int le = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int pos = lb * EPB + le;
+    const bool active = lb * EPB < m.nel && pos < m.nel;
+    double local = 0.0;
+    const int e = active ? (eorder ? eorder[pos] : pos) : 0;
+    Elem<NPC, NVC> el;
+    if (active) {
+        load_elem<NPC, NVC, UHAT>(m, f, e, el);
+        // each lane of the quad fetches a quarter of the element vector (static indices: no scratch arrays)
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            if ((i & 3) == sub) {
+                const int node = i / 3, c = i - 3 * node;
+                const int g = node < NPC ? 3 * el.pid[node < NPC ? node : 0] + c : m.ndof_u + 3 * el.vid[node >= NPC ? node - NPC : 0] + c;
+                sx[le][i] = x[g];
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        double ye[LD];
+#pragma unroll
+        for (int i = 0; i < LD; ++i) ye[i] = 0.0;
+        const int nq = stab.nq;
+        for (int q = sub; q < nq; q += 4) {
+            // re-derive the LDS row every iteration: keeps the compiler from hoisting the 39 nodal values
+            // out of the loop into 78 registers
+            int row = le;
+            asm volatile("" : "+v"(row));
+            const double* xe = sx[row];
+            QPG g;
+            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, stab.N1[q], stab.dN1[q], g);
+            Mat mat, ex;
+            material<DERIV_NONE>(interp<NVC>(stab.N1[q], el.hn), interp<NVC>(stab.N1[q], el.En),
+                                 interp<NVC>(stab.N1[q], el.nun), el.hK, stab.w[q] * g.det, g.Ju, mat, ex);
+            const Gen s = strains_q<NPC, NVC>(stab, q, g, xe);
+            const Gen t = stress_of(s, mat);
+            strains_T_q<NPC, NVC>(stab, q, g, t, ye);
+        }
+#pragma unroll
+        for (int i = 0; i < LD; ++i) ye[i] = quad_xor_sum(ye[i]);
+        // lane `sub` owns the outputs i == sub (mod 4); the element's 39 results go to its own slot of ybuf
+        // (plain stores, 320 contiguous bytes per element) -- k_gather_sum adds them up per node: no atomics,
+        // and a fixed summation order
+        double* out = ybuf + (size_t)pos * YSTRIDE;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            if ((i & 3) == sub) {
+                out[i] = ye[i];
+                local += sx[le][i] * ye[i];
+            }
+        }
+    }
+    if (dotslot) block_accumulate(local, dotslot);
+}
+
 // diag += diag(K_elastic)
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
