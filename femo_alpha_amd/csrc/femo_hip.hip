@@ -3,6 +3,7 @@
 #include "../../include/femo_hip.h"
 #include "shell_device.h"
 #include "frontal.h"
+#include "shape_sens.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1033,6 +1034,30 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
     return fail(c, "unknown functional '" + s + "'");
 }
 
+// out (3 nn) += scale * d/d uhat of: mode 0 lam.(K w - F) [+ penalty], 1 int u.u J, 2 mass, 3 elastic energy
+static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const double* lam, double scale, double* out) {
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int nthreads = c->nel * 3 * c->nvc;
+    if (c->quad)
+        hipLaunchKernelGGL((k_shape_gradient<9, 4, true>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, c->tab, mode, w, lam,
+                           scale, out);
+    else
+        hipLaunchKernelGGL((k_shape_gradient<6, 3, false>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, c->tab, mode, w,
+                           lam, scale, out);
+    if (mode == 0 && c->nf > 0) {
+        const int nt = c->nf * 3 * c->nvc;
+        if (c->quad)
+            hipLaunchKernelGGL((k_shape_gradient_penalty<4, true>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta,
+                               w, lam, scale, out);
+        else
+            hipLaunchKernelGGL((k_shape_gradient_penalty<3, false>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta,
+                               w, lam, scale, out);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // gradient of a functional into a device buffer `out` (length n, zero-filled here)
 static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string& wrt, double* out, int64_t n) {
     int64_t len;
@@ -1043,7 +1068,11 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
-    if (wrt == "uhat") return fail(c, "derivatives with respect to 'uhat' are not implemented in this build");
+    if (wrt == "uhat") {
+        const int mode = fn == "compliance" ? 1 : fn == "mass" ? 2 : fn == "elastic_energy" ? 3 : -1;
+        if (mode < 0) return fail(c, "unknown functional '" + fn + "'");
+        return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
+    }
     if (fn == "compliance") {
         if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out);
         else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
@@ -1074,6 +1103,7 @@ static int dRdarg_T_dev(femo_ctx* c, const std::string& arg, const double* lam, 
     else if (arg == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
     else if (arg == "F_solid") ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
     else if (arg == "density") { /* R does not depend on density */ }
+    else if (arg == "uhat") { if (shape_gradient_dev(c, 0, c->w, lam, scale, out)) return 1; }
     else return fail(c, "(dR/d" + arg + ")^T is not implemented in this build");
     HIPCHK(c, hipGetLastError());
     return 0;

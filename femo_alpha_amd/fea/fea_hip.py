@@ -13,27 +13,9 @@ replaced by light handles onto a ``ShellContext`` (all arithmetic runs in libfem
 """
 from __future__ import annotations
 
-import warnings
-
 import numpy as np
 
 from ..backend import ShellContext
-
-
-class ShapeDerivativeWarning(UserWarning):
-    """Derivatives with respect to the mesh motion ``uhat`` are a 'next' row (SURVEY.md section 8f
-    rank 2): they are reported as zero, so totals with respect to ``node_disp`` are incomplete."""
-
-
-def _uhat_zeros(n):
-    warnings.warn("d/d(uhat) is not implemented in this build and is reported as zero; totals with respect "
-                  "to node_disp are incomplete", ShapeDerivativeWarning, stacklevel=3)
-    return np.zeros(n)
-
-__all__ = ["FEA", "Function", "FunctionSpace", "Form", "ResidualForm", "PartialForm", "JacobianOperator",
-           "LinearSolver", "update", "getFuncArray", "setFuncArray", "assemble", "assembleVector",
-           "assembleScalar", "assembleMatrix", "assembleSystem", "computePartials", "createFunction",
-           "computeMatVecProductFwd", "computeMatVecProductBwd", "setUpKSP_MUMPS", "solveNonlinear"]
 
 
 class FunctionSpace:
@@ -127,8 +109,6 @@ class JacobianOperator:
     def multTranspose(self, lam):
         if self.wrt == "state":
             return self.ctx.apply_K(lam)                   # symmetric
-        if self.wrt == "uhat":
-            return _uhat_zeros(self.shape[1])
         return self.ctx.dRdarg_T(self.wrt, lam)
 
 
@@ -175,8 +155,6 @@ def assembleVector(v):
         return v.ctx.residual()
     if isinstance(v, PartialForm) and isinstance(v.form, Form):
         wrt = "disp_solid" if v.wrt.role == "state" else v.wrt.role
-        if wrt == "uhat":
-            return _uhat_zeros(v.wrt.function_space.dim)
         return v.form.ctx.dfunctional(v.form.name, wrt)
     raise TypeError("assembleVector: unsupported form")
 

@@ -133,11 +133,11 @@ int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iter
  * rm_shell/rm_shell_pde.py:64-110). */
 int femo_functional(femo_ctx* ctx, const char* name, double* value);
 /* Gradient vector of a scalar output with respect to "disp_solid", "thickness", "density", "E", "nu",
- * "F_solid" or "uhat" (zeros where the form does not depend on the argument; "uhat" not yet
- * implemented -> error) -- replaces assemble(derivative(form, arg), dim=1)
+ * "F_solid" or "uhat" (zeros where the form does not depend on the argument; "uhat" = shape sensitivity
+ * through F = I + grad(uhat), kinematics.py:12-44) -- replaces assemble(derivative(form, arg), dim=1)
  * (csdl_alpha_opt/output_operation.py:58-69). n must equal the argument's length. */
 int femo_dfunctional(femo_ctx* ctx, const char* name, const char* wrt, double* out, int64_t n);
-/* out = (dR/d arg)^T lambda at the stored state, arg in "thickness","E","nu","F_solid" --
+/* out = (dR/d arg)^T lambda at the stored state, arg in "thickness","E","nu","F_solid","uhat" --
  * replaces assembleMatrix(dR/d arg) + computeMatVecProductBwd
  * (csdl_alpha_opt/state_operation.py:174-184,283-286; fea/utils_dolfinx.py:294-306). */
 int femo_dRdarg_T(femo_ctx* ctx, const char* arg, const double* lambda, double* out, int64_t n);

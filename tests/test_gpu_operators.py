@@ -62,6 +62,17 @@ def test_rm_shell_model_protocol(element_wise_material, penalty):
     eb = f_d * 2.0 * 10.0 ** 4 / (8 * E_val * 2.0 * h_val ** 3 / 12)
     assert 0.8 * eb < np.abs(out.disp_solid.value[:mesh.ndof_u]).max() < 1.2 * eb
 
+    # shape derivative through the protocol: d compliance / d node_disp against a finite difference of the oracle
+    dJu = recorder.compute_totals(out.compliance, node_disp)
+    assert dJu.shape == (nn, 3)
+    v = nn // 2
+    def J_of(uh):
+        o.set_fields(uhat=uh); return o.compliance(o.solve())
+    up = np.zeros((nn, 3)); up[v, 2] = 1e-5
+    fd = (J_of(up) - J_of(-up)) / 2e-5
+    o.set_fields(uhat=np.zeros((nn, 3)))
+    assert abs(dJu[v, 2] - fd) < 1e-4 * max(np.abs(dJu).max(), abs(fd))
+
     # total derivative through the operator protocol == oracle adjoint
     dJ = recorder.compute_totals(out.compliance, thickness)
     assert np.abs(dJ - dJ_ref).max() < 1e-7 * np.abs(dJ_ref).max()
