@@ -44,6 +44,8 @@ SIGNATURES = {
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_set_stress_params": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "femo_field_output": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_int64]),
     "femo_functional": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p]),
     "femo_dfunctional": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, _c_double_p, C.c_int64]),
     "femo_dRdarg_T": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, _c_double_p, C.c_int64]),

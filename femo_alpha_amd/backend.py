@@ -186,6 +186,14 @@ class ShellContext:
         self._chk(self.lib.femo_functional(self._h, name.encode(), C.byref(v)))
         return v.value
 
+    def set_stress_params(self, m=1e-6, rho=100.0):
+        self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
+
+    def field_output(self, name="stress"):
+        out = np.empty(self.mesh.nvc * self.mesh.nel)
+        self._chk(self.lib.femo_field_output(self._h, name.encode(), dptr(out), out.size))
+        return out
+
     def arg_size(self, wrt):
         return self.ndof if wrt == "disp_solid" else self.field_size(wrt)
 

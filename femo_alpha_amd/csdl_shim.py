@@ -58,6 +58,26 @@ class Variable:
         _ViewOp.register(out, lambda: self.value.reshape(shape))
         return out
 
+    # scalar arithmetic used by the stress aggregation (rm_shell_model.py:501-503): c * v and v ** p
+    def _unary(self, fn, dfn):
+        out = Variable(fn(self.value))
+        out._producer = ("unary", self, dfn)
+        _ViewOp.register(out, lambda: fn(self.value))
+        return out
+
+    def __mul__(self, c):
+        c = float(c)
+        return self._unary(lambda v: c * v, lambda v: c * np.ones_like(v))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, c):
+        return self.__mul__(1.0 / float(c))
+
+    def __pow__(self, p):
+        p = float(p)
+        return self._unary(lambda v: v ** p, lambda v: p * v ** (p - 1.0))
+
     def __repr__(self):
         return f"Variable({self.name}, shape={self.shape})"
 
@@ -188,6 +208,8 @@ class Recorder:
                 var, bar = p[1], bar.reshape(p[1].shape)
             elif isinstance(p, tuple) and p and p[0] == "transpose":
                 var, bar = p[1], bar.reshape(var.shape).T
+            elif isinstance(p, tuple) and p and p[0] == "unary":
+                var, bar = p[1], bar.reshape(var.shape) * p[2](p[1].value)
             else:
                 break
         key = id(var)

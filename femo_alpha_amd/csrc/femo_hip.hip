@@ -4,6 +4,7 @@
 #include "shell_device.h"
 #include "frontal.h"
 #include "shape_sens.h"
+#include "stress.h"
 
 #include <hip/hip_runtime.h>
 
@@ -38,6 +39,8 @@ struct femo_ctx {
     double* ybuf = nullptr;     // element results of the operator, YSTRIDE doubles per slot
     double* hK = nullptr;
     Tables* tab = nullptr;
+    Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
+    double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0;
     // fields
     double *h = nullptr, *E = nullptr, *nu = nullptr, *rho = nullptr, *f = nullptr, *uhat = nullptr;
     // dirichlet
@@ -699,6 +702,10 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     build_tables(c->quad, nquad, T);
     HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    Tables TS_;
+    build_tables(c->quad, 3, TS_);               // quadrature_degree 4 (rm_shell_model.py:200-201)
+    HIPCHK(c, hipMalloc((void**)&c->tab_s, sizeof(Tables)));
+    HIPCHK(c, hipMemcpy(c->tab_s, &TS_, sizeof(Tables), hipMemcpyHostToDevice));
     c->nT = c->ewm ? nel : c->nn;
     c->nF = c->ewp ? nel : c->nn;
     if (alloc_d(c, &c->h, c->nT) || alloc_d(c, &c->E, c->nT) || alloc_d(c, &c->nu, c->nT) || alloc_d(c, &c->rho, c->nT) ||
@@ -763,7 +770,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1012,6 +1019,19 @@ static int functionals_dev(femo_ctx* c, double out3[3]) {
     return 0;
 }
 
+// int (m vm)^rho J dx over the cells and (first call) the reference area alpha
+static int pnorm_dev(femo_ctx* c, double out2[2]) {
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+    ELEM_LAUNCH(c, k_pnorm, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab_s, 0, c->stress_m, c->stress_rho, 1.0,
+                c->w, (double*)nullptr, c->scal);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out2[0] = c->scal_host[0]; out2[1] = c->scal_host[1];
+    if (c->stress_alpha < 0) c->stress_alpha = out2[1];
+    return 0;
+}
+
 int femo_functional(femo_ctx* c, const char* name, double* value) {
     HIPCHK(c, hipSetDevice(c->device));
     const std::string s(name ? name : "");
@@ -1031,6 +1051,12 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
         *value = 0.5 * c->scal_host[7];
         return 0;
     }
+    if (s == "pnorm_stress") {
+        double v[2];
+        if (pnorm_dev(c, v)) return 1;
+        *value = v[0] / c->stress_alpha;
+        return 0;
+    }
     return fail(c, "unknown functional '" + s + "'");
 }
 
@@ -1039,12 +1065,13 @@ static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const doub
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int nthreads = c->nel * 3 * c->nvc;
+    const Tables* tb = mode == 4 ? c->tab_s : c->tab;
     if (c->quad)
-        hipLaunchKernelGGL((k_shape_gradient<9, 4, true>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, c->tab, mode, w, lam,
-                           scale, out);
+        hipLaunchKernelGGL((k_shape_gradient<9, 4, true>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w, lam,
+                           scale, c->stress_m, c->stress_rho, out);
     else
-        hipLaunchKernelGGL((k_shape_gradient<6, 3, false>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, c->tab, mode, w,
-                           lam, scale, out);
+        hipLaunchKernelGGL((k_shape_gradient<6, 3, false>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w,
+                           lam, scale, c->stress_m, c->stress_rho, out);
     if (mode == 0 && c->nf > 0) {
         const int nt = c->nf * 3 * c->nvc;
         if (c->quad)
@@ -1069,8 +1096,12 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
     if (wrt == "uhat") {
-        const int mode = fn == "compliance" ? 1 : fn == "mass" ? 2 : fn == "elastic_energy" ? 3 : -1;
+        const int mode = fn == "compliance" ? 1 : fn == "mass" ? 2 : fn == "elastic_energy" ? 3 : fn == "pnorm_stress" ? 4 : -1;
         if (mode < 0) return fail(c, "unknown functional '" + fn + "'");
+        if (mode == 4) {
+            if (c->stress_alpha < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
+            return shape_gradient_dev(c, 4, c->w, nullptr, 1.0 / c->stress_alpha, out);
+        }
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
     if (fn == "compliance") {
@@ -1084,6 +1115,12 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         else if (wrt == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
         else if (wrt == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
         else if (wrt == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+    } else if (fn == "pnorm_stress") {
+        if (c->stress_alpha < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
+        const int mode = wrt == "disp_solid" ? 1 : wrt == "thickness" ? 2 : wrt == "E" ? 3 : wrt == "nu" ? 4 : 0;
+        if (mode)
+            ELEM_LAUNCH(c, k_pnorm, NOEXTRA, g, EB, m, f, c->tab_s, mode, c->stress_m, c->stress_rho, 1.0 / c->stress_alpha, c->w, out,
+                        (double*)nullptr);
     } else {
         return fail(c, "unknown functional '" + fn + "'");
     }
@@ -1391,6 +1428,26 @@ int femo_field_gradient_vec(femo_ctx* c, const char* functional, const char* arg
     }
     hipFree(d);
     return rc;
+}
+
+int femo_set_stress_params(femo_ctx* c, double m, double rho) {
+    if (!(m > 0) || !(rho > 0)) return fail(c, "stress aggregation parameters must be positive");
+    c->stress_m = m; c->stress_rho = rho;
+    return 0;
+}
+
+int femo_field_output(femo_ctx* c, const char* name, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (std::string(name ? name : "") != "stress") return fail(c, "unknown field output");
+    if (n != (int64_t)c->nvc * c->nel) return fail(c, "the DG1 stress field has nvc * nel entries");
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+    ELEM_LAUNCH(c, k_stress_field, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, d);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d);
+    HIPCHK(c, e);
+    return 0;
 }
 
 int femo_last_timing(const femo_ctx* c, double* out5) {

@@ -172,10 +172,11 @@ __device__ __forceinline__ D1 energy_density_dual(const GenD& a, const GenD& b, 
 // mode 1: int u.u J dx      (compliance without the regularisation, which has no uhat dependence)
 // mode 2: int rho h J dx    (mass)
 // mode 3: 1/2 w . K w       (elastic energy)
+// mode 4: int (m vm_top)^rho J dx   (p-norm stress before the 1/alpha scaling)
 template <int NPC, int NVC, bool QUAD>
 __global__ void __launch_bounds__(128)
 k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, const double* __restrict__ w,
-                 const double* __restrict__ lam, double scale, double* __restrict__ out) {
+                 const double* __restrict__ lam, double scale, double ms, double rho, double* __restrict__ out) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gid / (3 * NVC), dir = gid - e * (3 * NVC);
@@ -226,6 +227,31 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
                 for (int a = 0; a < NPC; ++a)
                     for (int c = 0; c < 3; ++c) lq[c] += tab->N2[q][a] * le[3 * a + c];
                 phi = phi - (wdet * dot3(fq, lq)) * s.Ju;
+            }
+        } else if (mode == 4) {
+            const double Eq = interp<NVC>(tab->N1[q], el.En), nuq = interp<NVC>(tab->N1[q], el.nun);
+            const GenD sw = strains_dual<NPC, NVC>(*tab, q, g, s, we);
+            double th[3] = {0, 0, 0};
+            D1 gh0 = mk(0.0), gh1 = mk(0.0);
+            for (int b = 0; b < NVC; ++b) {
+                for (int c = 0; c < 3; ++c) th[c] += tab->N1[q][b] * we[3 * NPC + 3 * b + c];
+                if (!f.ewm) {
+                    const double r0 = tab->dN1[q][b][0], r1 = tab->dN1[q][b][1];
+                    gh0 = gh0 + el.hn[b] * (r0 * s.Q[0][0] + r1 * s.Q[1][0]);
+                    gh1 = gh1 + el.hn[b] * (r0 * s.Q[0][1] + r1 * s.Q[1][1]);
+                }
+            }
+            const double b0 = -dot3(th, g.E1), b1 = dot3(th, g.E0), z = 0.5 * hq;
+            const D1 e0 = sw.e00 - z * sw.k00 - (0.5 * b0) * gh0;
+            const D1 e1 = sw.e11 - z * sw.k11 - (0.5 * b1) * gh1;
+            const D1 gg = sw.g01 - z * sw.k01 - 0.5 * (b0 * gh1 + b1 * gh0);
+            const double cc = Eq / (1.0 - nuq * nuq);
+            const D1 s0 = cc * (e0 + nuq * e1), s1 = cc * (nuq * e0 + e1), s2 = (cc * 0.5 * (1.0 - nuq)) * gg;
+            const D1 vm = dsqrt(s0 * s0 - s0 * s1 + s1 * s1 + 3.0 * (s2 * s2));
+            if (vm.v > 0.0) {
+                const double p = pow(ms * vm.v, rho);
+                const D1 pw = mk(p, rho * p / vm.v * vm.d);
+                phi = phi + wdet * (pw * s.Ju);
             }
         } else if (mode == 1) {
             double uq[3] = {0, 0, 0};

@@ -76,6 +76,13 @@ class Form:
         self.ctx, self.name = ctx, name
 
 
+class FieldForm:
+    """Field output known to the backend: 'stress' (top-surface von Mises, projected onto DG1)."""
+
+    def __init__(self, ctx, name):
+        self.ctx, self.name = ctx, name
+
+
 class ResidualForm:
     """R(w; thickness, F_solid, E, nu, uhat) of the shell, Dirichlet treatment included."""
 
@@ -249,7 +256,16 @@ class FEA:
         self.outputs_dict[name] = dict(form=form, shape=1, arguments=arguments, partials=partials)
 
     def add_field_output(self, name, form, arguments, function_space=("CG", 1), record=False, vtk=False):
-        raise NotImplementedError("field outputs (L2-projected stress) are a 'next' row, SURVEY.md section 8f rank 1")
+        if tuple(function_space) != ("DG", 1):
+            raise NotImplementedError("field outputs are projected onto ('DG', 1), the space rm_shell_model.py:237 asks for")
+        space = FunctionSpace.__new__(FunctionSpace)
+        space.ctx, space.kind, space.dim = form.ctx, "DG1", form.ctx.mesh.nvc * form.ctx.mesh.nel
+        self.outputs_field_dict[name] = dict(form=form, function=Function(space), shape=space.dim, arguments=arguments,
+                                             partials=[], recorder=None, record=False)
+
+    def projectFieldOutput(self, form, func):
+        """L2 projection of the field form onto its DG1 function (fea_dolfinx.py:205-206)."""
+        func.set(form.ctx.field_output(form.name))
 
     def add_strong_bc(self, ubc, locate_BC_list, function_space=None):
         for dofs in locate_BC_list:

@@ -2,10 +2,9 @@
 
 Constructor and ``evaluate`` follow femo_alpha/rm_shell/rm_shell_model.py:31-81,364-490; the
 ``mesh`` argument is a ``femo_alpha_amd.mesh.ShellMesh`` (nodes + connectivity, the data
-``reconstructFEAMesh`` takes) instead of a dolfinx mesh.  Outputs registered in this build:
-``disp_solid`` (state), ``compliance``, ``mass``, ``elastic_energy``, ``disp_extracted``; the
-stress outputs (``pnorm_stress``, ``stress``, ``aggregated_stress``) are a 'next' row
- and are absent from the returned group until they land.
+``reconstructFEAMesh`` takes) instead of a dolfinx mesh.  Outputs, as in the reference:
+``disp_solid`` (state), ``compliance``, ``mass``, ``elastic_energy``, ``pnorm_stress``, the DG1 field
+``stress``, ``disp_extracted`` and ``aggregated_stress``.
 """
 from __future__ import annotations
 
@@ -87,6 +86,9 @@ class RMShellModel:
         compliance_form = shell_pde.compliance(w, uhat, h, f)
         mass_form = shell_pde.mass(uhat, h, density)
         elastic_energy_form = shell_pde.elastic_energy(w, uhat, h, E)
+        pnorm_stress_form = shell_pde.pnorm_stress(w, uhat, h, E, nu, None, m=self.m, rho=self.rho, alpha=None,
+                                                   regularization=False)
+        stress_form = shell_pde.von_Mises_stress(w, uhat, h, E, nu, surface="Top")
         fea.add_input("thickness", h, init_val=0.001)
         fea.add_input("F_solid", f, init_val=1.0)
         fea.add_input("E", E, init_val=1.0)
@@ -98,6 +100,9 @@ class RMShellModel:
         fea.add_output(name="compliance", form=compliance_form, arguments=["disp_solid", "F_solid", "thickness", "uhat"])
         fea.add_output(name="mass", form=mass_form, arguments=["thickness", "density", "uhat"])
         fea.add_output(name="elastic_energy", form=elastic_energy_form, arguments=["thickness", "disp_solid", "E", "uhat"])
+        fea.add_output(name="pnorm_stress", form=pnorm_stress_form, arguments=["thickness", "disp_solid", "E", "nu", "uhat"])
+        fea.add_field_output(name="stress", form=stress_form, arguments=["thickness", "disp_solid", "E", "nu", "uhat"],
+                             function_space=("DG", 1), record=False, vtk=True)
         self.fea = fea
 
     def evaluate(self, force_vector, thickness, E, nu, density, node_disp=None, debug_mode=False, is_pressure=True):
@@ -130,6 +135,9 @@ class RMShellModel:
         disp_extracted = DisplacementExtractionModel(shell_pde=self.shell_pde).evaluate(shell_outputs.disp_solid)
         disp_extracted.add_name("disp_extracted")
         shell_outputs.disp_extracted = disp_extracted
+        aggregated_stress = AggregatedStressModel(m=self.m, rho=self.rho).evaluate(shell_outputs.pnorm_stress)
+        aggregated_stress.add_name("aggregated_stress")
+        shell_outputs.aggregated_stress = aggregated_stress
         return shell_outputs
 
 

@@ -11,7 +11,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from ..backend import PENALTY_BETA, ShellContext
-from ..fea.fea_hip import Form, Function, FunctionSpace, ResidualForm
+from ..fea.fea_hip import FieldForm, Form, Function, FunctionSpace, ResidualForm
 
 
 class FacetSet:
@@ -57,11 +57,18 @@ class RMShellPDE:
     def elastic_energy(self, w, uhat, h, E):
         return Form(self.ctx, "elastic_energy")
 
-    def pnorm_stress(self, *args, **kwargs):
-        raise NotImplementedError("p-norm stress aggregation is a 'next' row (SURVEY.md section 8f, rank 1)")
+    def pnorm_stress(self, w, uhat, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False):
+        """1/alpha int (m vm_top)^rho J dx with the degree-4 measure (rm_shell_pde.py:112-128); alpha is the
+        reference area, evaluated by the backend on first use."""
+        if regularization or alpha is not None:
+            raise NotImplementedError("only the reference's call pattern (alpha=None, regularization=False) is supported")
+        self.ctx.set_stress_params(m, rho)
+        return Form(self.ctx, "pnorm_stress")
 
-    def von_Mises_stress(self, *args, **kwargs):
-        raise NotImplementedError("von Mises stress field is a 'next' row (SURVEY.md section 8f, rank 1)")
+    def von_Mises_stress(self, w, uhat, h, E, nu, surface="Top"):
+        if surface != "Top":
+            raise NotImplementedError("only the top-surface stress is provided (the one rm_shell_model.py:207-208 registers)")
+        return FieldForm(self.ctx, "stress")
 
     # ------------------------------------------------------------------ maps
     def construct_nodal_disp_map(self):

@@ -128,7 +128,14 @@ int femo_solve_state(femo_ctx* ctx, int zero_guess, int32_t* iters, double* relr
  * the same call serves both modes (reference quirk Q3). */
 int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iters, double* relres);
 
-/* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy" --
+/* Stress aggregation parameters (m, rho) of pnorm_stress = 1/alpha int (m vm_top)^rho J dx
+ * (rm_shell/rm_shell_pde.py:112-128; defaults 1e-6, 100 as rm_shell_model.py:63). */
+int femo_set_stress_params(femo_ctx* ctx, double m, double rho);
+/* Field output "stress": top-surface von Mises stress L2-projected onto DG1, nvc*nel values (cell-major, the
+ * cell's vertices in connectivity order) -- replaces FEA.projectFieldOutput (fea/fea_dolfinx.py:205-206,
+ * csdl_alpha_opt/output_operation.py:116-123). */
+int femo_field_output(femo_ctx* ctx, const char* name, double* out, int64_t n);
+/* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy", "pnorm_stress" --
  * replaces assemble_scalar(form(c)) (csdl_alpha_opt/output_operation.py:51-56; forms at
  * rm_shell/rm_shell_pde.py:64-110). */
 int femo_functional(femo_ctx* ctx, const char* name, double* value);

@@ -493,6 +493,53 @@ class ShellOracle:
                 np.add.at(out, self.mesh.cells[sl].ravel(), np.einsum("eq,qb->eb", wj, self.N1).ravel())
         return out
 
+    # ------------------------------------------------------------------ stress outputs
+    def von_mises_top(self, w, sl=slice(None)):
+        """Top-surface von Mises stress at the quadrature points of this oracle's rule, (ne,nq), following
+        ShellStressRM (linear_shell_model.py:393-467) with xi2 = h/2 a *field* (rm_shell_pde.py:117-119):
+        eps = eps_m - h/2 kappa - 1/2 sym((E2 x theta)_loc (x) gradx(h)_loc)."""
+        B, g = self._B(sl)
+        we = w[self.dofs[sl]]
+        s = np.einsum("eqij,ej->eqi", B, we)
+        h, E, nu = self._at_qp(self.h, sl), self._at_qp(self.E, sl), self._at_qp(self.nu, sl)
+        th = np.einsum("qb,ebc->eqc", self.N1, we[:, 3 * self.npc:].reshape(-1, self.nvc, 3))
+        b0 = -np.einsum("eqc,eqc->eq", th, g["E1"]); b1 = np.einsum("eqc,eqc->eq", th, g["E0"])
+        if self.ewm:
+            gh0 = gh1 = np.zeros_like(h)
+        else:
+            gxM = np.einsum("eqbk,eqkj->eqbj", g["gradM"], g["Finv"])
+            hn = self.h[self.mesh.cells[sl]]
+            gh = np.einsum("eb,eqbj->eqj", hn, gxM)
+            gh0 = np.einsum("eqj,eqj->eq", g["E0"], gh); gh1 = np.einsum("eqj,eqj->eq", g["E1"], gh)
+        e0 = s[..., 0] - 0.5 * h * s[..., 3] - 0.5 * b0 * gh0
+        e1 = s[..., 1] - 0.5 * h * s[..., 4] - 0.5 * b1 * gh1
+        gg = s[..., 2] - 0.5 * h * s[..., 5] - 0.5 * (b0 * gh1 + b1 * gh0)
+        c = E / (1 - nu ** 2)
+        s0, s1, s2 = c * (e0 + nu * e1), c * (nu * e0 + e1), c * 0.5 * (1 - nu) * gg
+        return np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2 + 3 * s2 ** 2), g
+
+    def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None):
+        """1/alpha int (m vm)^rho J dx (rm_shell_pde.py:112-128); use an oracle built with nquad=3 for the
+        reference's degree-4 measure (rm_shell_model.py:200-205).  alpha defaults to the reference area."""
+        val, area = 0.0, 0.0
+        for sl in self._chunks():
+            vm, g = self.von_mises_top(w, sl)
+            wd = self.wts[None, :] * g["det"]
+            val += np.sum(wd * g["Ju"] * (m * vm) ** rho)
+            area += np.sum(wd)
+        return val / (area if alpha is None else alpha)
+
+    def stress_dg1(self, w):
+        """L2 projection of the top-surface von Mises stress onto DG1, (nel, nvc) (utils_dolfinx.py:568-602)."""
+        out = np.zeros((self.mesh.nel, self.nvc))
+        for sl in self._chunks():
+            vm, g = self.von_mises_top(w, sl)
+            wd = self.wts[None, :] * g["det"]
+            M = np.einsum("eq,qi,qj->eij", wd, self.N1, self.N1)
+            b = np.einsum("eq,qi,eq->ei", wd, self.N1, vm)
+            out[sl] = np.linalg.solve(M, b[..., None])[..., 0]
+        return out
+
     # ------------------------------------------------------------------ (dR/d arg)^T lambda
     def dRdfield_T(self, name, w, lam):
         """(dR/d field)^T lam for field in {'h','E','nu'} -- what

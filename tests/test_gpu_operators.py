@@ -62,6 +62,20 @@ def test_rm_shell_model_protocol(element_wise_material, penalty):
     eb = f_d * 2.0 * 10.0 ** 4 / (8 * E_val * 2.0 * h_val ** 3 / 12)
     assert 0.8 * eb < np.abs(out.disp_solid.value[:mesh.ndof_u]).max() < 1.2 * eb
 
+    # stress outputs (rm_shell_model.py:200-208, 230-239, 452-455)
+    from oracle.rm_shell_oracle import ShellOracle as _SO
+    o3 = _SO(mesh, element_wise_material=element_wise_material, nquad=3)
+    o3.set_fields(h=h0, E=E_val, nu=nu_val)
+    pn = o3.pnorm_stress(w_ref, 1e-6, 100)
+    assert abs(out.pnorm_stress.value[0] - pn) < 1e-6 * pn
+    assert abs(out.aggregated_stress.value[0] - 1e6 * pn ** 0.01) < 1e-7 * 1e6 * pn ** 0.01
+    assert out.stress.shape == (4 * nel,)
+    assert np.abs(out.stress.value.reshape(nel, 4) - o.stress_dg1(w_ref)).max() < 1e-6 * np.abs(o.stress_dg1(w_ref)).max()
+    dA = recorder.compute_totals(out.aggregated_stress, thickness)
+    i0 = int(np.argmax(np.abs(dA)))
+    rows = recorder.check_totals(out.aggregated_stress, thickness, step=1e-4, indices=[i0])
+    assert abs(rows[0][1] - rows[0][2]) < 1e-3 * abs(rows[0][2]), rows
+
     # shape derivative through the protocol: d compliance / d node_disp against a finite difference of the oracle
     dJu = recorder.compute_totals(out.compliance, node_disp)
     assert dJu.shape == (nn, 3)

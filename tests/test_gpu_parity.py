@@ -196,3 +196,53 @@ def test_shape_sensitivities_vs_oracle_finite_differences(kind, bc):
             fd = [(a - b) / (2 * step) for a, b in zip(fp, fm)]
             for name, g, d in (("compliance", g_c, fd[0]), ("mass", g_m, fd[1]), ("energy", g_e, fd[2]), ("residual", g_r, fd[3])):
                 assert abs(g[v, comp] - d) <= 2e-6 * np.abs(g).max() + 1e-9 * abs(d), (name, v, comp, g[v, comp], d)
+
+
+@pytest.mark.parametrize("kind,ewm,uhat", [("warped", False, False), ("warped", True, True), ("plate", False, False)])
+def test_stress_outputs(kind, ewm, uhat):
+    """p-norm aggregate and DG1 field of the top-surface von Mises stress, and the partial gradients of the
+    aggregate, against the oracle (value) and finite differences of the oracle (gradients)."""
+    from oracle.rm_shell_oracle import ShellOracle
+    m, o, c, rng = _pair(kind, ewm=ewm, uhat=uhat, beta=1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-4
+    c.set_state(w)
+    o3 = ShellOracle(m, element_wise_material=ewm, nquad=3)            # the degree-4 measure
+    o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
+    mval, rho = 1e-6, 6.0
+    c.set_stress_params(mval, rho)
+    assert abs(c.functional("pnorm_stress") - o3.pnorm_stress(w, mval, rho)) < 1e-10 * o3.pnorm_stress(w, mval, rho)
+    if kind != "tri":
+        assert rel(c.field_output("stress").reshape(m.nel, -1), o.stress_dg1(w)) < 1e-10
+    # reference defaults (m = 1e-6, rho = 100) on the value
+    c.set_stress_params(1e-6, 100.0)
+    v100 = o3.pnorm_stress(w, 1e-6, 100)
+    assert abs(c.functional("pnorm_stress") - v100) < 1e-9 * v100
+    c.set_stress_params(mval, rho)
+    area = o3.pnorm_stress(w * 0, mval, 0.0, alpha=1.0)                # int J dx with rho = 0 -> area (uhat included)
+    o0 = ShellOracle(m, element_wise_material=ewm, nquad=3); alpha = o0.pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
+    P = lambda ww=w: o3.pnorm_stress(ww, mval, rho, alpha=alpha)
+    g_w = c.dfunctional("pnorm_stress", "disp_solid")
+    for i in rng.choice(m.ndof, 6, replace=False):
+        st = 1e-6 * max(abs(w[i]), 1e-4)
+        wp = w.copy(); wp[i] += st; wm = w.copy(); wm[i] -= st
+        fd = (P(wp) - P(wm)) / (2 * st)
+        assert abs(g_w[i] - fd) <= 2e-6 * np.abs(g_w).max() + 1e-7 * abs(fd), (i, g_w[i], fd)
+    base = dict(h=o3.h.copy(), E=o3.E.copy(), nu=o3.nu.copy())
+    for arg, key in (("thickness", "h"), ("E", "E"), ("nu", "nu")):
+        g = c.dfunctional("pnorm_stress", arg)
+        for i in rng.choice(g.size, 3, replace=False):
+            v = base[key].copy(); st = 1e-6 * v[i]
+            v[i] += st; o3.set_fields(**{key: v}); fp = P()
+            v[i] -= 2 * st; o3.set_fields(**{key: v}); fm = P()
+            o3.set_fields(**{key: base[key]})
+            fd = (fp - fm) / (2 * st)
+            assert abs(g[i] - fd) <= 5e-6 * np.abs(g).max() + 1e-7 * abs(fd), (arg, i, g[i], fd)
+    g_u = c.dfunctional("pnorm_stress", "uhat").reshape(-1, 3)
+    u0 = o3.uhat.copy()
+    for v_ in rng.choice(m.nn, 2, replace=False):
+        for comp in range(3):
+            up = u0.copy(); up[v_, comp] += 1e-6; o3.set_fields(uhat=up); fp = P()
+            up[v_, comp] -= 2e-6; o3.set_fields(uhat=up); fm = P()
+            o3.set_fields(uhat=u0)
+            fd = (fp - fm) / 2e-6
+            assert abs(g_u[v_, comp] - fd) <= 5e-6 * np.abs(g_u).max() + 1e-7 * abs(fd), (v_, comp, g_u[v_, comp], fd)
