@@ -44,6 +44,14 @@ SIGNATURES = {
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_set_operator": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "femo_set_strain_quadrature": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_op_apply_vec2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int]),
+    "femo_solve_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, _c_int32_p, _c_double_p]),
+    "femo_vec_mask_zero": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_grad_reset": (C.c_int, [C.c_void_p]),
+    "femo_grad_add": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_double]),
+    "femo_grad_get": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
     "femo_set_stress_params": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "femo_field_output": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_int64]),
     "femo_functional": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p]),

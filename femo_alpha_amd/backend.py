@@ -186,6 +186,35 @@ class ShellContext:
         self._chk(self.lib.femo_functional(self._h, name.encode(), C.byref(v)))
         return v.value
 
+    # ------------------------------------------------------------------ dynamic-shell building blocks
+    def set_operator(self, aK=1.0, aM=0.0):
+        self._chk(self.lib.femo_set_operator(self._h, float(aK), float(aM)))
+
+    def set_strain_quadrature(self, nred):
+        self._chk(self.lib.femo_set_strain_quadrature(self._h, int(nred)))
+
+    def op_apply_vec2(self, src, dst, aK, aM, with_penalty=True):
+        self._chk(self.lib.femo_op_apply_vec2(self._h, self.VEC_IDS[src], self.VEC_IDS[dst], float(aK), float(aM), int(with_penalty)))
+
+    def solve_vec(self, b, x, zero_guess=True):
+        it = C.c_int32(); rr = C.c_double()
+        self._chk(self.lib.femo_solve_vec(self._h, self.VEC_IDS[b], self.VEC_IDS[x], int(zero_guess), C.byref(it), C.byref(rr)))
+        return it.value, rr.value
+
+    def vec_mask_zero(self, name):
+        self._chk(self.lib.femo_vec_mask_zero(self._h, self.VEC_IDS[name]))
+
+    def grad_reset(self):
+        self._chk(self.lib.femo_grad_reset(self._h))
+
+    def grad_add(self, kind, x, y, scale):
+        self._chk(self.lib.femo_grad_add(self._h, {"K": 0, "M": 1}[kind], self.VEC_IDS[x], self.VEC_IDS[y], float(scale)))
+
+    def grad_get(self):
+        out = np.empty(self.field_size("thickness"))
+        self._chk(self.lib.femo_grad_get(self._h, dptr(out), out.size))
+        return out
+
     def set_stress_params(self, m=1e-6, rho=100.0):
         self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
 

@@ -41,6 +41,9 @@ struct femo_ctx {
     Tables* tab = nullptr;
     Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
     double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0;
+    double* gradbuf = nullptr;
+    double op_aK = 1.0, op_aM = 0.0;      // the operator every solve / factorisation uses: aK * K + aM * M
+    int nquad = 4, nred = 0;
     // fields
     double *h = nullptr, *E = nullptr, *nu = nullptr, *rho = nullptr, *f = nullptr, *uhat = nullptr;
     // dirichlet
@@ -139,19 +142,24 @@ static void lag1(double t, double* v, double* d) {
     d[0] = -0.5; d[1] = 0.5;
 }
 
-static void build_tables(bool quad, int nquad, Tables& T) {
+// nred > 0 (quads): the membrane / bending / shear energies are integrated with nred x nred Gauss points, everything
+// else with nquad x nquad: the table then lists both point sets, each with a zero weight for the terms of the other
+static void build_tables(bool quad, int nquad, Tables& T, int nred = 0) {
     memset(&T, 0, sizeof T);
     if (quad) {
         static const int Q2I[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
         static const int Q1I[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
         double gx[8], gw[8];
-        gauss_legendre(nquad, gx, gw);
-        T.nq = nquad * nquad;
-        for (int i = 0; i < nquad; ++i)
-            for (int j = 0; j < nquad; ++j) {
-                const int q = i * nquad + j;
+        int q0 = 0;
+        for (int pass = (nred > 0 ? 0 : 1); pass < 2; ++pass) {
+        const int n1 = pass == 0 ? nred : nquad;
+        gauss_legendre(n1, gx, gw);
+        for (int i = 0; i < n1; ++i)
+            for (int j = 0; j < n1; ++j) {
+                const int q = q0 + i * n1 + j;
                 const double xi = gx[i], eta = gx[j];
-                T.w[q] = gw[i] * gw[j];
+                T.w[q] = pass == 1 ? gw[i] * gw[j] : 0.0;
+                T.wS[q] = (pass == 0 || nred <= 0) ? gw[i] * gw[j] : 0.0;
                 double a[3], da[3], b[3], db[3], c[2], dc[2], d[2], dd[2];
                 lag2(xi, a, da); lag2(eta, b, db); lag1(xi, c, dc); lag1(eta, d, dd);
                 for (int n = 0; n < 9; ++n) {
@@ -167,6 +175,9 @@ static void build_tables(bool quad, int nquad, Tables& T) {
                     T.dN1[q][n][1] = c[ii] * dd[jj];
                 }
             }
+        q0 += n1 * n1;
+        }
+        T.nq = q0;
     } else {
         // degree-6, 12-point symmetric rule on the unit triangle
         const double a1 = 0.063089014491502, b1 = 0.873821971016996, w1 = 0.050844906370207;
@@ -180,6 +191,7 @@ static void build_tables(bool quad, int nquad, Tables& T) {
         for (int q = 0; q < 12; ++q) {
             const double x = P[q][0], y = P[q][1];
             T.w[q] = 0.5 * P[q][2];
+            T.wS[q] = T.w[q];
             const double L[3] = {1 - x - y, x, y};
             for (int i = 0; i < 3; ++i) {
                 T.N1[q][i] = L[i];
@@ -249,10 +261,11 @@ static int refresh_penalty(femo_ctx* c) {
 }
 
 // y = K_elastic x (+ penalty): element pass into ybuf, then one gather-sum per node (no atomics, fixed order)
-static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, double* za, double* zb, bool with_penalty) {
+static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, double* za, double* zb, bool with_penalty,
+                    double aK = 1.0, double aM = 0.0) {
     {
         const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
-        ELEM_LAUNCH(c, k_apply4, NOEXTRA, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, x, c->ybuf, dotslot, za, zb);
+        ELEM_LAUNCH(c, k_apply4, NOEXTRA, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
         const int nthreads = c->nP2 + c->nghost;
         if (c->quad)
             hipLaunchKernelGGL((k_gather_sum<9, 4>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,
@@ -298,6 +311,7 @@ static int load_vector_dev(femo_ctx* c, double* F) {
 
 // Jacobi-preconditioned CG on the device; b is overwritten only on masked rows (set to zero)
 static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    if (c->op_aM != 0.0 || c->op_aK != 1.0) return fail(c, "the Jacobi solver only handles the static operator; use preconditioner 2");
     const int64_t n = c->ndof;
     const int vg = vec_grid(n);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
@@ -311,7 +325,7 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
     } else {
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, x, mask, n);
-        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
     }
     hipLaunchKernelGGL(k_pcg_init, dim3(vg), dim3(256), 0, c->stream, b, c->Ap, c->dinv, mask, c->r, c->z, c->p, n, c->scal,
                        zero_guess ? 0 : 1);
@@ -332,7 +346,7 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
             for (int j = 0; j < chunk; ++j, ++k) {
                 const int s = k & 1;
                 // K1 also clears the rz/rr slots the update kernel of this iteration accumulates into
-                if (op_apply(c, c->p, c->Ap, c->scal + s, c->scal + 2 + (1 - s), c->scal + 4 + (1 - s), true)) return 1;
+                if (op_apply(c, c->p, c->Ap, c->scal + s, c->scal + 2 + (1 - s), c->scal + 4 + (1 - s), true, c->op_aK, c->op_aM)) return 1;
                 hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, x, c->r, c->z, c->p, c->Ap, c->dinv, mask, n,
                                    c->scal, s);
                 hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, s);
@@ -394,7 +408,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
         if (refresh_penalty(c)) return 1;
         { ProfScope ps(c, 4);
-        ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, fd, fr.elem_front, fr.elem_map, mask); }
+        ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+                    fr.elem_map, mask); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
                                fr.elem_map, c->ld, c->npc, c->nvc, mask);
@@ -557,7 +572,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     } else {
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, x, mask, n);
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
-        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+        if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
         HIPCHK(c, hipMemcpyAsync(c->r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -1.0, c->Ap, 1.0, n);
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->r, mask, n);
@@ -576,7 +591,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
         }
         rz = rz_new;
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
-        if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true)) return 1;
+        if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
         ++napply;
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->Ap, mask, n);
         if (dot(c->p, c->Ap, &pAp)) return 1;
@@ -699,6 +714,7 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipMalloc((void**)&c->hK, (size_t)nel * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
     Tables T;
+    c->nquad = nquad;
     build_tables(c->quad, nquad, T);
     HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
@@ -770,7 +786,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->gradbuf, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1009,13 +1025,13 @@ int femo_solve_linear(femo_ctx* c, const double* rhs, double* x, int32_t* iters,
     return 0;
 }
 
-static int functionals_dev(femo_ctx* c, double out3[3]) {
+static int functionals_dev(femo_ctx* c, double* out3, int nout = 3) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
     ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, c->scal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 3; ++i) out3[i] = c->scal_host[i];
+    for (int i = 0; i < nout; ++i) out3[i] = c->scal_host[i];
     return 0;
 }
 
@@ -1035,10 +1051,10 @@ static int pnorm_dev(femo_ctx* c, double out2[2]) {
 int femo_functional(femo_ctx* c, const char* name, double* value) {
     HIPCHK(c, hipSetDevice(c->device));
     const std::string s(name ? name : "");
-    if (s == "compliance" || s == "mass") {
-        double v[3];
-        if (functionals_dev(c, v)) return 1;
-        *value = s == "mass" ? v[2] : v[0] + v[1];
+    if (s == "compliance" || s == "mass" || s == "volume") {
+        double v[4];
+        if (functionals_dev(c, v, 4)) return 1;
+        *value = s == "mass" ? v[2] : s == "volume" ? v[3] : v[0] + v[1];
         return 0;
     }
     if (s == "elastic_energy") {
@@ -1110,6 +1126,8 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
     } else if (fn == "mass") {
         if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
         else if (wrt == "density") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
+    } else if (fn == "volume") {
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 3, out);
     } else if (fn == "elastic_energy") {
         if (wrt == "disp_solid") { if (op_apply(c, c->w, out, nullptr, nullptr, nullptr, false)) return 1; }
         else if (wrt == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
@@ -1428,6 +1446,83 @@ int femo_field_gradient_vec(femo_ctx* c, const char* functional, const char* arg
     }
     hipFree(d);
     return rc;
+}
+
+
+// ---- dynamic shell: operator A = aK K + aM M, device-vector building blocks (femo_alpha_amd/dynamic_rm_shell) ----
+int femo_set_operator(femo_ctx* c, double aK, double aM) {
+    if (aK != c->op_aK || aM != c->op_aM) { c->op_aK = aK; c->op_aM = aM; c->diag_dirty = true; c->fr.factored = false; }
+    return 0;
+}
+
+int femo_set_strain_quadrature(femo_ctx* c, int32_t nred) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->quad) return fail(c, "reduced strain quadrature is implemented for quadrilaterals only");
+    if (nred < 0 || nred > 5 || nred * nred + c->nquad * c->nquad > MAXQ) return fail(c, "unsupported reduced rule");
+    Tables T;
+    build_tables(true, c->nquad, T, nred);
+    HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    c->nred = nred; c->diag_dirty = true; c->fr.factored = false;
+    return 0;
+}
+
+int femo_op_apply_vec2(femo_ctx* c, int32_t src, int32_t dst, double aK, double aM, int with_penalty) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double *x = vec_by_id(c, src), *y = vec_by_id(c, dst);
+    if (!x || !y || x == y) return fail(c, "bad vector ids");
+    if (op_apply(c, x, y, nullptr, nullptr, nullptr, with_penalty != 0, aK, aM)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_solve_vec(femo_ctx* c, int32_t b, int32_t x, int zero_guess, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double *vb = vec_by_id(c, b), *vx = vec_by_id(c, x);
+    if (!vb || !vx || vb == vx) return fail(c, "bad vector ids");
+    if (vb == c->r || vb == c->z || vb == c->p || vb == c->Ap || vx == c->r || vx == c->z || vx == c->p || vx == c->Ap)
+        return fail(c, "vectors 2..5 are the solver's work space");
+    return solve_dispatch(c, vb, vx, zero_guess != 0, iters, relres);
+}
+
+int femo_vec_mask_zero(femo_ctx* c, int32_t id) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double* v = vec_by_id(c, id);
+    if (!v) return fail(c, "bad vector id");
+    if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, v, c->mask, (int64_t)c->ndof);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// thickness-gradient accumulator on the device:  g += scale * y^T (dK/dh) x   or   g += scale * y^T (dM/dh) x
+int femo_grad_reset(femo_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->gradbuf) HIPCHK(c, hipMalloc((void**)&c->gradbuf, (size_t)std::max<int64_t>(c->nT, 1) * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->gradbuf, 0, (size_t)c->nT * sizeof(double), c->stream));
+    return 0;
+}
+
+int femo_grad_add(femo_ctx* c, int kind, int32_t x, int32_t y, double scale) {
+    HIPCHK(c, hipSetDevice(c->device));
+    double *vx = vec_by_id(c, x), *vy = vec_by_id(c, y);
+    if (!vx || !vy) return fail(c, "bad vector ids");
+    if (!c->gradbuf) return fail(c, "call femo_grad_reset first");
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int g = nblk(c->nel, EB);
+    if (kind == 0) ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
+    else if (kind == 1) ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
+    else return fail(c, "kind must be 0 (stiffness) or 1 (inertia)");
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int femo_grad_get(femo_ctx* c, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->gradbuf || n != c->nT) return fail(c, "gradient accumulator not initialised or wrong length");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->gradbuf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int femo_set_stress_params(femo_ctx* c, double m, double rho) {

@@ -41,8 +41,8 @@ struct FrontDev {
 // lower-triangle entries into the element's leaf front.  Masked (strong-BC) rows/columns are skipped.
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(64)
-k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, FrontDev fd, const int* __restrict__ elem_front,
-                 const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
+k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double aK, double aM, FrontDev fd,
+                 const int* __restrict__ elem_front, const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x;
     const int j = threadIdx.x;
@@ -62,11 +62,18 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, FrontDe
         double d[NPC][2], mm[NVC][2];
         local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
         Mat mat, ex;
-        material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+        const double hq = interp<NVC>(tab->N1[q], el.hn);
+        material<DERIV_NONE>(hq, interp<NVC>(tab->N1[q], el.En),
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
+        mat.cm *= aK; mat.cb *= aK; mat.cs *= aK; mat.cd *= aK;
         const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
         const Gen t = stress_of(s, mat);
         strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+        if (aM != 0.0) {
+            double rq = 0.0;
+            for (int b = 0; b < NVC; ++b) rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
+            mass_qp<NPC, NVC>(*tab, q, aM * rq * hq * tab->w[q] * g.det * g.Ju, el.hK, xe, ye);
+        }
     }
     const int t = elem_front[e];
     const int nf = fd.nf[t];

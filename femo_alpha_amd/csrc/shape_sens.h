@@ -158,10 +158,10 @@ __device__ __forceinline__ GenD strains_dual(const Tables& t, int q, const QPG& 
 
 // lam-strain . C . w-strain with the reference's J placement (membrane/bending: none; shear/drilling: J)
 __device__ __forceinline__ D1 energy_density_dual(const GenD& a, const GenD& b, double h, double E, double nu, double hK,
-                                                  double wdet, D1 Ju) {
+                                                  double wdetS, double wdet, D1 Ju) {
     const double c = E / (1.0 - nu * nu), sh = 0.5 * (1.0 - nu);
-    const double cm = c * h * wdet, cb = c * h * h * h / 12.0 * wdet;
-    const D1 cs = (K_SHEAR * E / (2.0 * (1.0 + nu)) * h * wdet) * Ju;
+    const double cm = c * h * wdetS, cb = c * h * h * h / 12.0 * wdetS;
+    const D1 cs = (K_SHEAR * E / (2.0 * (1.0 + nu)) * h * wdetS) * Ju;
     const D1 cd = (E * h * h * h / (hK * hK) * wdet) * Ju;
     const D1 mem = cm * ((a.e00 + nu * a.e11) * b.e00 + (nu * a.e00 + a.e11) * b.e11 + sh * (a.g01 * b.g01));
     const D1 ben = cb * ((a.k00 + nu * a.k11) * b.k00 + (nu * a.k00 + a.k11) * b.k11 + sh * (a.k01 * b.k01));
@@ -211,16 +211,16 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
         qp_geometry<NVC, QUAD, false>(el.X, zero, tab->N1[q], tab->dN1[q], g);
         QPD s;
         qp_shape_dual<NVC, QUAD>(el.X, Uh, tab->dN1[q], g, s);
-        const double wdet = tab->w[q] * g.det;
+        const double wdet = tab->w[q] * g.det, wdetS = tab->wS[q] * g.det;
         const double hq = interp<NVC>(tab->N1[q], el.hn);
         if (mode == 0 || mode == 3) {
             const double Eq = interp<NVC>(tab->N1[q], el.En), nuq = interp<NVC>(tab->N1[q], el.nun);
             const GenD sw = strains_dual<NPC, NVC>(*tab, q, g, s, we);
             if (mode == 3) {
-                phi = phi + 0.5 * energy_density_dual(sw, sw, hq, Eq, nuq, el.hK, wdet, s.Ju);
+                phi = phi + 0.5 * energy_density_dual(sw, sw, hq, Eq, nuq, el.hK, wdetS, wdet, s.Ju);
             } else {
                 const GenD sl = strains_dual<NPC, NVC>(*tab, q, g, s, le);
-                phi = phi + energy_density_dual(sw, sl, hq, Eq, nuq, el.hK, wdet, s.Ju);
+                phi = phi + energy_density_dual(sw, sl, hq, Eq, nuq, el.hK, wdetS, wdet, s.Ju);
                 double fq[3] = {0, 0, 0}, lq[3] = {0, 0, 0};
                 for (int b = 0; b < NVC; ++b)
                     for (int c = 0; c < 3; ++c) fq[c] += tab->N1[q][b] * fn[b][c];

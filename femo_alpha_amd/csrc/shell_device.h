@@ -25,7 +25,9 @@ constexpr double REG_ALPHA1 = 1.0e-2;   // rm_shell_pde.py:67
 struct Tables {
     int nq;
     int pad;
-    double w[MAXQ];
+    double w[MAXQ];       // weight of the full rule: drilling, inertia, load, outputs (0 at reduced-rule-only points)
+    double wS[MAXQ];      // weight for the membrane / bending / shear energies (the reference's dx_inplane, dx_shear;
+                          // equal to w unless a reduced degree is requested, dynamic_rm_shell/plate_sim.py:82-91)
     double N2[MAXQ][9];
     double dN2[MAXQ][9][2];
     double N1[MAXQ][4];
@@ -237,7 +239,7 @@ enum { DERIV_NONE = 0, DERIV_H = 1, DERIV_E = 2, DERIV_NU = 3 };
 
 // constitutive coefficients at a point; which = derivative selector
 template <int WHICH>
-__device__ __forceinline__ void material(double h, double E, double nu, double hK, double wdet, double Ju, Mat& m,
+__device__ __forceinline__ void material(double h, double E, double nu, double hK, double wdetS, double wdet, double Ju, Mat& m,
                                          Mat& dm_dnu_extra) {
     const double om = 1.0 - nu * nu;
     const double c = E / om;
@@ -245,28 +247,28 @@ __device__ __forceinline__ void material(double h, double E, double nu, double h
     const double ihk2 = 1.0 / (hK * hK);
     m.nu = nu;
     if (WHICH == DERIV_NONE) {
-        m.cm = c * h * wdet;
-        m.cb = c * h * h * h / 12.0 * wdet;
-        m.cs = K_SHEAR * E * G2 * h * Ju * wdet;
+        m.cm = c * h * wdetS;
+        m.cb = c * h * h * h / 12.0 * wdetS;
+        m.cs = K_SHEAR * E * G2 * h * Ju * wdetS;
         m.cd = E * h * h * h * ihk2 * Ju * wdet;
     } else if (WHICH == DERIV_H) {
-        m.cm = c * wdet;
-        m.cb = c * h * h / 4.0 * wdet;
-        m.cs = K_SHEAR * E * G2 * Ju * wdet;
+        m.cm = c * wdetS;
+        m.cb = c * h * h / 4.0 * wdetS;
+        m.cs = K_SHEAR * E * G2 * Ju * wdetS;
         m.cd = 3.0 * E * h * h * ihk2 * Ju * wdet;
     } else if (WHICH == DERIV_E) {
-        m.cm = h / om * wdet;
-        m.cb = h * h * h / 12.0 / om * wdet;
-        m.cs = K_SHEAR * G2 * h * Ju * wdet;
+        m.cm = h / om * wdetS;
+        m.cb = h * h * h / 12.0 / om * wdetS;
+        m.cs = K_SHEAR * G2 * h * Ju * wdetS;
         m.cd = h * h * h * ihk2 * Ju * wdet;
     } else {   // d/dnu: C' = c' P + c P',  c' = 2 nu E / (1-nu^2)^2
         const double dc = 2.0 * nu * E / (om * om);
-        m.cm = dc * h * wdet;
-        m.cb = dc * h * h * h / 12.0 * wdet;
-        m.cs = -K_SHEAR * E * h * 2.0 * G2 * G2 * Ju * wdet;
+        m.cm = dc * h * wdetS;
+        m.cb = dc * h * h * h / 12.0 * wdetS;
+        m.cs = -K_SHEAR * E * h * 2.0 * G2 * G2 * Ju * wdetS;
         m.cd = 0.0;
-        dm_dnu_extra.cm = c * h * wdet;                  // multiplies P' = [[0,1,0],[1,0,0],[0,0,-1/2]]
-        dm_dnu_extra.cb = c * h * h * h / 12.0 * wdet;
+        dm_dnu_extra.cm = c * h * wdetS;                  // multiplies P' = [[0,1,0],[1,0,0],[0,0,-1/2]]
+        dm_dnu_extra.cb = c * h * h * h / 12.0 * wdetS;
     }
 }
 
@@ -438,7 +440,7 @@ k_apply(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __
             local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
             Mat mat, ex;
             material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                                 interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+                                 interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
             const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
             const Gen t = stress_of(s, mat);
             strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
@@ -544,6 +546,31 @@ __device__ __forceinline__ void strains_T_q(const Tables& t, int q, const QPG& g
     }
 }
 
+// inertia of the dynamic shell, y += cm * M x at one quadrature point:  rho h (u.v + h_K^2 theta.eta) J
+// (reference linear_shell_model.py:335-348 -- the vendored sibling of the un-vendored DynamicElasticModel,
+// dynamic_rm_shell/plate_sim.py:197-201); cm already holds aM * rho * h * w * det * Ju
+template <int NPC, int NVC>
+__device__ __forceinline__ void mass_qp(const Tables& t, int q, double cm, double hK, const double* xe, double* ye) {
+    double uq[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) uq[c] += t.N2[q][a] * xe[3 * a + c];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tq[c] += t.N1[q][b] * xe[3 * NPC + 3 * b + c];
+#pragma unroll
+    for (int a = 0; a < NPC; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * a + c] += cm * t.N2[q][a] * uq[c];
+    const double ct = cm * hK * hK;
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += ct * t.N1[q][b] * tq[c];
+}
+
 // ---- the production element operator: 4 lanes per element (each lane a quarter of the quadrature points),
 // nodal values staged in LDS, partial results combined inside the quad with DPP, XCD-aware block order.
 __device__ __forceinline__ double quad_xor_sum(double v) {
@@ -599,7 +626,7 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
 
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(256, 2)
-k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __restrict__ eorder,
+k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __restrict__ eorder, double aK, double aM,
          const double* __restrict__ x, double* __restrict__ ybuf, double* dotslot, double* zero_a, double* zero_b) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     constexpr int EPB = 64;                     // elements per block (256 threads / 4 lanes)
@@ -650,11 +677,19 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
             QPG g;
             qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, stab.N1[q], stab.dN1[q], g);
             Mat mat, ex;
-            material<DERIV_NONE>(interp<NVC>(stab.N1[q], el.hn), interp<NVC>(stab.N1[q], el.En),
-                                 interp<NVC>(stab.N1[q], el.nun), el.hK, stab.w[q] * g.det, g.Ju, mat, ex);
+            const double hq = interp<NVC>(stab.N1[q], el.hn);
+            material<DERIV_NONE>(hq, interp<NVC>(stab.N1[q], el.En),
+                                 interp<NVC>(stab.N1[q], el.nun), el.hK, stab.wS[q] * g.det, stab.w[q] * g.det, g.Ju, mat, ex);
+            mat.cm *= aK; mat.cb *= aK; mat.cs *= aK; mat.cd *= aK;
             const Gen s = strains_q<NPC, NVC>(stab, q, g, xe);
             const Gen t = stress_of(s, mat);
             strains_T_q<NPC, NVC>(stab, q, g, t, ye);
+            if (aM != 0.0) {
+                double rq = 0.0;
+#pragma unroll
+                for (int b = 0; b < NVC; ++b) rq += stab.N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
+                mass_qp<NPC, NVC>(stab, q, aM * rq * hq * stab.w[q] * g.det * g.Ju, el.hK, xe, ye);
+            }
         }
 #pragma unroll
         for (int i = 0; i < LD; ++i) ye[i] = quad_xor_sum(ye[i]);
@@ -693,7 +728,7 @@ k_diag(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restric
         local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
         Mat mat, ex;
         material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
         const double sh = 0.5 * (1.0 - mat.nu);
 #pragma unroll
         for (int a = 0; a < NPC; ++a)
@@ -772,12 +807,12 @@ k_load(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restric
         for (int c = 0; c < 3; ++c) atomicAdd(&F[3 * el.pid[a] + c], scale * Fe[3 * a + c]);
 }
 
-// scalar functionals: slot[0] += int u.u J dx ; slot[1] += regularisation ; slot[2] += mass
+// scalar functionals: slot[0] += int u.u J dx ; slot[1] += regularisation ; slot[2] += mass ; slot[3] += volume
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
 k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double* slots) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    double uu = 0.0, reg = 0.0, mass = 0.0;
+    double uu = 0.0, reg = 0.0, mass = 0.0, vol = 0.0;
     if (e < m.nel) {
         Elem<NPC, NVC> el;
         load_elem<NPC, NVC, UHAT>(m, f, e, el);
@@ -802,6 +837,7 @@ k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doub
             uu += wd * g.Ju * dot3(uq, uq);
             const double hq = interp<NVC>(tab->N1[q], el.hn);
             mass += wd * g.Ju * hq * interp<NVC>(tab->N1[q], rhon);
+            vol += wd * g.Ju * hq;                          // int h J dx (dynamic_rm_shell/volume_operation.py:68-70)
             if (f.ewm) {
                 reg += 0.5 * REG_ALPHA1 * wd * hq * hq;                    // L2, rm_shell_pde.py:79-81
             } else {
@@ -818,6 +854,7 @@ k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doub
     block_accumulate(uu, slots + 0);
     block_accumulate(reg, slots + 1);
     block_accumulate(mass, slots + 2);
+    block_accumulate(vol, slots + 3);
 }
 
 // out_u += 2 int N_a u J dx  (d compliance / d w)
@@ -858,7 +895,7 @@ k_dcompliance_du(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const d
         for (int c = 0; c < 3; ++c) atomicAdd(&out[3 * el.pid[a] + c], ge[3 * a + c]);
 }
 
-// field-space gradients that need no state:  mode 0: d reg / d h ; 1: d mass / d h ; 2: d mass / d rho
+// field-space gradients that need no state:  mode 0: d reg / d h ; 1: d mass / d h ; 2: d mass / d rho ; 3: d volume / d h
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
 k_field_grad(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double* __restrict__ out) {
@@ -893,7 +930,7 @@ k_field_grad(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, d
                 for (int b = 0; b < NVC; ++b) ge[b] += REG_ALPHA1 * wd * (d0[b] * g0 + d1[b] * g1);
             }
         } else {
-            const double other = (mode == 1) ? interp<NVC>(tab->N1[q], rhon) : interp<NVC>(tab->N1[q], el.hn);
+            const double other = (mode == 1) ? interp<NVC>(tab->N1[q], rhon) : (mode == 2 ? interp<NVC>(tab->N1[q], el.hn) : 1.0);
             if (f.ewm) {
                 ge[0] += wd * g.Ju * other;
             } else {
@@ -946,7 +983,7 @@ k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doubl
         local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
         Mat mat, ex;
         material<WHICH>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                        interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+                        interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
         const Gen sw = strains<NPC, NVC>(g, d, mm, tab->N1[q], we);
         const Gen sl = strains<NPC, NVC>(g, d, mm, tab->N1[q], le);
         Gen t = stress_of(sw, mat);
@@ -965,6 +1002,45 @@ k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doubl
 #pragma unroll
         for (int b = 0; b < NVC; ++b) atomicAdd(&out[el.vid[b]], scale * ge[b]);
     }
+}
+
+// out += scale * y^T (dM/dh) x  per thickness DOF:  int rho M_b (x_u.y_u + h_K^2 x_theta.y_theta) J dx
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_dMdh_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ x, const double* __restrict__ y,
+         double scale, double* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double ge[NVC];
+    for (int b = 0; b < NVC; ++b) ge[b] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        if (tab->w[q] == 0.0) continue;
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        double xu[3] = {0, 0, 0}, yu[3] = {0, 0, 0}, xt[3] = {0, 0, 0}, yt[3] = {0, 0, 0}, rq = 0.0;
+        for (int a = 0; a < NPC; ++a)
+            for (int c = 0; c < 3; ++c) {
+                xu[c] += tab->N2[q][a] * x[3 * el.pid[a] + c];
+                yu[c] += tab->N2[q][a] * y[3 * el.pid[a] + c];
+            }
+        for (int b = 0; b < NVC; ++b) {
+            rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
+            for (int c = 0; c < 3; ++c) {
+                xt[c] += tab->N1[q][b] * x[m.ndof_u + 3 * el.vid[b] + c];
+                yt[c] += tab->N1[q][b] * y[m.ndof_u + 3 * el.vid[b] + c];
+            }
+        }
+        const double dens = tab->w[q] * g.det * g.Ju * rq * (dot3(xu, yu) + el.hK * el.hK * dot3(xt, yt));
+        if (f.ewm) ge[0] += dens;
+        else
+            for (int b = 0; b < NVC; ++b) ge[b] += dens * tab->N1[q][b];
+    }
+    if (f.ewm) out[e] += scale * ge[0];
+    else
+        for (int b = 0; b < NVC; ++b) atomicAdd(&out[el.vid[b]], scale * ge[b]);
 }
 
 // out += scale * int M_b lam_u J dx    ((dR/df)^T lam uses scale = -1)
@@ -1044,7 +1120,7 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
         local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
         Mat mat, ex;
         material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->w[q] * g.det, g.Ju, mat, ex);
+                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
         const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
         const Gen t = stress_of(s, mat);
         strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);

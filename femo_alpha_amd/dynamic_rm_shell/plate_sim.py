@@ -1,0 +1,181 @@
+"""``PlateSim``: transient (midpoint / Newmark) RM shell on one MI355X.
+
+Interface of femo_alpha/dynamic_rm_shell/plate_sim.py:60-361 (constructor, ``update_t``,
+``update_f_history``, ``solve_dynamic_problem``, ``assembleStrainEnergy``) plus the adjoint pieces the dynamic
+operators need.  Time discretisation as in the reference (:131-140):
+
+    w_mid = (w_old + w)/2,  wdot = 2/dt (w - w_old) - wdot_old,  wddot = (wdot - wdot_old)/dt
+    R_i   = M wddot_i + K w_mid,i - F_i = 0     (force taken at the new level, :312-316)
+
+so every step solves  (2/dt^2 M + K/2) w_i = F_i + M (2/dt^2 w_{i-1} + 2/dt wdot_{i-1}) - K/2 w_{i-1}.
+
+PARITY UNPINNED for this path: the energy / inertia forms of the reference come from ``shell_analysis_fenicsx``,
+which is neither vendored nor version-pinned (plate_sim.py:17,193-201); the vendored sibling is used as the
+nearest text: elastic energy of linear_shell_model.py:275-306 at uhat = 0, inertia rho t (u.v + h_K^2 theta.eta)
+(:335-348), membrane/bending/shear on the degree-``quad_deg`` rule, drilling and inertia on the full rule.
+
+The operator is linear and constant over the march, so it is factorised once per thickness (the reference
+re-assembles and re-factorises it every step, nonlinear_utils.py:210-233) and each step is one preconditioned
+solve; the adjoint is the O(T) two-vector recursion instead of the reference's O(T^2) history sums
+(state_operation_dynamic.py:606-702).  History layout at the boundary: (fe_dofs, time_levels), flattened
+column-major by the operators (dynamic_rm_shell/utils.py:9-16).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..backend import ShellContext
+
+
+class PlateSim:
+    def __init__(self, mesh, E, nu, rho, dt, Nsteps, element_wise_thickness=False, custom_bc_func=None,
+                 add_self_weight=False, g_factor=None, quad_deg=3, comm=None, device=0, leaf_size=16):
+        import torch
+        self.torch = torch
+        self.mesh, self.E, self.nu, self.rho, self.dt = mesh, E, nu, rho, dt
+        self.Nsteps, self.time_levels = Nsteps, Nsteps + 1
+        self.nn, self.nel = mesh.nn, mesh.nel
+        self.element_wise_thickness = element_wise_thickness
+        self.add_self_weight, self.g_factor, self.quad_deg = add_self_weight, g_factor, quad_deg
+        if add_self_weight and element_wise_thickness:
+            raise NotImplementedError("self weight is applied through the nodal pressure field")
+        ctx = self.ctx = ShellContext(mesh, element_wise_material=element_wise_thickness, device=device)
+        ctx.set_field("E", [E]); ctx.set_field("nu", [nu]); ctx.set_field("density", [rho])
+        marker = custom_bc_func if custom_bc_func is not None else (lambda x: np.isclose(x[0], 0.0, atol=1e-6))
+        self.bc_dofs = mesh.locate_dofs_geometrical(marker)            # plate_sim.py:34-58
+        ctx.set_strong_dofs(self.bc_dofs)
+        npts = (quad_deg + 2) // 2                                       # Gauss points per direction for that degree
+        if mesh.is_quad and npts < 4:
+            ctx.set_strain_quadrature(npts)
+        ctx.enable_frontal(leaf_size)
+        ctx.set_solver(preconditioner=2, rtol=1e-11, maxit=50, check_every=1)
+        self.a, self.b = 2.0 / dt ** 2, 2.0 / dt
+        ctx.set_operator(0.5, self.a)
+        self.fe_dofs = ctx.ndof
+        self.num_var = ctx.field_size("thickness")
+        self.f_history = np.zeros((self.time_levels, 3 * mesh.nn))
+        self.t = np.full(self.num_var, 1e-3)
+        self.opt_iter = 0
+        self.W = None                      # device history, (time_levels, fe_dofs)
+        self.solve_info = []
+        self._v = {n: ctx.vec_tensor(n) for n in ("state", "adjoint", "r", "z", "p", "Ap", "b")}
+
+    # ------------------------------------------------------------------ inputs
+    def update_t(self, t_array):
+        self.t = np.asarray(t_array, dtype=np.float64).ravel().copy()
+        self.ctx.set_field("thickness", self.t)
+
+    def update_f_history(self, f_history_array):
+        self.f_history = np.asarray(f_history_array, dtype=np.float64).reshape(-1, 3 * self.nn)
+
+    def update_nsteps(self, Nsteps):
+        self.Nsteps, self.time_levels = Nsteps, Nsteps + 1
+
+    def _force_at(self, i):
+        f = self.f_history[min(i, self.f_history.shape[0] - 1)].reshape(-1, 3).copy()
+        if self.add_self_weight:
+            g = (-1.0 if self.g_factor is None else self.g_factor) * 9.81
+            f[:, 2] += self.rho * self.t * g                             # f_d = (0, 0, rho t g), plate_sim.py:204-211
+        return f
+
+    # ------------------------------------------------------------------ forward march
+    def _sync(self):
+        self.torch.cuda.synchronize()
+
+    def solve_dynamic_problem(self, residual=None, saving_outputs=False, PATH=None, timing=False):
+        """March from zero initial conditions; returns the (fe_dofs, time_levels) history."""
+        ctx, v, torch = self.ctx, self._v, self.torch
+        W = self.W = torch.zeros((self.time_levels, self.fe_dofs), dtype=torch.float64, device=v["state"].device)
+        wdot = torch.zeros_like(v["state"])
+        self.solve_info = []
+        for i in range(1, self.time_levels):
+            w_old = W[i - 1]
+            ctx.set_field("F_solid", self._force_at(i))
+            ctx.load_vec("b")                                            # F_i with BC rows zeroed
+            v["p"].copy_(w_old).mul_(self.a).add_(wdot, alpha=self.b)    # 2/dt^2 w_old + 2/dt wdot_old
+            v["adjoint"].copy_(w_old)
+            self._sync()
+            ctx.op_apply_vec2("p", "Ap", 0.0, 1.0, False)               # M (...)
+            ctx.op_apply_vec2("adjoint", "z", 1.0, 0.0, False)          # K w_old
+            v["b"].add_(v["Ap"]).add_(v["z"], alpha=-0.5)
+            self._sync()
+            ctx.vec_mask_zero("b")
+            self.solve_info.append(ctx.solve_vec("b", "state", zero_guess=True))
+            W[i].copy_(v["state"])
+            wdot = self.b * (W[i] - w_old) - wdot                        # plate_sim.py:243-244, 333
+        self._sync()
+        return W.T.cpu().numpy().copy(order="F")
+
+    # ------------------------------------------------------------------ outputs on one level
+    def assembleStrainEnergy(self, w):
+        self.ctx.set_state(np.asarray(w, dtype=np.float64))
+        return self.ctx.functional("elastic_energy")
+
+    def strain_energy_gradients(self, w):
+        """(dE/dt, dE/dw) of the strain energy at one level."""
+        self.ctx.set_state(np.asarray(w, dtype=np.float64))
+        return self.ctx.dfunctional("elastic_energy", "thickness"), self.ctx.dfunctional("elastic_energy", "disp_solid")
+
+    def volume(self):
+        return self.ctx.functional("volume")
+
+    def dvolume_dt(self):
+        return self.ctx.dfunctional("volume", "thickness")
+
+    # ------------------------------------------------------------------ adjoint
+    def adjoint_history(self, G):
+        """Lambda solving (dR/dy)^T Lambda = G for the whole-history residual R(y) (y = all levels), by the
+        backward two-vector recursion
+            mu_i = b M lam_{i+1} - mu_{i+1},   A lam_i = G_i + b mu_i + (a M - K/2) lam_{i+1} - b mu_{i+1},
+        lam_0 = G_0 + (a M - K/2) lam_1 - b mu_1.  G, Lambda: (fe_dofs, time_levels)."""
+        ctx, v, torch = self.ctx, self._v, self.torch
+        dev = v["state"].device
+        Gd = torch.as_tensor(np.ascontiguousarray(np.asarray(G, dtype=np.float64).T), device=dev)
+        Lam = torch.zeros_like(Gd)
+        lam_next = torch.zeros_like(v["state"])
+        mu_next = torch.zeros_like(v["state"])
+        keep = torch.ones_like(v["state"]); keep[torch.as_tensor(self.bc_dofs.astype(np.int64), device=dev)] = 0.0
+        for i in range(self.time_levels - 1, -1, -1):
+            v["p"].copy_(lam_next)
+            self._sync()
+            ctx.op_apply_vec2("p", "Ap", 0.0, 1.0, False)               # M lam_{i+1}
+            ctx.op_apply_vec2("p", "z", 1.0, 0.0, False)                # K lam_{i+1}
+            mu_i = self.b * v["Ap"] * keep - mu_next
+            rhs = Gd[i] + (self.a * v["Ap"] - 0.5 * v["z"]) * keep - self.b * mu_next
+            if i == 0:
+                Lam[0] = rhs
+                break
+            v["b"].copy_(rhs + self.b * mu_i)
+            self._sync()
+            ctx.vec_mask_zero("b")
+            ctx.solve_vec("b", "adjoint", zero_guess=True)
+            Lam[i].copy_(v["adjoint"])
+            lam_next, mu_next = Lam[i].clone(), mu_i
+        self._sync()
+        self.Lam = Lam
+        return Lam.T.cpu().numpy().copy(order="F")
+
+    def residual_T_products(self, Lam_host):
+        """(sum_i (dR_i/dt)^T lam_i,  [(dR_i/df)^T lam_i]_i) for the history self.W of the last march."""
+        ctx, v, torch = self.ctx, self._v, self.torch
+        dev = v["state"].device
+        Lam = torch.as_tensor(np.ascontiguousarray(np.asarray(Lam_host, dtype=np.float64).T), device=dev)
+        W = self.W
+        wdot = torch.zeros_like(v["state"])
+        ctx.grad_reset()
+        dF = np.zeros((self.time_levels, 3 * self.nn))
+        g_sw = np.zeros(self.num_var)
+        for i in range(1, self.time_levels):
+            v["adjoint"].copy_(Lam[i])
+            v["p"].copy_(W[i] + W[i - 1])
+            v["z"].copy_(W[i] - W[i - 1]).mul_(self.a).add_(wdot, alpha=-self.b)
+            self._sync()
+            ctx.grad_add("K", "p", "adjoint", 0.5)                       # 1/2 lam^T K' (w_i + w_{i-1})
+            ctx.grad_add("M", "z", "adjoint", 1.0)                       # lam^T M' (a (w_i - w_{i-1}) - b wdot_{i-1})
+            dfi = ctx.dRdarg_T("F_solid", Lam[i].cpu().numpy())
+            dF[i] = dfi
+            if self.add_self_weight:
+                g = (-1.0 if self.g_factor is None else self.g_factor) * 9.81
+                g_sw += dfi.reshape(-1, 3)[:, 2] * self.rho * g
+            wdot = self.b * (W[i] - W[i - 1]) - wdot
+        return ctx.grad_get() + g_sw, dF

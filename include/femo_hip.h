@@ -128,6 +128,19 @@ int femo_solve_state(femo_ctx* ctx, int zero_guess, int32_t* iters, double* relr
  * the same call serves both modes (reference quirk Q3). */
 int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iters, double* relres);
 
+/* ---- Dynamic shell (reference femo_alpha/dynamic_rm_shell/plate_sim.py:131-140,190-215): building blocks on
+ * device vectors.  The time loop and its adjoint live in femo_alpha_amd/dynamic_rm_shell (Python, like the
+ * reference's PlateSim); these calls supply the operator A = aK K + aM M of one midpoint/Newmark step, its
+ * factorisation and solves, the reduced strain quadrature, and the thickness-gradient pieces. */
+int femo_set_operator(femo_ctx* ctx, double aK, double aM);          /* operator used by solves and femo_factorize */
+int femo_set_strain_quadrature(femo_ctx* ctx, int32_t nred);         /* nred x nred Gauss for membrane/bending/shear; 0 = full rule */
+int femo_op_apply_vec2(femo_ctx* ctx, int32_t src, int32_t dst, double aK, double aM, int with_penalty);
+int femo_solve_vec(femo_ctx* ctx, int32_t b, int32_t x, int zero_guess, int32_t* iters, double* relres);
+int femo_vec_mask_zero(femo_ctx* ctx, int32_t id);
+int femo_grad_reset(femo_ctx* ctx);                                   /* thickness-gradient accumulator := 0 */
+int femo_grad_add(femo_ctx* ctx, int kind, int32_t x, int32_t y, double scale);   /* += scale y^T dK/dh x (0) or y^T dM/dh x (1) */
+int femo_grad_get(femo_ctx* ctx, double* out, int64_t n);
+
 /* Stress aggregation parameters (m, rho) of pnorm_stress = 1/alpha int (m vm_top)^rho J dx
  * (rm_shell/rm_shell_pde.py:112-128; defaults 1e-6, 100 as rm_shell_model.py:63). */
 int femo_set_stress_params(femo_ctx* ctx, double m, double rho);

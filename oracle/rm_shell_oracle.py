@@ -128,7 +128,7 @@ class ShellOracle:
     (attributes nodes, cells, cell_p2, nV, nP2, ndof, ndof_u, is_quad)."""
 
     def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False,
-                 nquad=4, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None):
+                 nquad=4, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None, nred=0):
         self.mesh = mesh
         self.ewm = bool(element_wise_material)
         self.ewp = bool(elementwise_pressure)
@@ -139,9 +139,18 @@ class ShellOracle:
                             else np.unique(np.asarray(strong_dofs, np.int32)))
         if mesh.is_quad:
             self.pts, self.wts = quad_rule(nquad) if rule is None else rule
+            self.wts_strain = self.wts
+            if nred:
+                # membrane / bending / shear energies on an nred x nred rule (the dynamic path's quadrature degree 3,
+                # dynamic_rm_shell/plate_sim.py:65-67,82-91), everything else on the full rule: one point list, two weights
+                pr, wr = quad_rule(nred)
+                self.wts_strain = np.concatenate([wr, 0 * self.wts])
+                self.wts = np.concatenate([0 * wr, self.wts])
+                self.pts = np.vstack([pr, self.pts])
             self.N2, self.dN2, self.N1, self.dN1 = quad_tables(self.pts)
         else:
             self.pts, self.wts = tri_rule() if rule is None else rule
+            self.wts_strain = self.wts
             self.N2, self.dN2, self.N1, self.dN1 = tri_tables(self.pts)
         self.nq = self.pts.shape[0]
         self.npc = mesh.cell_p2.shape[1]
@@ -247,6 +256,7 @@ class ShellOracle:
         returns the derivative with respect to the (point value of the) field."""
         h, E, nu = self._at_qp(self.h, sl), self._at_qp(self.E, sl), self._at_qp(self.nu, sl)
         wdet = self.wts[None, :] * g["det"]
+        wdetS = self.wts_strain[None, :] * g["det"]
         Ju = g["Ju"]
         hK2 = (self.hK[sl] ** 2)[:, None]
         k = SHEAR_CORRECTION
@@ -281,9 +291,9 @@ class ShellOracle:
         else:
             raise ValueError(deriv)
         C = np.zeros(wdet.shape + (9, 9))
-        C[..., 0:3, 0:3] = Cm * wdet[..., None, None]          # membrane: no J(uhat)  (:278-279)
-        C[..., 3:6, 3:6] = Cb * wdet[..., None, None]          # bending : no J(uhat)  (:281-282)
-        sw = cs * Ju * wdet
+        C[..., 0:3, 0:3] = Cm * wdetS[..., None, None]         # membrane: no J(uhat)  (:278-279)
+        C[..., 3:6, 3:6] = Cb * wdetS[..., None, None]         # bending : no J(uhat)  (:281-282)
+        sw = cs * Ju * wdetS
         C[..., 6, 6] = sw; C[..., 7, 7] = sw                   # shear   : J(uhat)     (:275-276)
         C[..., 8, 8] = cd * Ju * wdet                          # drilling: J(uhat)     (:284-296)
         return C
@@ -356,6 +366,46 @@ class ShellOracle:
         if with_strong and self.strong_dofs.size:
             K = self._apply_strong(K)
         return K
+
+    def assemble_M(self):
+        """Inertia of the dynamic shell: rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348)."""
+        n = self.mesh.ndof
+        rows, cols, vals = [], [], []
+        for sl in self._chunks():
+            g = self._geometry(sl, self.N1, self.dN1)
+            c = self.wts[None, :] * g["det"] * g["Ju"] * self._at_qp(self.rho, sl) * self._at_qp(self.h, sl)
+            Mu = np.einsum("eq,qa,qb->eab", c, self.N2, self.N2)
+            Mt = np.einsum("eq,qa,qb->eab", c * (self.hK[sl] ** 2)[:, None], self.N1, self.N1)
+            d = self.dofs[sl]
+            for comp in range(3):
+                du = d[:, comp:3 * self.npc:3]
+                dt = d[:, 3 * self.npc + comp::3]
+                rows.append(np.repeat(du, self.npc, axis=1).ravel()); cols.append(np.tile(du, (1, self.npc)).ravel()); vals.append(Mu.ravel())
+                rows.append(np.repeat(dt, self.nvc, axis=1).ravel()); cols.append(np.tile(dt, (1, self.nvc)).ravel()); vals.append(Mt.ravel())
+        return sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr()
+
+    def dynamic_history(self, f_history, dt, nsteps):
+        """Midpoint / Newmark march of the reference's PlateSim (dynamic_rm_shell/plate_sim.py:131-140, 281-361):
+        (2/dt^2 M + K/2) w_i = F_i + M (2/dt^2 w_{i-1} + 2/dt wdot_{i-1}) - K/2 w_{i-1}; strong BCs; zero initial state.
+        Returns the (ndof, nsteps+1) history."""
+        K = self.assemble_K(with_strong=False)
+        M = self.assemble_M()
+        a, b = 2.0 / dt ** 2, 2.0 / dt
+        A = (a * M + 0.5 * K).tocsr()
+        keep = np.ones(self.mesh.ndof); keep[self.strong_dofs] = 0.0
+        D = sp.diags(keep)
+        lu = spla.splu((D @ A @ D + sp.diags(1.0 - keep)).tocsc())
+        W = np.zeros((self.mesh.ndof, nsteps + 1))
+        wd = np.zeros(self.mesh.ndof)
+        f0 = self.f.copy()
+        for i in range(1, nsteps + 1):
+            self.f = np.asarray(f_history[min(i, len(f_history) - 1)], dtype=np.float64).reshape(-1, 3)
+            rhs = self.load_vector() + keep * (M @ (a * W[:, i - 1] + b * wd) - 0.5 * (K @ W[:, i - 1]))
+            rhs[self.strong_dofs] = 0.0
+            W[:, i] = lu.solve(rhs)
+            wd = b * (W[:, i] - W[:, i - 1]) - wd
+        self.f = f0
+        return W
 
     def _apply_strong(self, K):
         """Zero BC rows/columns, unit diagonal -- dolfinx assemble_matrix(bcs) semantics

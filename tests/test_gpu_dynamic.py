@@ -1,0 +1,84 @@
+"""Transient path (BASELINE config 5 family): PlateSim march and its adjoint on the GPU against the CPU oracle's
+restatement of the reference's time discretisation (parity unpinned: see femo_alpha_amd/dynamic_rm_shell/plate_sim.py)."""
+import numpy as np
+import pytest
+
+from femo_alpha_amd import csdl
+from femo_alpha_amd.mesh import plate_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _gust(time_levels, nn, dt):
+    # 1-cosine gust of ex_simple_dynamic_shell_opt.py:45-95 (V_p = 50, T0 = 0.02, T1 = 0.12), scaled
+    t = np.arange(time_levels) * dt
+    fz = np.where((t >= 0.02) & (t <= 0.14), 0.1 * 50 * (1 - np.cos(2 * np.pi * (t - 0.02) / 0.12)), 0.0)
+    F = np.zeros((time_levels, nn, 3))
+    F[:, :, 2] = fz[:, None]
+    return F.reshape(time_levels, -1)
+
+
+@pytest.mark.parametrize("ewt", [False, True])
+def test_march_and_adjoint(ewt):
+    from femo_alpha_amd.dynamic_rm_shell.operations import StateOperation, TotalStrainEnergyOperation, VolumeOperation
+    from femo_alpha_amd.dynamic_rm_shell.plate_sim import PlateSim
+    from oracle.rm_shell_oracle import ShellOracle
+    mesh = plate_mesh(2.0, 10.0, 4, 12)
+    E, nu, rho, dt, N = 1e8, 0.3, 10.0, 0.01, 12
+    ps = PlateSim(mesh, E, nu, rho, dt, N, element_wise_thickness=ewt, quad_deg=3, leaf_size=8)
+    n_t = mesh.nel if ewt else mesh.nn
+    rng = np.random.default_rng(0)
+    t0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, n_t))
+    F = _gust(N + 1, mesh.nn, dt)
+
+    o = ShellOracle(mesh, element_wise_material=ewt, strong_dofs=ps.bc_dofs, nred=2)
+    def march(t):
+        o.set_fields(h=t, E=E, nu=nu, rho=rho)
+        return o.dynamic_history(F.reshape(N + 1, -1, 3), dt, N)
+    W_ref = march(t0)
+
+    rec = csdl.Recorder(inline=True); rec.start()
+    grp = csdl.VariableGroup()
+    grp.thickness = csdl.Variable(value=t0, name="thickness")
+    grp.force_history = csdl.Variable(value=F, name="force_history")
+    hist = StateOperation(ps).evaluate(grp)
+    grp.disp_history = hist
+    tse = TotalStrainEnergyOperation(ps).evaluate(grp)
+    vol = VolumeOperation(ps).evaluate(grp)
+    rec.stop()
+
+    W = hist.value.reshape((mesh.ndof, N + 1), order="F")
+    assert np.abs(W[:, 0]).max() == 0.0
+    assert np.abs(W - W_ref).max() < 1e-8 * np.abs(W_ref).max()
+    assert all(it <= 4 for it, rr in ps.solve_info)
+    Kel = o.assemble_K(with_strong=False)
+    tse_ref = sum(0.5 * W_ref[:, i] @ (Kel @ W_ref[:, i]) for i in range(N + 1))
+    assert abs(tse.value[0] - tse_ref) < 1e-8 * tse_ref
+    o.set_fields(rho=1.0); vref = o.mass(); o.set_fields(rho=rho)
+    assert abs(vol.value[0] - vref) < 1e-12 * vref
+
+    # adjoint of the total strain energy w.r.t. thickness against central finite differences of the oracle march
+    g = rec.compute_totals(tse, grp.thickness)
+    def J(t):
+        Wt = march(t)
+        o.set_fields(h=t)
+        K = o.assemble_K(with_strong=False)
+        return sum(0.5 * Wt[:, i] @ (K @ Wt[:, i]) for i in range(N + 1))
+    for i in rng.choice(n_t, 3, replace=False):
+        st = 1e-4 * t0[i]
+        tp = t0.copy(); tp[i] += st; tm = t0.copy(); tm[i] -= st
+        fd = (J(tp) - J(tm)) / (2 * st)
+        assert abs(g[i] - fd) < 2e-5 * np.abs(g).max(), (i, g[i], fd)
+    gv = rec.compute_totals(vol, grp.thickness)
+    assert abs(gv.sum() - 20.0) < 1e-9                     # d/dt int t dx summed over the partition of unity = area
+    # sensitivity to the load history through the same adjoint
+    gF = rec.compute_totals(tse, grp.force_history)
+    k, node = 5, mesh.nn // 2
+    Fp = F.copy(); Fp[k, 3 * node + 2] += 1e-3
+    def JF(Fh):
+        Wt = o.dynamic_history(Fh.reshape(N + 1, -1, 3), dt, N)
+        return sum(0.5 * Wt[:, i] @ (Kel @ Wt[:, i]) for i in range(N + 1))
+    o.set_fields(h=t0)
+    Fm = F.copy(); Fm[k, 3 * node + 2] -= 1e-3
+    fd = (JF(Fp) - JF(Fm)) / 2e-3
+    assert abs(gF[k, 3 * node + 2] - fd) < 1e-5 * np.abs(gF).max()
