@@ -239,6 +239,9 @@ class Recorder:
                     op.compute_jacvec_product(ivals, ovals, d_in, {}, {key: d_res[key]}, "rev")
                     for k, v in op._inputs.items():
                         self._push_to_source(v, -d_in[k], sink)        # dy/dx = -(dR/dy)^-1 dR/dx
+                elif hasattr(op, "vjp"):
+                    (k, v), = op._inputs.items()
+                    self._push_to_source(v, np.asarray(op.vjp(bar), dtype=np.float64), sink)
                 else:
                     derivs = {}
                     op.compute_derivatives(ivals, ovals, derivs)

@@ -17,6 +17,31 @@ from ..mesh import ShellMesh
 from .rm_shell_pde import FacetSet, RMShellPDE
 
 
+def solve_linear(A, b):
+    """pressure = A^-1 force as a differentiable node: ``csdl.solve_linear`` when csdl_alpha is installed (what the
+    reference calls, rm_shell_model.py:420), otherwise a small explicit operation of the stand-in."""
+    if csdl.HAVE_CSDL_ALPHA:
+        return csdl.solve_linear(A.toarray(), b)
+    import scipy.sparse.linalg as spla
+    lu = spla.splu(A.tocsc())
+
+    class _Solve(csdl.CustomExplicitOperation):
+        def evaluate(self, rhs):
+            self.declare_input("b", rhs)
+            x = self.create_output("x", rhs.shape)
+            self.declare_derivative_parameters("x", "*", dependent=True)
+            self._finish_evaluate()
+            return x
+
+        def compute(self, input_vals, output_vals):
+            output_vals["x"] = lu.solve(np.asarray(input_vals["b"], dtype=np.float64))
+
+        def vjp(self, bar):                      # A is symmetric: bar_b = A^-T bar_x
+            return lu.solve(bar)
+
+    return _Solve().evaluate(b)
+
+
 def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: int):
     """Tagged facet measure (femo_alpha/fea/utils_dolfinx.py:555-565): 'ds' = boundary facets whose
     vertices all satisfy the marker, 'dS' = interior facets, integrated from both sides."""
@@ -117,9 +142,12 @@ class RMShellModel:
         shell_inputs.density = density[mat_idx]
         prs_idx = np.arange(mesh.nel if self.elementwise_pressure else mesh.nn)
         reshaped_force = csdl.reshape(force_vector[prs_idx], (-1,))
-        if not is_pressure:
-            raise NotImplementedError("force -> pressure conversion is a 'next' row (SURVEY.md section 8f, rank 4)")
-        shell_inputs.F_solid = reshaped_force
+        if is_pressure:
+            shell_inputs.F_solid = reshaped_force
+        else:
+            # nodal forces -> nodal pressures through the consistent mass matrix (rm_shell_model.py:414-421)
+            A = self.shell_pde.construct_force_to_pressure_map()
+            shell_inputs.F_solid = solve_linear(A, reshaped_force)
         shell_inputs.F_solid.add_name("F_solid")
         if node_disp is None:
             node_disp = csdl.Variable(value=0.0, shape=(mesh.nn, 3), name="node_disp")

@@ -117,3 +117,24 @@ def test_operator_error_behaviour():
         op.apply_inverse_jacobian({}, {}, {}, {}, "sideways")
     with pytest.raises(TypeError):
         StateOperation(fea="not an FEA", args_name_list=[], state_name="disp_solid")
+
+
+def test_forces_instead_of_pressures():
+    """is_pressure=False: nodal forces are turned into pressures with the consistent CG1 mass matrix
+    (reference rm_shell_model.py:414-421, rm_shell_pde.py:194-209); a uniform pressure must be recovered from
+    its own consistent nodal forces, and totals flow back through the map."""
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    mesh = plate_mesh(2.0, 10.0, 3, 9)
+    nn = mesh.nn
+    rec = csdl.Recorder(inline=True); rec.start()
+    model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False)
+    A = model.shell_pde.construct_force_to_pressure_map()
+    p_uniform = np.zeros((nn, 3)); p_uniform[:, 2] = 5.0
+    forces = csdl.Variable(value=(A @ p_uniform.ravel()).reshape(nn, 3), name="force_vector")
+    assert abs(forces.value[:, 2].sum() - 5.0 * 20.0) < 1e-10          # total force = pressure x area
+    mk = lambda v, n: csdl.Variable(value=v * np.ones(nn), name=n)
+    out_f = model.evaluate(forces, mk(0.1, "thickness"), mk(1e8, "E"), mk(0.3, "nu"), mk(10.0, "density"), is_pressure=False)
+    rec.stop()
+    assert np.abs(out_f.F_solid.value.reshape(nn, 3) - p_uniform).max() < 1e-10
+    g = rec.compute_totals(out_f.compliance, forces)
+    assert g.shape == (nn, 3) and np.abs(g[:, 2]).max() > 0
