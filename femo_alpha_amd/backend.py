@@ -215,6 +215,24 @@ class ShellContext:
         self._chk(self.lib.femo_grad_get(self._h, dptr(out), out.size))
         return out
 
+    # ------------------------------------------------------------------ CSR export
+    def enable_csr(self):
+        """Pattern + destination-sorted contribution map (host, mesh only), uploaded once."""
+        from .csr import build_csr_map
+        self.csr = build_csr_map(self.mesh)
+        self._chk(self.lib.femo_set_csr_map(self._h, self.csr["nnz"], self.csr["perm"].size, iptr(self.csr["perm"]),
+                                            iptr(self.csr["dest"])))
+        return self.csr
+
+    def assemble_csr(self):
+        """scipy CSR matrix of the elastic stiffness for the current fields (no Dirichlet treatment)."""
+        import scipy.sparse as sp
+        vals = np.empty(self.csr["nnz"]); ms = np.zeros(2)
+        self._chk(self.lib.femo_assemble_csr(self._h, dptr(vals), dptr(ms)))
+        self.csr_timing = dict(element_matrices_ms=ms[0], scatter_ms=ms[1])
+        n = self.mesh.ndof
+        return sp.csr_matrix((vals, self.csr["colidx"], self.csr["rowptr"]), shape=(n, n))
+
     def set_stress_params(self, m=1e-6, rho=100.0):
         self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
 

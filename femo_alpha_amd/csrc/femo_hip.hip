@@ -42,6 +42,10 @@ struct femo_ctx {
     Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
     double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0;
     double* gradbuf = nullptr;
+    // CSR assembly
+    long long csr_ncontrib = 0; int csr_nnz = 0;
+    int *csr_perm = nullptr, *csr_dest = nullptr;
+    double *csr_vals = nullptr, *csr_ke = nullptr;
     double op_aK = 1.0, op_aM = 0.0;      // the operator every solve / factorisation uses: aK * K + aM * M
     int nquad = 4, nred = 0;
     // fields
@@ -786,7 +790,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->gradbuf, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1522,6 +1526,52 @@ int femo_grad_get(femo_ctx* c, double* out, int64_t n) {
     if (!c->gradbuf || n != c->nT) return fail(c, "gradient accumulator not initialised or wrong length");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->gradbuf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+
+// ---- CSR assembly of the elastic stiffness (what assembleMatrix(dR_du) returns in the reference,
+// csdl_alpha_opt/state_operation.py:289; fea/utils_dolfinx.py:200-206) -----------------------------------------
+// perm[k]: index into the element-matrix buffer (element * ld*ld + i*ld + j) of the k-th contribution in
+// destination order; dest[k]: its position in the CSR value array (non-decreasing).
+int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* perm, const int32_t* dest) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (ncontrib != (int64_t)c->nel * c->ld * c->ld) return fail(c, "ncontrib must be nel * ldof^2");
+    for (int64_t k = 0; k < ncontrib; ++k) {
+        if (perm[k] < 0 || perm[k] >= ncontrib || dest[k] < 0 || dest[k] >= nnz || (k && dest[k] < dest[k - 1]))
+            return fail(c, "bad CSR map (range or ordering)");
+    }
+    void* old[] = {c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke};
+    for (void* p : old) if (p) hipFree(p);
+    c->csr_perm = c->csr_dest = nullptr; c->csr_vals = c->csr_ke = nullptr;
+    HIPCHK(c, hipMalloc((void**)&c->csr_perm, (size_t)ncontrib * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_dest, (size_t)ncontrib * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_vals, (size_t)nnz * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_ke, (size_t)ncontrib * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->csr_perm, perm, (size_t)ncontrib * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->csr_dest, dest, (size_t)ncontrib * sizeof(int), hipMemcpyHostToDevice));
+    c->csr_ncontrib = ncontrib; c->csr_nnz = nnz;
+    return 0;
+}
+
+// vals (host, nnz) = CSR values of aK K + (no inertia) for the current fields; ms[0] = element matrices, ms[1] = scatter
+int femo_assemble_csr(femo_ctx* c, double* vals, double* ms2) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->csr_perm) return fail(c, "call femo_set_csr_map first");
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    ELEM_LAUNCH(c, k_element_matrices, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, 0, c->nel, c->csr_ke);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->csr_vals, 0, (size_t)c->csr_nnz * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_csr_segmented, dim3((unsigned)((c->csr_ncontrib + 255) / 256)), dim3(256), 0, c->stream, c->csr_ncontrib,
+                       c->csr_perm, c->csr_dest, c->csr_ke, c->csr_vals);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float a = 0, b = 0;
+    hipEventElapsedTime(&a, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&b, c->ev[1], c->ev[2]);
+    if (ms2) { ms2[0] = a; ms2[1] = b; }
+    if (vals) HIPCHK(c, hipMemcpy(vals, c->csr_vals, (size_t)c->csr_nnz * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

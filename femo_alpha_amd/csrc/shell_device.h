@@ -1130,6 +1130,40 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
     for (int i = 0; i < LD; ++i) out[i * LD + j] = ye[i];
 }
 
+// ------------------------------------------------------------------------------------------ CSR assembly
+// Scatter-add of the element matrices into CSR values with wave-level segmentation: the nel*LD*LD element
+// contributions are visited in the order of their CSR destination (perm), so the 64 lanes of a wave hold runs of
+// equal destinations.  A ballot of the run heads drives a segmented shuffle scan; the last lane of every run
+// writes the run's sum -- a plain, coalesced store when the run lies inside the wave, an atomic add only for runs
+// cut by a wave boundary.  (Scattered fp64 atomics run at ~10 G/s on this chip; sorted destinations avoid them.)
+__global__ void __launch_bounds__(256)
+k_csr_segmented(long long ncontrib, const int* __restrict__ perm, const int* __restrict__ dest,
+                const double* __restrict__ Ke, double* __restrict__ vals) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool act = t < ncontrib;
+    const int d = act ? dest[t] : -1;
+    double v = act ? Ke[perm[t]] : 0.0;
+    const int d_prev = __shfl_up(d, 1, 64);
+    const bool head = lane == 0 || d != d_prev;
+    const unsigned long long heads = __ballot(head);
+    // lane index of the head of my run: highest set bit of heads at or below my lane
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int my_head = 63 - __clzll((long long)below);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(v, o, 64);
+        if (lane - o >= my_head) v += up;
+    }
+    const int d_next = __shfl_down(d, 1, 64);
+    const bool tail = lane == 63 || d != d_next;
+    if (act && tail && d >= 0) {
+        const bool cut = my_head == 0 || lane == 63;          // the run may continue in a neighbouring wave
+        if (cut) atomicAdd(&vals[d], v);
+        else vals[d] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ penalty facets
 struct FacetDev {
     int nf;

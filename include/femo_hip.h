@@ -141,6 +141,13 @@ int femo_grad_reset(femo_ctx* ctx);                                   /* thickne
 int femo_grad_add(femo_ctx* ctx, int kind, int32_t x, int32_t y, double scale);   /* += scale y^T dK/dh x (0) or y^T dM/dh x (1) */
 int femo_grad_get(femo_ctx* ctx, double* out, int64_t n);
 
+/* ---- CSR assembly of the elastic stiffness matrix (what assembleMatrix(dR_du) hands back in the reference,
+ * csdl_alpha_opt/state_operation.py:289, fea/utils_dolfinx.py:200-206).  The solver never needs it (the operator is
+ * matrix-free); it exists for callers that want the matrix.  The map comes from femo_alpha_amd/csr.py: the
+ * nel*ldof^2 element contributions sorted by CSR destination.  ms2 = { element matrices ms, scatter ms }. */
+int femo_set_csr_map(femo_ctx* ctx, int32_t nnz, int64_t ncontrib, const int32_t* perm, const int32_t* dest);
+int femo_assemble_csr(femo_ctx* ctx, double* vals, double* ms2);
+
 /* Stress aggregation parameters (m, rho) of pnorm_stress = 1/alpha int (m vm_top)^rho J dx
  * (rm_shell/rm_shell_pde.py:112-128; defaults 1e-6, 100 as rm_shell_model.py:63). */
 int femo_set_stress_params(femo_ctx* ctx, double m, double rho);

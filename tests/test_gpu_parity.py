@@ -246,3 +246,16 @@ def test_stress_outputs(kind, ewm, uhat):
             o3.set_fields(uhat=u0)
             fd = (fp - fm) / 2e-6
             assert abs(g_u[v_, comp] - fd) <= 5e-6 * np.abs(g_u).max() + 1e-7 * abs(fd), (v_, comp, g_u[v_, comp], fd)
+
+
+@pytest.mark.parametrize("kind", ["plate", "warped", "tri"])
+def test_csr_assembly(kind):
+    """Wave-segmented scatter-add of the element matrices into CSR against the oracle's scipy assembly."""
+    m, o, c, rng = _pair(kind)
+    info = c.enable_csr()
+    K = c.assemble_csr()
+    Kref = o.assemble_K(with_penalty=False, with_strong=False)
+    assert info["nnz"] == Kref.nnz
+    assert abs(K - Kref).max() < 1e-11 * abs(Kref).max()
+    K2 = c.assemble_csr()                                    # repeatable
+    assert abs(K2 - K).max() <= 1e-13 * abs(Kref).max()
