@@ -19,6 +19,10 @@
 
 using namespace femo;
 
+// tree levels whose largest pivot block exceeds this run the triangular solves with the wide (multi-workgroup)
+// kernels and the precomputed 128 x 128 diagonal-block inverses; smaller fronts use one workgroup per front
+static int WIDE_NP = 512;           // FEMO_WIDE_NP overrides it when a plan is uploaded (tests force the wide path on small meshes)
+
 #define FEMO_VERSION 100
 
 static std::string g_create_error;
@@ -78,8 +82,10 @@ struct femo_ctx {
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
-        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr;
-        double *F = nullptr, *Linv = nullptr;
+        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *spoff = nullptr;
+        double *F = nullptr, *Linv = nullptr, *Sinv = nullptr;
+        int *sp_front = nullptr, *sp_index = nullptr;
+        int nsp = 0;
         long long f_doubles = 0, linv_doubles = 0;
         int max_nf = 0;
         double t_factor_ms = 0, t_assemble_ms = 0;
@@ -379,7 +385,7 @@ static FrontDev front_dev(const femo_ctx* c) {
     FrontDev fd;
     fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.foff = c->fr.foff; fd.doff = c->fr.doff;
     fd.dofs = c->fr.dofs; fd.upmap = c->fr.upmap; fd.parent = c->fr.parent; fd.child[0] = c->fr.left; fd.child[1] = c->fr.right;
-    fd.linvoff = c->fr.linvoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv;
+    fd.linvoff = c->fr.linvoff; fd.spoff = c->fr.spoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv; fd.Sinv = c->fr.Sinv;
     return fd;
 }
 
@@ -463,6 +469,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         }
         HIPCHK(c, hipGetLastError());
     }
+    if (l1 == fr.nlevels && fr.nsp > 0) {
+        // all levels done: inverses of the 128 x 128 diagonal blocks for the triangular solves
+        ProfScope ps(c, 0);
+        hipLaunchKernelGGL(k_super_inverse, dim3(fr.nsp), dim3(256), 0, c->stream, fd, fr.sp_front, fr.sp_index);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int info = 0;
     HIPCHK(c, hipMemcpyAsync(&info, fr.info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -489,7 +501,6 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
 static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0, c->fr.nlevels, true); }
 
 // v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
-static const int WIDE_NP = 192;    // levels whose largest pivot block exceeds this use the panel-parallel kernels
 static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
@@ -499,17 +510,15 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp > WIDE_NP) {
-            const int npan = (maxnp + NB - 1) / NB;
-            for (int k = 0; k < npan; ++k) {
-                const int rows = maxnp + maxnb - k * NB;          // upper bound of rows below the panel
-                hipLaunchKernelGGL(k_front_fwd_panel, dim3(std::max(1, (rows + 255) / 256), cnt), dim3(256), 0, c->stream, fd, lev,
-                                   k, v, y);
+            for (int c0 = 0; c0 < maxnp; c0 += SP) {
+                const int rows = maxnp + maxnb - c0;              // upper bound of rows below the super panel
+                hipLaunchKernelGGL(k_front_fwd_tri, dim3(cnt), dim3(256), 0, c->stream, fd, lev, c0, v, y);
+                if (rows - SP > 0)
+                    hipLaunchKernelGGL(k_front_fwd_upd, dim3((rows + PB - 1) / PB, cnt), dim3(PB), 0, c->stream, fd, lev, c0, v, y);
             }
         } else {
             const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
-            hipLaunchKernelGGL(k_front_fwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
-            if (maxnb > 0)
-                hipLaunchKernelGGL(k_front_fwd_bnd, dim3((maxnb + 255) / 256, cnt), dim3(256), 0, c->stream, fd, lev, v, y);
+            hipLaunchKernelGGL(k_front_fwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -525,16 +534,18 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
-        if (maxnb > 0)
-            hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + 3) / 4, cnt), dim3(256), 0, c->stream, fd, lev, y, v);
         if (maxnp > WIDE_NP) {
-            const int npan = (maxnp + NB - 1) / NB;
-            for (int k = npan - 1; k >= 0; --k)
-                hipLaunchKernelGGL(k_front_bwd_panel, dim3(std::max(1, (k * NB + 255) / 256), cnt), dim3(256), 0, c->stream, fd, lev,
-                                   k, y, v);
+            if (maxnb > 0)
+                hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + 3) / 4, cnt), dim3(256), 0, c->stream, fd, lev, y, v);
+            for (int c0 = ((maxnp - 1) / SP) * SP; c0 >= 0; c0 -= SP)
+            {
+                hipLaunchKernelGGL(k_front_bwd_tri, dim3(cnt), dim3(256), 0, c->stream, fd, lev, c0, y, v);
+                if (c0 > 0)
+                    hipLaunchKernelGGL(k_front_bwd_upd, dim3((c0 + PB - 1) / PB, cnt), dim3(PB), 0, c->stream, fd, lev, c0, y, v);
+            }
         } else {
-            const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
-            hipLaunchKernelGGL(k_front_bwd_piv, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
+            const size_t shm = (size_t)(maxnp + maxnb + NB) * sizeof(double);
+            hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -796,7 +807,8 @@ void femo_destroy(femo_ctx* c) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
-                     c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv};
+                     c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv,
+                     c->fr.spoff, c->fr.Sinv, c->fr.sp_front, c->fr.sp_index};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -1225,6 +1237,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipSetDevice(c->device));
     auto& fr = c->fr;
     if (fr.ready) return fail(c, "frontal plan already set for this context");
+    if (const char* e = getenv("FEMO_WIDE_NP")) WIDE_NP = std::max(1, atoi(e));
     if (ntree < 1 || nlevels < 1) return fail(c, "empty frontal plan");
     fr.ntree = ntree; fr.nlevels = nlevels;
     fr.h_nf.assign(nf, nf + ntree); fr.h_npiv.assign(npiv, npiv + ntree);
@@ -1280,13 +1293,34 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipMemcpy(fr.doff, dof_off, (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&fr.linvoff, (ntree + 1) * sizeof(long long)));
     HIPCHK(c, hipMemcpy(fr.linvoff, linvoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    {
+        std::vector<long long> spoff(ntree + 1, 0);
+        std::vector<int> spf, spi;
+        std::vector<char> wide(ntree, 0);                 // fronts of the levels that take the wide solve kernels
+        for (int L = 0; L < nlevels; ++L)
+            if (fr.h_level_maxnp[L] > WIDE_NP)
+                for (int i = level_off[L]; i < level_off[L + 1]; ++i) wide[level_nodes[i]] = 1;
+        for (int t = 0; t < ntree; ++t) {
+            const int n = wide[t] ? (npiv[t] + SP - 1) / SP : 0;
+            spoff[t + 1] = spoff[t] + n;
+            for (int k = 0; k < n; ++k) { spf.push_back(t); spi.push_back(k); }
+        }
+        fr.nsp = (int)spf.size();
+        HIPCHK(c, hipMalloc((void**)&fr.spoff, (ntree + 1) * sizeof(long long)));
+        HIPCHK(c, hipMemcpy(fr.spoff, spoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&fr.sp_front, std::max<size_t>(spf.size(), 1) * sizeof(int)));
+        HIPCHK(c, hipMalloc((void**)&fr.sp_index, std::max<size_t>(spi.size(), 1) * sizeof(int)));
+        HIPCHK(c, hipMemcpy(fr.sp_front, spf.data(), spf.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(fr.sp_index, spi.data(), spi.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&fr.Sinv, std::max<size_t>((size_t)fr.nsp, 1) * SP * SP * sizeof(double)));
+    }
     HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
     if ((size_t)(fr.max_nf + NB) * sizeof(double) > 48 * 1024) {
         const int bytes = (int)((fr.max_nf + NB) * sizeof(double));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_piv, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_piv, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     fr.ready = true;
     fr.factored = false;

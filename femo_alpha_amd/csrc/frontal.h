@@ -32,8 +32,10 @@ struct FrontDev {
     const int* parent;
     const int* child[2];        // left / right
     const long long* linvoff;   // doubles, [ntree+1]
+    const long long* spoff;     // number of 128-column super panels before front t, [ntree+1]
     double* F;
     double* Linv;
+    double* Sinv;               // inverse of every 128 x 128 diagonal block of L11 (SP*SP doubles each)
 };
 
 // ------------------------------------------------------------------------------------------ assembly
@@ -380,11 +382,15 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max
 // block inverses) and a wide part on the rectangular block L21 (plain / transposed GEMV spread over
 // many workgroups), which holds most of the factor's bytes.
 
-// forward, part A: y_p = L11^-1 v_p for every front of the level; y goes to yv
+// ---- small fronts (tree levels whose largest pivot block is <= WIDE_NP): one workgroup per front does the
+// whole sweep of that front; inner loops are unrolled so that many loads are in flight per thread.
+
+// forward: y_p = L11^-1 v_p -> yv ; v_B -= L21 y_p
 __global__ void __launch_bounds__(256)
-k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ v, double* __restrict__ yv) {
+k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v, double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
+    if (np == 0) return;
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
@@ -399,6 +405,7 @@ k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* 
         if (threadIdx.x < wb) {
             const int r = threadIdx.x;
             double s = 0.0;
+#pragma unroll 8
             for (int mm = 0; mm <= r; ++mm) s += Li[r + NB * mm] * y[c0 + mm];
             yk[r] = s;
         }
@@ -406,39 +413,63 @@ k_front_fwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* 
         if (threadIdx.x < wb) y[c0 + threadIdx.x] = yk[threadIdx.x];
         for (int r = c0 + wb + threadIdx.x; r < np; r += blockDim.x) {
             double s = 0.0;
-            for (int mm = 0; mm < wb; ++mm) s += F[r + (size_t)nf * (c0 + mm)] * yk[mm];
+            const double* row = F + r + (size_t)nf * c0;
+#pragma unroll 8
+            for (int mm = 0; mm < wb; ++mm) s += row[(size_t)nf * mm] * yk[mm];
             y[r] -= s;
         }
         __syncthreads();
     }
     for (int p = threadIdx.x; p < np; p += blockDim.x) yv[gd[p]] = y[p];
+    for (int r = np + threadIdx.x; r < nf; r += blockDim.x) {
+        double s = 0.0;
+        const double* row = F + r;
+#pragma unroll 8
+        for (int c = 0; c < np; ++c) s += row[(size_t)nf * c] * y[c];
+        atomicAdd(&v[gd[r]], -s);
+    }
 }
 
-// forward, part B: v_B -= L21 y_p ; 256 boundary rows per workgroup, y_p staged in LDS in chunks
+// backward: x_p = L11^-T (y_p - L21^T x_B)
 __global__ void __launch_bounds__(256)
-k_front_fwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v, const double* __restrict__ yv) {
-    const int t = level_nodes[blockIdx.y];
+k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
+    const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    const int r = np + blockIdx.x * 256 + threadIdx.x;
-    if (np + blockIdx.x * 256 >= nf) return;
+    if (np == 0) return;
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
-    __shared__ double ys[256];
-    double s = 0.0;
-    for (int c0 = 0; c0 < np; c0 += 256) {
-        const int w = min(256, np - c0);
-        __syncthreads();
-        if (threadIdx.x < w) ys[threadIdx.x] = yv[gd[c0 + threadIdx.x]];
-        __syncthreads();
-        if (r < nf) {
-            const double* col = F + r + (size_t)nf * c0;
-            for (int c = 0; c < w; ++c) s += col[(size_t)nf * c] * ys[c];
+    extern __shared__ double sh[];
+    double* x = sh;            // nf
+    double* sk = sh + nf;      // NB
+    for (int p = threadIdx.x; p < nf; p += blockDim.x) x[p] = p < np ? sv[gd[p]] : xv[gd[p]];
+    __syncthreads();
+    const int npan = (np + NB - 1) / NB;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = npan - 1; k >= 0; --k) {
+        const int c0 = k * NB, wb = min(NB, np - c0);
+        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+        for (int c = wid; c < wb; c += nw) {
+            double s = 0.0;
+            const double* col = F + (size_t)nf * (c0 + c);
+#pragma unroll 4
+            for (int r = c0 + wb + lane; r < nf; r += 64) s += col[r] * x[r];
+            s = wave_sum(s);
+            if (lane == 0) sk[c] = x[c0 + c] - s;
         }
+        __syncthreads();
+        if (threadIdx.x < wb) {
+            const int c = threadIdx.x;
+            double s = 0.0;
+#pragma unroll 8
+            for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
+            x[c0 + c] = s;
+        }
+        __syncthreads();
     }
-    if (r < nf) atomicAdd(&v[gd[r]], -s);
+    for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
 }
 
-// backward, part A: s_c = y_c - sum_{r in boundary} L21[r][c] x[r] ; one wave per pivot column, 4 per workgroup
+// backward, boundary part for the wide levels: s_c = y_c - sum_{r in boundary} L21[r][c] x[r]; one wave per pivot column
 __global__ void __launch_bounds__(256)
 k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.y];
@@ -449,113 +480,174 @@ k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
     const double* col = fd.F + fd.foff[t] + (size_t)nf * c;
     const int* gd = fd.dofs + fd.doff[t];
     double s = 0.0;
+#pragma unroll 4
     for (int r = np + lane; r < nf; r += 64) s += col[r] * xv[gd[r]];
     s = wave_sum(s);
     if (lane == 0) sv[gd[c]] -= s;
 }
 
-// backward, part B: x_p = L11^-T s_p
+constexpr int SP = 128;    // columns handled per launch by the wide solve kernels (4 diagonal blocks)
+
+constexpr int PB = 64;     // rows (forward) / columns (backward) per workgroup of the wide update kernels: one wave,
+                           // so that even a level with a handful of fronts spreads over hundreds of workgroups
+
+// After the factorisation: inverse of the 128 x 128 diagonal block of L11 that starts at column c0 = 128 * sp,
+// built from the stored 32 x 32 diagonal-block inverses and the off-diagonal blocks of L:
+//   X_jj = Linv_jj ;  X_ij = -Linv_ii * sum_{k=j}^{i-1} L_ik X_kj   (i > j).   One workgroup per super panel.
 __global__ void __launch_bounds__(256)
-k_front_bwd_piv(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
-    const int t = level_nodes[blockIdx.x];
+k_super_inverse(FrontDev fd, const int* __restrict__ sp_front, const int* __restrict__ sp_index) {
+    const int t = sp_front[blockIdx.x], sp = sp_index[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
+    const int c0 = sp * SP;
+    const int W = min(SP, np - c0);
+    const int nkb = (W + NB - 1) / NB;
     const double* F = fd.F + fd.foff[t];
-    const int* gd = fd.dofs + fd.doff[t];
-    extern __shared__ double sh[];
-    double* x = sh;            // np
-    double* sk = sh + np;      // NB
-    for (int p = threadIdx.x; p < np; p += blockDim.x) x[p] = sv[gd[p]];
-    __syncthreads();
-    const int npan = (np + NB - 1) / NB;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = npan - 1; k >= 0; --k) {
-        const int c0 = k * NB, wb = min(NB, np - c0);
-        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-        for (int c = wid; c < wb; c += nw) {
-            double s = 0.0;
-            const double* col = F + (size_t)nf * (c0 + c);
-            for (int r = c0 + wb + lane; r < np; r += 64) s += col[r] * x[r];
-            s = wave_sum(s);
-            if (lane == 0) sk[c] = x[c0 + c] - s;
+    double* S = fd.Sinv + (size_t)(fd.spoff[t] + sp) * SP * SP;
+    __shared__ double X[SP][NB + 1];      // block column j of the inverse, rows 0..127
+    __shared__ double Tm[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < SP * SP; idx += 256) S[idx] = 0.0;
+    for (int j = 0; j < nkb; ++j) {
+        const int wj = min(NB, np - (c0 + NB * j));
+        __syncthreads();
+        for (int idx = tid; idx < SP * NB; idx += 256) X[idx / NB][idx % NB] = 0.0;
+        __syncthreads();
+        const double* Lj = fd.Linv + fd.linvoff[t] + (size_t)(c0 / NB + j) * NB * NB;
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx % NB, c = idx / NB;
+            X[NB * j + r][c] = (r < wj && c < wj) ? Lj[r + NB * c] : 0.0;
+        }
+        for (int i = j + 1; i < nkb; ++i) {
+            const int wi = min(NB, np - (c0 + NB * i));
+            __syncthreads();
+            // T = sum_{k=j}^{i-1} L_ik X_kj  (rows of block i, columns of block j)
+            for (int idx = tid; idx < NB * NB; idx += 256) {
+                const int r = idx % NB, c = idx / NB;
+                double s = 0.0;
+                if (r < wi && c < wj)
+                    for (int k = NB * j; k < NB * i; ++k) s += F[(c0 + NB * i + r) + (size_t)nf * (c0 + k)] * X[k][c];
+                Tm[r][c] = s;
+            }
+            __syncthreads();
+            const double* Li = fd.Linv + fd.linvoff[t] + (size_t)(c0 / NB + i) * NB * NB;
+            for (int idx = tid; idx < NB * NB; idx += 256) {
+                const int r = idx % NB, c = idx / NB;
+                double s = 0.0;
+                if (r < wi && c < wj)
+                    for (int mm = 0; mm <= r; ++mm) s += Li[r + NB * mm] * Tm[mm][c];
+                X[NB * i + r][c] = -s;
+            }
         }
         __syncthreads();
-        if (threadIdx.x < wb) {
-            const int c = threadIdx.x;
-            double s = 0.0;
-            for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
-            x[c0 + c] = s;
+        for (int idx = tid; idx < SP * NB; idx += 256) {
+            const int r = idx % SP, c = idx / SP;
+            if (r < W && c < wj) S[r + (size_t)SP * (NB * j + c)] = X[r][c];
         }
-        __syncthreads();
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
 }
 
-// ---- wide variants for the upper tree levels (few, large fronts): the panel loop runs on the host and
-// every launch spreads one panel's update over many workgroups.  Each workgroup recomputes the 32-vector
-// of the panel from the stored diagonal-block inverse (1k flops) instead of waiting for another one.
-
-// forward panel k:  y_k = Linv_kk v_k -> yv ;  v_r -= L[r, panel k] y_k for all rows r below the panel
+// forward, columns [c0, c0+SP), step 1 (one workgroup per front): y = L11[c0.., c0..]^-1 v[c0..] -> yv
 __global__ void __launch_bounds__(256)
-k_front_fwd_panel(FrontDev fd, const int* __restrict__ level_nodes, int k, double* __restrict__ v, double* __restrict__ yv) {
+k_front_fwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ v, double* __restrict__ yv) {
+    const int t = level_nodes[blockIdx.x];
+    const int np = fd.npiv[t];
+    if (c0 >= np) return;
+    const int W = min(SP, np - c0);
+    const int* gd = fd.dofs + fd.doff[t];
+    const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
+    __shared__ double bs[SP];
+    __shared__ double part[2][SP];
+    const int tid = threadIdx.x;
+    if (tid < SP) bs[tid] = tid < W ? v[gd[c0 + tid]] : 0.0;
+    __syncthreads();
+    // y_r = sum_{m <= r} S[r][m] b[m]: two threads per row (halves of the columns), coalesced along rows
+    const int r = tid & (SP - 1), half = tid >> 7;
+    double s = 0.0;
+    if (r < W) {
+        const int m0 = half * (SP / 2), m1 = min(r + 1, m0 + SP / 2);
+#pragma unroll 16
+        for (int mm = m0; mm < m1; ++mm) s += S[r + (size_t)SP * mm] * bs[mm];
+    }
+    part[half][r] = s;
+    __syncthreads();
+    if (tid < W) yv[gd[c0 + tid]] = part[0][tid] + part[1][tid];
+}
+
+// forward, step 2:  v_r -= L[r, c0..c0+W) y  for all rows r below the super panel, 64 rows per workgroup
+__global__ void __launch_bounds__(PB)
+k_front_fwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ v, const double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    const int c0 = k * NB;
     if (c0 >= np) return;
-    const int wb = min(NB, np - c0);
-    const int r0 = c0 + wb + blockIdx.x * 256;
-    if (r0 >= nf && blockIdx.x > 0) return;
+    const int W = min(SP, np - c0);
+    const int r0 = c0 + W + blockIdx.x * PB;
+    if (r0 >= nf) return;
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
-    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-    __shared__ double bk[NB], yk[NB];
-    if (threadIdx.x < NB) bk[threadIdx.x] = threadIdx.x < wb ? v[gd[c0 + threadIdx.x]] : 0.0;
+    __shared__ double ys[SP];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SP; i += PB) ys[i] = i < W ? yv[gd[c0 + i]] : 0.0;
     __syncthreads();
-    if (threadIdx.x < NB) {
-        double s = 0.0;
-        for (int mm = 0; mm <= (int)threadIdx.x; ++mm) s += Li[threadIdx.x + NB * mm] * bk[mm];
-        yk[threadIdx.x] = s;
-        if (blockIdx.x == 0 && threadIdx.x < wb) yv[gd[c0 + threadIdx.x]] = s;
-    }
-    __syncthreads();
-    const int r = r0 + threadIdx.x;
+    const int r = r0 + tid;
     if (r < nf) {
         double s = 0.0;
         const double* row = F + r + (size_t)nf * c0;
-        for (int mm = 0; mm < wb; ++mm) s += row[(size_t)nf * mm] * yk[mm];
+#pragma unroll 16
+        for (int mm = 0; mm < W; ++mm) s += row[(size_t)nf * mm] * ys[mm];
         if (r < np) v[gd[r]] -= s;
         else atomicAdd(&v[gd[r]], -s);
     }
 }
 
-// backward panel k (descending):  x_k = Linv_kk^T s_k -> xv ;  s_j -= L[panel k, j]^T x_k for all columns j < c0
+// backward, columns [c0, c0+SP), step 1 (one workgroup per front): x = L11[c0.., c0..]^-T s[c0..] -> xv
 __global__ void __launch_bounds__(256)
-k_front_bwd_panel(FrontDev fd, const int* __restrict__ level_nodes, int k, double* __restrict__ sv, double* __restrict__ xv) {
+k_front_bwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ sv, double* __restrict__ xv) {
+    const int t = level_nodes[blockIdx.x];
+    const int np = fd.npiv[t];
+    if (c0 >= np) return;
+    const int W = min(SP, np - c0);
+    const int* gd = fd.dofs + fd.doff[t];
+    const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
+    __shared__ double ss[SP];
+    __shared__ double part[2][SP];
+    const int tid = threadIdx.x;
+    if (tid < SP) ss[tid] = tid < W ? sv[gd[c0 + tid]] : 0.0;
+    __syncthreads();
+    // x_c = sum_{r >= c} S[r][c] s[r]: two threads per column, each walks half of the (contiguous) column
+    const int c = tid & (SP - 1), half = tid >> 7;
+    double s = 0.0;
+    if (c < W) {
+        const int r0 = max(c, half * (SP / 2)), r1 = min(W, (half + 1) * (SP / 2));
+        const double* col = S + (size_t)SP * c;
+#pragma unroll 16
+        for (int r = r0; r < r1; ++r) s += col[r] * ss[r];
+    }
+    part[half][c] = s;
+    __syncthreads();
+    if (tid < W) xv[gd[c0 + tid]] = part[0][tid] + part[1][tid];
+}
+
+// backward, step 2:  s_j -= L[c0..c0+W, j]^T x  for all columns j < c0, 64 columns per workgroup
+__global__ void __launch_bounds__(PB)
+k_front_bwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    const int c0 = k * NB;
     if (c0 >= np) return;
-    const int wb = min(NB, np - c0);
-    const int j0 = blockIdx.x * 256;
-    if (j0 >= c0 && blockIdx.x > 0) return;
+    const int W = min(SP, np - c0);
+    const int j0 = blockIdx.x * PB;
+    if (j0 >= c0) return;
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
-    const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-    __shared__ double sk[NB], xk[NB];
-    if (threadIdx.x < NB) sk[threadIdx.x] = threadIdx.x < wb ? sv[gd[c0 + threadIdx.x]] : 0.0;
+    __shared__ double xs[SP];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SP; i += PB) xs[i] = i < W ? xv[gd[c0 + i]] : 0.0;
     __syncthreads();
-    if (threadIdx.x < NB) {
-        const int c = threadIdx.x;
-        double s = 0.0;
-        for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
-        xk[c] = s;
-        if (blockIdx.x == 0 && c < wb) xv[gd[c0 + c]] = s;
-    }
-    __syncthreads();
-    const int j = j0 + threadIdx.x;
+    const int j = j0 + tid;
     if (j < c0) {
         const double* col = F + c0 + (size_t)nf * j;
         double s = 0.0;
-        for (int i = 0; i < wb; ++i) s += col[i] * xk[i];
+#pragma unroll 16
+        for (int i = 0; i < W; ++i) s += col[i] * xs[i];
         sv[gd[j]] -= s;
     }
 }

@@ -139,8 +139,14 @@ def test_errors_are_loud():
 def test_multifrontal_preconditioner(kind, ewm, bc, uhat):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
     the same parity triple as the reference's direct (MUMPS LU) solve."""
+    import os
     m, o, c, rng = _pair(kind, ewm=ewm, bc=bc, uhat=uhat)
-    plan = c.enable_frontal(leaf_size=8)
+    if kind == "plate24":
+        os.environ["FEMO_WIDE_NP"] = "96"            # force the wide (multi-workgroup) solve kernels on this small mesh
+    try:
+        plan = c.enable_frontal(leaf_size=8)
+    finally:
+        os.environ.pop("FEMO_WIDE_NP", None)
     assert plan.ntree > 1
     if kind == "plate24":
         assert plan.npiv.max() > 192
