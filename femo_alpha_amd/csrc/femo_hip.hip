@@ -464,7 +464,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             if (max_nf > C0 + 1) {
                 ProfScope ps(c, 2);
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
-                hipLaunchKernelGGL(k_trailing, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
+                static const bool use_valu = getenv("FEMO_TRAILING_VALU") != nullptr;
+                if (use_valu) hipLaunchKernelGGL(k_trailing, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
+                else hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
             }
         }
         HIPCHK(c, hipGetLastError());

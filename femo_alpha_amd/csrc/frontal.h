@@ -376,6 +376,72 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max
     }
 }
 
+// P2 on the matrix cores: the same trailing update with v_mfma_f64_16x16x4_f64.
+// Workgroup = 4 waves = one 64x64 tile of the front; wave w owns the 32x32 quarter (w&1 rows, w>>1 columns) as
+// 2x2 MFMA blocks.  To make the stores run along rows of the column-major front (coalesced), the product is
+// formed transposed: A[i][k] = L[c0+i][k] (tile columns), B[k][j] = L[r0+j][k] (tile rows), so D[i][j] = C[r0+j][c0+i];
+// per the CDNA4 f64 layout a lane holds A[lane&15][lane>>4], B[lane>>4][lane&15] and D[(lane>>4) + 4*reg][lane&15].
+// LDS rows are padded to 80 doubles so that the four 16-lane groups of a ds_read_b64 hit disjoint banks.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+constexpr int LSTR = TS + 16;
+
+__global__ void __launch_bounds__(256)
+k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max) {
+    const int t = level_nodes[blockIdx.z];
+    const int np = fd.npiv[t];
+    if (kc0 >= np) return;
+    const int kw = min(kw_max, np - kc0);
+    const int nf = fd.nf[t];
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;           // row tiles start at the column tile (lower triangle)
+    if (ri >= nf) return;
+    double* F = fd.F + fd.foff[t];
+    constexpr int KC = 16;                         // factor columns staged per step: 20 KB of LDS per workgroup -> 8 workgroups per CU
+    __shared__ double si[KC][LSTR];                // rows of the tile:    si[k][r] = L[ri + r][kc0 + k0 + k]
+    __shared__ double sj[KC][LSTR];                // columns of the tile: sj[k][c] = L[cj + c][kc0 + k0 + k]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;     // this wave's quarter: rows wr.., columns wc..
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const int wb = min(KC, kw - k0);
+        __syncthreads();
+        for (int idx = tid; idx < KC * TS; idx += 256) {
+            const int r = idx % TS, c = idx / TS;
+            si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            sj[c][r] = (cj + r < nf && c < wb) ? F[(cj + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            // A: tile columns (index i), B: tile rows (index j); k = kk + (lane >> 4)
+            const double a0 = sj[kk + l4][wc + l15], a1 = sj[kk + l4][wc + 16 + l15];
+            const double b0 = si[kk + l4][wr + l15], b1 = si[kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b][reg];
+            }
+}
+
 // ------------------------------------------------------------------------------------------ solves
 // M^-1 = L^-T L^-1 applied level by level.  Each sweep is split per level into a sequential part on
 // the triangular pivot block L11 (one workgroup per front, panels chained through the stored diagonal
