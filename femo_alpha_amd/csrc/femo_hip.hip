@@ -275,7 +275,10 @@ static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, do
                     double aK = 1.0, double aM = 0.0) {
     {
         const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
-        ELEM_LAUNCH(c, k_apply4, NOEXTRA, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+#define COMMA_TRUE , true
+#define COMMA_FALSE , false
+        if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
         const int nthreads = c->nP2 + c->nghost;
         if (c->quad)
             hipLaunchKernelGGL((k_gather_sum<9, 4>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,

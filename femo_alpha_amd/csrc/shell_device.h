@@ -624,13 +624,15 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
     return lb;
 }
 
-template <int NPC, int NVC, bool QUAD, bool UHAT>
+template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS>
 __global__ void __launch_bounds__(256, 2)
 k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __restrict__ eorder, double aK, double aM,
          const double* __restrict__ x, double* __restrict__ ybuf, double* dotslot, double* zero_a, double* zero_b) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     constexpr int EPB = 64;                     // elements per block (256 threads / 4 lanes)
+    constexpr int GEO = 3 * NVC + 3 * NVC + 4 * NVC;    // per element: X, uhat, (h, E, nu, rho) at the vertices
     __shared__ double sx[EPB][LD + 1];
+    __shared__ double sg[EPB][GEO + 1];
     // the lanes of a quad work on different quadrature points, so the tables are indexed per lane: keep
     // them in LDS (a per-lane global/scalar load would park ~40 doubles of table data in VGPRs)
     __shared__ Tables stab;
@@ -649,15 +651,39 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
     const bool active = lb * EPB < m.nel && pos < m.nel;
     double local = 0.0;
     const int e = active ? (eorder ? eorder[pos] : pos) : 0;
-    Elem<NPC, NVC> el;
+    double hK = 0.0;
     if (active) {
-        load_elem<NPC, NVC, UHAT>(m, f, e, el);
-        // each lane of the quad fetches a quarter of the element vector (static indices: no scratch arrays)
+        // lane `sub` of the quad stages vertex `sub` (geometry, fields) and a quarter of the element vector in LDS:
+        // nothing element-specific stays in registers across the quadrature loop except the 39 partial results
+        hK = m.hK[e];
+        int pid[NPC], vid[NVC];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) vid[b] = m.cells[b * m.nel + e];
+#pragma unroll
+        for (int a = 0; a < NPC; ++a) pid[a] = m.cellp2[a * m.nel + e];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) {
+            if (b == sub || (NVC < 4 && sub == 3 && b == 0)) {
+                if (b == sub) {
+                    const int v = vid[b];
+                    const int tq = f.ewm ? e : v;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        sg[le][3 * b + c] = m.xyz[3 * v + c];
+                        sg[le][3 * NVC + 3 * b + c] = UHAT ? f.uhat[3 * v + c] : 0.0;
+                    }
+                    sg[le][6 * NVC + b] = f.h[tq];
+                    sg[le][7 * NVC + b] = f.E[tq];
+                    sg[le][8 * NVC + b] = f.nu[tq];
+                    sg[le][9 * NVC + b] = MASS ? f.rho[tq] : 0.0;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
             if ((i & 3) == sub) {
                 const int node = i / 3, c = i - 3 * node;
-                const int g = node < NPC ? 3 * el.pid[node < NPC ? node : 0] + c : m.ndof_u + 3 * el.vid[node >= NPC ? node - NPC : 0] + c;
+                const int g = node < NPC ? 3 * pid[node < NPC ? node : 0] + c : m.ndof_u + 3 * vid[node >= NPC ? node - NPC : 0] + c;
                 sx[le][i] = x[g];
             }
         }
@@ -669,26 +695,27 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
         for (int i = 0; i < LD; ++i) ye[i] = 0.0;
         const int nq = stab.nq;
         for (int q = sub; q < nq; q += 4) {
-            // re-derive the LDS row every iteration: keeps the compiler from hoisting the 39 nodal values
-            // out of the loop into 78 registers
+            // re-derive the LDS rows every iteration: keeps the compiler from hoisting the staged values
+            // out of the loop into registers
             int row = le;
             asm volatile("" : "+v"(row));
             const double* xe = sx[row];
+            const double* ge = sg[row];
+            const double (*X)[3] = reinterpret_cast<const double (*)[3]>(ge);
+            const double (*Uh)[3] = reinterpret_cast<const double (*)[3]>(ge + 3 * NVC);
             QPG g;
-            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, stab.N1[q], stab.dN1[q], g);
+            qp_geometry<NVC, QUAD, UHAT>(X, Uh, stab.N1[q], stab.dN1[q], g);
             Mat mat, ex;
-            const double hq = interp<NVC>(stab.N1[q], el.hn);
-            material<DERIV_NONE>(hq, interp<NVC>(stab.N1[q], el.En),
-                                 interp<NVC>(stab.N1[q], el.nun), el.hK, stab.wS[q] * g.det, stab.w[q] * g.det, g.Ju, mat, ex);
+            const double hq = interp<NVC>(stab.N1[q], ge + 6 * NVC);
+            material<DERIV_NONE>(hq, interp<NVC>(stab.N1[q], ge + 7 * NVC), interp<NVC>(stab.N1[q], ge + 8 * NVC), hK,
+                                 stab.wS[q] * g.det, stab.w[q] * g.det, g.Ju, mat, ex);
             mat.cm *= aK; mat.cb *= aK; mat.cs *= aK; mat.cd *= aK;
             const Gen s = strains_q<NPC, NVC>(stab, q, g, xe);
             const Gen t = stress_of(s, mat);
             strains_T_q<NPC, NVC>(stab, q, g, t, ye);
-            if (aM != 0.0) {
-                double rq = 0.0;
-#pragma unroll
-                for (int b = 0; b < NVC; ++b) rq += stab.N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
-                mass_qp<NPC, NVC>(stab, q, aM * rq * hq * stab.w[q] * g.det * g.Ju, el.hK, xe, ye);
+            if (MASS) {          // compiled out of the static operator: keeps its register budget
+                const double rq = interp<NVC>(stab.N1[q], ge + 9 * NVC);
+                mass_qp<NPC, NVC>(stab, q, aM * rq * hq * stab.w[q] * g.det * g.Ju, hK, xe, ye);
             }
         }
 #pragma unroll
