@@ -228,10 +228,14 @@ def main():
     apply_ms = ctx.bench_kernel("apply", 100)
     alg_bytes = 16.0 * m.ndof + 340.0 * m.nel          # SURVEY.md section 8d, B_spmv,ebe per launch
     achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the committed rocprofv3 counter passes (scripts/aggregate_pmc.py; separate
+    # FETCH_SIZE and WRITE_SIZE runs, gfx950 correction 2*FETCH+WRITE) -- counters cannot be read from inside bench.py
+    traffic = traffic_trailing = None
     pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("apply_hbm_bytes_per_launch")
+        pj = json.load(open(pmc))
+        traffic = pj.get("apply_hbm_bytes_per_launch")
+        traffic_trailing = pj.get("trailing_hbm_bytes_per_launch")
     roof_spmv = {"bound": "hbm", "kernel": "k_apply (matrix-free CG2xCG1 shell operator)",
                  "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                  "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms}
@@ -244,7 +248,7 @@ def main():
         tr = prof["trailing"]
         tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "k_trailing (fp64 trailing update of the multifrontal Cholesky)",
-                "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic_trailing,
                 "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
                 "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}
 

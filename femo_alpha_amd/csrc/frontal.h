@@ -163,9 +163,13 @@ k_extend_add(FrontDev fd, const int* __restrict__ level_nodes, int side) {
 }
 
 // ------------------------------------------------------------------------------------------ factorisation
-// Cholesky of a 32x32 block and the inverse of its factor, in registers of one wave:
-// lane r < 32 owns row r of the block; pivots and multipliers travel by v_readlane (static lane ids).
-// On return lane r holds row r of L in a[] and lane c holds COLUMN c of L^-1 in x[] (x[r] = Linv[r][c]).
+// Cholesky of a 32x32 block and the inverse of its factor, in the registers of one wave.
+// Lanes 0..31 own the rows of the block, lanes 32..63 the columns of an identity: running the same
+// elimination on both halves (A = L L^T on the left, L X = I on the right) yields the factor and its inverse
+// from one instruction stream -- the multipliers L[c][j] are the same for both.
+// On entry a[] = row `lane` of the block (lanes < 32) or column `lane - 32` of the identity (lanes >= 32);
+// on return lane r < 32 holds row r of L, lane 32 + c holds column c of L^-1 (a[r] = Linv[r][c]).
+// Pivots and multipliers travel by v_readlane (static lane ids).
 // Returns the number of non-positive pivots that had to be repaired.
 // broadcast of a double from a compile-time lane: two v_readlane_b32 (a 64-wide __shfl here sends hipcc's
 // optimiser into a compile that does not finish within minutes once the loops below are unrolled)
@@ -176,9 +180,8 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ int chol32_inverse(double (&a)[NB], double (&x)[NB], int wb, int lane) {
+__device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane) {
     int bad = 0;
-    double idiag[NB];                                   // 1 / L[j][j], wave-uniform
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         double d = rl(a[j], j);
@@ -193,23 +196,17 @@ __device__ __forceinline__ int chol32_inverse(double (&a)[NB], double (&x)[NB], 
         y = y + 0.5 * y * e;
         e = 1.0 - d * y * y;
         y = y + 0.5 * y * e;
-        idiag[j] = y;
-        const double l = (lane == j) ? d * y : a[j] * y;     // column j of L for this lane's row (valid for lane >= j)
+        // left half: column j of L for this lane's row (valid for lane >= j); right half: row j of L^-1
+        const double l = (lane == j) ? d * y : a[j] * y;
         a[j] = l;
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             const double lc = rl(l, c);                       // L[c][j]
-            a[c] -= l * lc;                                   // only entries with c <= row are meaningful
+            a[c] -= l * lc;                                   // left half: only entries with c <= row are meaningful
+            // pin the update to this step: a[c] is not consumed before step c, and left to itself the compiler
+            // defers the FMAs until then, keeping every broadcast alive in SGPRs (1500 of them spilled)
+            asm volatile("" : "+v"(a[c]));
         }
-    }
-    // X = L^-1: X[r][c] = (delta_rc - sum_{m<r} L[r][m] X[m][c]) / L[r][r]; lane c owns column c of X,
-    // rows of L live in other lanes -> broadcast L[r][m] from lane r.
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        double s = (lane == r) ? 1.0 : 0.0;
-#pragma unroll
-        for (int mm = 0; mm < r; ++mm) s -= rl(a[mm], r) * x[mm];
-        x[r] = s * idiag[r];
     }
     return bad;
 }
@@ -223,6 +220,13 @@ __device__ __forceinline__ int chol32_inverse(double (&a)[NB], double (&x)[NB], 
 //   3. L_ik = A_ik Linv_kk^T for the workgroup's rows.  Workgroup x == 0 stores Linv_kk.
 // The diagonal block of F is left as assembled (nothing reads it afterwards: the solves use Linv_kk),
 // which is what makes the redundant factorisation race-free.
+#ifdef FEMO_PANEL_STAMPS
+__device__ long long g_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 __global__ void __launch_bounds__(256)
 k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* __restrict__ info) {
     const int t = level_nodes[blockIdx.y];
@@ -242,6 +246,7 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
     __shared__ double pd[NBO - NB][NB + 1];     // previous columns of the outer panel, diagonal rows [m][row]
     __shared__ double pr[NB][TS + 1];           // chunk of previous columns, current row tile [m][row]
     const int tid = threadIdx.x;
+    STAMP(0);
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int r = idx % NB, c = idx / NB;
         sd[r][c] = (r < wb && c < wb && c <= r) ? F[(c0 + r) + (size_t)nf * (c0 + c)] : (r == c ? 1.0 : 0.0);
@@ -251,6 +256,7 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
         pd[mm][r] = (r < wb) ? F[(c0 + r) + (size_t)nf * (C0 + mm)] : 0.0;
     }
     __syncthreads();
+    STAMP(1);
     // 1a. left-looking update of the diagonal block with the columns [C0, c0)
     if (kprev > 0) {
         for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -264,23 +270,26 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
         __syncthreads();
     }
     // 2. Cholesky + inverse of the diagonal block in wave 0
+    STAMP(2);
     if (tid < 64) {
         const int lane = tid;
-        double a[NB], x[NB];
+        double a[NB];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? sd[lane][c] : 0.0;
-        const int bad = chol32_inverse(a, x, wb, lane);
-        if (lane < NB) {
+        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? sd[lane][c] : (c == lane - NB ? 1.0 : 0.0);
+        const int bad = chol32_inverse(a, wb, lane);
+        if (lane >= NB) {
+            const int cl = lane - NB;                   // this lane holds column cl of the inverse
 #pragma unroll
-            for (int r = 0; r < NB; ++r) sl[r][lane] = (lane < wb && r < wb && lane <= r) ? x[r] : 0.0;
+            for (int r = 0; r < NB; ++r) sl[r][cl] = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
             if (blockIdx.x == 0) {
 #pragma unroll
-                for (int r = 0; r < NB; ++r) Li[r + NB * lane] = (lane < wb && r < wb && lane <= r) ? x[r] : 0.0;
-                if (lane == 0 && bad) atomicAdd(info, bad);
+                for (int r = 0; r < NB; ++r) Li[r + NB * cl] = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
+                if (cl == 0 && bad) atomicAdd(info, bad);
             }
         }
     }
     // 1b + 3. this workgroup's share of the 64-row tiles below the block
+    STAMP(3);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int r0 = c0 + wb + tile * TS;
         __syncthreads();
@@ -295,6 +304,7 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
                 pr[mm][r] = (r0 + r < nf) ? F[(r0 + r) + (size_t)nf * (C0 + m0 + mm)] : 0.0;
             }
             __syncthreads();
+            STAMP(4 + m0 / NB);
             for (int idx = tid; idx < NB * TS; idx += 256) {
                 const int r = idx % TS, c = idx / TS;
                 double s = 0.0;
@@ -304,6 +314,7 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
             }
         }
         __syncthreads();
+        STAMP(8);
         for (int idx = tid; idx < NB * TS; idx += 256) {
             const int r = idx % TS, c = idx / TS;
             if (r0 + r < nf && c < wb) {
@@ -312,6 +323,7 @@ k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* _
                 F[(r0 + r) + (size_t)nf * (c0 + c)] = s;
             }
         }
+        STAMP(9);
     }
 }
 

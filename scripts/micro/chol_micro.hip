@@ -6,14 +6,14 @@ using namespace femo;
 
 __global__ void __launch_bounds__(64) k_reg(double* A, double* X, int reps) {
     const int lane = threadIdx.x;
-    double a[NB], x[NB];
+    double a[NB];
     for (int it = 0; it < reps; ++it) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? A[(lane % NB) * NB + c] : 0.0;
-        chol32_inverse(a, x, NB, lane);
-        if (lane < NB)
+        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? A[(lane % NB) * NB + c] : (c == lane - NB ? 1.0 : 0.0);
+        chol32_inverse(a, NB, lane);
+        if (lane >= NB)
 #pragma unroll
-            for (int r = 0; r < NB; ++r) X[r * NB + lane] = x[r] + it;
+            for (int r = 0; r < NB; ++r) X[r * NB + lane - NB] = a[r] + it;
     }
 }
 
