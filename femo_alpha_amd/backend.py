@@ -154,7 +154,7 @@ class ShellContext:
         """One factorisation timed per kernel class with HIP events on the context's stream."""
         t = np.zeros(13)
         self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)))
-        names = ["super_inverse", "panel", "trailing", "extend_add", "front_assemble", "memset"]
+        names = ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset"]
         out = {n: dict(ms=t[i], launches=int(t[6 + i])) for i, n in enumerate(names)}
         out["trailing_flops"] = t[12]
         return out

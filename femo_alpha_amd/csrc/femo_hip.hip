@@ -83,7 +83,7 @@ struct femo_ctx {
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
         long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *spoff = nullptr;
-        double *F = nullptr, *Linv = nullptr, *Sinv = nullptr;
+        double *F = nullptr, *Linv = nullptr, *Sinv = nullptr, *Swork = nullptr;
         int *sp_front = nullptr, *sp_index = nullptr;
         int nsp = 0;
         long long f_doubles = 0, linv_doubles = 0;
@@ -451,18 +451,17 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         }
         int max_nf = 0;
         for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
-        // two-level blocking: outer panels of NBO columns (one wide trailing update each), inner panels of NB
-        // factorised left-looking inside the outer panel (one launch each)
+        // outer panels of NBO columns, three launches each: the diagonal block (factor + inverse, one workgroup per
+        // front), the rows below it (one GEMM against the inverse), the trailing update
+        const bool wide = fr.h_level_maxnp[L] > WIDE_NP;            // these levels keep S for the triangular solves
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
-            const int WO = std::min(NBO, max_np - C0);
-            for (int c0 = C0; c0 < C0 + WO; c0 += NB) {
-                // few large fronts: one workgroup per 64-row tile; many small fronts: one workgroup per front looping
-                // over its tiles, so that the redundant diagonal-block factorisation is not multiplied
-                const int rows_below = std::max(0, max_nf - c0 - 1);
-                const int tiles = std::max(1, (rows_below + TS - 1) / TS);
-                const int gx = std::max(1, std::min(tiles, 1024 / cnt));
-                ProfScope ps(c, 1);
-                hipLaunchKernelGGL(k_panel, dim3(gx, cnt), dim3(256), 0, c->stream, fd, lev, C0, c0, fr.info);
+            double* sw = wide ? nullptr : fr.Swork;
+            { ProfScope ps(c, 1);
+              hipLaunchKernelGGL(k_diag_block, dim3(cnt), dim3(256), 0, c->stream, fd, lev, C0, sw, fr.info); }
+            const int tiles = (std::max(0, max_nf - C0 - 1) + TS - 1) / TS;
+            if (tiles > 0) {
+                ProfScope ps(c, 0);
+                hipLaunchKernelGGL(k_panel_rows, dim3(tiles, cnt), dim3(256), 0, c->stream, fd, lev, C0, sw);
             }
             if (max_nf > C0 + 1) {
                 ProfScope ps(c, 2);
@@ -472,12 +471,6 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 else hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
             }
         }
-        HIPCHK(c, hipGetLastError());
-    }
-    if (l1 == fr.nlevels && fr.nsp > 0) {
-        // all levels done: inverses of the 128 x 128 diagonal blocks for the triangular solves
-        ProfScope ps(c, 0);
-        hipLaunchKernelGGL(k_super_inverse, dim3(fr.nsp), dim3(256), 0, c->stream, fd, fr.sp_front, fr.sp_index);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -813,7 +806,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv,
-                     c->fr.spoff, c->fr.Sinv, c->fr.sp_front, c->fr.sp_index};
+                     c->fr.spoff, c->fr.Sinv, c->fr.Swork, c->fr.sp_front, c->fr.sp_index};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -1318,6 +1311,11 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         HIPCHK(c, hipMemcpy(fr.sp_front, spf.data(), spf.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(fr.sp_index, spi.data(), spi.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc((void**)&fr.Sinv, std::max<size_t>((size_t)fr.nsp, 1) * SP * SP * sizeof(double)));
+        // scratch for the diagonal-block inverses of the other levels (needed only between k_diag_block and k_panel_rows)
+        int max_cnt = 0;
+        for (int L = 0; L < nlevels; ++L)
+            if (fr.h_level_maxnp[L] <= WIDE_NP) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
+        HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SP * SP * sizeof(double)));
     }
     HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));

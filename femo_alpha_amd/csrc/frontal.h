@@ -6,7 +6,10 @@
 // Here the elimination tree comes from a geometric nested dissection of the elements
 // (femo_alpha_amd/solver/symbolic.py); element matrices are summed straight into the leaf fronts;
 // every level of the tree is factorised by batched, blocked, right-looking partial Cholesky kernels
-// whose grids span all fronts of the level (panel width NB = 32, 64x64 trailing tiles staged in LDS).
+// whose grids span all fronts of the level: per outer panel of 128 columns the diagonal block is
+// factorised and inverted by one workgroup per front (32x32 register Cholesky + fp64 MFMA), the rows
+// below become factor rows by one GEMM against that inverse, and 64x64 trailing tiles are updated
+// on the matrix cores.
 //
 // Storage: front t is a dense column-major nf x nf block at F + foff[t]; only the lower triangle is
 // maintained.  After factorisation its first npiv columns hold [L11; L21]; the trailing block is
@@ -20,6 +23,7 @@ namespace femo {
 constexpr int NB = 32;     // panel width
 constexpr int TS = 64;     // trailing-update tile
 constexpr int NBO = 128;   // outer panel: the wide trailing update applies this many factor columns per pass
+constexpr int SPD = 128;   // leading dimension of the stored diagonal-block inverses (== SP of the solve kernels)
 
 struct FrontDev {
     int ntree;
@@ -211,119 +215,190 @@ __device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane)
     return bad;
 }
 
-// P01: inner panel [c0, c0+32) of the outer panel that starts at C0, for every front of the level
-// (left-looking inside the outer panel, so that one launch per inner panel suffices):
-//   1. apply the factor columns [C0, c0) already computed in this outer panel to the 32x32 diagonal block
-//      and to this workgroup's 64 rows below it;
-//   2. factorise the diagonal block and invert its factor in the registers of wave 0 -- every workgroup
-//      does this redundantly, so no workgroup waits for another one;
-//   3. L_ik = A_ik Linv_kk^T for the workgroup's rows.  Workgroup x == 0 stores Linv_kk.
-// The diagonal block of F is left as assembled (nothing reads it afterwards: the solves use Linv_kk),
-// which is what makes the redundant factorisation race-free.
-#ifdef FEMO_PANEL_STAMPS
-__device__ long long g_stamps[16];
-#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
-#else
-#define STAMP(i)
-#endif
+// ---- outer panel of <= 128 columns in two launches ----------------------------------------------------------
+// 16x16 MFMA sub-block product helpers: wave w of a 4-wave workgroup owns sub-block (w & 1, w >> 1) of a 32x32
+// result.  v_mfma_f64_16x16x4_f64: a lane supplies A[i = lane & 15][k = lane >> 4] and B[k = lane >> 4][j = lane & 15]
+// and holds D[i = (lane >> 4) + 4 reg][j = lane & 15].
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double blk32[NB][NB + 1];
 
+// acc += A(32 x 32) * B(32 x 32) restricted to this wave's sub-block; TA / TB: the operand is stored transposed
+template <bool TA, bool TB>
+__device__ __forceinline__ void mfma_blk(mfma_d4& acc, const blk32& A, const blk32& B, int si, int sj, int l15, int l4) {
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+        const double a = TA ? A[kk + l4][16 * si + l15] : A[16 * si + l15][kk + l4];
+        const double b = TB ? B[16 * sj + l15][kk + l4] : B[kk + l4][16 * sj + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+}
+
+// PA: the diagonal block [C0, C0+kw) x [C0, C0+kw), kw <= 128, of every front of the level -- one workgroup per front.
+// The block is held in LDS as 32x32 sub-blocks (lower block triangle).  For each block column j: wave 0 factorises
+// the diagonal sub-block and inverts its factor in registers (chol32_inverse); the four waves then form
+// L_ij = D_ij Linv_j^T and D_ik -= L_ij L_kj^T on the matrix cores.  Afterwards the inverse S of the whole kw x kw
+// factor is accumulated block-wise (S_jj = Linv_j, S_ij = -Linv_i sum_{k=j}^{i-1} L_ik S_kj) and stored
+// column-major with leading dimension 128: k_panel_rows turns the rows below the block into factor rows with one
+// GEMM against S^T, and the wide triangular solves use the same S.
+// Outputs: off-diagonal sub-blocks of L into F, the 32x32 inverses into Linv, S into Sout.
+// The diagonal sub-blocks of F are left as they were (nothing reads them afterwards).
 __global__ void __launch_bounds__(256)
-k_panel(FrontDev fd, const int* __restrict__ level_nodes, int C0, int c0, int* __restrict__ info) {
-    const int t = level_nodes[blockIdx.y];
+k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* __restrict__ Swork, int* __restrict__ info) {
+    const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t];
-    if (c0 >= np) return;
-    const int wb = min(NB, np - c0);
+    if (C0 >= np) return;
+    const int kw = min(NBO, np - C0);
+    const int nkb = (kw + NB - 1) / NB;
     const int nf = fd.nf[t];
-    const int ntiles = (nf - c0 - wb + TS - 1) / TS;          // 64-row tiles below the diagonal block
-    if ((int)blockIdx.x >= max(ntiles, 1)) return;
-    const int k = c0 / NB;
-    const int kprev = c0 - C0;                                 // factor columns of this outer panel already done
     double* F = fd.F + fd.foff[t];
-    double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-    __shared__ double sd[NB][NB + 1];           // diagonal block [row][col]
-    __shared__ double sl[NB][NB + 1];           // Linv_kk [row][col]
-    __shared__ double sa[NB][TS + 1];           // A_ik [col][row]
-    __shared__ double pd[NBO - NB][NB + 1];     // previous columns of the outer panel, diagonal rows [m][row]
-    __shared__ double pr[NB][TS + 1];           // chunk of previous columns, current row tile [m][row]
-    const int tid = threadIdx.x;
-    STAMP(0);
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx % NB, c = idx / NB;
-        sd[r][c] = (r < wb && c < wb && c <= r) ? F[(c0 + r) + (size_t)nf * (c0 + c)] : (r == c ? 1.0 : 0.0);
-    }
-    for (int idx = tid; idx < NB * kprev; idx += 256) {
-        const int r = idx % NB, mm = idx / NB;
-        pd[mm][r] = (r < wb) ? F[(c0 + r) + (size_t)nf * (C0 + mm)] : 0.0;
-    }
-    __syncthreads();
-    STAMP(1);
-    // 1a. left-looking update of the diagonal block with the columns [C0, c0)
-    if (kprev > 0) {
+    double* Sout = Swork ? Swork + (size_t)blockIdx.x * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    __shared__ blk32 D[10];                 // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
+    __shared__ blk32 Sx[3];                 // column j of S below its diagonal sub-block
+    __shared__ blk32 Wt;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
+    // load (identity padding beyond kw; only the lower triangle of the front is maintained)
+    for (int b = 0; b < 10; ++b) {
+        int bi = 0;
+        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2;
+        if (bi >= nkb) break;
         for (int idx = tid; idx < NB * NB; idx += 256) {
             const int r = idx % NB, c = idx / NB;
-            if (c <= r) {
-                double s = 0.0;
-                for (int mm = 0; mm < kprev; ++mm) s += pd[mm][r] * pd[mm][c];
-                sd[r][c] -= s;
-            }
+            const int gr = NB * bi + r, gc = NB * bj + c;
+            double v = (gr == gc) ? 1.0 : 0.0;
+            if (gr < kw && gc < kw && gc <= gr) v = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
+            else if (gc > gr) v = 0.0;
+            D[b][r][c] = v;
         }
-        __syncthreads();
     }
-    // 2. Cholesky + inverse of the diagonal block in wave 0
-    STAMP(2);
-    if (tid < 64) {
-        const int lane = tid;
-        double a[NB];
+    for (int idx = tid; idx < SPD * SPD; idx += 256) Sout[idx] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < nkb; ++j) {
+        blk32& Djj = D[j * (j + 1) / 2 + j];
+        const int wb = min(NB, kw - NB * j);
+        if (wv == 0) {
+            double a[NB];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? sd[lane][c] : (c == lane - NB ? 1.0 : 0.0);
-        const int bad = chol32_inverse(a, wb, lane);
-        if (lane >= NB) {
-            const int cl = lane - NB;                   // this lane holds column cl of the inverse
+            for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? Djj[lane][c] : (c == lane - NB ? 1.0 : 0.0);
+            const int bad = chol32_inverse(a, wb, lane);
+            if (lane >= NB) {
+                const int cl = lane - NB;               // this lane holds column cl of the inverse
+                double* Li = fd.Linv + fd.linvoff[t] + (size_t)(C0 / NB + j) * NB * NB;
 #pragma unroll
-            for (int r = 0; r < NB; ++r) sl[r][cl] = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
-            if (blockIdx.x == 0) {
-#pragma unroll
-                for (int r = 0; r < NB; ++r) Li[r + NB * cl] = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
+                for (int r = 0; r < NB; ++r) {
+                    const double v = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
+                    Djj[r][cl] = v;                     // the diagonal sub-block now holds Linv_j
+                    Li[r + NB * cl] = v;
+                }
                 if (cl == 0 && bad) atomicAdd(info, bad);
             }
         }
+        __syncthreads();
+        if (j + 1 < nkb) {
+            // L_ij = D_ij Linv_j^T for the sub-blocks below
+            mfma_d4 acc[3];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                acc[i - 1] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+                if (j + i < nkb) mfma_blk<false, true>(acc[i - 1], D[(j + i) * (j + i + 1) / 2 + j], Djj, si, sj, l15, l4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                if (j + i >= nkb) continue;
+                blk32& Dij = D[(j + i) * (j + i + 1) / 2 + j];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+                    Dij[r][c] = acc[i - 1][reg];
+                    const int gr = NB * (j + i) + r, gc = NB * j + c;
+                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)nf * (C0 + gc)] = acc[i - 1][reg];
+                }
+            }
+            __syncthreads();
+            // D_ik -= L_ij L_kj^T, i >= k > j (each wave updates its own sub-block of every D_ik)
+            for (int i = j + 1; i < nkb; ++i)
+                for (int k = j + 1; k <= i; ++k) {
+                    mfma_d4 u = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+                    mfma_blk<false, true>(u, D[i * (i + 1) / 2 + j], D[k * (k + 1) / 2 + j], si, sj, l15, l4);
+                    blk32& Dik = D[i * (i + 1) / 2 + k];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) Dik[16 * si + l4 + 4 * reg][16 * sj + l15] -= u[reg];
+                }
+            __syncthreads();
+        }
     }
-    // 1b + 3. this workgroup's share of the 64-row tiles below the block
-    STAMP(3);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int r0 = c0 + wb + tile * TS;
-        __syncthreads();
-        for (int idx = tid; idx < NB * TS; idx += 256) {
-            const int r = idx % TS, c = idx / TS;
-            sa[c][r] = (r0 + r < nf && c < wb) ? F[(r0 + r) + (size_t)nf * (c0 + c)] : 0.0;
+    // inverse of the kw x kw factor, block column by block column
+    for (int j = 0; j < nkb; ++j) {
+        const blk32& Sjj = D[j * (j + 1) / 2 + j];
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx % NB, c = idx / NB;
+            Sout[(NB * j + r) + (size_t)SPD * (NB * j + c)] = Sjj[r][c];
         }
-        for (int m0 = 0; m0 < kprev; m0 += NB) {
+        for (int i = j + 1; i < nkb; ++i) {
+            // W = sum_{k=j}^{i-1} L_ik S_kj
+            mfma_d4 w = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k)
+                mfma_blk<false, false>(w, D[i * (i + 1) / 2 + k], k == j ? Sjj : Sx[k - j - 1], si, sj, l15, l4);
+            __syncthreads();                                   // previous readers of Wt are done
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Wt[16 * si + l4 + 4 * reg][16 * sj + l15] = w[reg];
             __syncthreads();
-            for (int idx = tid; idx < NB * TS; idx += 256) {
-                const int r = idx % TS, mm = idx / TS;
-                pr[mm][r] = (r0 + r < nf) ? F[(r0 + r) + (size_t)nf * (C0 + m0 + mm)] : 0.0;
+            // S_ij = -Linv_i W
+            mfma_d4 x = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            mfma_blk<false, false>(x, D[i * (i + 1) / 2 + i], Wt, si, sj, l15, l4);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+                if (i - j - 1 < 3) Sx[i - j - 1][r][c] = -x[reg];
+                Sout[(NB * i + r) + (size_t)SPD * (NB * j + c)] = -x[reg];
             }
             __syncthreads();
-            STAMP(4 + m0 / NB);
-            for (int idx = tid; idx < NB * TS; idx += 256) {
-                const int r = idx % TS, c = idx / TS;
-                double s = 0.0;
-#pragma unroll 8
-                for (int mm = 0; mm < NB; ++mm) s += pr[mm][r] * pd[m0 + mm][c];
-                sa[c][r] -= s;
-            }
         }
-        __syncthreads();
-        STAMP(8);
-        for (int idx = tid; idx < NB * TS; idx += 256) {
-            const int r = idx % TS, c = idx / TS;
-            if (r0 + r < nf && c < wb) {
-                double s = 0.0;
-                for (int mm = 0; mm <= c; ++mm) s += sa[mm][r] * sl[c][mm];
-                F[(r0 + r) + (size_t)nf * (c0 + c)] = s;
-            }
+    }
+}
+
+// PB: rows below the diagonal block of the outer panel: L[r][C0 + c] = sum_{k <= c} A[r][C0 + k] S[c][k] -- one GEMM
+// per 64-row tile against the inverse S of the diagonal block's factor (k_diag_block).  A wave owns 16 rows: their
+// kw <= 128 entries sit in registers as the MFMA B operand (read once, so the result can overwrite them in place),
+// S streams from L2 as the A operand, and the product is formed transposed so that the stores run along the
+// columns of the column-major front.
+__global__ void __launch_bounds__(256)
+k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const double* __restrict__ Swork) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t];
+    if (C0 >= np) return;
+    const int kw = min(NBO, np - C0);
+    const int nf = fd.nf[t];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = C0 + kw + blockIdx.x * TS + 16 * wv;
+    if (row0 >= nf) return;
+    double* F = fd.F + fd.foff[t];
+    const double* S = Swork ? Swork + (size_t)blockIdx.y * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    const int row = row0 + l15;
+    const bool rok = row < nf;
+    double a[NBO / 4];
+#pragma unroll
+    for (int kk = 0; kk < NBO / 4; ++kk) {
+        const int k = 4 * kk + l4;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)nf * (C0 + k)] : 0.0;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NBO / 16; ++cb) {
+        if (16 * cb >= kw) break;
+        mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4 * cb + 4; ++kk) {
+            const double sv = S[(16 * cb + l15) + (size_t)SPD * (4 * kk + l4)];       // S[c][k]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sv, a[kk], acc, 0, 0, 0);      // D[i = column][j = row]
         }
-        STAMP(9);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = 16 * cb + l4 + 4 * reg;
+            if (rok && c < kw) F[row + (size_t)nf * (C0 + c)] = acc[reg];
+        }
     }
 }
 
@@ -394,7 +469,6 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max
 // formed transposed: A[i][k] = L[c0+i][k] (tile columns), B[k][j] = L[r0+j][k] (tile rows), so D[i][j] = C[r0+j][c0+i];
 // per the CDNA4 f64 layout a lane holds A[lane&15][lane>>4], B[lane>>4][lane&15] and D[(lane>>4) + 4*reg][lane&15].
 // LDS rows are padded to 80 doubles so that the four 16-lane groups of a ds_read_b64 hit disjoint banks.
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 constexpr int LSTR = TS + 16;
 
 __global__ void __launch_bounds__(256)
@@ -568,61 +642,6 @@ constexpr int SP = 128;    // columns handled per launch by the wide solve kerne
 
 constexpr int PB = 64;     // rows (forward) / columns (backward) per workgroup of the wide update kernels: one wave,
                            // so that even a level with a handful of fronts spreads over hundreds of workgroups
-
-// After the factorisation: inverse of the 128 x 128 diagonal block of L11 that starts at column c0 = 128 * sp,
-// built from the stored 32 x 32 diagonal-block inverses and the off-diagonal blocks of L:
-//   X_jj = Linv_jj ;  X_ij = -Linv_ii * sum_{k=j}^{i-1} L_ik X_kj   (i > j).   One workgroup per super panel.
-__global__ void __launch_bounds__(256)
-k_super_inverse(FrontDev fd, const int* __restrict__ sp_front, const int* __restrict__ sp_index) {
-    const int t = sp_front[blockIdx.x], sp = sp_index[blockIdx.x];
-    const int np = fd.npiv[t], nf = fd.nf[t];
-    const int c0 = sp * SP;
-    const int W = min(SP, np - c0);
-    const int nkb = (W + NB - 1) / NB;
-    const double* F = fd.F + fd.foff[t];
-    double* S = fd.Sinv + (size_t)(fd.spoff[t] + sp) * SP * SP;
-    __shared__ double X[SP][NB + 1];      // block column j of the inverse, rows 0..127
-    __shared__ double Tm[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < SP * SP; idx += 256) S[idx] = 0.0;
-    for (int j = 0; j < nkb; ++j) {
-        const int wj = min(NB, np - (c0 + NB * j));
-        __syncthreads();
-        for (int idx = tid; idx < SP * NB; idx += 256) X[idx / NB][idx % NB] = 0.0;
-        __syncthreads();
-        const double* Lj = fd.Linv + fd.linvoff[t] + (size_t)(c0 / NB + j) * NB * NB;
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            X[NB * j + r][c] = (r < wj && c < wj) ? Lj[r + NB * c] : 0.0;
-        }
-        for (int i = j + 1; i < nkb; ++i) {
-            const int wi = min(NB, np - (c0 + NB * i));
-            __syncthreads();
-            // T = sum_{k=j}^{i-1} L_ik X_kj  (rows of block i, columns of block j)
-            for (int idx = tid; idx < NB * NB; idx += 256) {
-                const int r = idx % NB, c = idx / NB;
-                double s = 0.0;
-                if (r < wi && c < wj)
-                    for (int k = NB * j; k < NB * i; ++k) s += F[(c0 + NB * i + r) + (size_t)nf * (c0 + k)] * X[k][c];
-                Tm[r][c] = s;
-            }
-            __syncthreads();
-            const double* Li = fd.Linv + fd.linvoff[t] + (size_t)(c0 / NB + i) * NB * NB;
-            for (int idx = tid; idx < NB * NB; idx += 256) {
-                const int r = idx % NB, c = idx / NB;
-                double s = 0.0;
-                if (r < wi && c < wj)
-                    for (int mm = 0; mm <= r; ++mm) s += Li[r + NB * mm] * Tm[mm][c];
-                X[NB * i + r][c] = -s;
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < SP * NB; idx += 256) {
-            const int r = idx % SP, c = idx / SP;
-            if (r < W && c < wj) S[r + (size_t)SP * (NB * j + c)] = X[r][c];
-        }
-    }
-}
 
 // forward, columns [c0, c0+SP), step 1 (one workgroup per front): y = L11[c0.., c0..]^-1 v[c0..] -> yv
 __global__ void __launch_bounds__(256)

@@ -1,6 +1,5 @@
-// micro-benchmark: phases of k_panel (wall_clock64 stamps of workgroup (0,0)) and launch durations of the
-// panel / trailing kernels on a batch of synthetic fronts.   usage: panel_micro [nfronts nf npiv]
-#define FEMO_PANEL_STAMPS
+// micro-benchmark: launch durations of the diagonal-block / panel-rows / trailing kernels on a batch of synthetic
+// fronts.   usage: panel_micro [nfronts nf npiv]
 #include "../../femo_alpha_amd/csrc/frontal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +26,7 @@ int main(int argc, char** argv) {
     double* F; CK(hipMalloc(&F, sizeof(double) * foff[nfr]));
     double* Li; CK(hipMalloc(&Li, sizeof(double) * linvoff[nfr]));
     fd.F = F; fd.Linv = Li;
+    double* Sw; CK(hipMalloc(&Sw, sizeof(double) * (size_t)nfr * SPD * SPD));
     int* dlev = up(lev); int* info; CK(hipMalloc(&info, 4)); CK(hipMemset(info, 0, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
@@ -34,21 +34,20 @@ int main(int argc, char** argv) {
         double tp = 0, tt = 0;
         for (int C0 = 0; C0 < np; C0 += NBO) {
             const int kw = std::min(NBO, np - C0);
-            for (int c0 = C0; c0 < C0 + kw; c0 += NB) {
-                const int tiles = std::max(1, (nf - c0 - NB + TS - 1) / TS);
-                const int gx = std::max(1, std::min(tiles, 1024 / nfr));
+            {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_panel, dim3(gx, nfr), dim3(256), 0, 0, fd, dlev, C0, c0, info);
+                hipLaunchKernelGGL(k_diag_block, dim3(nfr), dim3(256), 0, 0, fd, dlev, C0, Sw, info);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tp += ms;
-                if (rep == 1 && (C0 == 0 || C0 + NBO >= np)) {
-                    long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
-                    printf("panel c0=%4d kprev=%3d gx=%3d: %6.1f us | load %5.2f diag-upd %5.2f chol %5.2f", c0, c0 - C0, gx, ms * 1e3,
-                           (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01);
-                    long long prev = st[3];
-                    for (int m = 0; m < (c0 - C0) / NB; ++m) { printf(" chunk%d %5.2f", m, (st[4 + m] - prev) * 0.01); prev = st[4 + m]; }
-                    printf(" ->trsm-start %5.2f trsm %5.2f (last tile)\n", (st[8] - prev) * 0.01, (st[9] - st[8]) * 0.01);
+                const int tiles = (nf - C0 - kw + TS - 1) / TS;
+                float ms2 = 0;
+                if (tiles > 0) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, nfr), dim3(256), 0, 0, fd, dlev, C0, Sw);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms2, e0, e1)); tp += ms2;
                 }
+                if (rep == 1) printf("C0=%4d: diag block %6.1f us, rows (%d tiles) %6.1f us\n", C0, ms * 1e3, tiles, ms2 * 1e3);
             }
             const int nt = (nf - C0 - kw + TS - 1) / TS;
             if (nt > 0) {
