@@ -484,38 +484,29 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int k
     const int ri = cj + blockIdx.x * TS;           // row tiles start at the column tile (lower triangle)
     if (ri >= nf) return;
     double* F = fd.F + fd.foff[t];
-    constexpr int KC = 16;                         // factor columns staged per step: 20 KB of LDS per workgroup -> 8 workgroups per CU
-    __shared__ double si[KC][LSTR];                // rows of the tile:    si[k][r] = L[ri + r][kc0 + k0 + k]
-    __shared__ double sj[KC][LSTR];                // columns of the tile: sj[k][c] = L[cj + c][kc0 + k0 + k]
+    // 16 factor columns per stage, two LDS buffers (20 KB each): the next stage travels global -> registers while the
+    // matrix cores work on the current one, and one barrier per stage suffices
+    constexpr int KC = 16, NQ = KC / 4;
+    __shared__ double si[2][KC][LSTR];             // rows of the tile:    si[.][k][r] = L[ri + r][kc0 + k0 + k]
+    __shared__ double sj[2][KC][LSTR];             // columns of the tile: sj[.][k][c] = L[cj + c][kc0 + k0 + k]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;     // this wave's quarter: rows wr.., columns wc..
     const int l15 = lane & 15, l4 = lane >> 4;
-    mfma_d4 acc[2][2];
+    const int lr = tid % TS, lc = tid / TS;                // staging: row lr of the tile, columns lc, lc + 4, ...
+    const bool iok = ri + lr < nf, jok = cj + lr < nf;
+    double pi[NQ], pj[NQ];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < kw; k0 += KC) {
-        const int wb = min(KC, kw - k0);
-        __syncthreads();
-        for (int idx = tid; idx < KC * TS; idx += 256) {
-            const int r = idx % TS, c = idx / TS;
-            si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
-            sj[c][r] = (cj + r < nf && c < wb) ? F[(cj + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            const int c = lc + 4 * q;
+            pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            pj[q] = (jok && k0 + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
         }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4) {
-            // A: tile columns (index i), B: tile rows (index j); k = kk + (lane >> 4)
-            const double a0 = sj[kk + l4][wc + l15], a1 = sj[kk + l4][wc + 16 + l15];
-            const double b0 = si[kk + l4][wr + l15], b1 = si[kk + l4][wr + 16 + l15];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
+    };
+    fetch(0);
+    // the tile of C is read up front as well: its latency hides behind the whole K loop instead of ending the kernel
     // D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
+    double cpre[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -524,7 +515,46 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int k
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b][reg];
+                cpre[a][b][reg] = (r < nf && cc < nf && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+            }
+    mfma_d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { si[0][lc + 4 * q][lr] = pi[q]; sj[0][lc + 4 * q][lr] = pj[q]; }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const bool more = k0 + KC < kw;
+        if (more) fetch(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            // A: tile columns (index i), B: tile rows (index j); k = kk + (lane >> 4)
+            const double a0 = sj[cur][kk + l4][wc + l15], a1 = sj[cur][kk + l4][wc + 16 + l15];
+            const double b0 = si[cur][kk + l4][wr + l15], b1 = si[cur][kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { si[cur ^ 1][lc + 4 * q][lr] = pi[q]; sj[cur ^ 1][lc + 4 * q][lr] = pj[q]; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] = cpre[a][b][reg] - acc[a][b][reg];
             }
 }
 

@@ -1,0 +1,312 @@
+// micro-benchmark: what bounds the trailing update?  Variants of k_trailing_mfma with parts switched off.
+//   mode 0: full; 1: no C read-modify-write (store only one value per lane); 2: no L loads from global (LDS left as is)
+//   usage: trailing_micro [nfronts nf kw]
+#include "../../femo_alpha_amd/csrc/frontal.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace femo;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_var(double* Fall, int nf, int kc0, int kw) {
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    constexpr int KC = 16;
+    __shared__ double si[KC][LSTR];
+    __shared__ double sj[KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    if (MODE == 2) { for (int idx = tid; idx < KC * LSTR; idx += 256) { (&si[0][0])[idx] = 1e-3 * idx; (&sj[0][0])[idx] = 1e-3; } }
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        __syncthreads();
+        if (MODE != 2)
+        for (int idx = tid; idx < KC * TS; idx += 256) {
+            const int r = idx % TS, c = idx / TS;
+            si[c][r] = (ri + r < nf) ? F[(ri + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            sj[c][r] = (cj + r < nf) ? F[(cj + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = sj[kk + l4][wc + l15], a1 = sj[kk + l4][wc + 16 + l15];
+            const double b0 = si[kk + l4][wr + l15], b1 = si[kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    if (MODE == 1) {
+        double s = 0;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int reg = 0; reg < 4; ++reg) s += acc[a][b][reg];
+        if (s == 1.2345) F[ri + (size_t)nf * cj] = s;
+        return;
+    }
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int reg = 0; reg < 4; ++reg) {
+        const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+        const int r = ri + wr + 16 * b + l15;
+        if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b][reg];
+    }
+}
+
+// pipelined variant: next stage's L values prefetched into registers during the MFMAs, C tile preloaded at the start,
+// optional non-temporal C accesses
+template <bool NT, bool PRELOAD, bool PIPE>
+__global__ void __launch_bounds__(256)
+k_pipe(double* Fall, int nf, int kc0, int kw) {
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    constexpr int KC = 16;
+    __shared__ double si[KC][LSTR];
+    __shared__ double sj[KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    double cpre[2][2][4];
+    if (PRELOAD) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const double* p = &F[r + (size_t)nf * cc];
+                    cpre[a][b][reg] = (r < nf && cc < nf && r >= cc) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+                }
+    }
+    // thread's slots of a stage: 4 rows-of-16-columns pieces for si and sj
+    const int lr = tid % TS, lc = tid / TS;          // lc in 0..3; columns lc, lc+4, lc+8, lc+12
+    double pi[4], pj[4];
+    const bool iok = ri + lr < nf, jok = cj + lr < nf;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lc + 4 * q;
+            pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            pj[q] = (jok && k0 + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { si[lc + 4 * q][lr] = pi[q]; sj[lc + 4 * q][lr] = pj[q]; }
+        __syncthreads();
+        if (PIPE) { if (k0 + KC < kw) fetch(k0 + KC); }
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = sj[kk + l4][wc + l15], a1 = sj[kk + l4][wc + 16 + l15];
+            const double b0 = si[kk + l4][wr + l15], b1 = si[kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (!PIPE) { if (k0 + KC < kw) fetch(k0 + KC); }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    const double old = PRELOAD ? cpre[a][b][reg] : (NT ? __builtin_nontemporal_load(p) : *p);
+                    if (NT) __builtin_nontemporal_store(old - acc[a][b][reg], p); else *p = old - acc[a][b][reg];
+                }
+            }
+}
+
+// 128x128 tile per workgroup, wave = 64x64 (4x4 MFMA blocks), register prefetch of the next stage
+template <bool PIPE>
+__global__ void __launch_bounds__(256, 2)
+k_big(double* Fall, int nf, int kc0, int kw) {
+    constexpr int TB = 128, KC = 16, LS = TB + 16;
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TB;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TB;
+    if (ri >= nf) return;
+    __shared__ double si[KC][LS];
+    __shared__ double sj[KC][LS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 64, wc = (wv >> 1) * 64;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int lr = tid % TB, lc = tid / TB;          // lc in 0..1; columns lc, lc+2, ...
+    double pi[8], pj[8];
+    const bool iok = ri + lr < nf, jok = cj + lr < nf;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = lc + 2 * q;
+            pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            pj[q] = (jok && k0 + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { si[lc + 2 * q][lr] = pi[q]; sj[lc + 2 * q][lr] = pj[q]; }
+        __syncthreads();
+        if (PIPE) { if (k0 + KC < kw) fetch(k0 + KC); }
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = sj[kk + l4][wc + 16 * a + l15]; bv[a] = si[kk + l4][wr + 16 * a + l15]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (!PIPE) { if (k0 + KC < kw) fetch(k0 + KC); }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b][reg];
+            }
+}
+
+// 64x64 tile, C preloaded, LDS double-buffered: one barrier per 16-column stage
+template <bool NT, int KC>
+__global__ void __launch_bounds__(256)
+k_db(double* Fall, int nf, int kc0, int kw) {
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    __shared__ double si[2][KC][LSTR];
+    __shared__ double sj[2][KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    constexpr int NQ = KC / 4;
+    const int lr = tid % TS, lc = tid / TS;
+    double pi[NQ], pj[NQ];
+    const bool iok = ri + lr < nf, jok = cj + lr < nf;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = lc + 4 * q;
+            pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            pj[q] = (jok && k0 + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+        }
+    };
+    fetch(0);
+    double cpre[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                const double* p = &F[r + (size_t)nf * cc];
+                cpre[a][b][reg] = (r < nf && cc < nf && r >= cc) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+            }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { si[0][lc + 4 * q][lr] = pi[q]; sj[0][lc + 4 * q][lr] = pj[q]; }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const bool more = k0 + KC < kw;
+        if (more) fetch(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = sj[cur][kk + l4][wc + l15], a1 = sj[cur][kk + l4][wc + 16 + l15];
+            const double b0 = si[cur][kk + l4][wr + l15], b1 = si[cur][kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { si[cur ^ 1][lc + 4 * q][lr] = pi[q]; sj[cur ^ 1][lc + 4 * q][lr] = pj[q]; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    if (NT) __builtin_nontemporal_store(cpre[a][b][reg] - acc[a][b][reg], p); else *p = cpre[a][b][reg] - acc[a][b][reg];
+                }
+            }
+}
+
+int main(int argc, char** argv) {
+    const int nfr = argc > 1 ? atoi(argv[1]) : 8, nf = argc > 2 ? atoi(argv[2]) : 3200, kw = argc > 3 ? atoi(argv[3]) : 128;
+    double* F; CK(hipMalloc(&F, sizeof(double) * (size_t)nfr * nf * nf));
+    CK(hipMemset(F, 0, sizeof(double) * (size_t)nfr * nf * nf));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int nt = (nf - kw + TS - 1) / TS;
+    const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
+    for (int mode = 0; mode < 13; ++mode)
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 1) hipLaunchKernelGGL(k_var<1>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 2) hipLaunchKernelGGL(k_var<2>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 3) hipLaunchKernelGGL((k_pipe<false, false, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 4) hipLaunchKernelGGL((k_pipe<true, false, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 5) hipLaunchKernelGGL((k_pipe<false, true, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 6) hipLaunchKernelGGL((k_pipe<false, true, true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 7) hipLaunchKernelGGL((k_pipe<true, true, true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            const int nb = (nf - kw + 127) / 128;
+            if (mode == 8) hipLaunchKernelGGL((k_big<false>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 10) hipLaunchKernelGGL((k_db<false, 16>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 11) hipLaunchKernelGGL((k_db<true, 16>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 12) hipLaunchKernelGGL((k_db<false, 32>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep == 2) printf("mode %d: %8.1f us  %6.2f TFLOP/s\n", mode, ms * 1e3, flops / (ms * 1e-3) / 1e12);
+        }
+    return 0;
+}
