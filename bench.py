@@ -206,6 +206,7 @@ def main():
         t0 = time.perf_counter()
         it, rr = ctx.solve_state(zero_guess=True)
         t1 = time.perf_counter()
+        step.timing = ctx.last_timing()
         g, it2, rr2 = ctx.total_gradient("compliance", "thickness")
         t2 = time.perf_counter()
         return (t1 - t0, t2 - t1, it, rr, it2, rr2)
@@ -277,6 +278,7 @@ def main():
                        "parallelism": "replicas" if world > 1 else "single"},
             "roofline": roof,
             "roofline_spmv": roof_spmv,
+            "forward_split_ms": {"assemble_factorise": step.timing["setup_ms"], "pcg": step.timing["krylov_ms"]},
         }
         if prof is not None:
             out["factorisation_profile_ms"] = {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)}

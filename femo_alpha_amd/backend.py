@@ -236,6 +236,14 @@ class ShellContext:
     def set_stress_params(self, m=1e-6, rho=100.0):
         self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
 
+    def set_cell_tags(self, tags, ntags):
+        """Sub-domain index of every cell (-1: none) for the per-tag stress aggregates."""
+        t = np.ascontiguousarray(tags, dtype=np.int32)
+        self._chk(self.lib.femo_set_cell_tags(self._h, iptr(t), t.size, int(ntags)))
+
+    def select_subdomain(self, sel=-1):
+        self._chk(self.lib.femo_select_subdomain(self._h, int(sel)))
+
     def field_output(self, name="stress"):
         out = np.empty(self.mesh.nvc * self.mesh.nel)
         self._chk(self.lib.femo_field_output(self._h, name.encode(), dptr(out), out.size))

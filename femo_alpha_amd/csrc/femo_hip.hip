@@ -45,6 +45,9 @@ struct femo_ctx {
     Tables* tab = nullptr;
     Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
     double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0;
+    int* ctag = nullptr;                     // sub-domain index per cell
+    int csel = -1, ntags = 0;
+    std::vector<double> alpha_tag;           // reference area of every sub-domain (frozen at first use, like stress_alpha)
     double* gradbuf = nullptr;
     // CSR assembly
     long long csr_ncontrib = 0; int csr_nnz = 0;
@@ -229,6 +232,7 @@ static MeshDev mesh_dev(const femo_ctx* c) {
     MeshDev m;
     m.nn = c->nn; m.nel = c->nel; m.nP2 = c->nP2; m.ndof_u = c->ndof_u; m.ndof = c->ndof;
     m.xyz = c->xyz; m.cells = c->cells; m.cellp2 = c->cellp2; m.hK = c->hK;
+    m.ctag = c->ctag; m.csel = c->csel;
     return m;
 }
 static FieldsDev fields_dev(const femo_ctx* c) {
@@ -799,7 +803,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1049,6 +1053,9 @@ static int functionals_dev(femo_ctx* c, double* out3, int nout = 3) {
     return 0;
 }
 
+// reference area the stress aggregate is divided by: of the whole mesh or of the selected sub-domain
+static double& stress_alpha_ref(femo_ctx* c) { return c->csel < 0 ? c->stress_alpha : c->alpha_tag[c->csel]; }
+
 // int (m vm)^rho J dx over the cells and (first call) the reference area alpha
 static int pnorm_dev(femo_ctx* c, double out2[2]) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
@@ -1058,7 +1065,7 @@ static int pnorm_dev(femo_ctx* c, double out2[2]) {
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out2[0] = c->scal_host[0]; out2[1] = c->scal_host[1];
-    if (c->stress_alpha < 0) c->stress_alpha = out2[1];
+    if (stress_alpha_ref(c) < 0) stress_alpha_ref(c) = out2[1];
     return 0;
 }
 
@@ -1084,7 +1091,7 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
     if (s == "pnorm_stress") {
         double v[2];
         if (pnorm_dev(c, v)) return 1;
-        *value = v[0] / c->stress_alpha;
+        *value = v[0] / stress_alpha_ref(c);
         return 0;
     }
     return fail(c, "unknown functional '" + s + "'");
@@ -1129,8 +1136,8 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         const int mode = fn == "compliance" ? 1 : fn == "mass" ? 2 : fn == "elastic_energy" ? 3 : fn == "pnorm_stress" ? 4 : -1;
         if (mode < 0) return fail(c, "unknown functional '" + fn + "'");
         if (mode == 4) {
-            if (c->stress_alpha < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
-            return shape_gradient_dev(c, 4, c->w, nullptr, 1.0 / c->stress_alpha, out);
+            if (stress_alpha_ref(c) < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
+            return shape_gradient_dev(c, 4, c->w, nullptr, 1.0 / stress_alpha_ref(c), out);
         }
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
@@ -1148,10 +1155,10 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         else if (wrt == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
         else if (wrt == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
     } else if (fn == "pnorm_stress") {
-        if (c->stress_alpha < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
+        if (stress_alpha_ref(c) < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
         const int mode = wrt == "disp_solid" ? 1 : wrt == "thickness" ? 2 : wrt == "E" ? 3 : wrt == "nu" ? 4 : 0;
         if (mode)
-            ELEM_LAUNCH(c, k_pnorm, NOEXTRA, g, EB, m, f, c->tab_s, mode, c->stress_m, c->stress_rho, 1.0 / c->stress_alpha, c->w, out,
+            ELEM_LAUNCH(c, k_pnorm, NOEXTRA, g, EB, m, f, c->tab_s, mode, c->stress_m, c->stress_rho, 1.0 / stress_alpha_ref(c), c->w, out,
                         (double*)nullptr);
     } else {
         return fail(c, "unknown functional '" + fn + "'");
@@ -1615,6 +1622,25 @@ int femo_assemble_csr(femo_ctx* c, double* vals, double* ms2) {
 int femo_set_stress_params(femo_ctx* c, double m, double rho) {
     if (!(m > 0) || !(rho > 0)) return fail(c, "stress aggregation parameters must be positive");
     c->stress_m = m; c->stress_rho = rho;
+    return 0;
+}
+
+int femo_set_cell_tags(femo_ctx* c, const int32_t* tags, int64_t n, int32_t ntags) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n != c->nel) return fail(c, "cell tags need one entry per cell");
+    if (ntags < 0) return fail(c, "negative number of sub-domains");
+    for (int64_t i = 0; i < n; ++i)
+        if (tags[i] < -1 || tags[i] >= ntags) return fail(c, "cell tag out of range");
+    if (!c->ctag) HIPCHK(c, hipMalloc((void**)&c->ctag, (size_t)c->nel * sizeof(int)));
+    HIPCHK(c, hipMemcpy(c->ctag, tags, (size_t)c->nel * sizeof(int), hipMemcpyHostToDevice));
+    c->ntags = ntags; c->csel = -1;
+    c->alpha_tag.assign(ntags, -1.0);
+    return 0;
+}
+
+int femo_select_subdomain(femo_ctx* c, int32_t sel) {
+    if (sel < -1 || sel >= c->ntags) return fail(c, "unknown sub-domain");
+    c->csel = sel;
     return 0;
 }
 

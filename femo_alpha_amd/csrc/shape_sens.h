@@ -181,6 +181,7 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gid / (3 * NVC), dir = gid - e * (3 * NVC);
     if (e >= m.nel) return;
+    if (mode == 4 && !cell_selected(m, e)) return;
     const int bseed = dir / 3, iseed = dir - 3 * bseed;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, true>(m, f, e, el);

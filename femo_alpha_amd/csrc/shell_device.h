@@ -40,7 +40,12 @@ struct MeshDev {
     const int* cells;     // SoA [nvc][nel]
     const int* cellp2;    // SoA [npc][nel]
     const double* hK;     // nel, UFL CellDiameter
+    const int* ctag;      // nel, sub-domain index of every cell (-1: none), or null
+    int csel;             // sub-domain the stress aggregate integrates over; -1: the whole mesh
 };
+
+// false for cells outside the selected sub-domain (the reference's dxx(i) measure, rm_shell_model.py:242-253)
+__device__ __forceinline__ bool cell_selected(const MeshDev& m, int e) { return m.csel < 0 || (m.ctag && m.ctag[e] == m.csel); }
 
 struct FieldsDev {
     const double* h;

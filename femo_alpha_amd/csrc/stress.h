@@ -73,7 +73,7 @@ k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0, area = 0.0;
-    if (e < m.nel) {
+    if (e < m.nel && cell_selected(m, e)) {
         Elem<NPC, NVC> el;
         load_elem<NPC, NVC, UHAT>(m, f, e, el);
         double xe[LD], ye[LD], ge[NVC];

@@ -16,6 +16,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..backend import ShellContext
+from ..mesh_io import readFEAMesh, reconstructFEAMesh            # noqa: F401  (same names as fea/utils_dolfinx.py)
 
 
 class FunctionSpace:
@@ -70,10 +71,16 @@ class Function:
 
 
 class Form:
-    """Scalar output known to the backend: 'compliance', 'mass', 'elastic_energy'."""
+    """Scalar output known to the backend: 'compliance', 'mass', 'elastic_energy', 'pnorm_stress', 'volume'.
+    ``subdomain`` restricts the stress aggregate to one tagged set of cells (the reference's ``dxx(i)`` measure)."""
 
-    def __init__(self, ctx, name):
-        self.ctx, self.name = ctx, name
+    def __init__(self, ctx, name, subdomain=-1):
+        self.ctx, self.name, self.subdomain = ctx, name, subdomain
+
+    def _select(self):
+        if self.subdomain >= 0 or getattr(self.ctx, "_subdomain", -1) >= 0:
+            self.ctx.select_subdomain(self.subdomain)
+            self.ctx._subdomain = self.subdomain
 
 
 class FieldForm:
@@ -154,6 +161,7 @@ def createFunction(function: Function):
 
 
 def assembleScalar(c: Form):
+    c._select()
     return c.ctx.functional(c.name)
 
 
@@ -162,6 +170,7 @@ def assembleVector(v):
         return v.ctx.residual()
     if isinstance(v, PartialForm) and isinstance(v.form, Form):
         wrt = "disp_solid" if v.wrt.role == "state" else v.wrt.role
+        v.form._select()
         return v.form.ctx.dfunctional(v.form.name, wrt)
     raise TypeError("assembleVector: unsupported form")
 

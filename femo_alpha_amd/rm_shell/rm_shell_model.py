@@ -73,13 +73,26 @@ class RMShellModel:
         self.nel, self.nn = mesh.nel, mesh.nn
         self.elementwise_pressure = elementwise_pressure
         self.device = device
-        if mesh_tags is not None:
-            raise NotImplementedError("per-tag sub-domain outputs are out of scope (SURVEY.md section 2.1 row 3)")
+        self.association_table = None
         if shell_bc_func is None:
             raise ValueError("Please provide the shell bc location function.\n"
                              " Example:\n def ClampedBoundary(x):\n    return np.less(x[1], 0.0)")
         self.set_up_bcs(shell_bc_func, PENALTY_BC)
         self.set_up_fea()
+
+    def set_up_subdomains(self, mesh_tags):
+        """mesh_tags: {tag: [cell indices]} without duplicates (rm_shell_model.py:101-133).  Builds
+        ``association_table`` {tag: sub-domain index} and hands the per-cell index array to the backend."""
+        vals = -np.ones(self.mesh.nel, dtype=np.int32)
+        for i, inds in enumerate(mesh_tags.values()):
+            inds = np.asarray(inds, dtype=np.int64)
+            if inds.size and (inds.min() < 0 or inds.max() >= self.mesh.nel):
+                raise ValueError("mesh_tags: cell index out of range")
+            if np.any(vals[inds] != -1):
+                raise ValueError("mesh_tags: a cell may carry one tag only")
+            vals[inds] = i
+        self.association_table = {key: i for i, key in enumerate(mesh_tags.keys())}
+        self.shell_pde.ctx.set_cell_tags(vals, len(mesh_tags))
 
     def set_up_bcs(self, bc_locs_func, PENALTY_BC):
         if PENALTY_BC:
@@ -126,6 +139,13 @@ class RMShellModel:
         fea.add_output(name="mass", form=mass_form, arguments=["thickness", "density", "uhat"])
         fea.add_output(name="elastic_energy", form=elastic_energy_form, arguments=["thickness", "disp_solid", "E", "uhat"])
         fea.add_output(name="pnorm_stress", form=pnorm_stress_form, arguments=["thickness", "disp_solid", "E", "nu", "uhat"])
+        if self.mesh_tags is not None:
+            self.set_up_subdomains(self.mesh_tags)
+            for tag, i in self.association_table.items():
+                # a stress aggregate per sub-domain, named after the caller's tag (rm_shell_model.py:242-253)
+                form_i = shell_pde.pnorm_stress(w, uhat, h, E, nu, i, m=self.m, rho=self.rho, alpha=None, regularization=False)
+                fea.add_output(name="pnorm_stress_" + str(tag), form=form_i,
+                               arguments=["thickness", "disp_solid", "E", "nu", "uhat"])
         fea.add_field_output(name="stress", form=stress_form, arguments=["thickness", "disp_solid", "E", "nu", "uhat"],
                              function_space=("DG", 1), record=False, vtk=True)
         self.fea = fea

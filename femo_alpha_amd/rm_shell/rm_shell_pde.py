@@ -63,7 +63,8 @@ class RMShellPDE:
         if regularization or alpha is not None:
             raise NotImplementedError("only the reference's call pattern (alpha=None, regularization=False) is supported")
         self.ctx.set_stress_params(m, rho)
-        return Form(self.ctx, "pnorm_stress")
+        # dx: None for the whole mesh, or the index i of a tagged sub-domain (the reference passes dxx(i))
+        return Form(self.ctx, "pnorm_stress", subdomain=-1 if dx is None else int(dx))
 
     def von_Mises_stress(self, w, uhat, h, E, nu, surface="Top"):
         if surface != "Top":

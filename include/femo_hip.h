@@ -151,6 +151,12 @@ int femo_assemble_csr(femo_ctx* ctx, double* vals, double* ms2);
 /* Stress aggregation parameters (m, rho) of pnorm_stress = 1/alpha int (m vm_top)^rho J dx
  * (rm_shell/rm_shell_pde.py:112-128; defaults 1e-6, 100 as rm_shell_model.py:63). */
 int femo_set_stress_params(femo_ctx* ctx, double m, double rho);
+/* Sub-domains for the stress aggregate -- the reference's mesh tags / dxx(i) measure
+ * (rm_shell/rm_shell_model.py:101-133, 242-253).  tags[nel] holds the sub-domain index of every cell
+ * (0 .. ntags-1, or -1 for none).  femo_select_subdomain(sel) restricts "pnorm_stress" and its derivatives to the
+ * cells of sub-domain sel, normalised by that sub-domain's reference area; sel = -1 selects the whole mesh again. */
+int femo_set_cell_tags(femo_ctx* ctx, const int32_t* tags, int64_t n, int32_t ntags);
+int femo_select_subdomain(femo_ctx* ctx, int32_t sel);
 /* Field output "stress": top-surface von Mises stress L2-projected onto DG1, nvc*nel values (cell-major, the
  * cell's vertices in connectivity order) -- replaces FEA.projectFieldOutput (fea/fea_dolfinx.py:205-206,
  * csdl_alpha_opt/output_operation.py:116-123). */

@@ -568,13 +568,17 @@ class ShellOracle:
         s0, s1, s2 = c * (e0 + nu * e1), c * (nu * e0 + e1), c * 0.5 * (1 - nu) * gg
         return np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2 + 3 * s2 ** 2), g
 
-    def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None):
+    def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None, cells=None):
         """1/alpha int (m vm)^rho J dx (rm_shell_pde.py:112-128); use an oracle built with nquad=3 for the
-        reference's degree-4 measure (rm_shell_model.py:200-205).  alpha defaults to the reference area."""
+        reference's degree-4 measure (rm_shell_model.py:200-205).  alpha defaults to the reference area.
+        ``cells``: restrict the measure to a sub-domain (the reference's dxx(i), rm_shell_model.py:242-253)."""
         val, area = 0.0, 0.0
+        sel = None if cells is None else np.isin(np.arange(self.mesh.nel), np.asarray(cells))
         for sl in self._chunks():
             vm, g = self.von_mises_top(w, sl)
             wd = self.wts[None, :] * g["det"]
+            if sel is not None:
+                wd = wd * sel[sl][:, None]
             val += np.sum(wd * g["Ju"] * (m * vm) ** rho)
             area += np.sum(wd)
         return val / (area if alpha is None else alpha)

@@ -138,3 +138,41 @@ def test_forces_instead_of_pressures():
     assert np.abs(out_f.F_solid.value.reshape(nn, 3) - p_uniform).max() < 1e-10
     g = rec.compute_totals(out_f.compliance, forces)
     assert g.shape == (nn, 3) and np.abs(g[:, 2]).max() > 0
+
+
+def test_mesh_tags_give_per_tag_stress_aggregates():
+    """RMShellModel(mesh_tags=...) registers pnorm_stress_<tag> per sub-domain (rm_shell_model.py:101-133, 242-253)."""
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    from oracle.rm_shell_oracle import ShellOracle
+    mesh = plate_mesh(2.0, 10.0, 4, 20)
+    nn, nel = mesh.nn, mesh.nel
+    cx = mesh.nodes[mesh.cells].mean(axis=1)[:, 0]
+    mesh_tags = {"root_bay": np.nonzero(cx < 3.0)[0].tolist(), 7: np.nonzero(cx > 6.0)[0].tolist()}
+    recorder = csdl.Recorder(inline=True)
+    recorder.start()
+    pressure = csdl.Variable(value=np.zeros((nn, 3)), name="force_vector")
+    pressure.value[:, 2] = 5.0
+    thickness = csdl.Variable(value=0.1 * np.ones(nn), name="thickness")
+    E = csdl.Variable(value=1e8 * np.ones(nn), name="E")
+    nu = csdl.Variable(value=0.3 * np.ones(nn), name="nu")
+    density = csdl.Variable(value=10.0 * np.ones(nn), name="density")
+    model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False, mesh_tags=mesh_tags)
+    assert model.association_table == {"root_bay": 0, 7: 1}
+    model.shell_pde.ctx.set_solver(rtol=1e-12, maxit=400000, check_every=100)
+    out = model.evaluate(pressure, thickness, E, nu, density)
+    recorder.stop()
+    o = ShellOracle(mesh, penalty_facets=mesh.penalty_facets(ClampedBoundary))
+    o.set_fields(h=0.1, E=1e8, nu=0.3, rho=10.0, f=pressure.value)
+    w_ref = o.solve()
+    o3 = ShellOracle(mesh, nquad=3)
+    o3.set_fields(h=0.1, E=1e8, nu=0.3)
+    for tag, cells in mesh_tags.items():
+        ref = o3.pnorm_stress(w_ref, 1e-6, 100, cells=cells)
+        got = getattr(out, "pnorm_stress_" + str(tag)).value[0]
+        assert abs(got - ref) < 1e-6 * ref, (tag, got, ref)
+    whole = o3.pnorm_stress(w_ref, 1e-6, 100)
+    assert abs(out.pnorm_stress.value[0] - whole) < 1e-6 * whole
+    # the root bay carries the largest stresses of a cantilever
+    assert out.pnorm_stress_root_bay.value[0] > getattr(out, "pnorm_stress_7").value[0]
+    with pytest.raises(ValueError, match="one tag only"):
+        RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False, mesh_tags={"a": [0, 1], "b": [1]})

@@ -254,6 +254,56 @@ def test_stress_outputs(kind, ewm, uhat):
             assert abs(g_u[v_, comp] - fd) <= 5e-6 * np.abs(g_u).max() + 1e-7 * abs(fd), (v_, comp, g_u[v_, comp], fd)
 
 
+@pytest.mark.parametrize("kind,uhat", [("warped", True), ("tri", False)])
+def test_stress_aggregate_on_subdomains(kind, uhat):
+    """Per-tag stress aggregates (the reference's dxx(i) measure, rm_shell_model.py:242-253): value and partial
+    gradients restricted to a sub-domain, each normalised by its own reference area; selecting -1 restores the mesh."""
+    from oracle.rm_shell_oracle import ShellOracle
+    m, o, c, rng = _pair(kind, uhat=uhat, beta=1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-4
+    c.set_state(w)
+    o3 = ShellOracle(m, nquad=3)
+    o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
+    o0 = ShellOracle(m, nquad=3)                                        # reference configuration: the frozen areas
+    mval, rho = 1e-6, 6.0
+    c.set_stress_params(mval, rho)
+    perm = rng.permutation(m.nel)
+    groups = [perm[: m.nel // 3], perm[m.nel // 3: m.nel // 2]]          # the rest stays untagged
+    tags = -np.ones(m.nel, dtype=np.int32)
+    for i, g in enumerate(groups):
+        tags[g] = i
+    c.set_cell_tags(tags, len(groups))
+    whole = c.functional("pnorm_stress")
+    assert abs(whole - o3.pnorm_stress(w, mval, rho)) < 1e-10 * whole
+    for i, g in enumerate(groups):
+        alpha = o0.pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0, cells=g)
+        P = lambda ww=w: o3.pnorm_stress(ww, mval, rho, alpha=alpha, cells=g)
+        c.select_subdomain(i)
+        assert abs(c.functional("pnorm_stress") - P()) < 1e-10 * P()
+        g_w = c.dfunctional("pnorm_stress", "disp_solid")
+        touched = np.unique(m.cell_dofs()[g])
+        assert np.all(g_w[np.setdiff1d(np.arange(m.ndof), touched)] == 0.0)
+        for k in rng.choice(touched, 4, replace=False):
+            st = 1e-6 * max(abs(w[k]), 1e-4)
+            wp = w.copy(); wp[k] += st; wm = w.copy(); wm[k] -= st
+            fd = (P(wp) - P(wm)) / (2 * st)
+            assert abs(g_w[k] - fd) <= 2e-6 * np.abs(g_w).max() + 1e-7 * abs(fd), (k, g_w[k], fd)
+        g_h = c.dfunctional("pnorm_stress", "thickness")
+        h0 = o3.h.copy()
+        k = int(np.argmax(np.abs(g_h)))
+        hp = h0.copy(); hp[k] *= 1 + 1e-6; o3.set_fields(h=hp); fp = P()
+        hp[k] = h0[k] * (1 - 1e-6); o3.set_fields(h=hp); fm = P()
+        o3.set_fields(h=h0)
+        fd = (fp - fm) / (2e-6 * h0[k])
+        assert abs(g_h[k] - fd) <= 5e-6 * abs(fd), (g_h[k], fd)
+        g_u = c.dfunctional("pnorm_stress", "uhat").reshape(-1, 3)
+        assert np.all(g_u[np.setdiff1d(np.arange(m.nn), np.unique(m.cells[g]))] == 0.0)
+    c.select_subdomain(-1)
+    assert c.functional("pnorm_stress") == whole
+    with pytest.raises(Exception, match="unknown sub-domain"):
+        c.select_subdomain(5)
+
+
 @pytest.mark.parametrize("kind", ["plate", "warped", "tri"])
 def test_csr_assembly(kind):
     """Wave-segmented scatter-add of the element matrices into CSR against the oracle's scipy assembly."""

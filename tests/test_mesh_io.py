@@ -1,0 +1,121 @@
+"""Mesh files: XDMF (inline XML) round trip, reconstructFEAMesh, Gmsh ASCII 2.2 / 4.1 readers (CPU only)."""
+import numpy as np
+import pytest
+
+from femo_alpha_amd.mesh import plate_mesh, quads_to_triangles
+from femo_alpha_amd.mesh_io import read_msh, read_xdmf, readFEAMesh, reconstructFEAMesh, write_xdmf
+
+
+@pytest.mark.parametrize("tri", [False, True])
+def test_xdmf_round_trip(tmp_path, tri):
+    m = plate_mesh(2.0, 10.0, 3, 7)
+    if tri:
+        m = quads_to_triangles(m)
+    path = tmp_path / "mesh.xdmf"
+    write_xdmf(path, m.nodes, m.cells)
+    r = readFEAMesh(str(path), format="XML")
+    assert np.array_equal(r.cells, m.cells)
+    assert np.allclose(r.nodes, m.nodes, rtol=0, atol=0)
+    assert r.ndof == m.ndof
+    assert np.array_equal(read_xdmf(path).cell_dofs(), m.cell_dofs())
+
+
+def test_read_fea_mesh_rejects_unknown_format(tmp_path):
+    m = plate_mesh(1.0, 1.0, 1, 1)
+    path = tmp_path / "m.xdmf"
+    write_xdmf(path, m.nodes, m.cells)
+    with pytest.raises(ValueError, match="Invalid mesh file type"):
+        readFEAMesh(str(path), format="VTK")
+
+
+def test_reconstruct_fea_mesh(tmp_path):
+    m = plate_mesh(2.0, 10.0, 2, 5)
+    path = tmp_path / "wing.xdmf"
+    r = reconstructFEAMesh(str(path), m.nodes, m.cells)
+    assert r.nel == m.nel and r.nn == m.nn
+    assert np.array_equal(read_xdmf(path).cells, m.cells)
+    with pytest.raises(ValueError, match="Invalid cell shape"):
+        reconstructFEAMesh(str(path), m.nodes, np.zeros((3, 5), dtype=int))
+
+
+MSH22 = """$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$PhysicalNames
+2
+2 7 "upper skin"
+2 9 "rib"
+$EndPhysicalNames
+$Nodes
+7
+1 0 0 0
+2 1 0 0
+3 1 1 0
+4 0 1 0
+5 2 0 0.5
+6 2 1 0.5
+99 5 5 5
+$EndNodes
+$Elements
+4
+1 15 2 0 1 1
+2 1 2 0 1 1 2
+3 3 2 7 1 1 2 3 4
+4 3 2 9 2 2 5 6 3
+$EndElements
+"""
+
+MSH41 = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$PhysicalNames
+1
+2 3 "skin"
+$EndPhysicalNames
+$Entities
+0 0 2 0
+1 0 0 0 1 1 0 1 3 0
+2 1 0 0 2 1 0 0 0
+$EndEntities
+$Nodes
+1 5 1 5
+2 1 0 5
+1
+2
+3
+4
+5
+0 0 0
+1 0 0
+1 1 0
+0 1 0
+2 0.5 0
+$EndNodes
+$Elements
+2 3 1 3
+2 1 2 2
+1 1 2 3
+2 1 3 4
+2 2 2 1
+3 2 5 3
+$EndElements
+"""
+
+
+def test_read_msh_22(tmp_path):
+    p = tmp_path / "a.msh"
+    p.write_text(MSH22)
+    mesh, tags = read_msh(p, rescale=[2.0, 2.0, 2.0])
+    assert mesh.nel == 2 and mesh.nn == 6                 # the unused node 99 is dropped
+    assert mesh.cells.shape == (2, 4)
+    assert tags == {"upper skin": [0], "rib": [1]}
+    assert np.allclose(mesh.nodes[mesh.cells[1]][:, 0], [2.0, 4.0, 4.0, 2.0])
+
+
+def test_read_msh_41(tmp_path):
+    p = tmp_path / "b.msh"
+    p.write_text(MSH41)
+    mesh, tags = read_msh(p)
+    assert mesh.nel == 3 and mesh.nn == 5 and mesh.cells.shape[1] == 3
+    assert tags == {"skin": [0, 1]}
+    assert mesh.ndof == 3 * (mesh.nn + mesh.edges.shape[0]) + 3 * mesh.nn
