@@ -286,13 +286,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
             if args.workload == "wing1m":
-                sample = wing_skin_mesh(29, 145)            # same surface, 1/16 of the cells
+                sample = wing_skin_mesh(58, 290)            # same surface, 1/4 of the cells: ~10-20 s of one host core
                 def sample_fields(sm):
                     return dict(h=1.27e-3, E=73.1e9, nu=0.33, rho=2780.0,
                                 f=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (sm.nn, 1)))
                 out["cpu_baseline"] = cpu_baseline(sample, sample_fields, lambda x: np.less(x[1], 1e-9))
             else:
-                sample = plate_mesh(2.0, 10.0, 29, 145)
+                sample = plate_mesh(2.0, 10.0, 58, 290)            # the workload itself
                 def sample_fields(sm):
                     rng = np.random.default_rng(0)
                     return dict(h=0.1 * (1 + 0.2 * rng.uniform(-1, 1, sm.nn)), E=1e8, nu=0.3, rho=10.0,
