@@ -670,11 +670,16 @@ k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
 
 constexpr int SP = 128;    // columns handled per launch by the wide solve kernels (4 diagonal blocks)
 
-constexpr int PB = 64;     // rows (forward) / columns (backward) per workgroup of the wide update kernels: one wave,
-                           // so that even a level with a handful of fronts spreads over hundreds of workgroups
+constexpr int PB = 64;     // rows per workgroup of the wide forward update
+constexpr int TRI_T = 1024; // threads of the wide triangular kernels: 8 per row / 16 waves over the columns
+constexpr int BU_COLS = 16; // columns per workgroup of the wide backward update (4 per wave)
+
+// The top levels of the tree are a chain of ~200 tiny dependent launches per sweep: each kernel is laid out for
+// latency, not throughput -- every thread issues all of its loads at once (16-32 independent ones) and the
+// partial sums meet in LDS.
 
 // forward, columns [c0, c0+SP), step 1 (one workgroup per front): y = L11[c0.., c0..]^-1 v[c0..] -> yv
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TRI_T)
 k_front_fwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ v, double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t];
@@ -683,25 +688,35 @@ k_front_fwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const 
     const int* gd = fd.dofs + fd.doff[t];
     const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
     __shared__ double bs[SP];
-    __shared__ double part[2][SP];
+    __shared__ double part[TRI_T / SP][SP];
     const int tid = threadIdx.x;
+    // y_r = sum_{m <= r} S[r][m] b[m]: eight threads per row (16 columns each), coalesced along the rows;
+    // the S loads do not depend on b and are issued before the gather of b has landed
+    const int r = tid & (SP - 1), p = tid >> 7;
+    double sv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int mm = 16 * p + k;
+        sv[k] = (mm <= r && r < W) ? S[r + (size_t)SP * mm] : 0.0;
+    }
     if (tid < SP) bs[tid] = tid < W ? v[gd[c0 + tid]] : 0.0;
     __syncthreads();
-    // y_r = sum_{m <= r} S[r][m] b[m]: two threads per row (halves of the columns), coalesced along rows
-    const int r = tid & (SP - 1), half = tid >> 7;
     double s = 0.0;
-    if (r < W) {
-        const int m0 = half * (SP / 2), m1 = min(r + 1, m0 + SP / 2);
-#pragma unroll 16
-        for (int mm = m0; mm < m1; ++mm) s += S[r + (size_t)SP * mm] * bs[mm];
-    }
-    part[half][r] = s;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sv[k] * bs[16 * p + k];
+    part[p][r] = s;
     __syncthreads();
-    if (tid < W) yv[gd[c0 + tid]] = part[0][tid] + part[1][tid];
+    if (tid < W) {
+        double y = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRI_T / SP; ++q) y += part[q][tid];
+        yv[gd[c0 + tid]] = y;
+    }
 }
 
-// forward, step 2:  v_r -= L[r, c0..c0+W) y  for all rows r below the super panel, 64 rows per workgroup
-__global__ void __launch_bounds__(PB)
+// forward, step 2:  v_r -= L[r, c0..c0+W) y  for all rows r below the super panel, 64 rows per workgroup,
+// four threads per row (32 columns each)
+__global__ void __launch_bounds__(256)
 k_front_fwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ v, const double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -712,22 +727,30 @@ k_front_fwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     __shared__ double ys[SP];
+    __shared__ double part[4][PB];
     const int tid = threadIdx.x;
-    for (int i = tid; i < SP; i += PB) ys[i] = i < W ? yv[gd[c0 + i]] : 0.0;
+    const int lr = tid & (PB - 1), p = tid >> 6;
+    const int r = r0 + lr;
+    double lv[32];
+    const double* row = F + r + (size_t)nf * (c0 + 32 * p);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) lv[k] = (r < nf && 32 * p + k < W) ? row[(size_t)nf * k] : 0.0;
+    if (tid < SP) ys[tid] = tid < W ? yv[gd[c0 + tid]] : 0.0;
     __syncthreads();
-    const int r = r0 + tid;
-    if (r < nf) {
-        double s = 0.0;
-        const double* row = F + r + (size_t)nf * c0;
-#pragma unroll 16
-        for (int mm = 0; mm < W; ++mm) s += row[(size_t)nf * mm] * ys[mm];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s += lv[k] * ys[32 * p + k];
+    part[p][lr] = s;
+    __syncthreads();
+    if (tid < PB && r < nf) {
+        s = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
         if (r < np) v[gd[r]] -= s;
         else atomicAdd(&v[gd[r]], -s);
     }
 }
 
 // backward, columns [c0, c0+SP), step 1 (one workgroup per front): x = L11[c0.., c0..]^-T s[c0..] -> xv
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TRI_T)
 k_front_bwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ sv, double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t];
@@ -736,46 +759,60 @@ k_front_bwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const 
     const int* gd = fd.dofs + fd.doff[t];
     const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
     __shared__ double ss[SP];
-    __shared__ double part[2][SP];
-    const int tid = threadIdx.x;
+    __shared__ double xs[SP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // x_c = sum_{r >= c} S[r][c] s[r]: wave wv takes the columns wv, wv + 16, ...; its lanes walk the (contiguous)
+    // column, two rows each
+    double a0[SP / 16], a1[SP / 16];
+#pragma unroll
+    for (int k = 0; k < SP / 16; ++k) {
+        const int c = wv + 16 * k;
+        const double* col = S + (size_t)SP * c;
+        a0[k] = (lane >= c && lane < W && c < W) ? col[lane] : 0.0;
+        a1[k] = (lane + 64 >= c && lane + 64 < W && c < W) ? col[lane + 64] : 0.0;
+    }
     if (tid < SP) ss[tid] = tid < W ? sv[gd[c0 + tid]] : 0.0;
     __syncthreads();
-    // x_c = sum_{r >= c} S[r][c] s[r]: two threads per column, each walks half of the (contiguous) column
-    const int c = tid & (SP - 1), half = tid >> 7;
-    double s = 0.0;
-    if (c < W) {
-        const int r0 = max(c, half * (SP / 2)), r1 = min(W, (half + 1) * (SP / 2));
-        const double* col = S + (size_t)SP * c;
-#pragma unroll 16
-        for (int r = r0; r < r1; ++r) s += col[r] * ss[r];
+    const double s0 = ss[lane], s1 = ss[lane + 64];
+#pragma unroll
+    for (int k = 0; k < SP / 16; ++k) {
+        const double x = wave_sum(a0[k] * s0 + a1[k] * s1);
+        if (lane == 0) xs[wv + 16 * k] = x;
     }
-    part[half][c] = s;
     __syncthreads();
-    if (tid < W) xv[gd[c0 + tid]] = part[0][tid] + part[1][tid];
+    if (tid < W) xv[gd[c0 + tid]] = xs[tid];
 }
 
-// backward, step 2:  s_j -= L[c0..c0+W, j]^T x  for all columns j < c0, 64 columns per workgroup
-__global__ void __launch_bounds__(PB)
+// backward, step 2:  s_j -= L[c0..c0+W, j]^T x  for all columns j < c0: 16 columns per workgroup, one wave per
+// column at a time, lanes along the (contiguous) column
+__global__ void __launch_bounds__(256)
 k_front_bwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
     if (c0 >= np) return;
     const int W = min(SP, np - c0);
-    const int j0 = blockIdx.x * PB;
+    const int j0 = blockIdx.x * BU_COLS;
     if (j0 >= c0) return;
     const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     __shared__ double xs[SP];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < SP; i += PB) xs[i] = i < W ? xv[gd[c0 + i]] : 0.0;
-    __syncthreads();
-    const int j = j0 + tid;
-    if (j < c0) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double a0[BU_COLS / 4], a1[BU_COLS / 4];
+#pragma unroll
+    for (int k = 0; k < BU_COLS / 4; ++k) {
+        const int j = j0 + wv + 4 * k;
         const double* col = F + c0 + (size_t)nf * j;
-        double s = 0.0;
-#pragma unroll 16
-        for (int i = 0; i < W; ++i) s += col[i] * xs[i];
-        sv[gd[j]] -= s;
+        a0[k] = (j < c0 && lane < W) ? col[lane] : 0.0;
+        a1[k] = (j < c0 && lane + 64 < W) ? col[lane + 64] : 0.0;
+    }
+    if (tid < SP) xs[tid] = tid < W ? xv[gd[c0 + tid]] : 0.0;
+    __syncthreads();
+    const double x0 = xs[lane], x1 = xs[lane + 64];
+#pragma unroll
+    for (int k = 0; k < BU_COLS / 4; ++k) {
+        const int j = j0 + wv + 4 * k;
+        const double s = wave_sum(a0[k] * x0 + a1[k] * x1);
+        if (lane == 0 && j < c0) sv[gd[j]] -= s;
     }
 }
 

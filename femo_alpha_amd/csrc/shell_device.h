@@ -65,10 +65,24 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// sum over the 64 lanes of a wave, returned in every lane: four DPP steps inside each row of 16 lanes
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row totals through
+// v_readlane -- no LDS traffic (a __shfl_down ladder costs six dependent ds_bpermute round trips)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 
 // one atomic per block into *slot (slot may be null)
