@@ -22,6 +22,8 @@ using namespace femo;
 // tree levels whose largest pivot block exceeds this run the triangular solves with the wide (multi-workgroup)
 // kernels and the precomputed 128 x 128 diagonal-block inverses; smaller fronts use one workgroup per front
 static int WIDE_NP = 512;           // FEMO_WIDE_NP overrides it when a plan is uploaded (tests force the wide path on small meshes)
+static int WIDE_CNT = 512;          // FEMO_WIDE_CNT: levels with at most this many fronts also take the wide (many workgroups per
+                                    // front) solve kernels -- one workgroup per front cannot pull a level's factor out of HBM
 
 #define FEMO_VERSION 100
 
@@ -83,6 +85,7 @@ struct femo_ctx {
         bool ready = false, factored = false;
         int ntree = 0, nlevels = 0;
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
+        std::vector<char> h_level_wide;              // level takes the wide solve kernels (and keeps S in Sinv)
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
         long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *spoff = nullptr;
@@ -457,7 +460,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
         // outer panels of NBO columns, three launches each: the diagonal block (factor + inverse, one workgroup per
         // front), the rows below it (one GEMM against the inverse), the trailing update
-        const bool wide = fr.h_level_maxnp[L] > WIDE_NP;            // these levels keep S for the triangular solves
+        const bool wide = fr.h_level_wide[L];                      // these levels keep S for the triangular solves
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             { ProfScope ps(c, 1);
@@ -511,11 +514,11 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
-        if (maxnp > WIDE_NP) {
+        if (fr.h_level_wide[L]) {
             for (int c0 = 0; c0 < maxnp; c0 += SP) {
                 const int rows = maxnp + maxnb - c0;              // upper bound of rows below the super panel
                 hipLaunchKernelGGL(k_front_fwd_tri, dim3(cnt), dim3(TRI_T), 0, c->stream, fd, lev, c0, v, y);
-                if (rows - SP > 0)
+                if (rows > 0)          // a front narrower than SP still has its boundary rows below the block
                     hipLaunchKernelGGL(k_front_fwd_upd, dim3((rows + PB - 1) / PB, cnt), dim3(256), 0, c->stream, fd, lev, c0, v, y);
             }
         } else {
@@ -536,7 +539,7 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
-        if (maxnp > WIDE_NP) {
+        if (fr.h_level_wide[L]) {
             if (maxnb > 0)
                 hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + 3) / 4, cnt), dim3(256), 0, c->stream, fd, lev, y, v);
             for (int c0 = ((maxnp - 1) / SP) * SP; c0 >= 0; c0 -= SP)
@@ -1243,6 +1246,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     auto& fr = c->fr;
     if (fr.ready) return fail(c, "frontal plan already set for this context");
     if (const char* e = getenv("FEMO_WIDE_NP")) WIDE_NP = std::max(1, atoi(e));
+    if (const char* e = getenv("FEMO_WIDE_CNT")) WIDE_CNT = std::max(0, atoi(e));
     if (ntree < 1 || nlevels < 1) return fail(c, "empty frontal plan");
     fr.ntree = ntree; fr.nlevels = nlevels;
     fr.h_nf.assign(nf, nf + ntree); fr.h_npiv.assign(npiv, npiv + ntree);
@@ -1285,6 +1289,9 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
             fr.h_level_maxnp[L] = std::max(fr.h_level_maxnp[L], npiv[t]);
             fr.h_level_maxnb[L] = std::max(fr.h_level_maxnb[L], nf[t] - npiv[t]);
         }
+    fr.h_level_wide.assign(nlevels, 0);
+    for (int L = 0; L < nlevels; ++L)
+        fr.h_level_wide[L] = fr.h_level_maxnp[L] > WIDE_NP || level_off[L + 1] - level_off[L] <= WIDE_CNT;
     fr.f_doubles = front_off[ntree];
     fr.linv_doubles = linvoff[ntree];
 #define UPI(dst, src, n) do { HIPCHK(c, hipMalloc((void**)&dst, std::max<size_t>((size_t)(n), 1) * sizeof(*dst))); \
@@ -1303,7 +1310,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         std::vector<int> spf, spi;
         std::vector<char> wide(ntree, 0);                 // fronts of the levels that take the wide solve kernels
         for (int L = 0; L < nlevels; ++L)
-            if (fr.h_level_maxnp[L] > WIDE_NP)
+            if (fr.h_level_wide[L])
                 for (int i = level_off[L]; i < level_off[L + 1]; ++i) wide[level_nodes[i]] = 1;
         for (int t = 0; t < ntree; ++t) {
             const int n = wide[t] ? (npiv[t] + SP - 1) / SP : 0;
@@ -1321,7 +1328,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         // scratch for the diagonal-block inverses of the other levels (needed only between k_diag_block and k_panel_rows)
         int max_cnt = 0;
         for (int L = 0; L < nlevels; ++L)
-            if (fr.h_level_maxnp[L] <= WIDE_NP) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
+            if (!fr.h_level_wide[L]) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
         HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SP * SP * sizeof(double)));
     }
     HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));

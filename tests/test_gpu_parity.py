@@ -133,20 +133,25 @@ def test_errors_are_loud():
     assert np.all(c.get_field("thickness") == 0.1)
 
 
-@pytest.mark.parametrize("kind,ewm,bc,uhat", [("plate", False, "penalty", False), ("warped", True, "strong", False),
-                                              ("warped", False, "penalty", True), ("tri", False, "penalty", False),
-                                              ("plate24", False, "penalty", False)])
-def test_multifrontal_preconditioner(kind, ewm, bc, uhat):
+@pytest.mark.parametrize("kind,ewm,bc,uhat,wide_cnt", [("plate", False, "penalty", False, None), ("warped", True, "strong", False, 0),
+                                                       ("warped", False, "penalty", True, None), ("tri", False, "penalty", False, 0),
+                                                       ("plate24", False, "penalty", False, 0), ("plate", False, "strong", False, 0)])
+def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
-    the same parity triple as the reference's direct (MUMPS LU) solve."""
+    the same parity triple as the reference's direct (MUMPS LU) solve.  Levels with few fronts take the wide
+    (many workgroups per front) solve kernels by default -- on these small meshes that is every level;
+    wide_cnt = 0 sends them through the one-workgroup-per-front kernels instead."""
     import os
     m, o, c, rng = _pair(kind, ewm=ewm, bc=bc, uhat=uhat)
     if kind == "plate24":
-        os.environ["FEMO_WIDE_NP"] = "96"            # force the wide (multi-workgroup) solve kernels on this small mesh
+        os.environ["FEMO_WIDE_NP"] = "96"            # wide kernels by pivot-block size: a mix of both paths in one tree
+    if wide_cnt is not None:
+        os.environ["FEMO_WIDE_CNT"] = str(wide_cnt)
     try:
         plan = c.enable_frontal(leaf_size=8)
     finally:
         os.environ.pop("FEMO_WIDE_NP", None)
+        os.environ.pop("FEMO_WIDE_CNT", None)
     assert plan.ntree > 1
     if kind == "plate24":
         assert plan.npiv.max() > 192
