@@ -87,7 +87,8 @@ struct femo_ctx {
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
         std::vector<char> h_level_wide;              // level takes the wide solve kernels (and keeps S in Sinv)
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
-            *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr;
+            *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr,
+            *cinv0 = nullptr, *cinv1 = nullptr;
         long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *spoff = nullptr;
         double *F = nullptr, *Linv = nullptr, *Sinv = nullptr, *Swork = nullptr;
         int *sp_front = nullptr, *sp_index = nullptr;
@@ -396,6 +397,7 @@ static FrontDev front_dev(const femo_ctx* c) {
     fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.foff = c->fr.foff; fd.doff = c->fr.doff;
     fd.dofs = c->fr.dofs; fd.upmap = c->fr.upmap; fd.parent = c->fr.parent; fd.child[0] = c->fr.left; fd.child[1] = c->fr.right;
     fd.linvoff = c->fr.linvoff; fd.spoff = c->fr.spoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv; fd.Sinv = c->fr.Sinv;
+    fd.cinv[0] = c->fr.cinv0; fd.cinv[1] = c->fr.cinv1;
     return fd;
 }
 
@@ -424,7 +426,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (assemble) {
-        { ProfScope ps(c, 5); HIPCHK(c, hipMemsetAsync(fr.F, 0, (size_t)fr.f_doubles * sizeof(double), c->stream)); }
+        { ProfScope ps(c, 5);
+          // only the leaf fronts start from zero (element matrices are added into them); every other front is written
+          // entry by entry by the extend-add gather of its level
+          const int cnt0 = fr.h_level_off[1] - fr.h_level_off[0];
+          int mx = 0;
+          for (int i = fr.h_level_off[0]; i < fr.h_level_off[1]; ++i) mx = std::max(mx, fr.h_nf[fr.h_level_nodes[i]]);
+          const int nt0 = (mx + TS - 1) / TS;
+          hipLaunchKernelGGL(k_zero_fronts, dim3(nt0 * (nt0 + 1) / 2, cnt0), dim3(256), 0, c->stream, fd, fr.level_nodes); }
         HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
         if (refresh_penalty(c)) return 1;
         { ProfScope ps(c, 4);
@@ -453,8 +462,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             const int nt = (max_nb + TS - 1) / TS;
             const dim3 grid(nt * (nt + 1) / 2, cnt);
-            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 0); }
-            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_add, grid, dim3(256), 0, c->stream, fd, lev, 1); }
+            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_gather, grid, dim3(256), 0, c->stream, fd, lev, mask); }
         }
         int max_nf = 0;
         for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
@@ -813,7 +821,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv,
-                     c->fr.spoff, c->fr.Sinv, c->fr.Swork, c->fr.sp_front, c->fr.sp_index};
+                     c->fr.spoff, c->fr.Sinv, c->fr.Swork, c->fr.sp_front, c->fr.sp_index, c->fr.cinv0, c->fr.cinv1};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -1331,7 +1339,24 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
             if (!fr.h_level_wide[L]) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
         HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SP * SP * sizeof(double)));
     }
+    {
+        // row maps of the extend-add gather: for every row of a front, the row of each child's front that lands there
+        std::vector<int> inv0((size_t)ndofs_total, -1), inv1((size_t)ndofs_total, -1);
+        for (int t = 0; t < ntree; ++t) {
+            const int p = parent[t];
+            if (p < 0) continue;
+            std::vector<int>& inv = left[p] == t ? inv0 : inv1;
+            if (left[p] != t && right[p] != t) return fail(c, "inconsistent frontal plan (parent / child links)");
+            for (int k = npiv[t]; k < nf[t]; ++k) {
+                const int pr = up_map[dof_off[t] + k];
+                if (pr < 0 || pr >= nf[p]) return fail(c, "inconsistent frontal plan (up_map out of range)");
+                inv[(size_t)dof_off[p] + pr] = k;
+            }
+        }
+        UPI(fr.cinv0, inv0.data(), ndofs_total); UPI(fr.cinv1, inv1.data(), ndofs_total);
+    }
     HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));
+    HIPCHK(c, hipMemset(fr.F, 0, (size_t)fr.f_doubles * sizeof(double)));      // once: the upper triangles are never written
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
     if ((size_t)(fr.max_nf + NB) * sizeof(double) > 48 * 1024) {

@@ -35,6 +35,7 @@ struct FrontDev {
     const int* upmap;           // row of the parent front (boundary rows only)
     const int* parent;
     const int* child[2];        // left / right
+    const int* cinv[2];         // per front row: the row of the left / right child's front that lands there, or -1
     const long long* linvoff;   // doubles, [ntree+1]
     const long long* spoff;     // number of 128-column super panels before front t, [ntree+1]
     double* F;
@@ -133,35 +134,68 @@ __global__ void k_front_mask_diag(FrontDev fd, const unsigned char* __restrict__
         if (mask[gd[p]]) F[p + (size_t)nf * p] = 1.0;
 }
 
-// parent front += child's Schur complement (one child side per launch -> no write conflicts)
+// lower triangle of every front of a level := 0 (the leaf fronts before the element matrices are added)
 __global__ void __launch_bounds__(256)
-k_extend_add(FrontDev fd, const int* __restrict__ level_nodes, int side) {
-    const int p = level_nodes[blockIdx.y];
-    const int c = fd.child[side][p];
-    if (c < 0) return;
-    const int nfc = fd.nf[c], npc = fd.npiv[c];
-    const int nb = nfc - npc;
-    const int nt = (nb + TS - 1) / TS;
-    // lower-triangle tile (ti >= tj) from the linear index
+k_zero_fronts(FrontDev fd, const int* __restrict__ level_nodes) {
+    const int t = level_nodes[blockIdx.y];
+    const int nf = fd.nf[t];
+    const int nt = (nf + TS - 1) / TS;
     const int lin = blockIdx.x;
     if (lin >= nt * (nt + 1) / 2) return;
     int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
     while (ti * (ti + 1) / 2 > lin) --ti;
     const int tj = lin - ti * (ti + 1) / 2;
-    const int nfp = fd.nf[p];
-    double* Fp = fd.F + fd.foff[p];
-    const double* Fc = fd.F + fd.foff[c];
-    const int* up = fd.upmap + fd.doff[c] + npc;
+    double* F = fd.F + fd.foff[t];
     const int r0 = ti * TS, c0 = tj * TS;
+    for (int idx = threadIdx.x; idx < TS * TS; idx += blockDim.x) {
+        const int r = r0 + idx % TS, cc = c0 + idx / TS;
+        if (r < nf && cc <= r) F[r + (size_t)nf * cc] = 0.0;
+    }
+}
+
+// extend-add as a gather: every entry of the parent's lower triangle is the sum of the entries of its children's
+// Schur complements that land there (row maps cinv) -- written once, never read: no zero fill of the parent, no
+// read-modify-write, one launch per level for both children.  Masked (strong-BC) pivots get their unit diagonal here.
+__global__ void __launch_bounds__(256)
+k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, const unsigned char* __restrict__ mask) {
+    const int p = level_nodes[blockIdx.y];
+    const int ch0 = fd.child[0][p], ch1 = fd.child[1][p];
+    if (ch0 < 0 && ch1 < 0) return;                      // nothing below: the front keeps what it was given
+    const int nfp = fd.nf[p], npp = fd.npiv[p];
+    const int nt = (nfp + TS - 1) / TS;
+    const int lin = blockIdx.x;
+    if (lin >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+    while (ti * (ti + 1) / 2 > lin) --ti;
+    const int tj = lin - ti * (ti + 1) / 2;
+    const int r0 = ti * TS, c0 = tj * TS;
+    __shared__ int rmap[2][TS], cmap[2][TS];
+    const long long dp = fd.doff[p];
+    for (int i = threadIdx.x; i < 4 * TS; i += blockDim.x) {
+        const int side = (i / TS) & 1, isc = i / (2 * TS), k = i % TS;
+        const int g = (isc ? c0 : r0) + k;
+        const int v = (g < nfp && (side ? ch1 : ch0) >= 0) ? fd.cinv[side][dp + g] : -1;
+        if (isc) cmap[side][k] = v; else rmap[side][k] = v;
+    }
+    __syncthreads();
+    double* Fp = fd.F + fd.foff[p];
+    const double* F0 = ch0 >= 0 ? fd.F + fd.foff[ch0] : nullptr;
+    const double* F1 = ch1 >= 0 ? fd.F + fd.foff[ch1] : nullptr;
+    const int n0 = ch0 >= 0 ? fd.nf[ch0] : 0, n1 = ch1 >= 0 ? fd.nf[ch1] : 0;
+    const int* gd = fd.dofs + dp;
     for (int idx = threadIdx.x; idx < TS * TS; idx += blockDim.x) {
         const int lr = idx % TS, lc = idx / TS;
         const int r = r0 + lr, cc = c0 + lc;
-        if (r < nb && cc <= r) {
-            const double v = Fc[(npc + r) + (size_t)nfc * (npc + cc)];
-            int pr = up[r], pc = up[cc];
-            if (pr < pc) { const int tmp = pr; pr = pc; pc = tmp; }
-            Fp[pr + (size_t)nfp * pc] += v;
+        if (r < nfp && cc <= r) {
+            double v = 0.0;
+            int a = rmap[0][lr], b = cmap[0][lc];
+            if (a >= 0 && b >= 0) v += F0[max(a, b) + (size_t)n0 * min(a, b)];
+            a = rmap[1][lr]; b = cmap[1][lc];
+            if (a >= 0 && b >= 0) v += F1[max(a, b) + (size_t)n1 * min(a, b)];
+            if (mask && r == cc && r < npp && mask[gd[r]]) v = 1.0;
+            Fp[r + (size_t)nfp * cc] = v;
         }
     }
 }
