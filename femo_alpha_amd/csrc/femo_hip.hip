@@ -469,8 +469,24 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // outer panels of NBO columns, three launches each: the diagonal block (factor + inverse, one workgroup per
         // front), the rows below it (one GEMM against the inverse), the trailing update
         const bool wide = fr.h_level_wide[L];                      // these levels keep S for the triangular solves
+        int max_nb = 0;
+        for (int i = b; i < e; ++i) max_nb = std::max(max_nb, fr.h_nf[fr.h_level_nodes[i]] - fr.h_npiv[fr.h_level_nodes[i]]);
+        // Rank-k updates, two schedules (FEMO_TRAILING = left | right | auto):
+        //   right-looking -- after every outer panel, everything behind it is updated with that panel's 128 columns;
+        //   left-looking  -- a panel's columns receive all earlier columns' updates just before they are factorised and
+        //                    the Schur complement is updated once with K = npiv (each entry read and written once).
+        // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
+        // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
+        static const char* sched = getenv("FEMO_TRAILING");
+        const bool right_looking = sched && sched[0] == 'r' ? true : sched && sched[0] == 'l' ? false : (cnt < 16 || cnt > 2048);
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
+            if (C0 > 0 && !right_looking) {
+                // left-looking update of this panel's columns with all factor columns to their left
+                ProfScope ps(c, 2);
+                const int ntr = (max_nf - C0 + TS - 1) / TS;
+                hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 0);
+            }
             { ProfScope ps(c, 1);
               hipLaunchKernelGGL(k_diag_block, dim3(cnt), dim3(256), 0, c->stream, fd, lev, C0, sw, fr.info); }
             const int tiles = (std::max(0, max_nf - C0 - 1) + TS - 1) / TS;
@@ -478,13 +494,17 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 ProfScope ps(c, 0);
                 hipLaunchKernelGGL(k_panel_rows, dim3(tiles, cnt), dim3(256), 0, c->stream, fd, lev, C0, sw);
             }
-            if (max_nf > C0 + 1) {
+            if (right_looking && max_nf > C0 + 1) {
                 ProfScope ps(c, 2);
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
-                static const bool use_valu = getenv("FEMO_TRAILING_VALU") != nullptr;
-                if (use_valu) hipLaunchKernelGGL(k_trailing, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
-                else hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr, ntr, cnt), dim3(256), 0, c->stream, fd, lev, C0, NBO);
+                hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
             }
+        }
+        if (max_nb > 0 && !right_looking) {
+            // Schur complement: one update with all npiv factor columns
+            ProfScope ps(c, 2);
+            const int ntr = (max_nb + TS - 1) / TS;
+            hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
         }
         HIPCHK(c, hipGetLastError());
     }

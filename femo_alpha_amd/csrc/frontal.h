@@ -436,68 +436,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
     }
 }
 
-// P2: trailing update behind an outer panel:  A[r][c] -= sum_m L[r][m] L[c][m] over the factor columns
-// m in [C0, C0+kw), kw <= 128, for all columns c >= C0+kw and rows r >= c (lower-triangle 64x64 tiles);
-// the factor columns are staged through LDS 32 at a time, so each tile of A is read and written once
-// per 128 columns instead of once per 32.
-__global__ void __launch_bounds__(256)
-k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max) {
-    const int t = level_nodes[blockIdx.z];
-    const int np = fd.npiv[t];
-    if (kc0 >= np) return;
-    const int kw = min(kw_max, np - kc0);
-    const int nf = fd.nf[t];
-    const int col_lo = kc0 + kw;
-    const int col_hi = nf;
-    const int cj = col_lo + blockIdx.y * TS;
-    if (cj >= col_hi) return;
-    const int ri = cj + blockIdx.x * TS;           // row tiles start at the column tile (lower triangle)
-    if (ri >= nf) return;
-    double* F = fd.F + fd.foff[t];
-    __shared__ double si[NB][TS];
-    __shared__ double sj[NB][TS];
-    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;   // rows 4*tx.., cols 4*ty..
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k0 = 0; k0 < kw; k0 += NB) {
-        const int wb = min(NB, kw - k0);
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < NB * TS; idx += 256) {
-            const int r = idx % TS, c = idx / TS;
-            si[c][r] = (ri + r < nf && c < wb) ? F[(ri + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
-            sj[c][r] = (cj + r < col_hi && c < wb) ? F[(cj + r) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int mm = 0; mm < NB; ++mm) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                av[a] = si[mm][4 * tx + a];
-                bv[a] = sj[mm][4 * ty + a];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int cc = cj + 4 * ty + b;
-        if (cc >= col_hi) continue;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int r = ri + 4 * tx + a;
-            if (r < nf && r >= cc) F[r + (size_t)nf * cc] -= acc[a][b];
-        }
-    }
-}
-
-// P2 on the matrix cores: the same trailing update with v_mfma_f64_16x16x4_f64.
+// P2: rank-k update  C[r][c] -= sum_m L[r][m] L[c][m]  of lower-triangle 64x64 tiles with v_mfma_f64_16x16x4_f64.
 // Workgroup = 4 waves = one 64x64 tile of the front; wave w owns the 32x32 quarter (w&1 rows, w>>1 columns) as
 // 2x2 MFMA blocks.  To make the stores run along rows of the column-major front (coalesced), the product is
 // formed transposed: A[i][k] = L[c0+i][k] (tile columns), B[k][j] = L[r0+j][k] (tile rows), so D[i][j] = C[r0+j][c0+i];
@@ -506,16 +445,37 @@ k_trailing(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max
 constexpr int LSTR = TS + 16;
 
 __global__ void __launch_bounds__(256)
-k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int kw_max) {
+k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int schur) {
     const int t = level_nodes[blockIdx.z];
     const int np = fd.npiv[t];
-    if (kc0 >= np) return;
-    const int kw = min(kw_max, np - kc0);
     const int nf = fd.nf[t];
-    const int col_lo = kc0 + kw;
-    const int cj = col_lo + blockIdx.y * TS;
-    if (cj >= nf) return;
-    const int ri = cj + blockIdx.x * TS;           // row tiles start at the column tile (lower triangle)
+    // left-looking: the 128 pivot columns of an outer panel receive the updates of ALL earlier factor columns right
+    // before they are factorised (schur == 0: columns [C0, C0+128) of the pivot block, K = [0, C0)); the Schur
+    // complement is updated once, after the last panel, with K = npiv (schur == 1).  Every entry of the front is then
+    // read and written once per factorisation instead of once per 128 factor columns.
+    // schur == 2: right-looking -- everything behind the outer panel at C0 is updated with that panel's columns
+    if (schur != 1 && C0 >= np) return;
+    const int kc0 = schur == 2 ? C0 : 0;
+    const int kw = schur == 2 ? min(NBO, np - C0) : (schur ? np : C0);
+    const int col_lo = schur == 2 ? C0 + kw : (schur ? np : C0);
+    const int col_hi = schur == 0 ? min(C0 + NBO, np) : nf;
+    if (kw == 0) return;
+    // tile from the linear block index: consecutive workgroups go to different XCDs, so a (row tile, column tile)
+    // grid whose x extent is a multiple of 8 would pin every row-tile offset to one XCD -- and the lower triangle has
+    // 8x more tiles at offset 0 than at offset 7.  The linear order spreads them evenly (measured: up to 2.2x).
+    int bx, by;
+    if (schur == 0) {
+        by = blockIdx.x & 1; bx = blockIdx.x >> 1;                 // two column tiles per panel
+    } else {
+        const int lin = blockIdx.x;
+        int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+        while (ti * (ti + 1) / 2 > lin) --ti;
+        by = lin - ti * (ti + 1) / 2; bx = ti - by;                 // column tile by, row tile by + bx
+    }
+    const int cj = col_lo + by * TS;
+    if (cj >= col_hi) return;
+    const int ri = cj + bx * TS;                   // row tiles start at the column tile (lower triangle)
     if (ri >= nf) return;
     double* F = fd.F + fd.foff[t];
     // 16 factor columns per stage, two LDS buffers (20 KB each): the next stage travels global -> registers while the
@@ -549,7 +509,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int k
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                cpre[a][b][reg] = (r < nf && cc < nf && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+                cpre[a][b][reg] = (r < nf && cc < col_hi && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
             }
     mfma_d4 acc[2][2];
 #pragma unroll
@@ -588,7 +548,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int kc0, int k
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] = cpre[a][b][reg] - acc[a][b][reg];
+                if (r < nf && cc < col_hi && r >= cc) F[r + (size_t)nf * cc] = cpre[a][b][reg] - acc[a][b][reg];
             }
 }
 

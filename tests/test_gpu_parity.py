@@ -147,16 +147,19 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
         os.environ["FEMO_WIDE_NP"] = "96"            # wide kernels by pivot-block size: a mix of both paths in one tree
     if wide_cnt is not None:
         os.environ["FEMO_WIDE_CNT"] = str(wide_cnt)
+    if kind in ("plate24", "tri"):
+        os.environ["FEMO_TRAILING"] = "left"         # left-looking rank-k updates (the default on small meshes is right-looking)
     try:
         plan = c.enable_frontal(leaf_size=8)
+        c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+        info = c.factorize()
     finally:
         os.environ.pop("FEMO_WIDE_NP", None)
         os.environ.pop("FEMO_WIDE_CNT", None)
+        os.environ.pop("FEMO_TRAILING", None)
     assert plan.ntree > 1
     if kind == "plate24":
         assert plan.npiv.max() > 192
-    c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
-    info = c.factorize()
     assert info["pivots_repaired"] == 0
     w_ref, J_ref, dJ_ref = o.forward_adjoint()
     it, rr = c.solve_state(zero_guess=True)
