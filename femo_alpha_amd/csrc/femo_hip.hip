@@ -32,6 +32,8 @@ static std::string g_create_error;
 struct femo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
+    hipEvent_t ev_la[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
     int nghost = 0;
     bool quad = true, ewm = false, ewp = false, has_uhat = false;
@@ -479,6 +481,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
         static const char* sched = getenv("FEMO_TRAILING");
         const bool right_looking = sched && sched[0] == 'r' ? true : sched && sched[0] == 'l' ? false : (cnt < 16 || cnt > 2048);
+        static const bool no_lookahead = getenv("FEMO_NO_LOOKAHEAD") != nullptr;
+        const bool lookahead = right_looking && cnt < 16 && !fr.profile && !no_lookahead;
+        bool bulk_pending = false;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             if (C0 > 0 && !right_looking) {
@@ -495,11 +500,29 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 hipLaunchKernelGGL(k_panel_rows, dim3(tiles, cnt), dim3(256), 0, c->stream, fd, lev, C0, sw);
             }
             if (right_looking && max_nf > C0 + 1) {
-                ProfScope ps(c, 2);
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
-                hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
+                if (!lookahead) {
+                    ProfScope ps(c, 2);
+                    hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
+                } else {
+                    // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
+                    // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
+                    // chain of latency-bound launches at the top of the tree.  The next narrow update touches columns
+                    // the bulk update also writes, so it waits for it (ev_la[1]).
+                    if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
+                    hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3);
+                    const int ntb = ntr - NBO / TS;
+                    if (ntb > 0) {
+                        HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
+                        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
+                        hipLaunchKernelGGL(k_trailing_mfma, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4);
+                        HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
+                        bulk_pending = true;
+                    }
+                }
             }
         }
+        if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
         if (max_nb > 0 && !right_looking) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
@@ -688,6 +711,8 @@ static int alloc_d(femo_ctx* c, double** p, int64_t n) {
 static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, const int32_t* cell_p2, int nquad) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamCreate(&c->stream));
+    HIPCHK(c, hipStreamCreate(&c->stream2));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     const int nel = c->nel, nvc = c->nvc, npc = c->npc;
     // SoA connectivity
@@ -847,6 +872,9 @@ void femo_destroy(femo_ctx* c) {
     if (c->scal_host) hipHostFree(c->scal_host);
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_la[i]) hipEventDestroy(c->ev_la[i]);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -453,18 +453,19 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int sc
     // before they are factorised (schur == 0: columns [C0, C0+128) of the pivot block, K = [0, C0)); the Schur
     // complement is updated once, after the last panel, with K = npiv (schur == 1).  Every entry of the front is then
     // read and written once per factorisation instead of once per 128 factor columns.
-    // schur == 2: right-looking -- everything behind the outer panel at C0 is updated with that panel's columns
+    // schur >= 2: right-looking -- everything behind the outer panel at C0 is updated with that panel's columns
+    // (2: all of it; 3: only the next panel's 128 columns; 4: everything behind those -- the look-ahead split)
     if (schur != 1 && C0 >= np) return;
-    const int kc0 = schur == 2 ? C0 : 0;
-    const int kw = schur == 2 ? min(NBO, np - C0) : (schur ? np : C0);
-    const int col_lo = schur == 2 ? C0 + kw : (schur ? np : C0);
-    const int col_hi = schur == 0 ? min(C0 + NBO, np) : nf;
+    const int kc0 = schur >= 2 ? C0 : 0;
+    const int kw = schur >= 2 ? min(NBO, np - C0) : (schur ? np : C0);
+    const int col_lo = schur >= 2 ? C0 + kw + (schur == 4 ? NBO : 0) : (schur ? np : C0);
+    const int col_hi = schur == 0 ? min(C0 + NBO, np) : schur == 3 ? min(C0 + kw + NBO, nf) : nf;
     if (kw == 0) return;
     // tile from the linear block index: consecutive workgroups go to different XCDs, so a (row tile, column tile)
     // grid whose x extent is a multiple of 8 would pin every row-tile offset to one XCD -- and the lower triangle has
     // 8x more tiles at offset 0 than at offset 7.  The linear order spreads them evenly (measured: up to 2.2x).
     int bx, by;
-    if (schur == 0) {
+    if (schur == 0 || schur == 3) {
         by = blockIdx.x & 1; bx = blockIdx.x >> 1;                 // two column tiles per panel
     } else {
         const int lin = blockIdx.x;

@@ -201,7 +201,7 @@ k_big(double* Fall, int nf, int kc0, int kw) {
 }
 
 // 64x64 tile, C preloaded, LDS double-buffered: one barrier per 16-column stage
-template <bool NT, int KC>
+template <bool NT, int KC, bool PRE = true>
 __global__ void __launch_bounds__(256)
 k_db(double* Fall, int nf, int kc0, int kw) {
     double* F = Fall + (size_t)blockIdx.z * nf * nf;
@@ -240,7 +240,7 @@ k_db(double* Fall, int nf, int kc0, int kw) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
                 const double* p = &F[r + (size_t)nf * cc];
-                cpre[a][b][reg] = (r < nf && cc < nf && r >= cc) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
+                cpre[a][b][reg] = (PRE && r < nf && cc < nf && r >= cc) ? (NT ? __builtin_nontemporal_load(p) : *p) : 0.0;
             }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { si[0][lc + 4 * q][lr] = pi[q]; sj[0][lc + 4 * q][lr] = pj[q]; }
@@ -275,7 +275,8 @@ k_db(double* Fall, int nf, int kc0, int kw) {
                 const int r = ri + wr + 16 * b + l15;
                 if (r < nf && cc < nf && r >= cc) {
                     double* p = &F[r + (size_t)nf * cc];
-                    if (NT) __builtin_nontemporal_store(cpre[a][b][reg] - acc[a][b][reg], p); else *p = cpre[a][b][reg] - acc[a][b][reg];
+                    const double old = PRE ? cpre[a][b][reg] : *p;
+                    if (NT) __builtin_nontemporal_store(old - acc[a][b][reg], p); else *p = old - acc[a][b][reg];
                 }
             }
 }
@@ -287,7 +288,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nt = (nf - kw + TS - 1) / TS;
     const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
-    for (int mode = 0; mode < 13; ++mode)
+    for (int mode = 0; mode < 16; ++mode)
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
@@ -302,6 +303,9 @@ int main(int argc, char** argv) {
             if (mode == 8) hipLaunchKernelGGL((k_big<false>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 10) hipLaunchKernelGGL((k_db<false, 16>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 11) hipLaunchKernelGGL((k_db<true, 16>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 13) hipLaunchKernelGGL((k_db<false, 16, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 14) hipLaunchKernelGGL((k_db<false, 32, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 15) hipLaunchKernelGGL((k_db<false, 8, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 12) hipLaunchKernelGGL((k_db<false, 32>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
