@@ -218,32 +218,51 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double rsqrt_newton(double d) {
+    // 1/sqrt(d): hardware estimate + two Newton steps (no fp64 sqrt / divide expansion on the critical path)
+    double y = __builtin_amdgcn_rsq(d);
+    double e = 1.0 - d * y * y;
+    y = y + 0.5 * y * e;
+    e = 1.0 - d * y * y;
+    y = y + 0.5 * y * e;
+    return y;
+}
+
 __device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane) {
     int bad = 0;
+    // pivot of step 0
+    double d = rl(a[0], 0);
+    if (!(d > 0.0)) { if (0 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+    double y = rsqrt_newton(d);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double d = rl(a[j], j);
-        if (j < wb) {
-            if (!(d > 0.0)) { bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
-        } else {
-            d = 1.0;
-        }
-        // 1/sqrt(d): hardware estimate + two Newton steps (no fp64 sqrt / divide expansion on the critical path)
-        double y = __builtin_amdgcn_rsq(d);
-        double e = 1.0 - d * y * y;
-        y = y + 0.5 * y * e;
-        e = 1.0 - d * y * y;
-        y = y + 0.5 * y * e;
         // left half: column j of L for this lane's row (valid for lane >= j); right half: row j of L^-1
         const double l = (lane == j) ? d * y : a[j] * y;
         a[j] = l;
+        if (j + 1 < NB) {
+            // the next pivot is final after the first update: start its reciprocal square root now, so that this
+            // dependent chain (~150 cycles) runs beside the remaining updates of this step instead of after them
+            a[j + 1] -= l * rl(l, j + 1);
+            asm volatile("" : "+v"(a[j + 1]));
+            d = rl(a[j + 1], j + 1);
+            if (j + 1 < wb) {
+                if (!(d > 0.0)) { bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+            } else {
+                d = 1.0;
+            }
+            y = rsqrt_newton(d);
+        }
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-            const double lc = rl(l, c);                       // L[c][j]
-            a[c] -= l * lc;                                   // left half: only entries with c <= row are meaningful
-            // pin the update to this step: a[c] is not consumed before step c, and left to itself the compiler
+        for (int c = j + 2; c < NB; c += 2) {
+            // two broadcasts ahead of two updates: no wait states between a v_readlane and the FMA that consumes it
+            const double lc0 = rl(l, c);                      // L[c][j]
+            const double lc1 = (c + 1 < NB) ? rl(l, c + 1) : 0.0;
+            a[c] -= l * lc0;                                  // left half: only entries with c <= row are meaningful
+            if (c + 1 < NB) a[c + 1] -= l * lc1;
+            // pin the updates to this step: a[c] is not consumed before step c, and left to itself the compiler
             // defers the FMAs until then, keeping every broadcast alive in SGPRs (1500 of them spilled)
             asm volatile("" : "+v"(a[c]));
+            if (c + 1 < NB) asm volatile("" : "+v"(a[c + 1]));
         }
     }
     return bad;
@@ -276,6 +295,13 @@ __device__ __forceinline__ void mfma_blk(mfma_d4& acc, const blk32& A, const blk
 // GEMM against S^T, and the wide triangular solves use the same S.
 // Outputs: off-diagonal sub-blocks of L into F, the 32x32 inverses into Linv, S into Sout.
 // The diagonal sub-blocks of F are left as they were (nothing reads them afterwards).
+#ifdef FEMO_PANEL_STAMPS
+__device__ long long g_stamps[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 __global__ void __launch_bounds__(256)
 k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* __restrict__ Swork, int* __restrict__ info) {
     const int t = level_nodes[blockIdx.x];
@@ -291,26 +317,40 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
     __shared__ blk32 Wt;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
-    // load (identity padding beyond kw; only the lower triangle of the front is maintained)
-    for (int b = 0; b < 10; ++b) {
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-        const int bj = b - bi * (bi + 1) / 2;
-        if (bi >= nkb) break;
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            const int gr = NB * bi + r, gc = NB * bj + c;
-            double v = (gr == gc) ? 1.0 : 0.0;
-            if (gr < kw && gc < kw && gc <= gr) v = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
-            else if (gc > gr) v = 0.0;
-            D[b][r][c] = v;
+    // load (identity padding beyond kw; only the lower triangle of the front is maintained): all 40 loads of a thread
+    // are issued before the first one is consumed -- a loop over the sub-blocks would pay the memory latency ten times
+    {
+        double v[10][4];
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+            const int bi = b < 1 ? 0 : b < 3 ? 1 : b < 6 ? 2 : 3;
+            const int bj = b - bi * (bi + 1) / 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                const int r = idx % NB, c = idx / NB;
+                const int gr = NB * bi + r, gc = NB * bj + c;
+                v[b][q] = (gr == gc) ? 1.0 : 0.0;
+                if (bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
+            }
         }
+#pragma unroll
+        for (int b = 0; b < 10; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                D[b][idx % NB][idx / NB] = v[b][q];
+            }
     }
-    for (int idx = tid; idx < SPD * SPD; idx += 256) Sout[idx] = 0.0;
+    // (no zero fill of S: every sub-block on or below the block diagonal is written in full below, and nothing above it
+    //  or beyond the kw columns is ever read)
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
     for (int j = 0; j < nkb; ++j) {
         blk32& Djj = D[j * (j + 1) / 2 + j];
         const int wb = min(NB, kw - NB * j);
+        STAMP(2 + 4 * j);
         if (wv == 0) {
             double a[NB];
 #pragma unroll
@@ -329,6 +369,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
             }
         }
         __syncthreads();
+        STAMP(3 + 4 * j);
         if (j + 1 < nkb) {
             // L_ij = D_ij Linv_j^T for the sub-blocks below
             mfma_d4 acc[3];
@@ -351,6 +392,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
                 }
             }
             __syncthreads();
+            STAMP(4 + 4 * j);
             // D_ik -= L_ij L_kj^T, i >= k > j (each wave updates its own sub-block of every D_ik)
             for (int i = j + 1; i < nkb; ++i)
                 for (int k = j + 1; k <= i; ++k) {
@@ -364,6 +406,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
         }
     }
     // inverse of the kw x kw factor, block column by block column
+    STAMP(20);
     for (int j = 0; j < nkb; ++j) {
         const blk32& Sjj = D[j * (j + 1) / 2 + j];
         for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -391,6 +434,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
             __syncthreads();
         }
     }
+    STAMP(21);
 }
 
 // PB: rows below the diagonal block of the outer panel: L[r][C0 + c] = sum_{k <= c} A[r][C0 + k] S[c][k] -- one GEMM

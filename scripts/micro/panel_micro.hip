@@ -1,5 +1,6 @@
 // micro-benchmark: launch durations of the diagonal-block / panel-rows / trailing kernels on a batch of synthetic
 // fronts.   usage: panel_micro [nfronts nf npiv]
+#define FEMO_PANEL_STAMPS
 #include "../../femo_alpha_amd/csrc/frontal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -48,11 +49,18 @@ int main(int argc, char** argv) {
                     CK(hipEventElapsedTime(&ms2, e0, e1)); tp += ms2;
                 }
                 if (rep == 1) printf("C0=%4d: diag block %6.1f us, rows (%d tiles) %6.1f us\n", C0, ms * 1e3, tiles, ms2 * 1e3);
+                if (rep == 1 && C0 == 0) {
+                    long long st[32]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
+                    printf("   load %.2f zero-S %.2f |", (st[0] - st[0]) * 0.01, (st[1] - st[0]) * 0.01);
+                    for (int j = 0; j < 4; ++j) printf(" step%d: chol %.2f trsm %.2f upd %.2f |", j, (st[3 + 4 * j] - st[2 + 4 * j]) * 0.01,
+                                                       j < 3 ? (st[4 + 4 * j] - st[3 + 4 * j]) * 0.01 : 0.0, j < 3 ? (st[2 + 4 * (j + 1)] - st[4 + 4 * j]) * 0.01 : 0.0);
+                    printf(" S-phase %.2f\n", (st[21] - st[20]) * 0.01);
+                }
             }
             const int nt = (nf - C0 - kw + TS - 1) / TS;
             if (nt > 0) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_trailing_mfma, dim3(nt, nt, nfr), dim3(256), 0, 0, fd, dlev, C0, NBO);
+                hipLaunchKernelGGL(k_trailing_mfma, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, C0, 2);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt += ms;
                 if (rep == 1) printf("  trailing C0=%4d nt=%3d: %7.1f us\n", C0, nt, ms * 1e3);
