@@ -61,7 +61,26 @@ def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: 
 class RMShellModel:
     def __init__(self, mesh: ShellMesh, shell_bc_func: callable = None, element_wise_material=False, rho=100,
                  PENALTY_BC=True, additional_outputs=None, mesh_tags=None, record=True, elementwise_pressure=False,
-                 device=0):
+                 device=0, renumber=False):
+        # caller order <-> solver order.  dolfinx reorders every mesh it is given and the reference carries the maps
+        # (rm_shell_model.py:116, 396-438, 505-527); with renumber=True this build does the same with a Morton order of
+        # the cells (ShellMesh.renumbered): inputs are gathered into solver order, nodal displacements come back in
+        # caller order, the state ``disp_solid`` lives in solver order as it does in the reference.
+        self.caller_mesh = mesh
+        if renumber:
+            mesh, self.vertex_of_new, self.cell_of_new = mesh.renumbered()
+        else:
+            self.vertex_of_new, self.cell_of_new = np.arange(mesh.nn), np.arange(mesh.nel)
+        self.new_of_vertex = np.empty(mesh.nn, dtype=np.int64)
+        self.new_of_vertex[self.vertex_of_new] = np.arange(mesh.nn)
+        self.new_of_cell = np.empty(mesh.nel, dtype=np.int64)
+        self.new_of_cell[self.cell_of_new] = np.arange(mesh.nel)
+        if mesh_tags is not None:
+            for inds in mesh_tags.values():
+                inds = np.asarray(inds, dtype=np.int64)
+                if inds.size and (inds.min() < 0 or inds.max() >= mesh.nel):
+                    raise ValueError("mesh_tags: cell index out of range")
+            mesh_tags = {tag: self.new_of_cell[np.asarray(inds, dtype=np.int64)] for tag, inds in mesh_tags.items()}
         self.mesh = mesh
         self.mesh_tags = mesh_tags
         self.additional_outputs = additional_outputs
@@ -155,12 +174,12 @@ class RMShellModel:
         mesh = self.mesh
         # caller order == solver order here; the gathers are kept so that a renumbered mesh object
         # can plug in its permutations exactly where the reference applies them (:398-438)
-        mat_idx = np.arange(mesh.nel if self.element_wise_material else mesh.nn)
+        mat_idx = self.cell_of_new if self.element_wise_material else self.vertex_of_new
         shell_inputs.thickness = thickness[mat_idx]
         shell_inputs.E = E[mat_idx]
         shell_inputs.nu = nu[mat_idx]
         shell_inputs.density = density[mat_idx]
-        prs_idx = np.arange(mesh.nel if self.elementwise_pressure else mesh.nn)
+        prs_idx = self.cell_of_new if self.elementwise_pressure else self.vertex_of_new
         reshaped_force = csdl.reshape(force_vector[prs_idx], (-1,))
         if is_pressure:
             shell_inputs.F_solid = reshaped_force
@@ -171,7 +190,7 @@ class RMShellModel:
         shell_inputs.F_solid.add_name("F_solid")
         if node_disp is None:
             node_disp = csdl.Variable(value=0.0, shape=(mesh.nn, 3), name="node_disp")
-        reshaped_node_disp = node_disp[np.arange(mesh.nn)].reshape((-1,))
+        reshaped_node_disp = node_disp[self.vertex_of_new].reshape((-1,))
         reshaped_node_disp.add_name("uhat")
         shell_inputs.uhat = reshaped_node_disp
         for n in ("thickness", "E", "nu", "density"):
@@ -181,6 +200,7 @@ class RMShellModel:
         shell_outputs = solid_model.evaluate(shell_inputs, debug_mode=debug_mode)
 
         disp_extracted = DisplacementExtractionModel(shell_pde=self.shell_pde).evaluate(shell_outputs.disp_solid)
+        disp_extracted = disp_extracted[self.new_of_vertex]              # solver order -> caller order
         disp_extracted.add_name("disp_extracted")
         shell_outputs.disp_extracted = disp_extracted
         aggregated_stress = AggregatedStressModel(m=self.m, rho=self.rho).evaluate(shell_outputs.pnorm_stress)

@@ -176,3 +176,45 @@ def test_mesh_tags_give_per_tag_stress_aggregates():
     assert out.pnorm_stress_root_bay.value[0] > getattr(out, "pnorm_stress_7").value[0]
     with pytest.raises(ValueError, match="one tag only"):
         RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False, mesh_tags={"a": [0, 1], "b": [1]})
+
+
+def test_renumbered_model_answers_in_caller_order():
+    """renumber=True: the solver works on a Morton-ordered copy of the mesh (as dolfinx reorders what it reads);
+    inputs, nodal displacements and gradients keep the caller's numbering (rm_shell_model.py:396-438, 505-527)."""
+    from femo_alpha_amd.mesh import wing_skin_mesh
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    from oracle.rm_shell_oracle import ShellOracle
+    mesh = wing_skin_mesh(8, 24, shuffle=True)
+    nn, nel = mesh.nn, mesh.nel
+    root = lambda x: np.less(x[1], 1e-12)
+    rng = np.random.default_rng(3)
+    h0 = 0.02 * (1 + 0.3 * rng.uniform(-1, 1, nn))
+    f0 = rng.uniform(-1, 1, (nn, 3)) * 40.0
+    recorder = csdl.Recorder(inline=True)
+    recorder.start()
+    pressure = csdl.Variable(value=f0, name="force_vector")
+    thickness = csdl.Variable(value=h0, name="thickness")
+    E = csdl.Variable(value=7e9 * np.ones(nn), name="E")
+    nu = csdl.Variable(value=0.3 * np.ones(nn), name="nu")
+    density = csdl.Variable(value=2700.0 * np.ones(nn), name="density")
+    tags = {"outboard": np.nonzero(mesh.nodes[mesh.cells].mean(axis=1)[:, 1] > 3.0)[0].tolist()}
+    model = RMShellModel(mesh, shell_bc_func=root, record=False, renumber=True, mesh_tags=tags)
+    assert not np.array_equal(model.vertex_of_new, np.arange(nn))
+    ctx = model.shell_pde.ctx
+    ctx.enable_frontal(8)
+    ctx.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    out = model.evaluate(pressure, thickness, E, nu, density)
+    recorder.stop()
+    o = ShellOracle(mesh, penalty_facets=mesh.penalty_facets(root))
+    o.set_fields(h=h0, E=7e9, nu=0.3, rho=2700.0, f=f0)
+    w_ref, J_ref, dJ_ref = o.forward_adjoint()
+    assert abs(out.compliance.value[0] - J_ref) < 1e-8 * abs(J_ref)
+    assert abs(out.mass.value[0] - o.mass()) < 1e-11 * o.mass()
+    u_ref = w_ref[:3 * nn].reshape(nn, 3)
+    assert np.abs(out.disp_extracted.value - u_ref).max() < 1e-7 * np.abs(u_ref).max()
+    dJ = recorder.compute_totals(out.compliance, thickness)
+    assert np.abs(np.ravel(dJ) - dJ_ref).max() < 1e-7 * np.abs(dJ_ref).max()
+    o3 = ShellOracle(mesh, nquad=3)
+    o3.set_fields(h=h0, E=7e9, nu=0.3)
+    ref = o3.pnorm_stress(w_ref, 1e-6, 100, cells=tags["outboard"])
+    assert abs(out.pnorm_stress_outboard.value[0] - ref) < 1e-6 * ref
