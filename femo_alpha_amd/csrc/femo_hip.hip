@@ -439,8 +439,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
         if (refresh_penalty(c)) return 1;
         { ProfScope ps(c, 4);
-        ELEM_LAUNCH(c, k_front_assemble, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
-                    fr.elem_map, mask); }
+        if (c->op_aM != 0.0)
+            ELEM_LAUNCH(c, k_front_assemble, COMMA_TRUE, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+                        fr.elem_map, mask);
+        else
+            ELEM_LAUNCH(c, k_front_assemble, COMMA_FALSE, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+                        fr.elem_map, mask); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
                                fr.elem_map, c->ld, c->npc, c->nvc, mask);

@@ -46,7 +46,7 @@ struct FrontDev {
 // ------------------------------------------------------------------------------------------ assembly
 // one wave per element; lane j evaluates column j of K_e (operator applied to e_j) and adds its
 // lower-triangle entries into the element's leaf front.  Masked (strong-BC) rows/columns are skipped.
-template <int NPC, int NVC, bool QUAD, bool UHAT>
+template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS>
 __global__ void __launch_bounds__(64)
 k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double aK, double aM, FrontDev fd,
                  const int* __restrict__ elem_front, const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
@@ -56,12 +56,13 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
     if (e >= m.nel || j >= LD) return;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, UHAT>(m, f, e, el);
-    double xe[LD], ye[LD];
+    double ye[LD];
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
-        xe[i] = (i == j) ? 1.0 : 0.0;
-        ye[i] = 0.0;
-    }
+    for (int i = 0; i < LD; ++i) ye[i] = 0.0;
+    // the lane's unit vector e_j: displacement component cj of P2 node aj, or rotation component cj of vertex aj
+    const bool is_u = j < 3 * NPC;
+    const int aj = is_u ? j / 3 : (j - 3 * NPC) / 3;
+    const int cj = j - 3 * (is_u ? aj : NPC + aj);
     const int nq = tab->nq;
     for (int q = 0; q < nq; ++q) {
         QPG g;
@@ -73,12 +74,30 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
         material<DERIV_NONE>(hq, interp<NVC>(tab->N1[q], el.En),
                              interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
         mat.cm *= aK; mat.cb *= aK; mat.cs *= aK; mat.cd *= aK;
-        const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
+        // strains of e_j without the 39-entry reduction: the reduced vectors are scalar multiples of one unit vector;
+        // the lane reads its own node's table row (a per-lane index into d[][] would send the array to scratch)
+        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
+        const double dk0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], dk1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double Mj = is_u ? 0.0 : tab->N1[q][aj];
+        double G0[3], G1[3], th[3], T0[3], T1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ec = (c == cj) ? 1.0 : 0.0;
+            G0[c] = is_u ? dk0 * ec : 0.0;
+            G1[c] = is_u ? dk1 * ec : 0.0;
+            th[c] = Mj * ec;
+            T0[c] = is_u ? 0.0 : dk0 * ec;
+            T1[c] = is_u ? 0.0 : dk1 * ec;
+        }
+        const Gen s = strains_reduced(g, G0, G1, th, T0, T1);
         const Gen t = stress_of(s, mat);
         strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
-        if (aM != 0.0) {
+        if (MASS) {            // compiled out of the static operator: keeps its register budget
             double rq = 0.0;
             for (int b = 0; b < NVC; ++b) rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
+            double xe[LD];
+#pragma unroll
+            for (int i = 0; i < LD; ++i) xe[i] = (i == j) ? 1.0 : 0.0;
             mass_qp<NPC, NVC>(*tab, q, aM * rq * hq * tab->w[q] * g.det * g.Ju, el.hK, xe, ye);
         }
     }
@@ -87,12 +106,14 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
     double* F = fd.F + fd.foff[t];
     const int* map = elem_map + (size_t)e * LD;
     const int* gd = fd.dofs + fd.doff[t];
+    // K_e is symmetric: the lane's column j is also row j.  Adding it as a ROW makes the 39 lanes of one atomic
+    // instruction hit one column of the front (a few cache lines) instead of 39 different columns.
     const int pj = map[j];
     if (mask && mask[gd[pj]]) return;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
         const int pi = map[i];
-        if (pi >= pj && !(mask && mask[gd[pi]])) atomicAdd(&F[pi + (size_t)nf * pj], ye[i]);
+        if (pj >= pi && !(mask && mask[gd[pi]])) atomicAdd(&F[pj + (size_t)nf * pi], ye[i]);
     }
 }
 
@@ -185,17 +206,29 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, const unsigned
     const double* F1 = ch1 >= 0 ? fd.F + fd.foff[ch1] : nullptr;
     const int n0 = ch0 >= 0 ? fd.nf[ch0] : 0, n1 = ch1 >= 0 ? fd.nf[ch1] : 0;
     const int* gd = fd.dofs + dp;
-    for (int idx = threadIdx.x; idx < TS * TS; idx += blockDim.x) {
-        const int lr = idx % TS, lc = idx / TS;
-        const int r = r0 + lr, cc = c0 + lc;
+    // a thread owns row lr of the tile and 16 of its columns: all child reads are issued before the first store
+    const int lr = threadIdx.x % TS, lc0 = threadIdx.x / TS;
+    const int r = r0 + lr;
+    const int ra0 = rmap[0][lr], ra1 = rmap[1][lr];
+    double v[TS / 4];
+#pragma unroll
+    for (int k = 0; k < TS / 4; ++k) {
+        const int lc = lc0 + 4 * k, cc = c0 + lc;
+        double x = 0.0;
         if (r < nfp && cc <= r) {
-            double v = 0.0;
-            int a = rmap[0][lr], b = cmap[0][lc];
-            if (a >= 0 && b >= 0) v += F0[max(a, b) + (size_t)n0 * min(a, b)];
-            a = rmap[1][lr]; b = cmap[1][lc];
-            if (a >= 0 && b >= 0) v += F1[max(a, b) + (size_t)n1 * min(a, b)];
-            if (mask && r == cc && r < npp && mask[gd[r]]) v = 1.0;
-            Fp[r + (size_t)nfp * cc] = v;
+            const int b0 = cmap[0][lc], b1 = cmap[1][lc];
+            if (ra0 >= 0 && b0 >= 0) x += F0[max(ra0, b0) + (size_t)n0 * min(ra0, b0)];
+            if (ra1 >= 0 && b1 >= 0) x += F1[max(ra1, b1) + (size_t)n1 * min(ra1, b1)];
+        }
+        v[k] = x;
+    }
+#pragma unroll
+    for (int k = 0; k < TS / 4; ++k) {
+        const int cc = c0 + lc0 + 4 * k;
+        if (r < nfp && cc <= r) {
+            double x = v[k];
+            if (mask && r == cc && r < npp && mask[gd[r]]) x = 1.0;
+            Fp[r + (size_t)nfp * cc] = x;
         }
     }
 }

@@ -337,6 +337,11 @@ __device__ __forceinline__ void local_derivs(const Tables& t, int q, const doubl
     }
 }
 
+// generalised strains from the six reduced 3-vectors  G_k = sum_a d[a][k] u_a,  th = sum_b M_b theta_b,
+// T_k = sum_b m[b][k] theta_b
+__device__ __forceinline__ Gen strains_reduced(const QPG& g, const double* G0, const double* G1, const double* th,
+                                               const double* T0, const double* T1);
+
 // strains of the element vector xe = [u_a xyz ..., theta_b xyz ...]
 template <int NPC, int NVC>
 __device__ __forceinline__ Gen strains(const QPG& g, const double (*d)[2], const double (*m)[2], const double* M,
@@ -359,6 +364,11 @@ __device__ __forceinline__ Gen strains(const QPG& g, const double (*d)[2], const
             T0[c] += m[b][0] * v;
             T1[c] += m[b][1] * v;
         }
+    return strains_reduced(g, G0, G1, th, T0, T1);
+}
+
+__device__ __forceinline__ Gen strains_reduced(const QPG& g, const double* G0, const double* G1, const double* th,
+                                               const double* T0, const double* T1) {
     Gen s;
     const double t00 = dot3(g.E0, G0), t01 = dot3(g.E0, G1), t10 = dot3(g.E1, G0), t11 = dot3(g.E1, G1);
     s.e00 = t00;
