@@ -596,7 +596,7 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (fr.h_level_wide[L]) {
             if (maxnb > 0)
-                hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + 3) / 4, cnt), dim3(256), 0, c->stream, fd, lev, y, v);
+                hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + BB_COLS - 1) / BB_COLS, cnt), dim3(256), (size_t)maxnb * sizeof(double), c->stream, fd, lev, y, v);
             for (int c0 = ((maxnp - 1) / SP) * SP; c0 >= 0; c0 -= SP)
             {
                 hipLaunchKernelGGL(k_front_bwd_tri, dim3(cnt), dim3(TRI_T), 0, c->stream, fd, lev, c0, y, v);
@@ -1415,6 +1415,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         const int bytes = (int)((fr.max_nf + NB) * sizeof(double));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_bnd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     fr.ready = true;
     fr.factored = false;

@@ -723,21 +723,46 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
     for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
 }
 
-// backward, boundary part for the wide levels: s_c = y_c - sum_{r in boundary} L21[r][c] x[r]; one wave per pivot column
+// backward, boundary part for the wide levels: s_c = y_c - sum_{r in boundary} L21[r][c] x[r].
+// A workgroup stages the boundary values x[gd[r]] once in LDS and takes BB_COLS pivot columns, four per wave at a
+// time with the lanes along the (contiguous) column -- eight independent loads per lane and iteration.
+constexpr int BB_COLS = 32;
 __global__ void __launch_bounds__(256)
 k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int c = blockIdx.x * 4 + wid;
-    if (c >= np || nf == np) return;
-    const double* col = fd.F + fd.foff[t] + (size_t)nf * c;
+    const int nb = nf - np;
+    const int c0 = blockIdx.x * BB_COLS;
+    if (c0 >= np || nb == 0) return;
+    extern __shared__ double xs[];                       // nb
     const int* gd = fd.dofs + fd.doff[t];
-    double s = 0.0;
-#pragma unroll 4
-    for (int r = np + lane; r < nf; r += 64) s += col[r] * xv[gd[r]];
-    s = wave_sum(s);
-    if (lane == 0) sv[gd[c]] -= s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int r = tid; r < nb; r += 256) xs[r] = xv[gd[np + r]];
+    __syncthreads();
+    const double* L21 = fd.F + fd.foff[t] + np;          // rows np.., column c at + nf * c
+    for (int g = 0; g < BB_COLS / 16; ++g) {
+        const int cb = c0 + 16 * g + 4 * wv;             // this wave's four columns
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        const double* col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)nf * min(cb + k, np - 1);
+        int r = lane;
+        for (; r + 64 < nb; r += 128) {
+            const double x0 = xs[r], x1 = xs[r + 64];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0 + col[k][r + 64] * x1;
+        }
+        if (r < nb) {
+            const double x0 = xs[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double tot = wave_sum(s[k]);
+            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
+        }
+    }
 }
 
 constexpr int SP = 128;    // columns handled per launch by the wide solve kernels (4 diagonal blocks)
