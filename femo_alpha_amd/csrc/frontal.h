@@ -482,12 +482,16 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
     if (C0 >= np) return;
     const int kw = min(NBO, np - C0);
     const int nf = fd.nf[t];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int row0 = C0 + kw + blockIdx.x * TS + 16 * wv;
-    if (row0 >= nf) return;
+    const int tile0 = C0 + kw + blockIdx.x * TS;
+    if (tile0 >= nf) return;
+    const int row0 = tile0 + 16 * wv;
     double* F = fd.F + fd.foff[t];
     const double* S = Swork ? Swork + (size_t)blockIdx.y * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    // S is shared by the four waves: the 16 rows of S that produce output columns [16 cb, 16 cb + 16) are staged in
+    // LDS (k-major, so that the MFMA A operand S[c][k] is a conflict-free read), double-buffered over cb
+    __shared__ double sb[2][NBO][16];
     const int row = row0 + l15;
     const bool rok = row < nf;
     double a[NBO / 4];
@@ -496,20 +500,36 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
         const int k = 4 * kk + l4;
         a[kk] = (rok && k < kw) ? F[row + (size_t)nf * (C0 + k)] : 0.0;
     }
+    const int sc = tid & 15, sk0 = tid >> 4;              // staging: column sc of the block, rows sk0, sk0 + 16, ...
+    double pre[NBO / 16];
+    // stage block 0
+#pragma unroll
+    for (int q = 0; q < 1; ++q) pre[q] = S[sc + (size_t)SPD * (sk0 + 16 * q)];
+    sb[0][sk0][sc] = pre[0];
+    __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < NBO / 16; ++cb) {
         if (16 * cb >= kw) break;
+        const int cur = cb & 1;
+        const bool more = cb + 1 < NBO / 16 && 16 * (cb + 1) < kw;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < cb + 2; ++q) pre[q] = S[(16 * (cb + 1) + sc) + (size_t)SPD * (sk0 + 16 * q)];
+        }
         mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < 4 * cb + 4; ++kk) {
-            const double sv = S[(16 * cb + l15) + (size_t)SPD * (4 * kk + l4)];       // S[c][k]
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sv, a[kk], acc, 0, 0, 0);      // D[i = column][j = row]
-        }
+        for (int kk = 0; kk < 4 * cb + 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sb[cur][4 * kk + l4][l15], a[kk], acc, 0, 0, 0);   // D[i = column][j = row]
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int c = 16 * cb + l4 + 4 * reg;
             if (rok && c < kw) F[row + (size_t)nf * (C0 + c)] = acc[reg];
         }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < cb + 2; ++q) sb[cur ^ 1][sk0 + 16 * q][sc] = pre[q];
+        }
+        __syncthreads();
     }
 }
 
