@@ -494,7 +494,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 // left-looking update of this panel's columns with all factor columns to their left
                 ProfScope ps(c, 2);
                 const int ntr = (max_nf - C0 + TS - 1) / TS;
-                hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 0);
+                hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 0);
             }
             { ProfScope ps(c, 1);
               hipLaunchKernelGGL(k_diag_block, dim3(cnt), dim3(256), 0, c->stream, fd, lev, C0, sw, fr.info); }
@@ -507,19 +507,19 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
                 if (!lookahead) {
                     ProfScope ps(c, 2);
-                    hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
+                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
                     // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
                     // chain of latency-bound launches at the top of the tree.  The next narrow update touches columns
                     // the bulk update also writes, so it waits for it (ev_la[1]).
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
-                    hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3);
+                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3);
                     const int ntb = ntr - NBO / TS;
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
-                        hipLaunchKernelGGL(k_trailing_mfma, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4);
+                        hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4);
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
@@ -531,7 +531,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
             const int ntr = (max_nb + TS - 1) / TS;
-            hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
+            if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
+            else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
         }
         HIPCHK(c, hipGetLastError());
     }

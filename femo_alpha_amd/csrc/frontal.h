@@ -541,6 +541,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
 // LDS rows are padded to 80 doubles so that the four 16-lane groups of a ds_read_b64 hit disjoint banks.
 constexpr int LSTR = TS + 16;
 
+template <bool PRE>
 __global__ void __launch_bounds__(256)
 k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int schur) {
     const int t = level_nodes[blockIdx.z];
@@ -596,7 +597,8 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int sc
         }
     };
     fetch(0);
-    // the tile of C is read up front as well: its latency hides behind the whole K loop instead of ending the kernel
+    // the tile of C is read up front as well (PRE): its latency hides behind the whole K loop instead of ending the
+    // kernel.  Long K loops (Schur updates with K = npiv >= 256) do better without: 32 registers less, one more wave per SIMD.
     // D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
     double cpre[2][2][4];
 #pragma unroll
@@ -607,7 +609,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int sc
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                cpre[a][b][reg] = (r < nf && cc < col_hi && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+                cpre[a][b][reg] = (PRE && r < nf && cc < col_hi && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
             }
     mfma_d4 acc[2][2];
 #pragma unroll
@@ -646,7 +648,10 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int sc
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (r < nf && cc < col_hi && r >= cc) F[r + (size_t)nf * cc] = cpre[a][b][reg] - acc[a][b][reg];
+                if (r < nf && cc < col_hi && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
+                }
             }
 }
 

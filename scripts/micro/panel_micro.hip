@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
             const int nt = (nf - C0 - kw + TS - 1) / TS;
             if (nt > 0) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_trailing_mfma, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, C0, 2);
+                hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, C0, 2);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt += ms;
                 if (rep == 1) printf("  trailing C0=%4d nt=%3d: %7.1f us\n", C0, nt, ms * 1e3);
