@@ -435,59 +435,6 @@ __device__ __forceinline__ double interp(const double* M, const double* v) {
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-// y += K_elastic x (element by element, matrix-free); *dotslot += x . K_elastic x
-template <int NPC, int NVC, bool QUAD, bool UHAT>
-__global__ void __launch_bounds__(128)
-k_apply(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ x, double* __restrict__ y,
-        double* dotslot, double* zero_a, double* zero_b) {
-    constexpr int LD = 3 * NPC + 3 * NVC;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (zero_a) *zero_a = 0.0;
-        if (zero_b) *zero_b = 0.0;
-    }
-    double local = 0.0;
-    if (e < m.nel) {
-        Elem<NPC, NVC> el;
-        load_elem<NPC, NVC, UHAT>(m, f, e, el);
-        double xe[LD], ye[LD];
-#pragma unroll
-        for (int a = 0; a < NPC; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) xe[3 * a + c] = x[3 * el.pid[a] + c];
-#pragma unroll
-        for (int b = 0; b < NVC; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = x[m.ndof_u + 3 * el.vid[b] + c];
-#pragma unroll
-        for (int i = 0; i < LD; ++i) ye[i] = 0.0;
-        const int nq = tab->nq;
-        for (int q = 0; q < nq; ++q) {
-            QPG g;
-            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
-            double d[NPC][2], mm[NVC][2];
-            local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
-            Mat mat, ex;
-            material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                                 interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
-            const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
-            const Gen t = stress_of(s, mat);
-            strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
-        }
-#pragma unroll
-        for (int i = 0; i < LD; ++i) local += xe[i] * ye[i];
-#pragma unroll
-        for (int a = 0; a < NPC; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&y[3 * el.pid[a] + c], ye[3 * a + c]);
-#pragma unroll
-        for (int b = 0; b < NVC; ++b)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(&y[m.ndof_u + 3 * el.vid[b] + c], ye[3 * NPC + 3 * b + c]);
-    }
-    if (dotslot) block_accumulate(local, dotslot);
-}
-
 // register-lean variants for the production operator: local derivatives are recomputed from the
 // (scalar-cached) tables where they are used instead of being kept in 26 register pairs
 template <int NPC, int NVC>

@@ -281,6 +281,92 @@ k_db(double* Fall, int nf, int kc0, int kw) {
             }
 }
 
+// 128 x 64 tile per workgroup (wave = 64 rows x 32 columns: 4 x 2 MFMA blocks), LDS double-buffered
+template <bool PRE>
+__global__ void __launch_bounds__(256)
+k_rect(double* Fall, int nf, int kc0, int kw) {
+    constexpr int TR = 128, TC = 64, KC = 16, LSR = TR + 16, LSC = TC + 16;
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TC;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TR;
+    if (ri >= nf) return;
+    __shared__ double si[2][KC][LSR];
+    __shared__ double sj[2][KC][LSC];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 64, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][4];                                  // [column block][row block]
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    // staging: rows tile 128 x 16 -> 8 per thread; cols tile 64 x 16 -> 4 per thread
+    const int lr = tid % TR, lcr = tid / TR;            // lcr in 0..1: columns lcr, lcr+2, ...
+    const int lc = tid % TC, lcc = tid / TC;            // lcc in 0..3
+    double pi[8], pj[4];
+    const bool iok = ri + lr < nf, jok = cj + lc < nf;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int c = lcr + 2 * q; pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = lcc + 4 * q; pj[q] = (jok && k0 + c < kw) ? F[(cj + lc) + (size_t)nf * (kc0 + k0 + c)] : 0.0; }
+    };
+    fetch(0);
+    double cpre[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                cpre[a][b][reg] = (PRE && r < nf && cc < nf && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+            }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) si[0][lcr + 2 * q][lr] = pi[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sj[0][lcc + 4 * q][lc] = pj[q];
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const bool more = k0 + KC < kw;
+        if (more) fetch(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = sj[cur][kk + l4][wc + 16 * a + l15];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = si[cur][kk + l4][wr + 16 * b + l15];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) si[cur ^ 1][lcr + 2 * q][lr] = pi[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sj[cur ^ 1][lcc + 4 * q][lc] = pj[q];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
+                }
+            }
+}
+
 int main(int argc, char** argv) {
     const int nfr = argc > 1 ? atoi(argv[1]) : 8, nf = argc > 2 ? atoi(argv[2]) : 3200, kw = argc > 3 ? atoi(argv[3]) : 128;
     double* F; CK(hipMalloc(&F, sizeof(double) * (size_t)nfr * nf * nf));
@@ -288,7 +374,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nt = (nf - kw + TS - 1) / TS;
     const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
-    for (int mode = 0; mode < 16; ++mode)
+    for (int mode = 0; mode < 18; ++mode)
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
@@ -307,6 +393,8 @@ int main(int argc, char** argv) {
             if (mode == 14) hipLaunchKernelGGL((k_db<false, 32, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 15) hipLaunchKernelGGL((k_db<false, 8, false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 12) hipLaunchKernelGGL((k_db<false, 32>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 16) hipLaunchKernelGGL((k_rect<true>), dim3((nf - kw + 127) / 128, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 17) hipLaunchKernelGGL((k_rect<false>), dim3((nf - kw + 127) / 128, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
