@@ -233,6 +233,9 @@ static void build_tables(bool quad, int nquad, Tables& T, int nred = 0) {
 // ------------------------------------------------------------------------------------------ launch helpers
 static inline int nblk(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 static inline int vec_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+// reductions end in one atomic per workgroup on a single address (~13 ns each, serialised): keep the grid at one
+// workgroup per CU
+static inline int red_grid(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 256); }
 
 static MeshDev mesh_dev(const femo_ctx* c) {
     MeshDev m;
@@ -342,7 +345,7 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
     if (refresh_diag(c)) return 1;
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
     if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
-    hipLaunchKernelGGL(k_dot, dim3(vg), dim3(256), 0, c->stream, b, b, n, c->scal + 6);
+    hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, b, b, n, c->scal + 6);
     hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
     if (zero_guess) {
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
@@ -632,7 +635,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     auto dot = [&](const double* a, const double* bb, double* out) -> int {
         HIPCHK(c, hipMemsetAsync(c->scal + 7, 0, sizeof(double), c->stream));
-        hipLaunchKernelGGL(k_dot, dim3(vg), dim3(256), 0, c->stream, a, bb, n, c->scal + 7);
+        hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, a, bb, n, c->scal + 7);
         HIPCHK(c, hipMemcpyAsync(c->scal_host + 7, c->scal + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         *out = c->scal_host[7];

@@ -1353,9 +1353,16 @@ __global__ void k_axpby(double* __restrict__ y, double a, const double* __restri
 }
 
 __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* slot) {
-    double s = 0.0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += a[i] * b[i];
-    block_accumulate(s, slot);
+    // four independent partial sums: a thread has 4 pairs of loads in flight per trip of the grid-stride loop
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        s0 += a[i] * b[i]; s1 += a[i + stride] * b[i + stride];
+        s2 += a[i + 2 * stride] * b[i + 2 * stride]; s3 += a[i + 3 * stride] * b[i + 3 * stride];
+    }
+    for (; i < n; i += stride) s0 += a[i] * b[i];
+    block_accumulate((s0 + s1) + (s2 + s3), slot);
 }
 
 // r = b - Ap (or r = b when Ap == null); masked rows zero; z = dinv r; p = z; Ap = 0; rz[0] += r.z; rr[0] += r.r
