@@ -576,9 +576,7 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
         if (fr.h_level_wide[L]) {
             for (int c0 = 0; c0 < maxnp; c0 += SP) {
                 const int rows = maxnp + maxnb - c0;              // upper bound of rows below the super panel
-                hipLaunchKernelGGL(k_front_fwd_tri, dim3(cnt), dim3(TRI_T), 0, c->stream, fd, lev, c0, v, y);
-                if (rows > 0)          // a front narrower than SP still has its boundary rows below the block
-                    hipLaunchKernelGGL(k_front_fwd_upd, dim3((rows + PB - 1) / PB, cnt), dim3(256), 0, c->stream, fd, lev, c0, v, y);
+                hipLaunchKernelGGL(k_front_fwd_blk, dim3(std::max(1, (rows + FB_ROWS - 1) / FB_ROWS), cnt), dim3(WT), 0, c->stream, fd, lev, c0, v, y);
             }
         } else {
             const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
@@ -602,11 +600,7 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
             if (maxnb > 0)
                 hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + BB_COLS - 1) / BB_COLS, cnt), dim3(256), (size_t)maxnb * sizeof(double), c->stream, fd, lev, y, v);
             for (int c0 = ((maxnp - 1) / SP) * SP; c0 >= 0; c0 -= SP)
-            {
-                hipLaunchKernelGGL(k_front_bwd_tri, dim3(cnt), dim3(TRI_T), 0, c->stream, fd, lev, c0, y, v);
-                if (c0 > 0)
-                    hipLaunchKernelGGL(k_front_bwd_upd, dim3((c0 + BU_COLS - 1) / BU_COLS, cnt), dim3(256), 0, c->stream, fd, lev, c0, y, v);
-            }
+                hipLaunchKernelGGL(k_front_bwd_blk, dim3(std::max(1, (c0 + BB_CB - 1) / BB_CB), cnt), dim3(WT), 0, c->stream, fd, lev, c0, y, v);
         } else {
             const size_t shm = (size_t)(maxnp + maxnb + NB) * sizeof(double);
             hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);

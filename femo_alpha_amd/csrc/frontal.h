@@ -792,106 +792,102 @@ k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __rest
 
 constexpr int SP = 128;    // columns handled per launch by the wide solve kernels (4 diagonal blocks)
 
-constexpr int PB = 64;     // rows per workgroup of the wide forward update
-constexpr int TRI_T = 1024; // threads of the wide triangular kernels: 8 per row / 16 waves over the columns
-constexpr int BU_COLS = 16; // columns per workgroup of the wide backward update (4 per wave)
+constexpr int WT = 1024;    // threads of the wide solve kernels
+constexpr int FB_ROWS = 128; // rows per workgroup of the wide forward step
+constexpr int BB_CB = 64;    // columns per workgroup of the wide backward step (4 per wave)
 
-// The top levels of the tree are a chain of ~200 tiny dependent launches per sweep: each kernel is laid out for
-// latency, not throughput -- every thread issues all of its loads at once (16-32 independent ones) and the
-// partial sums meet in LDS.
+// The top levels of the tree are a chain of dependent launches, one per 128 pivot columns and sweep: each kernel is
+// laid out for latency, not throughput -- every thread issues all of its loads at once (32 independent ones) and the
+// partial sums meet in LDS.  The triangular part (y = S v with the stored inverse of the 128 x 128 diagonal block) is
+// recomputed by every workgroup of the step instead of being a launch of its own: 131 KB of S from L2 per workgroup
+// buys one launch less on the chain.
 
-// forward, columns [c0, c0+SP), step 1 (one workgroup per front): y = L11[c0.., c0..]^-1 v[c0..] -> yv
-__global__ void __launch_bounds__(TRI_T)
-k_front_fwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ v, double* __restrict__ yv) {
-    const int t = level_nodes[blockIdx.x];
-    const int np = fd.npiv[t];
+// forward, columns [c0, c0+SP):  y = L11[c0.., c0..]^-1 v[c0..] -> yv ;  v_r -= L[r, c0..c0+W) y for the rows below
+__global__ void __launch_bounds__(WT)
+k_front_fwd_blk(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ v, double* __restrict__ yv) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
     if (c0 >= np) return;
     const int W = min(SP, np - c0);
+    const int r0 = c0 + W + blockIdx.x * FB_ROWS;
+    if (blockIdx.x > 0 && r0 >= nf) return;
+    const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
-    __shared__ double bs[SP];
-    __shared__ double part[TRI_T / SP][SP];
+    __shared__ double bs[SP], ys[SP];
+    __shared__ double part[WT / SP][SP];
     const int tid = threadIdx.x;
-    // y_r = sum_{m <= r} S[r][m] b[m]: eight threads per row (16 columns each), coalesced along the rows;
-    // the S loads do not depend on b and are issued before the gather of b has landed
-    const int r = tid & (SP - 1), p = tid >> 7;
-    double sv[16];
+    const int lr = tid & (SP - 1), p = tid >> 7;          // row lr of the block / of the tile, columns 16 p .. 16 p + 15
+    // all loads first: 16 of S (y_r = sum_{m <= r} S[r][m] b[m]), 16 of L (the rows below)
+    double sv[16], lv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int mm = 16 * p + k;
-        sv[k] = (mm <= r && r < W) ? S[r + (size_t)SP * mm] : 0.0;
+        sv[k] = (mm <= lr && lr < W) ? S[lr + (size_t)SP * mm] : 0.0;
     }
+    const int r = r0 + lr;
+    const double* row = F + r + (size_t)nf * (c0 + 16 * p);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lv[k] = (r < nf && 16 * p + k < W) ? row[(size_t)nf * k] : 0.0;
     if (tid < SP) bs[tid] = tid < W ? v[gd[c0 + tid]] : 0.0;
     __syncthreads();
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += sv[k] * bs[16 * p + k];
-    part[p][r] = s;
-    __syncthreads();
-    if (tid < W) {
-        double y = 0.0;
-#pragma unroll
-        for (int q = 0; q < TRI_T / SP; ++q) y += part[q][tid];
-        yv[gd[c0 + tid]] = y;
-    }
-}
-
-// forward, step 2:  v_r -= L[r, c0..c0+W) y  for all rows r below the super panel, 64 rows per workgroup,
-// four threads per row (32 columns each)
-__global__ void __launch_bounds__(256)
-k_front_fwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ v, const double* __restrict__ yv) {
-    const int t = level_nodes[blockIdx.y];
-    const int np = fd.npiv[t], nf = fd.nf[t];
-    if (c0 >= np) return;
-    const int W = min(SP, np - c0);
-    const int r0 = c0 + W + blockIdx.x * PB;
-    if (r0 >= nf) return;
-    const double* F = fd.F + fd.foff[t];
-    const int* gd = fd.dofs + fd.doff[t];
-    __shared__ double ys[SP];
-    __shared__ double part[4][PB];
-    const int tid = threadIdx.x;
-    const int lr = tid & (PB - 1), p = tid >> 6;
-    const int r = r0 + lr;
-    double lv[32];
-    const double* row = F + r + (size_t)nf * (c0 + 32 * p);
-#pragma unroll
-    for (int k = 0; k < 32; ++k) lv[k] = (r < nf && 32 * p + k < W) ? row[(size_t)nf * k] : 0.0;
-    if (tid < SP) ys[tid] = tid < W ? yv[gd[c0 + tid]] : 0.0;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) s += lv[k] * ys[32 * p + k];
     part[p][lr] = s;
     __syncthreads();
-    if (tid < PB && r < nf) {
-        s = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    if (tid < SP) {
+        double y = 0.0;
+#pragma unroll
+        for (int q = 0; q < WT / SP; ++q) y += part[q][tid];
+        ys[tid] = y;
+        if (blockIdx.x == 0 && tid < W) yv[gd[c0 + tid]] = y;
+    }
+    __syncthreads();
+    s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += lv[k] * ys[16 * p + k];
+    part[p][lr] = s;
+    __syncthreads();
+    if (tid < FB_ROWS && r < nf) {
+        s = 0.0;
+#pragma unroll
+        for (int q = 0; q < WT / SP; ++q) s += part[q][tid];
         if (r < np) v[gd[r]] -= s;
         else atomicAdd(&v[gd[r]], -s);
     }
 }
 
-// backward, columns [c0, c0+SP), step 1 (one workgroup per front): x = L11[c0.., c0..]^-T s[c0..] -> xv
-__global__ void __launch_bounds__(TRI_T)
-k_front_bwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const double* __restrict__ sv, double* __restrict__ xv) {
-    const int t = level_nodes[blockIdx.x];
-    const int np = fd.npiv[t];
+// backward, columns [c0, c0+SP):  x = L11[c0.., c0..]^-T s[c0..] -> xv ;  s_j -= L[c0..c0+W, j]^T x for the columns j < c0
+__global__ void __launch_bounds__(WT)
+k_front_bwd_blk(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ sv, double* __restrict__ xv) {
+    const int t = level_nodes[blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
     if (c0 >= np) return;
     const int W = min(SP, np - c0);
+    const int j0 = blockIdx.x * BB_CB;
+    if (blockIdx.x > 0 && j0 >= c0) return;
+    const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
     const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
-    __shared__ double ss[SP];
-    __shared__ double xs[SP];
+    __shared__ double ss[SP], xs[SP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // x_c = sum_{r >= c} S[r][c] s[r]: wave wv takes the columns wv, wv + 16, ...; its lanes walk the (contiguous)
-    // column, two rows each
-    double a0[SP / 16], a1[SP / 16];
+    // column, two rows each.  The columns j of L for the update are loaded in the same breath.
+    double a0[SP / 16], a1[SP / 16], l0[BB_CB / 16], l1[BB_CB / 16];
 #pragma unroll
     for (int k = 0; k < SP / 16; ++k) {
         const int c = wv + 16 * k;
         const double* col = S + (size_t)SP * c;
         a0[k] = (lane >= c && lane < W && c < W) ? col[lane] : 0.0;
         a1[k] = (lane + 64 >= c && lane + 64 < W && c < W) ? col[lane + 64] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < BB_CB / 16; ++k) {
+        const int j = j0 + wv + 16 * k;
+        const double* col = F + c0 + (size_t)nf * j;
+        l0[k] = (j < c0 && lane < W) ? col[lane] : 0.0;
+        l1[k] = (j < c0 && lane + 64 < W) ? col[lane + 64] : 0.0;
     }
     if (tid < SP) ss[tid] = tid < W ? sv[gd[c0 + tid]] : 0.0;
     __syncthreads();
@@ -902,38 +898,12 @@ k_front_bwd_tri(FrontDev fd, const int* __restrict__ level_nodes, int c0, const 
         if (lane == 0) xs[wv + 16 * k] = x;
     }
     __syncthreads();
-    if (tid < W) xv[gd[c0 + tid]] = xs[tid];
-}
-
-// backward, step 2:  s_j -= L[c0..c0+W, j]^T x  for all columns j < c0: 16 columns per workgroup, one wave per
-// column at a time, lanes along the (contiguous) column
-__global__ void __launch_bounds__(256)
-k_front_bwd_upd(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ sv, const double* __restrict__ xv) {
-    const int t = level_nodes[blockIdx.y];
-    const int np = fd.npiv[t], nf = fd.nf[t];
-    if (c0 >= np) return;
-    const int W = min(SP, np - c0);
-    const int j0 = blockIdx.x * BU_COLS;
-    if (j0 >= c0) return;
-    const double* F = fd.F + fd.foff[t];
-    const int* gd = fd.dofs + fd.doff[t];
-    __shared__ double xs[SP];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double a0[BU_COLS / 4], a1[BU_COLS / 4];
-#pragma unroll
-    for (int k = 0; k < BU_COLS / 4; ++k) {
-        const int j = j0 + wv + 4 * k;
-        const double* col = F + c0 + (size_t)nf * j;
-        a0[k] = (j < c0 && lane < W) ? col[lane] : 0.0;
-        a1[k] = (j < c0 && lane + 64 < W) ? col[lane + 64] : 0.0;
-    }
-    if (tid < SP) xs[tid] = tid < W ? xv[gd[c0 + tid]] : 0.0;
-    __syncthreads();
+    if (blockIdx.x == 0 && tid < W) xv[gd[c0 + tid]] = xs[tid];
     const double x0 = xs[lane], x1 = xs[lane + 64];
 #pragma unroll
-    for (int k = 0; k < BU_COLS / 4; ++k) {
-        const int j = j0 + wv + 4 * k;
-        const double s = wave_sum(a0[k] * x0 + a1[k] * x1);
+    for (int k = 0; k < BB_CB / 16; ++k) {
+        const int j = j0 + wv + 16 * k;
+        const double s = wave_sum(l0[k] * x0 + l1[k] * x1);
         if (lane == 0 && j < c0) sv[gd[j]] -= s;
     }
 }
