@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "wing1m"))
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
-    ap.add_argument("--leaf", type=int, default=16)
+    ap.add_argument("--leaf", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -280,7 +280,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
                        "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
-                                  f"(nested dissection, leaf {args.leaf})" if args.solver == "frontal"
+                                  f"(nested dissection, leaves of <= {args.leaf} cells)" if args.solver == "frontal"
                                   else "Jacobi-PCG, matrix-free element-by-element operator"), "rtol": args.rtol,
                        "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
                        "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],

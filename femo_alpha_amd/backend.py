@@ -124,7 +124,7 @@ class ShellContext:
         return Ke
 
     # ------------------------------------------------------------------ multifrontal preconditioner
-    def enable_frontal(self, leaf_size=16, plan=None):
+    def enable_frontal(self, leaf_size=12, plan=None):
         """Run the symbolic analysis on the host (mesh only) and upload it; afterwards
         ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner.
         ``plan`` may carry a ready-made plan (the multi-GPU driver passes rank-local plans)."""

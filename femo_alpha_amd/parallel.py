@@ -127,7 +127,7 @@ class HipEngine:
 class DistributedShell:
     """Forward solve, scalar outputs and the adjoint gradient on an element partition."""
 
-    def __init__(self, mesh, comm: Comm, bc_marker=None, beta=1.0e15, leaf_size=16, engine_factory=None,
+    def __init__(self, mesh, comm: Comm, bc_marker=None, beta=1.0e15, leaf_size=12, engine_factory=None,
                  element_wise_material=False, device=0, tree=None):
         import torch
         self.torch = torch

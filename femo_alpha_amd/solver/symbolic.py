@@ -59,7 +59,7 @@ def _node_dofs(nodes, nV, ndof_u):
     return out
 
 
-def analyse(mesh, leaf_size=16, min_depth=0) -> Tree:
+def analyse(mesh, leaf_size=12, min_depth=0) -> Tree:
     """Bisection tree, node ownership and boundary lists.  ``min_depth`` forces every branch to be
     split at least that deep (the multi-GPU driver needs 2^d subtrees)."""
     nel, nP2 = mesh.nel, mesh.nP2
@@ -185,7 +185,7 @@ def _assemble_plan(dof_lists, npiv, parent, left, right, level_of, elem_front, e
     return plan
 
 
-def build_plan(mesh, leaf_size=16) -> FrontalPlan:
+def build_plan(mesh, leaf_size=12) -> FrontalPlan:
     """Single-GPU plan: every tree node is a front, levels by height."""
     T = analyse(mesh, leaf_size)
     nV, ndof_u = mesh.nV, mesh.ndof_u

@@ -34,7 +34,7 @@ def _solver(m, fields, marker):
     for k, v in fields.items():
         c.set_field(k, v)
     c.set_penalty_facets(m.penalty_facets(marker))
-    c.enable_frontal(16)
+    c.enable_frontal()
     c.set_solver(preconditioner=2, rtol=1e-11, maxit=50, check_every=1)
     return c
 
