@@ -500,7 +500,23 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 0);
             }
             { ProfScope ps(c, 1);
-              hipLaunchKernelGGL(k_diag_block, dim3(cnt), dim3(256), 0, c->stream, fd, lev, C0, sw, fr.info); }
+              // classes of equal sub-block count (fronts are sorted by pivot count); small levels go in one launch
+              const int* hn = fr.h_level_nodes.data() + b;
+              auto first_above = [&](int thr) {          // first position whose front has more than thr pivots
+                  int lo = 0, hi = cnt;
+                  while (lo < hi) { const int mid = (lo + hi) / 2; if (fr.h_npiv[hn[mid]] > thr) hi = mid; else lo = mid + 1; }
+                  return lo;
+              };
+              int start = first_above(C0);
+              for (int nb4 = 1; nb4 <= NBO / NB && start < cnt; ++nb4) {
+                  int end = nb4 == NBO / NB ? cnt : first_above(C0 + NB * nb4);
+                  int nblk = nb4;
+                  if (cnt < 512) { end = cnt; nblk = std::min(NBO / NB, (fr.h_npiv[hn[cnt - 1]] - C0 + NB - 1) / NB); }
+                  if (end > start)
+                      hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                                         fd, lev, start, nblk, C0, sw, fr.info);
+                  start = end;
+              } }
             const int tiles = (std::max(0, max_nf - C0 - 1) + TS - 1) / TS;
             if (tiles > 0) {
                 ProfScope ps(c, 0);
@@ -1311,6 +1327,14 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     fr.h_level_off.assign(level_off, level_off + nlevels + 1);
     fr.h_level_nodes.assign(level_nodes, level_nodes + ntree);
     if (fr.h_level_off[nlevels] != ntree) return fail(c, "level_off does not cover all fronts");
+    for (int i = 0; i < ntree; ++i)
+        if (level_nodes[i] < 0 || level_nodes[i] >= ntree) return fail(c, "level_nodes out of range");
+    // inside a level the fronts are kept in order of pivot count: the diagonal-block kernel is launched per class of
+    // equal sub-block count (its LDS footprint, hence its occupancy, depends on it)
+    for (int L = 0; L < nlevels; ++L)
+        std::stable_sort(fr.h_level_nodes.begin() + level_off[L], fr.h_level_nodes.begin() + level_off[L + 1],
+                         [&](int a, int b) { return npiv[a] < npiv[b]; });
+    level_nodes = fr.h_level_nodes.data();
     long long piv_total = 0;
     std::vector<long long> linvoff(ntree + 1, 0);
     fr.max_nf = 0;
@@ -1415,6 +1439,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_bnd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
     fr.ready = true;
     fr.factored = false;
     return 0;

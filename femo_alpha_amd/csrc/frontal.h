@@ -335,19 +335,28 @@ __device__ long long g_stamps[32];
 #define STAMP(i)
 #endif
 
+// LDS is sized by the launch: `nblk` = the largest number of 32-column sub-blocks any front of the launch has in this
+// panel (the host sorts the fronts of a level by pivot count and launches them in classes), so that the many small
+// fronts at the bottom of the tree run two or three workgroups per CU instead of one.
+__device__ __host__ inline int diag_block_lds_blocks(int nblk) { return nblk * (nblk + 1) / 2 + (nblk - 1) + 1; }
+
 __global__ void __launch_bounds__(256)
-k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* __restrict__ Swork, int* __restrict__ info) {
-    const int t = level_nodes[blockIdx.x];
+k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
+             int* __restrict__ info) {
+    const int slot = first + blockIdx.x;                       // position of the front in its level
+    const int t = level_nodes[slot];
     const int np = fd.npiv[t];
     if (C0 >= np) return;
     const int kw = min(NBO, np - C0);
     const int nkb = (kw + NB - 1) / NB;
     const int nf = fd.nf[t];
     double* F = fd.F + fd.foff[t];
-    double* Sout = Swork ? Swork + (size_t)blockIdx.x * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
-    __shared__ blk32 D[10];                 // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
-    __shared__ blk32 Sx[3];                 // column j of S below its diagonal sub-block
-    __shared__ blk32 Wt;
+    double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    extern __shared__ double lds_raw[];
+    blk32* D = reinterpret_cast<blk32*>(lds_raw);              // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
+    blk32* Sx = D + nblk * (nblk + 1) / 2;                      // column j of S below its diagonal sub-block
+    blk32& Wt = Sx[nblk - 1];
+    const int nD = nblk * (nblk + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
     // load (identity padding beyond kw; only the lower triangle of the front is maintained): all 40 loads of a thread
@@ -364,7 +373,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
                 const int r = idx % NB, c = idx / NB;
                 const int gr = NB * bi + r, gc = NB * bj + c;
                 v[b][q] = (gr == gc) ? 1.0 : 0.0;
-                if (bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
+                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
             }
         }
 #pragma unroll
@@ -372,7 +381,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = tid + 256 * q;
-                D[b][idx % NB][idx / NB] = v[b][q];
+                if (b < nD) D[b][idx % NB][idx / NB] = v[b][q];
             }
     }
     // (no zero fill of S: every sub-block on or below the block diagonal is written in full below, and nothing above it
@@ -461,7 +470,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int C0, double* _
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
-                if (i - j - 1 < 3) Sx[i - j - 1][r][c] = -x[reg];
+                Sx[i - j - 1][r][c] = -x[reg];
                 Sout[(NB * i + r) + (size_t)SPD * (NB * j + c)] = -x[reg];
             }
             __syncthreads();

