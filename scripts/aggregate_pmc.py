@@ -51,9 +51,11 @@ def main():
             if r["kernel"].startswith("femo::k_apply4"):
                 d["apply_hbm_bytes_per_launch"] = r["hbm_bytes_corrected"]
                 d["apply_kernel"] = r["kernel"]
-            if r["kernel"].startswith("femo::k_trailing") and "trailing_hbm_bytes_per_launch" not in d:
-                d["trailing_hbm_bytes_per_launch"] = r["hbm_bytes_corrected"]
-                d["trailing_kernel"] = r["kernel"]
+        tr = [r for r in rows if r["kernel"].startswith("femo::k_trailing")]
+        if tr:          # both template instances of the rank-k update, weighted by their launches
+            n = sum(r["launches"] for r in tr)
+            d["trailing_hbm_bytes_per_launch"] = sum(r["hbm_bytes_corrected"] * r["launches"] for r in tr) / n
+            d["trailing_kernel"] = "femo::k_trailing_mfma (all instances)"
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         json.dump(d, open(os.path.join(root, "profiles", f"pmc_{workload}.json"), "w"), indent=1)
     for r in rows[:12]:
