@@ -1149,10 +1149,10 @@ static int pnorm_dev(femo_ctx* c, double out2[2]) {
 int femo_functional(femo_ctx* c, const char* name, double* value) {
     HIPCHK(c, hipSetDevice(c->device));
     const std::string s(name ? name : "");
-    if (s == "compliance" || s == "mass" || s == "volume") {
+    if (s == "compliance" || s == "mass" || s == "volume" || s == "regularization") {
         double v[4];
         if (functionals_dev(c, v, 4)) return 1;
-        *value = s == "mass" ? v[2] : s == "volume" ? v[3] : v[0] + v[1];
+        *value = s == "mass" ? v[2] : s == "volume" ? v[3] : s == "regularization" ? v[1] : v[0] + v[1];
         return 0;
     }
     if (s == "elastic_energy") {
@@ -1210,6 +1210,7 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
     if (wrt == "uhat") {
+        if (fn == "regularization") return 0;                 // integrates over the reference configuration only
         const int mode = fn == "compliance" ? 1 : fn == "mass" ? 2 : fn == "elastic_energy" ? 3 : fn == "pnorm_stress" ? 4 : -1;
         if (mode < 0) return fail(c, "unknown functional '" + fn + "'");
         if (mode == 4) {
@@ -1218,7 +1219,9 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         }
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
-    if (fn == "compliance") {
+    if (fn == "regularization") {         // the thickness term of the compliance (its only explicit thickness dependence)
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+    } else if (fn == "compliance") {
         if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out);
         else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "mass") {

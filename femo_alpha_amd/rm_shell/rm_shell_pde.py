@@ -50,6 +50,21 @@ class RMShellPDE:
         """int u.u J dx + regularisation(h) (rm_shell_pde.py:85-89)."""
         return Form(self.ctx, "compliance")
 
+    def regularization(self, h, type=None):
+        """Thickness regularisation added to the compliance (rm_shell_pde.py:64-83): 'H1' for nodal thickness,
+        'L2' for element-wise thickness -- the two the reference's compliance uses; None means no regularisation."""
+        if type is None:
+            return 0.0
+        expected = "L2" if self.element_wise_material else "H1"
+        if type != expected:
+            raise NotImplementedError(f"regularization type '{type}': the backend provides '{expected}' for this material layout "
+                                      "(the one the reference's compliance selects)")
+        return Form(self.ctx, "regularization")
+
+    def volume(self, uhat, h):
+        """int h J dx (rm_shell_pde.py:98-99)."""
+        return Form(self.ctx, "volume")
+
     def mass(self, uhat, h, rho):
         rho.bind("density")
         return Form(self.ctx, "mass")

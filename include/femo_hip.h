@@ -161,7 +161,8 @@ int femo_select_subdomain(femo_ctx* ctx, int32_t sel);
  * cell's vertices in connectivity order) -- replaces FEA.projectFieldOutput (fea/fea_dolfinx.py:205-206,
  * csdl_alpha_opt/output_operation.py:116-123). */
 int femo_field_output(femo_ctx* ctx, const char* name, double* out, int64_t n);
-/* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy", "pnorm_stress" --
+/* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy", "pnorm_stress", "volume",
+ * "regularization" (the thickness term of the compliance, rm_shell_pde.py:64-83) --
  * replaces assemble_scalar(form(c)) (csdl_alpha_opt/output_operation.py:51-56; forms at
  * rm_shell/rm_shell_pde.py:64-110). */
 int femo_functional(femo_ctx* ctx, const char* name, double* value);

@@ -367,6 +367,81 @@ k_rect(double* Fall, int nf, int kc0, int kw) {
             }
 }
 
+// as k_db, but the global loads run two stages ahead of the MFMAs (second register set)
+template <bool PRE>
+__global__ void __launch_bounds__(256)
+k_db2(double* Fall, int nf, int kc0, int kw) {
+    constexpr int KC = 16, NQ = KC / 4;
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    __shared__ double si[2][KC][LSTR];
+    __shared__ double sj[2][KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int lr = tid % TS, lc = tid / TS;
+    double pa[NQ], pb[NQ], qa[NQ], qb[NQ];
+    const bool iok = ri + lr < nf, jok = cj + lr < nf;
+#define FETCH(PI, PJ, K0) do { _Pragma("unroll") for (int q = 0; q < NQ; ++q) { const int c = lc + 4 * q; \
+        PI[q] = (iok && (K0) + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + (K0) + c)] : 0.0; \
+        PJ[q] = (jok && (K0) + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + (K0) + c)] : 0.0; } } while (0)
+#define PUT(BUF, PI, PJ) do { _Pragma("unroll") for (int q = 0; q < NQ; ++q) { si[BUF][lc + 4 * q][lr] = PI[q]; sj[BUF][lc + 4 * q][lr] = PJ[q]; } } while (0)
+#define COMPUTE(BUF) do { _Pragma("unroll") for (int kk = 0; kk < KC; kk += 4) { \
+        const double a0 = sj[BUF][kk + l4][wc + l15], a1 = sj[BUF][kk + l4][wc + 16 + l15]; \
+        const double b0 = si[BUF][kk + l4][wr + l15], b1 = si[BUF][kk + l4][wr + 16 + l15]; \
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0); } } while (0)
+    FETCH(pa, pb, 0);
+    FETCH(qa, qb, KC);
+    double cpre[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                cpre[a][b][reg] = (PRE && r < nf && cc < nf && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+            }
+    PUT(0, pa, pb);
+    __syncthreads();
+    // stages come in pairs so that the two register sets alternate without copies
+    for (int k0 = 0; k0 < kw; k0 += 2 * KC) {
+        // buffer 0 holds stage k0; qa/qb hold stage k0+KC; fetch k0+2KC into pa/pb
+        FETCH(pa, pb, k0 + 2 * KC);
+        COMPUTE(0);
+        PUT(1, qa, qb);
+        __syncthreads();
+        if (k0 + KC >= kw) break;
+        FETCH(qa, qb, k0 + 3 * KC);
+        COMPUTE(1);
+        PUT(0, pa, pb);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
+                }
+            }
+}
+
 int main(int argc, char** argv) {
     const int nfr = argc > 1 ? atoi(argv[1]) : 8, nf = argc > 2 ? atoi(argv[2]) : 3200, kw = argc > 3 ? atoi(argv[3]) : 128;
     double* F; CK(hipMalloc(&F, sizeof(double) * (size_t)nfr * nf * nf));
@@ -374,7 +449,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nt = (nf - kw + TS - 1) / TS;
     const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
-    for (int mode = 0; mode < 18; ++mode)
+    for (int mode = 0; mode < 20; ++mode)
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
@@ -395,6 +470,8 @@ int main(int argc, char** argv) {
             if (mode == 12) hipLaunchKernelGGL((k_db<false, 32>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 16) hipLaunchKernelGGL((k_rect<true>), dim3((nf - kw + 127) / 128, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 17) hipLaunchKernelGGL((k_rect<false>), dim3((nf - kw + 127) / 128, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 18) hipLaunchKernelGGL((k_db2<true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 19) hipLaunchKernelGGL((k_db2<false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -262,6 +262,26 @@ def test_stress_outputs(kind, ewm, uhat):
             assert abs(g_u[v_, comp] - fd) <= 5e-6 * np.abs(g_u).max() + 1e-7 * abs(fd), (v_, comp, g_u[v_, comp], fd)
 
 
+@pytest.mark.parametrize("kind,ewm", [("warped", False), ("warped", True)])
+def test_regularization_and_volume_outputs(kind, ewm):
+    """The thickness regularisation the reference adds to the compliance ('H1' nodal, 'L2' element-wise,
+    rm_shell_pde.py:64-89) and the volume int h J dx (rm_shell_pde.py:98-99) as outputs of their own."""
+    m, o, c, rng = _pair(kind, ewm=ewm, uhat=True)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-3
+    c.set_state(w)
+    reg = o.regularization()
+    assert abs(c.functional("regularization") - reg) <= 1e-12 * abs(reg)
+    assert abs(c.functional("compliance") - o.compliance(w)) <= 1e-12 * abs(o.compliance(w))
+    assert rel(c.dfunctional("regularization", "thickness"), o.dcompliance_dh(w)) < 1e-12
+    assert np.all(c.dfunctional("regularization", "uhat") == 0.0)
+    assert np.all(c.dfunctional("regularization", "disp_solid") == 0.0)
+    vol = c.functional("volume")
+    mass_unit = c.functional("mass")
+    c.set_field("density", np.ones(c.field_size("density")))
+    assert abs(c.functional("mass") - vol) <= 1e-13 * vol          # rho = 1: mass == volume
+    assert mass_unit > 0
+
+
 @pytest.mark.parametrize("kind,uhat", [("warped", True), ("tri", False)])
 def test_stress_aggregate_on_subdomains(kind, uhat):
     """Per-tag stress aggregates (the reference's dxx(i) measure, rm_shell_model.py:242-253): value and partial
