@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 
 def _context(kind):
     from femo_alpha_amd.backend import ShellContext
+    if kind == "tri170k":          # triangles (CG2xCG1 on simplices), element-wise material, strong clamp
+        from femo_alpha_amd.mesh import quads_to_triangles
+        m = quads_to_triangles(plate_mesh(2.0, 10.0, 40, 200))
+        rng = np.random.default_rng(2)
+        fields = dict(thickness=0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nel)), E=1e8 * (1 + 0.1 * rng.uniform(-1, 1, m.nel)),
+                      nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
+        marker = lambda x: np.less(x[0], 3e-16)
+        return m, fields, marker, rng
     if kind == "wing1m":
         m = wing_skin_mesh(116, 580)
         rng = np.random.default_rng(5)
@@ -28,22 +36,25 @@ def _context(kind):
     return m, fields, marker, rng
 
 
-def _solver(m, fields, marker):
+def _solver(m, fields, marker, ewm=False, strong=False):
     from femo_alpha_amd.backend import ShellContext
-    c = ShellContext(m)
+    c = ShellContext(m, element_wise_material=ewm)
     for k, v in fields.items():
         c.set_field(k, v)
-    c.set_penalty_facets(m.penalty_facets(marker))
+    if strong:
+        c.set_strong_dofs(m.locate_dofs_geometrical(marker))
+    else:
+        c.set_penalty_facets(m.penalty_facets(marker))
     c.enable_frontal()
     c.set_solver(preconditioner=2, rtol=1e-11, maxit=50, check_every=1)
     return c
 
 
-@pytest.mark.parametrize("kind", ["plate250k", "wing1m"])
+@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k"])
 def test_full_size_properties(kind):
     m, fields, marker, rng = _context(kind)
-    assert m.ndof == (1015470 if kind == "wing1m" else 255438)
-    c = _solver(m, fields, marker)
+    assert m.ndof == {"wing1m": 1015470, "plate250k": 255438}.get(kind, m.ndof)
+    c = _solver(m, fields, marker, ewm=kind == "tri170k", strong=kind == "tri170k")
     it, rr = c.solve_state(zero_guess=True)
     assert it <= 4 and rr <= 1e-11
     w = c.get_state()
@@ -62,6 +73,8 @@ def test_full_size_properties(kind):
     assert abs(a - b) <= 1e-12 * max(abs(a), abs(b))
     # 4. linearity of the solve: K (2w + z) = 2F + K z
     z = 1e-3 * np.abs(w).max() * rng.standard_normal(m.ndof)
+    if kind == "tri170k":
+        z[m.locate_dofs_geometrical(marker)] = 0.0           # strongly constrained rows are not part of the system
     s, it2, rr2 = c.solve_linear(2 * F + c.apply_K(z))
     assert it2 <= 4
     # (forward error ~ cond(K) * eps: a few 1e-8 on the plate, ~1e-7 on the 1.27 mm wing skin)
