@@ -257,7 +257,7 @@ def main():
         prof = ctx.factorize_profile()
         tr = prof["trailing"]
         tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "k_trailing_mfma (fp64 rank-k updates of the multifrontal Cholesky)",
+        roof = {"bound": "mfma", "kernel": "k_trailing_mfma<true|false>, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
                 "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic_trailing,
                 "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
                 "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}

@@ -408,15 +408,15 @@ static FrontDev front_dev(const femo_ctx* c) {
 
 // event pair around one launch group when profiling
 struct ProfScope {
-    femo_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(femo_ctx* c_, int cls_) : c(c_), cls(cls_) {
+    femo_ctx* c; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(femo_ctx* c_, int cls_, hipStream_t s_ = nullptr) : c(c_), cls(cls_), s(s_ ? s_ : c_->stream) {
         if (!c->fr.profile) return;
         hipEventCreate(&a); hipEventCreate(&b);
-        hipEventRecord(a, c->stream);
+        hipEventRecord(a, s);
     }
     ~ProfScope() {
         if (!c->fr.profile) return;
-        hipEventRecord(b, c->stream);
+        hipEventRecord(b, s);
         c->fr.pev.push_back(a); c->fr.pev.push_back(b); c->fr.pev.push_back((hipEvent_t)(intptr_t)(cls + 16 * c->fr.cur_level));
     }
 };
@@ -489,7 +489,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         static const char* sched = getenv("FEMO_TRAILING");
         const bool right_looking = sched && sched[0] == 'r' ? true : sched && sched[0] == 'l' ? false : (cnt < 16 || cnt > 2048);
         static const bool no_lookahead = getenv("FEMO_NO_LOOKAHEAD") != nullptr;
-        const bool lookahead = right_looking && cnt < 16 && !fr.profile && !no_lookahead;
+        const bool lookahead = right_looking && cnt < 16 && !no_lookahead;
         bool bulk_pending = false;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
@@ -533,12 +533,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     // chain of latency-bound launches at the top of the tree.  The next narrow update touches columns
                     // the bulk update also writes, so it waits for it (ev_la[1]).
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
-                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3);
+                    { ProfScope ps(c, 2);
+                      hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3); }
                     const int ntb = ntr - NBO / TS;
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
-                        hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4);
+                        { ProfScope ps(c, 2, c->stream2);
+                          hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
