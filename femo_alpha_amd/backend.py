@@ -169,6 +169,10 @@ class ShellContext:
     def set_solver(self, preconditioner=0, rtol=1e-10, maxit=200000, check_every=50):
         self._chk(self.lib.femo_set_solver(self._h, preconditioner, rtol, maxit, check_every))
 
+    def set_krylov(self, method="cg"):
+        """'cg' (default) or 'bicgstab' for the state, adjoint and linear solves."""
+        self._chk(self.lib.femo_set_krylov(self._h, {"cg": 0, "bicgstab": 1}[method]))
+
     def solve_state(self, zero_guess=True):
         it = C.c_int32(); rr = C.c_double()
         self._chk(self.lib.femo_solve_state(self._h, int(zero_guess), C.byref(it), C.byref(rr)))

@@ -32,6 +32,8 @@ static std::string g_create_error;
 struct femo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    int krylov = 0;                          // 0: conjugate gradients, 1: BiCGStab (femo_set_krylov)
+    double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
@@ -705,7 +707,109 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     return 0;
 }
 
+// Right-preconditioned BiCGStab on the same operator and preconditioners (Jacobi or the multifrontal factor).  The
+// operator of this path is symmetric positive definite, so conjugate gradients are the default; BiCGStab is the
+// second Krylov method the north star names and costs two operator / preconditioner applications per iteration.
+static int bicgstab(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->precond == 2) {
+        if (c->diag_dirty || !c->fr.factored) {
+            if (int rc = frontal_factorize(c)) return rc;
+            c->diag_dirty = false;
+        }
+    } else {
+        if (c->op_aM != 0.0 || c->op_aK != 1.0) return fail(c, "the Jacobi preconditioner only handles the static operator; use preconditioner 2");
+        if (refresh_diag(c)) return 1;
+    }
+    for (int i = 0; i < 5; ++i)
+        if (!c->bi[i]) HIPCHK(c, hipMalloc((void**)&c->bi[i], (size_t)n * sizeof(double)));
+    double *rh = c->bi[0], *v = c->bi[1], *s = c->bi[2], *t = c->bi[3], *y = c->bi[4], *r = c->r, *p = c->p, *z = c->z;
+    auto dot = [&](const double* a, const double* bb, double* out) -> int {
+        HIPCHK(c, hipMemsetAsync(c->scal + 7, 0, sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, a, bb, n, c->scal + 7);
+        HIPCHK(c, hipMemcpyAsync(c->scal_host + 7, c->scal + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *out = c->scal_host[7];
+        return 0;
+    };
+    auto copy = [&](double* dst, const double* src) { return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream); };
+    auto apply = [&](const double* in, double* out) -> int {               // out = A in (masked rows zero)
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, out, 0.0, n);
+        if (op_apply(c, in, out, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, out, mask, n);
+        return 0;
+    };
+    auto precond = [&](const double* in, double* out) -> int {             // out = M^-1 in
+        HIPCHK(c, copy(out, in));
+        if (c->precond == 2) return frontal_solve(c, out);
+        hipLaunchKernelGGL(k_mul, dim3(vg), dim3(256), 0, c->stream, out, c->dinv, n);
+        return 0;
+    };
+    if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
+    double bb = 0, rr = 0;
+    if (dot(b, b, &bb)) return 1;
+    if (zero_guess) {
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, x, 0.0, n);
+        HIPCHK(c, copy(r, b));
+    } else {
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, x, mask, n);
+        if (apply(x, t)) return 1;
+        HIPCHK(c, copy(r, b));
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, r, -1.0, t, 1.0, n);
+    }
+    HIPCHK(c, copy(rh, r));
+    if (dot(r, r, &rr)) return 1;
+    double rho = 1.0, alpha = 1.0, omega = 1.0;
+    hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, v, 0.0, n);
+    hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, p, 0.0, n);
+    int k = 0, napply = 0;
+    const double target = c->rtol * c->rtol * bb;
+    while (bb > 0 && rr > target && k < c->maxit) {
+        double rho_new = 0, rhv = 0, ts = 0, tt = 0;
+        if (dot(rh, r, &rho_new)) return 1;
+        if (rho_new == 0.0 || omega == 0.0) return fail(c, "BiCGStab broke down (rho or omega vanished)");
+        const double beta = (rho_new / rho) * (alpha / omega);
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, p, -omega, v, 1.0, n);       // p -= omega v
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, p, 1.0, r, beta, n);          // p = r + beta p
+        if (precond(p, y) || apply(y, v)) return 1;
+        ++napply;
+        if (dot(rh, v, &rhv)) return 1;
+        if (rhv == 0.0) return fail(c, "BiCGStab broke down (r_hat . v = 0)");
+        alpha = rho_new / rhv;
+        HIPCHK(c, copy(s, r));
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, s, -alpha, v, 1.0, n);        // s = r - alpha v
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, x, alpha, y, 1.0, n);         // x += alpha y
+        if (dot(s, s, &rr)) return 1;
+        ++k;
+        rho = rho_new;
+        if (rr <= target) break;
+        if (precond(s, z) || apply(z, t)) return 1;
+        ++napply;
+        if (dot(t, s, &ts) || dot(t, t, &tt)) return 1;
+        if (tt == 0.0) return fail(c, "BiCGStab broke down (t = 0)");
+        omega = ts / tt;
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, x, omega, z, 1.0, n);         // x += omega z
+        HIPCHK(c, copy(r, s));
+        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, r, -omega, t, 1.0, n);        // r = s - omega t
+        if (dot(r, r, &rr)) return 1;
+        if (!(rr == rr)) return fail(c, "BiCGStab broke down (NaN residual)");
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float t_loop = 0;
+    hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
+    c->timing[0] = c->precond == 2 ? c->fr.t_assemble_ms + c->fr.t_factor_ms : 0.0; c->timing[1] = t_loop;
+    c->timing[2] = c->timing[0] + t_loop; c->timing[4] = napply;
+    if (iters) *iters = k;
+    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+    return 0;
+}
+
 static int solve_dispatch(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
+    if (c->krylov == 1) return bicgstab(c, b, x, zero_guess, iters, relres);
     return c->precond == 2 ? pcg_frontal(c, b, x, zero_guess, iters, relres) : pcg(c, b, x, zero_guess, iters, relres);
 }
 
@@ -879,7 +983,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    void* ptrs[] = {c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1104,6 +1208,12 @@ int femo_set_solver(femo_ctx* c, int preconditioner, double rtol, int32_t maxit,
     if (preconditioner == 2 && !c->fr.ready) return fail(c, "preconditioner 2 needs femo_set_frontal_plan first");
     if (!(rtol > 0) || maxit < 1 || check_every < 1) return fail(c, "bad solver parameters");
     c->precond = preconditioner; c->rtol = rtol; c->maxit = maxit; c->check_every = check_every;
+    return 0;
+}
+
+int femo_set_krylov(femo_ctx* c, int method) {
+    if (method != 0 && method != 1) return fail(c, "Krylov method must be 0 (conjugate gradients) or 1 (BiCGStab)");
+    c->krylov = method;
     return 0;
 }
 

@@ -1352,6 +1352,11 @@ __global__ void k_axpby(double* __restrict__ y, double a, const double* __restri
         y[i] = a * x[i] + b * y[i];
 }
 
+// y *= d (Jacobi preconditioner as a vector operation)
+__global__ void k_mul(double* __restrict__ y, const double* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] *= d[i];
+}
+
 __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* slot) {
     // four independent partial sums: a thread has 4 pairs of loads in flight per trip of the grid-stride loop
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;

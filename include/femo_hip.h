@@ -115,6 +115,10 @@ int femo_frontal_info(const femo_ctx* ctx, double* out6);
 /* Solver configuration. preconditioner: 0 = Jacobi, 2 = multifrontal Cholesky (needs a frontal plan).
  * check_every: convergence is polled on the host every this many PCG iterations. */
 int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxit, int32_t check_every);
+/* Krylov method for the state / adjoint / linear solves: 0 = conjugate gradients (default; the operator is SPD),
+ * 1 = right-preconditioned BiCGStab with the same preconditioner (femo_set_solver).  Stands where the reference
+ * chooses its PETSc KSP type (fea/utils_dolfinx.py:495-531). */
+int femo_set_krylov(femo_ctx* ctx, int method);
 
 /* Forward solve R(w) = 0 for the current fields, result kept on the device as the state.
  * Replaces FEA.solve -> solveNonlinear -> NewtonSolver + MUMPS LU (fea/fea_dolfinx.py:159-170,

@@ -178,6 +178,51 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     assert rel(c.get_state(), o.solve()) < 1e-8
 
 
+@pytest.mark.parametrize("kind,bc,precond", [("plate", "penalty", 2), ("warped", "strong", 2), ("thick", "strong", 0),
+                                             ("thick", "penalty", 0)])
+def test_bicgstab_matches_conjugate_gradients(kind, bc, precond):
+    """The second Krylov method of the north star: right-preconditioned BiCGStab with the same preconditioners reaches
+    the same state and the same adjoint gradient as CG.  With the Jacobi preconditioner it runs its full recurrence
+    (tens of iterations) on a thick, well-conditioned plate -- on thin shells Jacobi-BiCGStab stagnates or breaks
+    down, which is why the multifrontal preconditioner exists."""
+    if kind == "thick":
+        from femo_alpha_amd.backend import ShellContext
+        from femo_alpha_amd.mesh import plate_mesh
+        m = plate_mesh(2.0, 2.0, 4, 4)
+        c = ShellContext(m)
+        for name, v in (("thickness", [0.5]), ("E", [1e6]), ("nu", [0.3]), ("density", [1.0]),
+                        ("F_solid", np.tile([0.0, 0.0, 1.0], (m.nn, 1)))):
+            c.set_field(name, v)
+        if bc == "penalty":
+            c.set_penalty_facets(m.penalty_facets(CLAMP), 1e8)
+        else:
+            c.set_strong_dofs(m.locate_dofs_geometrical(CLAMP))
+    else:
+        m, o, c, rng = _pair(kind, bc=bc)
+    if precond == 2:
+        c.enable_frontal(leaf_size=8)
+        c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    else:
+        c.set_solver(preconditioner=0, rtol=1e-11, maxit=200000, check_every=10)
+    it_cg, rr_cg = c.solve_state(zero_guess=True)
+    w_cg = c.get_state()
+    g_cg, _, _ = c.total_gradient("compliance", "thickness")
+    c.set_krylov("bicgstab")
+    it_b, rr_b = c.solve_state(zero_guess=True)
+    w_b = c.get_state()
+    g_b, it_g, _ = c.total_gradient("compliance", "thickness")
+    assert rr_b <= (1e-12 if precond == 2 else 1e-11)
+    if precond == 2:
+        assert it_b <= 3 and it_g <= 3
+    else:
+        assert it_b > 5                       # the recurrence really ran
+    assert rel(w_b, w_cg) < (1e-9 if precond == 2 else 1e-6)
+    assert rel(g_b, g_cg) < (1e-8 if precond == 2 else 1e-5)
+    c.set_krylov("cg")
+    with pytest.raises(KeyError):
+        c.set_krylov("gmres")
+
+
 @pytest.mark.parametrize("kind,bc", [("warped", "penalty"), ("tri", "penalty"), ("plate", "strong")])
 def test_shape_sensitivities_vs_oracle_finite_differences(kind, bc):
     """d/d uhat of the outputs and (dR/d uhat)^T lambda: dual-number kernels against central finite
