@@ -64,22 +64,37 @@ class ShellMesh:
         self.nE = ukey.size
         self.edges = np.stack([ukey // self.nn, ukey % self.nn], axis=1).astype(np.int32)
         self.cell_edges = inv.reshape(self.nel, nvc).astype(np.int32)
-        # edge -> (cell, local edge) for up to two cells
+        # edge -> incident (cell, local edge) pairs.  Surface meshes of built-up structures branch: a rib or spar
+        # meets the skin along edges shared by three or more cells -- the incidence is kept as CSR lists;
+        # edge_cells / edge_local hold its first two entries (all of it on a manifold mesh).
         order = np.argsort(inv, kind="stable")
         counts = np.bincount(inv, minlength=self.nE)
-        if counts.max(initial=0) > 2:
-            raise ValueError("non-manifold mesh: an edge is shared by more than two cells")
         start = np.concatenate([[0], np.cumsum(counts)[:-1]])
         flat_cell = (order // nvc).astype(np.int32)
         flat_loc = (order % nvc).astype(np.int32)
+        self.edge_count = counts.astype(np.int32)
+        self.edge_inc_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.edge_inc_cell, self.edge_inc_local = flat_cell, flat_loc
         self.edge_cells = -np.ones((self.nE, 2), dtype=np.int32)
         self.edge_local = -np.ones((self.nE, 2), dtype=np.int32)
         self.edge_cells[:, 0] = flat_cell[start]
         self.edge_local[:, 0] = flat_loc[start]
-        two = counts == 2
+        two = counts >= 2
         self.edge_cells[two, 1] = flat_cell[start[two] + 1]
         self.edge_local[two, 1] = flat_loc[start[two] + 1]
         self.boundary_edges = np.nonzero(counts == 1)[0].astype(np.int32)
+        self.is_manifold = bool(counts.max(initial=0) <= 2)
+
+    def facet_incidence(self, edges):
+        """(cell, local edge) pairs of all cells incident to the given edges, (n, 2) int32."""
+        edges = np.asarray(edges, dtype=np.int64)
+        if edges.size == 0:
+            return np.zeros((0, 2), dtype=np.int32)
+        cnt = self.edge_count[edges]
+        base = np.repeat(self.edge_inc_off[edges], cnt)
+        within = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        idx = base + within
+        return np.stack([self.edge_inc_cell[idx], self.edge_inc_local[idx]], axis=1).astype(np.int32)
 
     def _build_p2(self):
         nV, nE, nC = self.nn, self.nE, (self.nel if self.is_quad else 0)
@@ -148,6 +163,10 @@ class ShellMesh:
         ext = self.locate_facets(func, boundary_only=True)
         allf = self.locate_facets(func, boundary_only=False)
         inte = allf[self.edge_cells[allf, 1] >= 0]
+        if not self.is_manifold:
+            # a branching edge is penalised from every cell that meets it (dolfinx's dS would pick two of them; the
+            # penalty only pins the DOFs of the edge, so the solution does not depend on the choice)
+            return np.vstack([self.facet_incidence(ext), self.facet_incidence(inte)]).astype(np.int32)
         cells = np.concatenate([self.edge_cells[ext, 0], self.edge_cells[inte, 0], self.edge_cells[inte, 1]])
         locs = np.concatenate([self.edge_local[ext, 0], self.edge_local[inte, 0], self.edge_local[inte, 1]])
         return np.stack([cells, locs], axis=1).astype(np.int32)
@@ -269,6 +288,27 @@ def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True
         cells = pn[cells]
         cells = cells[rng.permutation(cells.shape[0])]
     return ShellMesh(nodes, cells)
+
+
+def tee_beam_mesh(width=1.0, height=0.5, length=5.0, nw=4, nh=2, nl=10):
+    """A T-section: a flange plate (x along the length, y across the width, z = 0) with a web standing on its centre
+    line (y = 0, 0 <= z <= height).  The edges along the junction are shared by three cells -- the smallest instance
+    of the branching surfaces (skin + ribs + spars) that the reference's wing meshes are made of.  nw must be even."""
+    if nw % 2:
+        raise ValueError("nw must be even (the web stands on a mesh line)")
+    xs = np.linspace(0.0, length, nl + 1)
+    ys = np.linspace(-width / 2, width / 2, nw + 1)
+    zs = np.linspace(0.0, height, nh + 1)
+    fl = np.arange((nl + 1) * (nw + 1)).reshape(nl + 1, nw + 1)
+    nodes = [np.stack([np.repeat(xs, nw + 1), np.tile(ys, nl + 1), np.zeros((nl + 1) * (nw + 1))], axis=1)]
+    cells = [np.stack([fl[:-1, :-1].ravel(), fl[1:, :-1].ravel(), fl[1:, 1:].ravel(), fl[:-1, 1:].ravel()], axis=1)]
+    # web nodes above the flange (row 0 of the web is the flange's centre line)
+    wb = np.empty((nl + 1, nh + 1), dtype=np.int64)
+    wb[:, 0] = fl[:, nw // 2]
+    wb[:, 1:] = fl.size + np.arange((nl + 1) * nh).reshape(nl + 1, nh)
+    nodes.append(np.stack([np.repeat(xs, nh), np.zeros((nl + 1) * nh), np.tile(zs[1:], nl + 1)], axis=1))
+    cells.append(np.stack([wb[:-1, :-1].ravel(), wb[1:, :-1].ravel(), wb[1:, 1:].ravel(), wb[:-1, 1:].ravel()], axis=1))
+    return ShellMesh(np.vstack(nodes), np.vstack(cells))
 
 
 def quads_to_triangles(mesh: ShellMesh):

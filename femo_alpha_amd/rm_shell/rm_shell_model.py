@@ -53,7 +53,10 @@ def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: 
     else:
         ed = mesh.locate_facets(SubdomainFunc, boundary_only=False)
         ed = ed[mesh.edge_cells[ed, 1] >= 0]
-        pairs = np.vstack([np.stack([mesh.edge_cells[ed, s], mesh.edge_local[ed, s]], axis=1) for s in (0, 1)])
+        if mesh.is_manifold:
+            pairs = np.vstack([np.stack([mesh.edge_cells[ed, s], mesh.edge_local[ed, s]], axis=1) for s in (0, 1)])
+        else:
+            pairs = mesh.facet_incidence(ed)           # branching edges: every incident cell
     sets = {tag: FacetSet(pairs)}
     return lambda t: sets.get(t, FacetSet(np.zeros((0, 2), np.int32)))
 

@@ -28,6 +28,9 @@ def _mesh(kind):
         return wing_skin_mesh(6, 14, shuffle=True)
     if kind == "tri":
         return quads_to_triangles(wing_skin_mesh(5, 9, shuffle=True))
+    if kind == "tee":                # branching surface: flange + web, edges shared by three cells
+        from femo_alpha_amd.mesh import tee_beam_mesh
+        return tee_beam_mesh(1.0, 0.5, 5.0, 4, 2, 10)
     raise ValueError(kind)
 
 
@@ -43,7 +46,7 @@ def _pair(kind, ewm=False, ewp=False, uhat=False, bc="penalty", beta=1e15, seed=
                   F_solid=rng.uniform(-1, 1, (nF, 3)))
     if uhat:
         fields["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
-    marker = CLAMP if kind.startswith("plate") else (lambda x: np.less(x[1], 1e-12))
+    marker = CLAMP if kind.startswith("plate") or kind == "tee" else (lambda x: np.less(x[1], 1e-12))
     pf = m.penalty_facets(marker) if bc == "penalty" else None
     sd = m.locate_dofs_geometrical(marker) if bc == "strong" else None
     o = ShellOracle(m, element_wise_material=ewm, elementwise_pressure=ewp, penalty_facets=pf, strong_dofs=sd, beta=beta)
@@ -61,7 +64,8 @@ def _pair(kind, ewm=False, ewp=False, uhat=False, bc="penalty", beta=1e15, seed=
 
 CASES = [("plate", False, False, False, "penalty"), ("warped", False, False, False, "penalty"),
          ("warped", True, True, False, "strong"), ("warped", False, False, True, "penalty"),
-         ("tri", False, False, False, "penalty"), ("tri", True, False, True, "strong")]
+         ("tri", False, False, False, "penalty"), ("tri", True, False, True, "strong"),
+         ("tee", False, False, True, "penalty")]
 
 
 @pytest.mark.parametrize("kind,ewm,ewp,uhat,bc", CASES)
@@ -135,7 +139,8 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("kind,ewm,bc,uhat,wide_cnt", [("plate", False, "penalty", False, None), ("warped", True, "strong", False, 0),
                                                        ("warped", False, "penalty", True, None), ("tri", False, "penalty", False, 0),
-                                                       ("plate24", False, "penalty", False, 0), ("plate", False, "strong", False, 0)])
+                                                       ("plate24", False, "penalty", False, 0), ("plate", False, "strong", False, 0),
+                                                       ("tee", False, "penalty", False, None), ("tee", True, "strong", True, 0)])
 def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
     the same parity triple as the reference's direct (MUMPS LU) solve.  Levels with few fronts take the wide

@@ -245,3 +245,32 @@ def test_uhat_scaling_of_flat_plate():
     # compliance has the J factor: int u.u J dx on the reference mesh == int u.u dx on the stretched one
     assert np.isclose(o.compliance(w) - o.regularization(), os_.compliance(w) - os_.regularization(), rtol=1e-12)
     assert np.isclose(o.mass(), os_.mass(), rtol=1e-12)
+
+
+def test_branching_surface_tee_beam():
+    """A T-section (flange + web meeting along edges shared by three cells -- the skin/rib/spar topology of the
+    reference's wing meshes): six rigid-body modes, and the clamped tip deflection under a line load follows
+    Euler-Bernoulli with the second moment of the T-section."""
+    import scipy.linalg as la
+    from femo_alpha_amd.mesh import tee_beam_mesh
+    m = tee_beam_mesh(1.0, 0.5, 5.0, 4, 2, 10)
+    assert not m.is_manifold and m.edge_count.max() == 3
+    o = ShellOracle(m)
+    o.set_fields(h=0.05, E=1e9, nu=0.3, rho=1.0, f=np.zeros((m.nn, 3)))
+    K = o.assemble_K(with_penalty=False, with_strong=False).toarray()
+    ev = la.eigvalsh(K)
+    assert np.sum(np.abs(ev) < 1e-9 * ev.max()) == 6
+    clamp = lambda x: np.less(x[0], 1e-12)
+    pf = m.penalty_facets(clamp)
+    assert len(pf) == 4 + 2                                           # four flange edges and two web edges at the root
+    o = ShellOracle(m, penalty_facets=pf)
+    f = np.zeros((m.nn, 3)); f[:, 2] = -10.0
+    o.set_fields(h=0.05, E=1e9, nu=0.3, rho=1.0, f=f)
+    w = o.solve()
+    tip = w[: 3 * m.nn].reshape(-1, 3)[np.argmax(m.nodes[:, 0]), 2]
+    A1, A2 = 1.0 * 0.05, 0.5 * 0.05
+    zbar = A2 * 0.25 / (A1 + A2)
+    I = 1.0 * 0.05 ** 3 / 12 + A1 * zbar ** 2 + 0.05 * 0.5 ** 3 / 12 + A2 * (0.25 - zbar) ** 2
+    q = 10.0 * (1.0 + 0.5)                                            # the load acts on flange and web area
+    eb = -q * 5.0 ** 4 / (8 * 1e9 * I)
+    assert abs(tip - eb) < 0.06 * abs(eb), (tip, eb)
