@@ -5,16 +5,18 @@
 // (reference femo_alpha/fea/utils_dolfinx.py:466,495-531) -- itself a multifrontal method.
 // Here the elimination tree comes from a geometric nested dissection of the elements
 // (femo_alpha_amd/solver/symbolic.py); element matrices are summed straight into the leaf fronts;
-// every level of the tree is factorised by batched, blocked, right-looking partial Cholesky kernels
-// whose grids span all fronts of the level: per outer panel of 128 columns the diagonal block is
-// factorised and inverted by one workgroup per front (32x32 register Cholesky + fp64 MFMA), the rows
-// below become factor rows by one GEMM against that inverse, and 64x64 trailing tiles are updated
-// on the matrix cores.
+// every level of the tree is factorised by batched, blocked partial Cholesky kernels whose grids span
+// all fronts of the level: parents are gathered from their children's Schur complements, then per
+// outer panel of 128 columns the diagonal block is factorised and inverted by one workgroup per front
+// (32x32 register Cholesky + fp64 MFMA), the rows below become factor rows by one GEMM against that
+// inverse, and 64x64 tiles receive the rank-k updates on the matrix cores (right-looking with
+// look-ahead at the top of the tree, left-looking on the levels with many fronts).
 //
 // Storage: front t is a dense column-major nf x nf block at F + foff[t]; only the lower triangle is
 // maintained.  After factorisation its first npiv columns hold [L11; L21]; the trailing block is
 // the Schur complement that the parent consumes.  Linv keeps the inverses of the NB x NB diagonal
-// blocks of L11 so that every triangular solve becomes a small GEMV.
+// blocks of L11, Sinv those of the 128 x 128 diagonal blocks (levels with few fronts), so that every
+// triangular solve becomes a GEMV.
 #pragma once
 #include "shell_device.h"
 
