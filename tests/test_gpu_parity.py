@@ -183,6 +183,33 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     assert rel(c.get_state(), o.solve()) < 1e-8
 
 
+@pytest.mark.parametrize("shape,tri", [((1, 1), False), ((1, 2), False), ((1, 1), True), ((3, 3), False)])
+def test_tiny_meshes_single_front(shape, tri):
+    """One to nine cells: the elimination tree is a single front (no extend-add, no Schur complement); forward and
+    adjoint solves against the oracle."""
+    from femo_alpha_amd.backend import ShellContext
+    from oracle.rm_shell_oracle import ShellOracle
+    m = plate_mesh(1.0, float(shape[1]), shape[0], shape[1])
+    if tri:
+        m = quads_to_triangles(m)
+    f = np.tile([0.0, 0.0, 1.0], (m.nn, 1))
+    c = ShellContext(m)
+    for k, v in (("thickness", [0.1]), ("E", [1e6]), ("nu", [0.3]), ("density", [1.0]), ("F_solid", f)):
+        c.set_field(k, v)
+    pf = m.penalty_facets(CLAMP)
+    c.set_penalty_facets(pf, 1e12)
+    plan = c.enable_frontal()
+    assert plan.ntree == 1
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=20, check_every=1)
+    it, rr = c.solve_state()
+    o = ShellOracle(m, penalty_facets=pf, beta=1e12)
+    o.set_fields(h=0.1, E=1e6, nu=0.3, rho=1.0, f=f)
+    w, J, dJ = o.forward_adjoint()
+    assert it <= 3 and rel(c.get_state(), w) < 1e-10
+    g, it2, rr2 = c.total_gradient("compliance", "thickness")
+    assert rel(g, dJ) < 1e-9
+
+
 @pytest.mark.parametrize("kind,bc,precond", [("plate", "penalty", 2), ("warped", "strong", 2), ("thick", "strong", 0),
                                              ("thick", "penalty", 0)])
 def test_bicgstab_matches_conjugate_gradients(kind, bc, precond):
