@@ -1232,9 +1232,12 @@ int femo_solve_linear(femo_ctx* c, const double* rhs, double* x, int32_t* iters,
     return 0;
 }
 
-static int functionals_dev(femo_ctx* c, double* out3, int nout = 3) {
+// whole-mesh integrals; restricted to the selected sub-domain only when asked (tip_disp, area: the reference's dxx(i))
+static MeshDev mesh_dev_all(const femo_ctx* c) { MeshDev m = mesh_dev(c); m.csel = -1; return m; }
+
+static int functionals_dev(femo_ctx* c, double* out3, int nout = 3, bool subdomain = false) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
-    ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, c->scal);
+    ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, subdomain ? mesh_dev(c) : mesh_dev_all(c), fields_dev(c), c->tab, c->w, c->scal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1265,6 +1268,12 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
         double v[4];
         if (functionals_dev(c, v, 4)) return 1;
         *value = s == "mass" ? v[2] : s == "volume" ? v[3] : s == "regularization" ? v[1] : v[0] + v[1];
+        return 0;
+    }
+    if (s == "tip_disp" || s == "area") {          // over the selected sub-domain (rm_shell_pde.py:95-96, 104-105)
+        double v[5];
+        if (functionals_dev(c, v, 5, true)) return 1;
+        *value = s == "area" ? v[4] : 0.5 * v[0];
         return 0;
     }
     if (s == "elastic_energy") {
@@ -1331,10 +1340,13 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         }
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
-    if (fn == "regularization") {         // the thickness term of the compliance (its only explicit thickness dependence)
+    if (fn == "tip_disp") {               // 0.5 int u.u J over the selected sub-domain
+        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out, 0.5);
+    } else if (fn == "area") {
+    } else if (fn == "regularization") {         // the thickness term of the compliance (its only explicit thickness dependence)
         if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "compliance") {
-        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out);
+        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, mesh_dev_all(c), f, c->tab, c->w, out, 1.0);
         else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "mass") {
         if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);

@@ -815,8 +815,8 @@ template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
 k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double* slots) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    double uu = 0.0, reg = 0.0, mass = 0.0, vol = 0.0;
-    if (e < m.nel) {
+    double uu = 0.0, reg = 0.0, mass = 0.0, vol = 0.0, area = 0.0;
+    if (e < m.nel && cell_selected(m, e)) {
         Elem<NPC, NVC> el;
         load_elem<NPC, NVC, UHAT>(m, f, e, el);
         double ue[3 * NPC];
@@ -841,6 +841,7 @@ k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doub
             const double hq = interp<NVC>(tab->N1[q], el.hn);
             mass += wd * g.Ju * hq * interp<NVC>(tab->N1[q], rhon);
             vol += wd * g.Ju * hq;                          // int h J dx (dynamic_rm_shell/volume_operation.py:68-70)
+            area += wd * g.Ju;                              // int J dx (rm_shell_pde.py:104-105)
             if (f.ewm) {
                 reg += 0.5 * REG_ALPHA1 * wd * hq * hq;                    // L2, rm_shell_pde.py:79-81
             } else {
@@ -858,15 +859,16 @@ k_functionals(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doub
     block_accumulate(reg, slots + 1);
     block_accumulate(mass, slots + 2);
     block_accumulate(vol, slots + 3);
+    block_accumulate(area, slots + 4);
 }
 
 // out_u += 2 int N_a u J dx  (d compliance / d w)
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
 k_dcompliance_du(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w,
-                 double* __restrict__ out) {
+                 double* __restrict__ out, double scale = 1.0) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m.nel) return;
+    if (e >= m.nel || !cell_selected(m, e)) return;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, UHAT>(m, f, e, el);
     double ue[3 * NPC], ge[3 * NPC];
@@ -881,7 +883,7 @@ k_dcompliance_du(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const d
     for (int q = 0; q < nq; ++q) {
         QPG g;
         qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
-        const double wj = 2.0 * tab->w[q] * g.det * g.Ju;
+        const double wj = 2.0 * scale * tab->w[q] * g.det * g.Ju;
         double uq[3] = {0, 0, 0};
 #pragma unroll
         for (int a = 0; a < NPC; ++a)

@@ -61,6 +61,18 @@ class RMShellPDE:
                                       "(the one the reference's compliance selects)")
         return Form(self.ctx, "regularization")
 
+    def tip_disp(self, u_mid, uhat, dxx):
+        """0.5 int u.u J over the tagged sub-domain ``dxx`` (its index; rm_shell_pde.py:95-96)."""
+        return Form(self.ctx, "tip_disp", subdomain=int(dxx))
+
+    def area_subdomain(self, uhat, dxx):
+        """int J over the tagged sub-domain ``dxx`` (rm_shell_pde.py:104-105)."""
+        return Form(self.ctx, "area", subdomain=int(dxx))
+
+    def sum_stress_subdomain(self, w, uhat, h, E, nu, dxx):
+        raise NotImplementedError("the global-component stress sums are only referenced from commented-out code in the "
+                                  "reference (rm_shell_model.py:255-262); use pnorm_stress over the sub-domain")
+
     def volume(self, uhat, h):
         """int h J dx (rm_shell_pde.py:98-99)."""
         return Form(self.ctx, "volume")

@@ -166,7 +166,8 @@ int femo_select_subdomain(femo_ctx* ctx, int32_t sel);
  * csdl_alpha_opt/output_operation.py:116-123). */
 int femo_field_output(femo_ctx* ctx, const char* name, double* out, int64_t n);
 /* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy", "pnorm_stress", "volume",
- * "regularization" (the thickness term of the compliance, rm_shell_pde.py:64-83) --
+ * "regularization" (the thickness term of the compliance, rm_shell_pde.py:64-83), and over the selected sub-domain
+ * (femo_select_subdomain; the whole mesh if none) "tip_disp" = 0.5 int u.u J and "area" = int J (rm_shell_pde.py:95-105) --
  * replaces assemble_scalar(form(c)) (csdl_alpha_opt/output_operation.py:51-56; forms at
  * rm_shell/rm_shell_pde.py:64-110). */
 int femo_functional(femo_ctx* ctx, const char* name, double* value);

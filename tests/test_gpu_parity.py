@@ -403,6 +403,28 @@ def test_stress_aggregate_on_subdomains(kind, uhat):
         assert abs(g_h[k] - fd) <= 5e-6 * abs(fd), (g_h[k], fd)
         g_u = c.dfunctional("pnorm_stress", "uhat").reshape(-1, 3)
         assert np.all(g_u[np.setdiff1d(np.arange(m.nn), np.unique(m.cells[g]))] == 0.0)
+    # tip_disp = 0.5 int u.u J and area = int J over a sub-domain (rm_shell_pde.py:95-105): the groups partition the
+    # tagged cells, so the pieces add up to the whole-mesh values
+    c.select_subdomain(-1)
+    comp_uu = c.functional("compliance") - c.functional("regularization")
+    tag_rest = tags.copy(); tag_rest[tags < 0] = len(groups)
+    c.set_cell_tags(tag_rest, len(groups) + 1)
+    parts, areas = [], []
+    for i in range(len(groups) + 1):
+        c.select_subdomain(i)
+        parts.append(c.functional("tip_disp")); areas.append(c.functional("area"))
+        g_t = c.dfunctional("tip_disp", "disp_solid")
+        cells_i = np.nonzero(tag_rest == i)[0]
+        touched = np.unique(m.cell_dofs()[cells_i])
+        assert np.all(g_t[np.setdiff1d(np.arange(m.ndof), touched)] == 0.0)
+    c.select_subdomain(-1)
+    assert abs(2.0 * sum(parts) - comp_uu) <= 1e-12 * comp_uu
+    assert abs(sum(areas) - c.functional("area")) <= 1e-13 * sum(areas)
+    g_all = c.dfunctional("compliance", "disp_solid")
+    c.select_subdomain(0)
+    # the compliance ignores the selection (atomic adds: the summation order may differ in the last bit)
+    assert np.abs(c.dfunctional("compliance", "disp_solid") - g_all).max() <= 1e-14 * np.abs(g_all).max()
+    c.set_cell_tags(tags, len(groups))
     c.select_subdomain(-1)
     assert c.functional("pnorm_stress") == whole
     with pytest.raises(Exception, match="unknown sub-domain"):
