@@ -70,6 +70,42 @@ class Function:
             self._host[:] = values
 
 
+    # ---- read-only stand-ins for the dolfinx post-processing idiom of the reference's examples
+    #      (``w.sub(0).collapse().x.array``, ex_simple_shell_opt.py:142-144)
+    @property
+    def x(self):
+        return _ArrayView(self.get())
+
+    def sub(self, i):
+        """Sub-function of the mixed state: 0 = mid-surface displacement (P2 nodes, xyz), 1 = rotation (vertices, xyz)."""
+        if self.function_space.kind != "W":
+            raise ValueError("only the mixed state function has sub-functions")
+        nu = self.ctx.mesh.ndof_u
+        w = self.get()
+        if i == 0:
+            return _SubFunction(w[:nu])
+        if i == 1:
+            return _SubFunction(w[nu:])
+        raise IndexError("the shell state has two sub-functions: displacement (0) and rotation (1)")
+
+
+class _ArrayView:
+    def __init__(self, a):
+        self.array = a
+
+
+class _SubFunction:
+    def __init__(self, values):
+        self._values = values
+
+    def collapse(self):
+        return self
+
+    @property
+    def x(self):
+        return _ArrayView(self._values)
+
+
 class Form:
     """Scalar output known to the backend: 'compliance', 'mass', 'elastic_energy', 'pnorm_stress', 'volume'.
     ``subdomain`` restricts the stress aggregate to one tagged set of cells (the reference's ``dxx(i)`` measure)."""

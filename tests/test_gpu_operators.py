@@ -62,6 +62,15 @@ def test_rm_shell_model_protocol(element_wise_material, penalty):
     eb = f_d * 2.0 * 10.0 ** 4 / (8 * E_val * 2.0 * h_val ** 3 / 12)
     assert 0.8 * eb < np.abs(out.disp_solid.value[:mesh.ndof_u]).max() < 1.2 * eb
 
+    # the post-processing idiom of the reference's example (ex_simple_shell_opt.py:142-147)
+    w_fun = model.fea.states_dict["disp_solid"]["function"]
+    u_mid = w_fun.sub(0).collapse().x.array
+    theta = w_fun.sub(1).collapse().x.array
+    assert u_mid.shape == (mesh.ndof_u,) and theta.shape == (3 * nn,)
+    assert np.array_equal(np.concatenate([u_mid, theta]), w_fun.x.array)
+    assert np.abs(u_mid - w_ref[: mesh.ndof_u]).max() < 1e-7 * np.abs(w_ref).max()
+    assert out.F_solid.shape == (3 * nn,)
+
     # stress outputs (rm_shell_model.py:200-208, 230-239, 452-455)
     from oracle.rm_shell_oracle import ShellOracle as _SO
     o3 = _SO(mesh, element_wise_material=element_wise_material, nquad=3)
