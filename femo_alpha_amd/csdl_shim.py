@@ -44,6 +44,23 @@ class Variable:
     def set_value(self, v):
         self.value[...] = np.asarray(v, dtype=np.float64).reshape(self.shape)
 
+    # optimisation roles: recorded on the variable (and on the active recorder) for whoever drives the optimiser;
+    # the stand-in has no optimiser of its own (the reference hands the recorder to modopt, ex_simple_shell_opt.py:114-131)
+    def _role(self, kind, **kw):
+        self.optimization_role = (kind, {k: v for k, v in kw.items() if v is not None})
+        if _active:
+            getattr(_active[-1], kind + "s").append(self)
+        return self
+
+    def set_as_design_variable(self, upper=None, lower=None, scaler=None):
+        return self._role("design_variable", upper=upper, lower=lower, scaler=scaler)
+
+    def set_as_constraint(self, upper=None, lower=None, equals=None, scaler=None):
+        return self._role("constraint", upper=upper, lower=lower, equals=equals, scaler=scaler)
+
+    def set_as_objective(self, scaler=None):
+        return self._role("objective", scaler=scaler)
+
     # fancy-index / reshape views that stay differentiable (the reference permutes inputs this way,
     # rm_shell_model.py:398-438)
     def __getitem__(self, idx):
@@ -178,6 +195,7 @@ class Recorder:
     def __init__(self, inline=True):
         self.inline = inline
         self.ops = []
+        self.design_variables, self.constraints, self.objectives = [], [], []
 
     def start(self):
         _active.append(self)
