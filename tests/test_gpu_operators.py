@@ -227,3 +227,39 @@ def test_renumbered_model_answers_in_caller_order():
     o3.set_fields(h=h0, E=7e9, nu=0.3)
     ref = o3.pnorm_stress(w_ref, 1e-6, 100, cells=tags["outboard"])
     assert abs(out.pnorm_stress_outboard.value[0] - ref) < 1e-6 * ref
+
+
+def test_thickness_optimisation_loop():
+    """The reference's example end to end (ex_simple_shell_opt.py:114-131): thickness design variable with bounds,
+    mass held at its initial value, an SLSQP loop in which every function evaluation is a forward solve and every
+    gradient an adjoint solve on the GPU.  A few iterations must lower the compliance markedly at constant mass."""
+    from femo_alpha_amd.optimize import slsqp
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    mesh = plate_mesh(2.0, 10.0, 4, 20)
+    nn = mesh.nn
+    recorder = csdl.Recorder(inline=True)
+    recorder.start()
+    pressure = csdl.Variable(value=np.zeros((nn, 3)), name="force_vector")
+    pressure.value[:, 2] = 5.0
+    thickness = csdl.Variable(value=0.1 * np.ones(nn), name="thickness")
+    E = csdl.Variable(value=1e8 * np.ones(nn), name="E")
+    nu = csdl.Variable(value=0.3 * np.ones(nn), name="nu")
+    density = csdl.Variable(value=10.0 * np.ones(nn), name="density")
+    model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False)
+    ctx = model.shell_pde.ctx
+    ctx.enable_frontal(8)
+    ctx.set_solver(preconditioner=2, rtol=1e-11, maxit=50, check_every=1)
+    out = model.evaluate(pressure, thickness, E, nu, density)
+    J0, m0 = float(out.compliance.value[0]), float(out.mass.value[0])
+    thickness.set_as_design_variable(upper=0.2, lower=2e-2)
+    out.mass.set_as_constraint(lower=m0, upper=m0)
+    out.compliance.set_as_objective(scaler=1.0 / J0)
+    res = slsqp(recorder, maxiter=8, ftol=1e-12)
+    recorder.stop()
+    J1, m1 = float(out.compliance.value[0]), float(out.mass.value[0])
+    assert J1 < 0.7 * J0, (J0, J1, res.message)
+    assert abs(m1 - m0) < 1e-6 * m0
+    assert thickness.value.min() >= 2e-2 - 1e-12 and thickness.value.max() <= 0.2 + 1e-12
+    # material moved towards the clamped root, as it must for a cantilever
+    x = mesh.nodes[:, 0]
+    assert thickness.value[x < 2.0].mean() > thickness.value[x > 8.0].mean()
