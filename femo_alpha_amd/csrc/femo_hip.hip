@@ -488,12 +488,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         //                    the Schur complement is updated once with K = npiv (each entry read and written once).
         // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
-        static const char* sched = getenv("FEMO_TRAILING");
-        static const int left_min = getenv("FEMO_LEFT_MIN") ? atoi(getenv("FEMO_LEFT_MIN")) : 16;
-        static const int left_max = getenv("FEMO_LEFT_MAX") ? atoi(getenv("FEMO_LEFT_MAX")) : 2048;
+        const char* sched = getenv("FEMO_TRAILING");
+        const int left_min = getenv("FEMO_LEFT_MIN") ? atoi(getenv("FEMO_LEFT_MIN")) : 16;
+        const int left_max = getenv("FEMO_LEFT_MAX") ? atoi(getenv("FEMO_LEFT_MAX")) : 2048;
         const bool right_looking = sched && sched[0] == 'r' ? true : sched && sched[0] == 'l' ? false : (cnt < left_min || cnt > left_max);
-        static const bool no_lookahead = getenv("FEMO_NO_LOOKAHEAD") != nullptr;
-        static const int la_cnt = getenv("FEMO_LOOKAHEAD_CNT") ? atoi(getenv("FEMO_LOOKAHEAD_CNT")) : 16;
+        const bool no_lookahead = getenv("FEMO_NO_LOOKAHEAD") != nullptr;
+        const int la_cnt = getenv("FEMO_LOOKAHEAD_CNT") ? atoi(getenv("FEMO_LOOKAHEAD_CNT")) : 16;
         const bool lookahead = right_looking && cnt < la_cnt && !no_lookahead;
         bool bulk_pending = false;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
