@@ -21,9 +21,9 @@ using namespace femo;
 
 // tree levels whose largest pivot block exceeds this run the triangular solves with the wide (multi-workgroup)
 // kernels and the precomputed 128 x 128 diagonal-block inverses; smaller fronts use one workgroup per front
-static int WIDE_NP = 512;           // FEMO_WIDE_NP overrides it when a plan is uploaded (tests force the wide path on small meshes)
-static int WIDE_CNT = 512;          // FEMO_WIDE_CNT: levels with at most this many fronts also take the wide (many workgroups per
-                                    // front) solve kernels -- one workgroup per front cannot pull a level's factor out of HBM
+constexpr int WIDE_NP_DEFAULT = 512;    // FEMO_WIDE_NP overrides it for the plan being uploaded (tests force the wide path on small meshes)
+constexpr int WIDE_CNT_DEFAULT = 512;   // FEMO_WIDE_CNT: levels with at most this many fronts also take the wide (many workgroups per
+                                        // front) solve kernels -- one workgroup per front cannot pull a level's factor out of HBM
 
 #define FEMO_VERSION 100
 
@@ -1449,8 +1449,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipSetDevice(c->device));
     auto& fr = c->fr;
     if (fr.ready) return fail(c, "frontal plan already set for this context");
-    if (const char* e = getenv("FEMO_WIDE_NP")) WIDE_NP = std::max(1, atoi(e));
-    if (const char* e = getenv("FEMO_WIDE_CNT")) WIDE_CNT = std::max(0, atoi(e));
+    const int WIDE_NP = getenv("FEMO_WIDE_NP") ? std::max(1, atoi(getenv("FEMO_WIDE_NP"))) : WIDE_NP_DEFAULT;
+    const int WIDE_CNT = getenv("FEMO_WIDE_CNT") ? std::max(0, atoi(getenv("FEMO_WIDE_CNT"))) : WIDE_CNT_DEFAULT;
     if (ntree < 1 || nlevels < 1) return fail(c, "empty frontal plan");
     fr.ntree = ntree; fr.nlevels = nlevels;
     fr.h_nf.assign(nf, nf + ntree); fr.h_npiv.assign(npiv, npiv + ntree);
