@@ -423,6 +423,10 @@ struct ProfScope {
     }
 };
 
+// grid y / z extents are limited to 65535: levels with more fronts are launched in chunks
+static int grid_chunk() { const char* e = getenv("FEMO_GRID_CHUNK"); return e ? std::max(1, atoi(e)) : 32768; }   // the env switch exists for the tests
+#define FOR_FRONT_CHUNKS(cnt_, off_, n_) for (int off_ = 0, gc_ = grid_chunk(), n_ = std::min((cnt_), gc_); off_ < (cnt_); off_ += gc_, n_ = std::min((cnt_) - off_, gc_))
+
 // levels [l0, l1) of the elimination tree; assemble != 0 first zeroes the fronts and sums the element matrices in
 static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     auto& fr = c->fr;
@@ -440,7 +444,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
           int mx = 0;
           for (int i = fr.h_level_off[0]; i < fr.h_level_off[1]; ++i) mx = std::max(mx, fr.h_nf[fr.h_level_nodes[i]]);
           const int nt0 = (mx + TS - 1) / TS;
-          hipLaunchKernelGGL(k_zero_fronts, dim3(nt0 * (nt0 + 1) / 2, cnt0), dim3(256), 0, c->stream, fd, fr.level_nodes); }
+          FOR_FRONT_CHUNKS(cnt0, off, n)
+              hipLaunchKernelGGL(k_zero_fronts, dim3(nt0 * (nt0 + 1) / 2, n), dim3(256), 0, c->stream, fd, fr.level_nodes, off); }
         HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
         if (refresh_penalty(c)) return 1;
         { ProfScope ps(c, 4);
@@ -473,7 +478,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             const int nt = (max_nb + TS - 1) / TS;
             const dim3 grid(nt * (nt + 1) / 2, cnt);
-            { ProfScope ps(c, 3); hipLaunchKernelGGL(k_extend_gather, grid, dim3(256), 0, c->stream, fd, lev, mask); }
+            { ProfScope ps(c, 3);
+              FOR_FRONT_CHUNKS(cnt, off, n)
+                  hipLaunchKernelGGL(k_extend_gather, dim3(grid.x, n), dim3(256), 0, c->stream, fd, lev, off, mask); }
         }
         int max_nf = 0;
         for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
@@ -502,7 +509,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 // left-looking update of this panel's columns with all factor columns to their left
                 ProfScope ps(c, 2);
                 const int ntr = (max_nf - C0 + TS - 1) / TS;
-                hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 0);
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0);
             }
             { ProfScope ps(c, 1);
               // classes of equal sub-block count (fronts are sorted by pivot count); small levels go in one launch
@@ -525,13 +533,15 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             const int tiles = (std::max(0, max_nf - C0 - 1) + TS - 1) / TS;
             if (tiles > 0) {
                 ProfScope ps(c, 0);
-                hipLaunchKernelGGL(k_panel_rows, dim3(tiles, cnt), dim3(256), 0, c->stream, fd, lev, C0, sw);
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, n), dim3(256), 0, c->stream, fd, lev, off, C0, sw);
             }
             if (right_looking && max_nf > C0 + 1) {
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
                 if (!lookahead) {
                     ProfScope ps(c, 2);
-                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 2);
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2);
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
                     // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
@@ -539,13 +549,13 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     // the bulk update also writes, so it waits for it (ev_la[1]).
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
                     { ProfScope ps(c, 2);
-                      hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, C0, 3); }
+                      hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3); }
                     const int ntb = ntr - NBO / TS;
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
-                          hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, C0, 4); }
+                          hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
@@ -557,8 +567,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
             const int ntr = (max_nb + TS - 1) / TS;
-            if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
-            else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, 1);
+            FOR_FRONT_CHUNKS(cnt, off, n) {
+                if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
+                else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
+            }
         }
         HIPCHK(c, hipGetLastError());
     }

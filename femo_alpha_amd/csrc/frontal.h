@@ -159,8 +159,8 @@ __global__ void k_front_mask_diag(FrontDev fd, const unsigned char* __restrict__
 
 // lower triangle of every front of a level := 0 (the leaf fronts before the element matrices are added)
 __global__ void __launch_bounds__(256)
-k_zero_fronts(FrontDev fd, const int* __restrict__ level_nodes) {
-    const int t = level_nodes[blockIdx.y];
+k_zero_fronts(FrontDev fd, const int* __restrict__ level_nodes, int first) {
+    const int t = level_nodes[first + blockIdx.y];
     const int nf = fd.nf[t];
     const int nt = (nf + TS - 1) / TS;
     const int lin = blockIdx.x;
@@ -181,8 +181,8 @@ k_zero_fronts(FrontDev fd, const int* __restrict__ level_nodes) {
 // Schur complements that land there (row maps cinv) -- written once, never read: no zero fill of the parent, no
 // read-modify-write, one launch per level for both children.  Masked (strong-BC) pivots get their unit diagonal here.
 __global__ void __launch_bounds__(256)
-k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, const unsigned char* __restrict__ mask) {
-    const int p = level_nodes[blockIdx.y];
+k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, const unsigned char* __restrict__ mask) {
+    const int p = level_nodes[first + blockIdx.y];
     const int ch0 = fd.child[0][p], ch1 = fd.child[1][p];
     if (ch0 < 0 && ch1 < 0) return;                      // nothing below: the front keeps what it was given
     const int nfp = fd.nf[p], npp = fd.npiv[p];
@@ -487,8 +487,9 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
 // S streams from L2 as the A operand, and the product is formed transposed so that the stores run along the
 // columns of the column-major front.
 __global__ void __launch_bounds__(256, 4)      // four waves per SIMD (measured: -15 % against three, 20 B of scratch)
-k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const double* __restrict__ Swork) {
-    const int t = level_nodes[blockIdx.y];
+k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork) {
+    const int slot = first + blockIdx.y;                       // position of the front in its level
+    const int t = level_nodes[slot];
     const int np = fd.npiv[t];
     if (C0 >= np) return;
     const int kw = min(NBO, np - C0);
@@ -499,7 +500,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int C0, const dou
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.F + fd.foff[t];
-    const double* S = Swork ? Swork + (size_t)blockIdx.y * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
     // S is shared by the four waves: the 16 rows of S that produce output columns [16 cb, 16 cb + 16) are staged in
     // LDS (k-major, so that the MFMA A operand S[c][k] is a conflict-free read), double-buffered over cb
     __shared__ double sb[2][NBO][16];
@@ -554,8 +555,8 @@ constexpr int LSTR = TS + 16;
 
 template <bool PRE>
 __global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
-k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int C0, int schur) {
-    const int t = level_nodes[blockIdx.z];
+k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur) {
+    const int t = level_nodes[first + blockIdx.z];
     const int np = fd.npiv[t];
     const int nf = fd.nf[t];
     // left-looking: the 128 pivot columns of an outer panel receive the updates of ALL earlier factor columns right

@@ -154,6 +154,8 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
         os.environ["FEMO_WIDE_CNT"] = str(wide_cnt)
     if kind in ("plate24", "tri"):
         os.environ["FEMO_TRAILING"] = "left"         # left-looking rank-k updates (the default on small meshes is right-looking)
+    if kind in ("warped", "plate24"):
+        os.environ["FEMO_GRID_CHUNK"] = "3"          # levels launched three fronts at a time (grid y/z extent limit)
     try:
         plan = c.enable_frontal(leaf_size=8)
         c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
@@ -162,6 +164,7 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
         os.environ.pop("FEMO_WIDE_NP", None)
         os.environ.pop("FEMO_WIDE_CNT", None)
         os.environ.pop("FEMO_TRAILING", None)
+        os.environ.pop("FEMO_GRID_CHUNK", None)
     assert plan.ntree > 1
     if kind == "plate24":
         assert plan.npiv.max() > 192
