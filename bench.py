@@ -46,12 +46,13 @@ def make_workload(name):
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
         desc = "synthetic wing skin 116x580 quads (cambered, tapered, twisted, jittered, renumbered), 1015470 DOF"
-    elif name == "wing4m":       # beyond BASELINE: four times the span, one GPU (the fronts take ~60 GB of the 288 GB)
-        m = wing_skin_mesh(116, 2320, span=24.0)
+    elif name in ("wing4m", "wing8m"):   # beyond BASELINE: 4x / 8x the span on one GPU (fronts: ~60 / ~125 GB of the 288 GB)
+        mult = 4 if name == "wing4m" else 8
+        m = wing_skin_mesh(116, 580 * mult, span=6.0 * mult)
         fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
-        desc = f"synthetic wing skin 116x2320 quads, {m.ndof} DOF"
+        desc = f"synthetic wing skin 116x{580 * mult} quads, {m.ndof} DOF"
     elif name == "plate8k":      # BASELINE.json configs[0] (plumbing size)
         m = plate_mesh(2.0, 10.0, 10, 50)
         fields = dict(thickness=[0.1], E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
