@@ -1,24 +1,47 @@
-"""Build libfemo_hip.so in-tree with hipcc for gfx950 (no CPU fallback exists)."""
+"""Build libfemo_hip.so in-tree with hipcc for gfx950 (no CPU fallback exists).
+
+Staleness is decided by content, not by time stamps: the digest of every source the library is compiled
+from (csrc/*.hip, csrc/*.h, include/*.h) and of the compiler flags is stored beside the library
+(``libfemo_hip.srchash``).  The pair travels to the GPU box together; ``_lib.load()`` refuses (or rebuilds,
+when hipcc is there) a library whose digest does not match the sources it sits next to."""
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+INCLUDE = os.path.normpath(os.path.join(CSRC, "..", "..", "include"))
 LIB = os.path.join(CSRC, "libfemo_hip.so")
+HASHFILE = os.path.join(CSRC, "libfemo_hip.srchash")
 SOURCES = ["femo_hip.hip"]
-HEADERS = ["shell_device.h", os.path.join("..", "..", "include", "femo_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wno-unused-value"]
 
 
+def dependencies():
+    """Every file the library is compiled from: the translation units, all headers next to them, the C ABI header."""
+    deps = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
+                  + glob.glob(os.path.join(INCLUDE, "*.h")))
+    return deps
+
+
+def source_digest() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in dependencies():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(HASHFILE) as fh:
+        return fh.read().strip() != source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -28,13 +51,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libfemo_hip.so cannot be built (there is no CPU fallback)")
-    cmd = [hipcc, *FLAGS, "-o", LIB, *SOURCES]
+    digest = source_digest()
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, *FLAGS, "-o", tmp, *SOURCES]
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd))
         print(res.stdout, res.stderr)
     if res.returncode:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed building libfemo_hip.so:\n" + res.stderr[-4000:])
+    os.replace(tmp, LIB)
+    with open(HASHFILE, "w") as fh:
+        fh.write(digest + "\n")
     return LIB
 
 

@@ -41,7 +41,9 @@ SIGNATURES = {
     "femo_factorize": (C.c_int, [C.c_void_p]),
     "femo_factorize_profile": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_frontal_info": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_sweep_profile": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
+    "femo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "femo_set_krylov": (C.c_int, [C.c_void_p, C.c_int]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
@@ -93,10 +95,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        raise FemoHipError(
-            f"{LIB} is missing: build it with `python -m femo_alpha_amd._build` (hipcc, gfx950). "
-            "femo_alpha_amd has no CPU fallback.")
+    from . import _build
+    if _build.needs_build():
+        # missing, or compiled from other sources than the ones beside it (content digest): rebuild, or refuse
+        try:
+            _build.build(force=True)
+        except RuntimeError as e:
+            raise FemoHipError(
+                f"{LIB} is missing or stale and cannot be rebuilt here ({e}); build it with "
+                "`python -m femo_alpha_amd._build` (hipcc, gfx950). femo_alpha_amd has no CPU fallback.") from e
     lib = C.CDLL(LIB)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it

@@ -14,6 +14,14 @@ from .mesh import ShellMesh
 PENALTY_BETA = 1.0e15      # reference linear_shell_model.py:324
 
 
+class FemoConvergenceError(FemoHipError):
+    """A Krylov solve stopped at maxit short of rtol (status 4; option 'strict')."""
+
+
+class FemoNotPositiveDefiniteError(FemoHipError):
+    """The multifrontal Cholesky met a non-positive pivot (status 5; option 'allow_pivot_repair')."""
+
+
 class ShellContext:
     VEC_IDS = {"state": 0, "adjoint": 1, "r": 2, "z": 3, "p": 4, "Ap": 5, "b": 6}
 
@@ -42,7 +50,17 @@ class ShellContext:
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):
         if rc:
-            raise FemoHipError(self.lib.femo_last_error(self._h).decode())
+            msg = self.lib.femo_last_error(self._h).decode()
+            if rc == 4:
+                raise FemoConvergenceError(msg)
+            if rc == 5:
+                raise FemoNotPositiveDefiniteError(msg)
+            raise FemoHipError(msg)
+
+    def set_option(self, key, value):
+        """Schedule switches and failure policy (femo_set_option): 'strict', 'allow_pivot_repair', 'trailing',
+        'left_min', 'left_max', 'lookahead', 'lookahead_cnt', 'grid_chunk', 'wide_np', 'wide_cnt', 'profile_verbose'."""
+        self._chk(self.lib.femo_set_option(self._h, key.encode(), float(value)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -124,12 +142,18 @@ class ShellContext:
         return Ke
 
     # ------------------------------------------------------------------ multifrontal preconditioner
-    def enable_frontal(self, leaf_size=12, plan=None):
+    def enable_frontal(self, leaf_size=12, plan=None, **options):
         """Run the symbolic analysis on the host (mesh only) and upload it; afterwards
         ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner.
-        ``plan`` may carry a ready-made plan (the multi-GPU driver passes rank-local plans)."""
+        ``plan`` may carry a ready-made plan (the multi-GPU driver passes rank-local plans);
+        ``options`` are plan-shaping switches set before the upload (``wide_np``, ``wide_cnt``)."""
+        import time
         from .solver.symbolic import build_plan
+        for k, v in options.items():
+            self.set_option(k, v)
+        t0 = time.perf_counter()
         plan = self.plan = build_plan(self.mesh, leaf_size) if plan is None else plan
+        self.symbolic_s = time.perf_counter() - t0
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
         level_off = i32(np.concatenate([[0], np.cumsum([len(l) for l in plan.level_nodes])]))
@@ -152,12 +176,18 @@ class ShellContext:
 
     def factorize_profile(self):
         """One factorisation timed per kernel class with HIP events on the context's stream."""
-        t = np.zeros(13)
+        t = np.zeros(16)
         self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)))
         names = ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset"]
         out = {n: dict(ms=t[i], launches=int(t[6 + i])) for i, n in enumerate(names)}
-        out["trailing_flops"] = t[12]
+        out["trailing_flops"], out["panel_rows_flops"], out["panel_diag_flops"] = t[12], t[13], t[14]
         return out
+
+    def sweep_profile(self):
+        """(nlevels, 2) array: ms of the forward / backward triangular sweep per tree level."""
+        t = np.zeros(2 * self.plan.nlevels)
+        self._chk(self.lib.femo_sweep_profile(self._h, dptr(t), t.size))
+        return t.reshape(-1, 2)
 
     def frontal_info(self):
         t = np.zeros(6)
@@ -168,6 +198,13 @@ class ShellContext:
     # ------------------------------------------------------------------ solves
     def set_solver(self, preconditioner=0, rtol=1e-10, maxit=200000, check_every=50):
         self._chk(self.lib.femo_set_solver(self._h, preconditioner, rtol, maxit, check_every))
+
+    def use_direct_solver(self, leaf_size=12, rtol=1e-12, maxit=40):
+        """What the reference's LU stands for (fea/utils_dolfinx.py:466,514-531): symbolic analysis once, then every
+        solve = multifrontal Cholesky of the current operator + a few refinement steps of PCG on the true residual."""
+        if getattr(self, "plan", None) is None:
+            self.enable_frontal(leaf_size)
+        self.set_solver(preconditioner=2, rtol=rtol, maxit=maxit, check_every=1)
 
     def set_krylov(self, method="cg"):
         """'cg' (default) or 'bicgstab' for the state, adjoint and linear solves."""

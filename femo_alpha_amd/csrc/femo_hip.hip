@@ -21,8 +21,8 @@ using namespace femo;
 
 // tree levels whose largest pivot block exceeds this run the triangular solves with the wide (multi-workgroup)
 // kernels and the precomputed 128 x 128 diagonal-block inverses; smaller fronts use one workgroup per front
-constexpr int WIDE_NP_DEFAULT = 512;    // FEMO_WIDE_NP overrides it for the plan being uploaded (tests force the wide path on small meshes)
-constexpr int WIDE_CNT_DEFAULT = 512;   // FEMO_WIDE_CNT: levels with at most this many fronts also take the wide (many workgroups per
+constexpr int WIDE_NP_DEFAULT = 512;    // option "wide_np" overrides it for the plan being uploaded (tests force the wide path on small meshes)
+constexpr int WIDE_CNT_DEFAULT = 512;   // option "wide_cnt": levels with at most this many fronts also take the wide (many workgroups per
                                         // front) solve kernels -- one workgroup per front cannot pull a level's factor out of HBM
 
 #define FEMO_VERSION 100
@@ -76,7 +76,18 @@ struct femo_ctx {
            *b = nullptr, *tmp = nullptr;
     double* scal = nullptr;        // device, 8 slots
     double* scal_host = nullptr;   // pinned, 8 slots
-    bool diag_dirty = true;
+    bool jacobi_dirty = true;      // the Jacobi diagonal is stale (fields / Dirichlet data / operator changed)
+    // schedule switches and failure policy (femo_set_option); never read from the environment
+    struct Options {
+        int trailing = 0;             // rank-k update schedule: 0 auto, 1 left-looking, 2 right-looking
+        int left_min = 16, left_max = 2048;   // auto: levels with this many fronts are left-looking
+        int lookahead = 1, lookahead_cnt = 16;
+        int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
+        int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
+        int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
+        int allow_pivot_repair = 0;   // non-positive pivots: 0 = the factorisation fails, 1 = replace and count
+        int profile_verbose = 0;
+    } opt;
     // solver
     int precond = 0;
     double rtol = 1e-10;
@@ -104,6 +115,7 @@ struct femo_ctx {
         bool profile = false;                 // time every kernel class with HIP events (slower)
         double prof_ms[6] = {0, 0, 0, 0, 0, 0};   // unused, panel, trailing, extend_add, assemble, memset
         long long prof_calls[6] = {0, 0, 0, 0, 0, 0};
+        double prof_flops[6] = {0, 0, 0, 0, 0, 0};   // algorithmic flops of what the launches of a class execute (lower triangles only)
         std::vector<hipEvent_t> pev;
         int cur_level = 0;
     } fr;
@@ -124,6 +136,9 @@ static int fail(femo_ctx* c, const std::string& msg) {
     c->err = msg;
     return 2;
 }
+
+// whatever the operator A = aK K + aM M (+ Dirichlet treatment) depends on has changed: both preconditioners are stale
+static void operator_changed(femo_ctx* c);
 
 // ------------------------------------------------------------------------------------------ tables
 static void gauss_legendre(int n, double* x, double* w) {
@@ -277,6 +292,8 @@ static FacetDev facet_dev(const femo_ctx* c) {
 
 static const int EB = 128;   // element kernels: threads per block (one element per thread)
 
+static void operator_changed(femo_ctx* c) { c->jacobi_dirty = true; c->fr.factored = false; }
+
 static int refresh_penalty(femo_ctx* c) {
     if (c->nf == 0 || !c->penalty_dirty) return 0;
     ELEM_LAUNCH(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
@@ -312,7 +329,7 @@ static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, do
 }
 
 static int refresh_diag(femo_ctx* c) {
-    if (!c->diag_dirty) return 0;
+    if (!c->jacobi_dirty) return 0;
     const int64_t n = c->ndof;
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv, 0.0, n);
     ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
@@ -324,7 +341,7 @@ static int refresh_diag(femo_ctx* c) {
     hipLaunchKernelGGL(k_invert_diag, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv,
                        c->has_mask ? c->mask : (const unsigned char*)nullptr, n);
     HIPCHK(c, hipGetLastError());
-    c->diag_dirty = false;
+    c->jacobi_dirty = false;
     return 0;
 }
 
@@ -334,6 +351,23 @@ static int load_vector_dev(femo_ctx* c, double* F) {
     ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, F, 1.0);
     if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, c->mask, n);
     HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// common exit of the Krylov solvers: report iterations / residual; stopping at maxit short of rtol is an error unless the
+// caller opted out (option "strict" = 0).  The reference solves with a direct LU (fea/utils_dolfinx.py:466,514-531), so an
+// unconverged state or adjoint has no counterpart there and must not flow silently into gradients.
+static int finish_solve(femo_ctx* c, const char* who, int k, double rr, double bb, double target, int32_t* iters, double* relres) {
+    const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
+    if (iters) *iters = k;
+    if (relres) *relres = rel;
+    if (bb > 0 && !(rr <= target) && c->opt.strict) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s did not converge: relative residual %.3e after %d iterations (rtol %.1e, maxit %d)", who, rel, k,
+                 c->rtol, c->maxit);
+        c->err = buf;
+        return 4;
+    }
     return 0;
 }
 
@@ -392,9 +426,7 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
     hipEventElapsedTime(&t_setup, c->ev[0], c->ev[1]);
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
     c->timing[0] = t_setup; c->timing[1] = t_loop; c->timing[2] = t_setup + t_loop; c->timing[4] = napply;
-    if (iters) *iters = k;
-    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
-    return 0;
+    return finish_solve(c, "Jacobi-PCG", k, rr, bb, c->rtol * c->rtol * bb, iters, relres);
 }
 
 
@@ -424,15 +456,15 @@ struct ProfScope {
 };
 
 // grid y / z extents are limited to 65535: levels with more fronts are launched in chunks
-static int grid_chunk() { const char* e = getenv("FEMO_GRID_CHUNK"); return e ? std::max(1, atoi(e)) : 32768; }   // the env switch exists for the tests
-#define FOR_FRONT_CHUNKS(cnt_, off_, n_) for (int off_ = 0, gc_ = grid_chunk(), n_ = std::min((cnt_), gc_); off_ < (cnt_); off_ += gc_, n_ = std::min((cnt_) - off_, gc_))
+// (option "grid_chunk" lowers the chunk so that the tests reach this path on small meshes)
+#define FOR_FRONT_CHUNKS(cnt_, off_, n_) for (int off_ = 0, gc_ = std::max(1, c->opt.grid_chunk), n_ = std::min((cnt_), gc_); off_ < (cnt_); off_ += gc_, n_ = std::min((cnt_) - off_, gc_))
 
 // levels [l0, l1) of the elimination tree; assemble != 0 first zeroes the fronts and sums the element matrices in
 static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     auto& fr = c->fr;
     if (!fr.ready) return fail(c, "no frontal plan: call femo_set_frontal_plan first");
     if (l0 < 0 || l1 > fr.nlevels || l0 > l1) return fail(c, "bad level range");
-    if (assemble) for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; }
+    if (assemble) for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; fr.prof_flops[i] = 0; }
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -489,29 +521,53 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const bool wide = fr.h_level_wide[L];                      // these levels keep S for the triangular solves
         int max_nb = 0;
         for (int i = b; i < e; ++i) max_nb = std::max(max_nb, fr.h_nf[fr.h_level_nodes[i]] - fr.h_npiv[fr.h_level_nodes[i]]);
-        // Rank-k updates, two schedules (FEMO_TRAILING = left | right | auto):
+        // Rank-k updates, two schedules (option "trailing": 0 auto, 1 left, 2 right):
         //   right-looking -- after every outer panel, everything behind it is updated with that panel's 128 columns;
         //   left-looking  -- a panel's columns receive all earlier columns' updates just before they are factorised and
         //                    the Schur complement is updated once with K = npiv (each entry read and written once).
         // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
-        const char* sched = getenv("FEMO_TRAILING");
-        const int left_min = getenv("FEMO_LEFT_MIN") ? atoi(getenv("FEMO_LEFT_MIN")) : 16;
-        const int left_max = getenv("FEMO_LEFT_MAX") ? atoi(getenv("FEMO_LEFT_MAX")) : 2048;
-        const bool right_looking = sched && sched[0] == 'r' ? true : sched && sched[0] == 'l' ? false : (cnt < left_min || cnt > left_max);
-        const bool no_lookahead = getenv("FEMO_NO_LOOKAHEAD") != nullptr;
-        const int la_cnt = getenv("FEMO_LOOKAHEAD_CNT") ? atoi(getenv("FEMO_LOOKAHEAD_CNT")) : 16;
-        const bool lookahead = right_looking && cnt < la_cnt && !no_lookahead;
+        const bool right_looking = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt < c->opt.left_min || cnt > c->opt.left_max);
+        const bool lookahead = right_looking && cnt < c->opt.lookahead_cnt && c->opt.lookahead != 0;
         bool bulk_pending = false;
+        // flops of one k_trailing_mfma launch over this level, with the kernel's own column / K ranges (profiling only)
+        auto count_trailing = [&](int C0, int schur) {
+            if (!fr.profile) return;
+            double fl = 0;
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i], np = fr.h_npiv[t], nf = fr.h_nf[t];
+                if (schur != 1 && C0 >= np) continue;
+                const int kw = schur >= 2 ? std::min(NBO, np - C0) : (schur ? np : C0);
+                const int col_lo = schur >= 2 ? C0 + kw + (schur == 4 ? NBO : 0) : (schur ? np : C0);
+                const int col_hi = schur == 0 ? std::min(C0 + NBO, np) : schur == 3 ? std::min(C0 + kw + NBO, nf) : nf;
+                if (kw <= 0 || col_lo >= col_hi) continue;
+                const double ncol = col_hi - col_lo;
+                fl += 2.0 * kw * (ncol * nf - 0.5 * ncol * (col_lo + col_hi - 1.0));
+            }
+            fr.prof_flops[2] += fl;
+        };
+        // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
+        auto count_panel = [&](int C0) {
+            if (!fr.profile) return;
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i], np = fr.h_npiv[t], nf = fr.h_nf[t];
+                if (C0 >= np) continue;
+                const double kw = std::min(NBO, np - C0), rows = nf - C0 - kw;
+                fr.prof_flops[1] += kw * kw * kw;
+                fr.prof_flops[0] += rows * kw * (kw + 1.0);
+            }
+        };
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             if (C0 > 0 && !right_looking) {
                 // left-looking update of this panel's columns with all factor columns to their left
                 ProfScope ps(c, 2);
+                count_trailing(C0, 0);
                 const int ntr = (max_nf - C0 + TS - 1) / TS;
                 FOR_FRONT_CHUNKS(cnt, off, n)
                     hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0);
             }
+            count_panel(C0);
             { ProfScope ps(c, 1);
               // classes of equal sub-block count (fronts are sorted by pivot count); small levels go in one launch
               const int* hn = fr.h_level_nodes.data() + b;
@@ -540,6 +596,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
                 if (!lookahead) {
                     ProfScope ps(c, 2);
+                    count_trailing(C0, 2);
                     FOR_FRONT_CHUNKS(cnt, off, n)
                         hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2);
                 } else {
@@ -549,12 +606,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     // the bulk update also writes, so it waits for it (ev_la[1]).
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
                     { ProfScope ps(c, 2);
+                      count_trailing(C0, 3);
                       hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3); }
                     const int ntb = ntr - NBO / TS;
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
+                          count_trailing(C0, 4);
                           hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
@@ -566,6 +625,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         if (max_nb > 0 && !right_looking) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
+            count_trailing(0, 1);
             const int ntr = (max_nb + TS - 1) / TS;
             FOR_FRONT_CHUNKS(cnt, off, n) {
                 if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
@@ -584,17 +644,28 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     if (assemble) { fr.t_assemble_ms = ta; fr.t_factor_ms = 0; }
     fr.t_factor_ms += tf; fr.pivots_fixed = info;
     fr.factored = (l1 == fr.nlevels);
+    int pivot_rc = 0;
+    if (info > 0 && !c->opt.allow_pivot_repair) {
+        // the reference's LU would factorise an indefinite matrix; a Cholesky factor of one does not exist, and a silently
+        // repaired factor is a preconditioner of something else: say so (option "allow_pivot_repair" restores the old behaviour)
+        char buf[200];
+        snprintf(buf, sizeof buf, "multifrontal Cholesky: %d non-positive pivot(s) -- the operator is not positive definite "
+                 "(negative thickness / modulus, or no Dirichlet data?)", info);
+        c->err = buf;
+        fr.factored = false;
+        pivot_rc = 5;
+    }
     for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
         float ms = 0;
         hipEventElapsedTime(&ms, fr.pev[i], fr.pev[i + 1]);
         const int tag = (int)(intptr_t)fr.pev[i + 2];
         const int cls = tag % 16;
         fr.prof_ms[cls] += ms; fr.prof_calls[cls] += 1;
-        if (getenv("FEMO_PROFILE_VERBOSE")) fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
+        if (c->opt.profile_verbose) fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
         hipEventDestroy(fr.pev[i]); hipEventDestroy(fr.pev[i + 1]);
     }
     fr.pev.clear();
-    return 0;
+    return pivot_rc;
 }
 
 static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0, c->fr.nlevels, true); }
@@ -656,11 +727,8 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     const int vg = vec_grid(n);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (c->diag_dirty || !c->fr.factored) {
+    if (!c->fr.factored)
         if (int rc = frontal_factorize(c)) return rc;
-        c->diag_dirty = false;
-        c->fr.factored = true;
-    }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     auto dot = [&](const double* a, const double* bb, double* out) -> int {
         HIPCHK(c, hipMemsetAsync(c->scal + 7, 0, sizeof(double), c->stream));
@@ -717,9 +785,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
     c->timing[0] = c->fr.t_assemble_ms + c->fr.t_factor_ms; c->timing[1] = t_loop; c->timing[2] = c->timing[0] + t_loop;
     c->timing[4] = napply;
-    if (iters) *iters = k;
-    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
-    return 0;
+    return finish_solve(c, "PCG (multifrontal preconditioner)", k, rr, bb, target, iters, relres);
 }
 
 // Right-preconditioned BiCGStab on the same operator and preconditioners (Jacobi or the multifrontal factor).  The
@@ -731,10 +797,8 @@ static int bicgstab(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t*
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     if (c->precond == 2) {
-        if (c->diag_dirty || !c->fr.factored) {
+        if (!c->fr.factored)
             if (int rc = frontal_factorize(c)) return rc;
-            c->diag_dirty = false;
-        }
     } else {
         if (c->op_aM != 0.0 || c->op_aK != 1.0) return fail(c, "the Jacobi preconditioner only handles the static operator; use preconditioner 2");
         if (refresh_diag(c)) return 1;
@@ -818,9 +882,7 @@ static int bicgstab(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t*
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
     c->timing[0] = c->precond == 2 ? c->fr.t_assemble_ms + c->fr.t_factor_ms : 0.0; c->timing[1] = t_loop;
     c->timing[2] = c->timing[0] + t_loop; c->timing[4] = napply;
-    if (iters) *iters = k;
-    if (relres) *relres = bb > 0 ? sqrt(rr / bb) : 0.0;
-    return 0;
+    return finish_solve(c, "BiCGStab", k, rr, bb, target, iters, relres);
 }
 
 static int solve_dispatch(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
@@ -1048,7 +1110,8 @@ int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double b
     c->fM2 = c->fM1 = nullptr;
     c->nf = 0;
     c->beta = beta;
-    c->penalty_dirty = c->diag_dirty = true;
+    c->penalty_dirty = true;
+    operator_changed(c);
     if (nf == 0) return 0;
     std::vector<int> hc((size_t)c->nvc * c->nel), hp((size_t)c->npc * c->nel);
     HIPCHK(c, hipMemcpy(hc.data(), c->cells, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -1088,7 +1151,7 @@ int femo_set_strong_dofs(femo_ctx* c, int32_t n, const int32_t* dofs) {
     }
     HIPCHK(c, hipMemcpy(c->mask, m.data(), m.size(), hipMemcpyHostToDevice));
     c->has_mask = n > 0;
-    c->diag_dirty = true;
+    operator_changed(c);
     return 0;
 }
 
@@ -1115,7 +1178,8 @@ int femo_set_field(femo_ctx* c, const char* name, const double* v, int64_t n) {
         c->has_uhat = any;
         c->penalty_dirty = true;
     }
-    if (d != c->f && d != c->rho) c->diag_dirty = true;
+    // the load never enters the operator; the density only through the inertia term aM M
+    if (d != c->f && (d != c->rho || c->op_aM != 0.0)) operator_changed(c);
     return 0;
 }
 
@@ -1194,7 +1258,7 @@ int femo_residual(femo_ctx* c, const double* w, double* r) {
 
 int femo_diagonal(femo_ctx* c, double* d) {
     HIPCHK(c, hipSetDevice(c->device));
-    c->diag_dirty = true;
+    c->jacobi_dirty = true;
     if (refresh_diag(c)) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<double> inv((size_t)c->ndof);
@@ -1223,6 +1287,28 @@ int femo_set_solver(femo_ctx* c, int preconditioner, double rtol, int32_t maxit,
     if (preconditioner == 2 && !c->fr.ready) return fail(c, "preconditioner 2 needs femo_set_frontal_plan first");
     if (!(rtol > 0) || maxit < 1 || check_every < 1) return fail(c, "bad solver parameters");
     c->precond = preconditioner; c->rtol = rtol; c->maxit = maxit; c->check_every = check_every;
+    return 0;
+}
+
+int femo_set_option(femo_ctx* c, const char* key, double value) {
+    const std::string k(key ? key : "");
+    const int v = (int)value;
+    auto& o = c->opt;
+    if (k == "trailing") { if (v < 0 || v > 2) return fail(c, "trailing: 0 auto, 1 left-looking, 2 right-looking"); o.trailing = v; }
+    else if (k == "left_min") o.left_min = v;
+    else if (k == "left_max") o.left_max = v;
+    else if (k == "lookahead") o.lookahead = v != 0;
+    else if (k == "lookahead_cnt") o.lookahead_cnt = v;
+    else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
+    else if (k == "wide_np" || k == "wide_cnt") {
+        if (c->fr.ready) return fail(c, "wide_np / wide_cnt shape the plan: set them before femo_set_frontal_plan");
+        if (v < 0) return fail(c, "negative threshold");
+        (k == "wide_np" ? o.wide_np : o.wide_cnt) = v;
+    }
+    else if (k == "strict") o.strict = v != 0;
+    else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
+    else if (k == "profile_verbose") o.profile_verbose = v != 0;
+    else return fail(c, "unknown option '" + k + "'");
     return 0;
 }
 
@@ -1461,16 +1547,22 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipSetDevice(c->device));
     auto& fr = c->fr;
     if (fr.ready) return fail(c, "frontal plan already set for this context");
-    const int WIDE_NP = getenv("FEMO_WIDE_NP") ? std::max(1, atoi(getenv("FEMO_WIDE_NP"))) : WIDE_NP_DEFAULT;
-    const int WIDE_CNT = getenv("FEMO_WIDE_CNT") ? std::max(0, atoi(getenv("FEMO_WIDE_CNT"))) : WIDE_CNT_DEFAULT;
+    const int WIDE_NP = std::max(1, c->opt.wide_np), WIDE_CNT = std::max(0, c->opt.wide_cnt);
     if (ntree < 1 || nlevels < 1) return fail(c, "empty frontal plan");
     fr.ntree = ntree; fr.nlevels = nlevels;
     fr.h_nf.assign(nf, nf + ntree); fr.h_npiv.assign(npiv, npiv + ntree);
     fr.h_level_off.assign(level_off, level_off + nlevels + 1);
     fr.h_level_nodes.assign(level_nodes, level_nodes + ntree);
-    if (fr.h_level_off[nlevels] != ntree) return fail(c, "level_off does not cover all fronts");
-    for (int i = 0; i < ntree; ++i)
-        if (level_nodes[i] < 0 || level_nodes[i] >= ntree) return fail(c, "level_nodes out of range");
+    if (level_off[0] != 0 || level_off[nlevels] != ntree) return fail(c, "level_off does not cover all fronts");
+    for (int L = 0; L < nlevels; ++L)
+        if (level_off[L + 1] < level_off[L]) return fail(c, "level_off must be non-decreasing");
+    {
+        std::vector<char> seen(ntree, 0);                 // every front is factorised exactly once
+        for (int i = 0; i < ntree; ++i) {
+            if (level_nodes[i] < 0 || level_nodes[i] >= ntree) return fail(c, "level_nodes out of range");
+            if (seen[level_nodes[i]]++) return fail(c, "level_nodes lists a front twice");
+        }
+    }
     // inside a level the fronts are kept in order of pivot count: the diagonal-block kernel is launched per class of
     // equal sub-block count (its LDS footprint, hence its occupancy, depends on it)
     for (int L = 0; L < nlevels; ++L)
@@ -1575,8 +1667,13 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipMemset(fr.F, 0, (size_t)fr.f_doubles * sizeof(double)));      // once: the upper triangles are never written
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
-    if ((size_t)(fr.max_nf + NB) * sizeof(double) > 48 * 1024) {
-        const int bytes = (int)((fr.max_nf + NB) * sizeof(double));
+    // dynamic LDS of the one-workgroup-per-front sweeps: forward maxnp + NB, backward maxnp + maxnb + NB doubles, where
+    // the two maxima of a level may come from different fronts
+    int max_sweep = fr.max_nf + NB;
+    for (int L = 0; L < nlevels; ++L) max_sweep = std::max(max_sweep, fr.h_level_maxnp[L] + fr.h_level_maxnb[L] + NB);
+    if ((size_t)max_sweep * sizeof(double) > 150 * 1024) return fail(c, "largest front does not fit the LDS solve kernels");
+    if ((size_t)max_sweep * sizeof(double) > 48 * 1024) {
+        const int bytes = (int)(max_sweep * sizeof(double));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_bnd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1590,33 +1687,61 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
 
 int femo_factorize(femo_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = frontal_factorize(c)) return rc;
-    c->diag_dirty = (c->precond != 2);
-    return 0;
+    return frontal_factorize(c);
 }
 
 /* out6: [0] element-matrix assembly into fronts (ms), [1] numeric factorisation (ms), [2] front storage (GB),
  *       [3] factor flops (GFLOP, from the plan sizes), [4] number of non-positive pivots repaired, [5] fronts */
 /* Run one factorisation with a HIP event pair around every kernel launch and report, per kernel class
- * (0 unused, 1 panel, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
- * also the algorithmic flop count of the trailing updates (lower triangle only). out13 = ms[6], calls[6], flops. */
-int femo_factorize_profile(femo_ctx* c, double* out13) {
+ * (0 panel rows, 1 diagonal blocks, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
+ * also the algorithmic flop counts (lower triangles only) of what the launches of classes 2, 0, 1 execute.
+ * out16 = ms[6], calls[6], flops(trailing, rows, diag), 0. */
+int femo_factorize_profile(femo_ctx* c, double* out16) {
     HIPCHK(c, hipSetDevice(c->device));
     c->fr.profile = true;
     int rc = frontal_factorize(c);
     c->fr.profile = false;
     if (rc) return rc;
-    for (int i = 0; i < 6; ++i) { out13[i] = c->fr.prof_ms[i]; out13[6 + i] = (double)c->fr.prof_calls[i]; }
-    double fl = 0;
-    for (int t = 0; t < c->fr.ntree; ++t) {
-        const int np = c->fr.h_npiv[t], nf = c->fr.h_nf[t];
-        for (int c0 = 0; c0 < np; c0 += NB) {
-            const double wb = std::min(NB, np - c0), rem = nf - c0 - wb;
-            fl += wb * rem * (rem + 1.0);
-        }
-    }
-    out13[12] = fl;
+    for (int i = 0; i < 6; ++i) { out16[i] = c->fr.prof_ms[i]; out16[6 + i] = (double)c->fr.prof_calls[i]; }
+    out16[12] = c->fr.prof_flops[2];      // what the k_trailing_mfma launches execute (their own K and column ranges)
+    out16[13] = c->fr.prof_flops[0];      // k_panel_rows
+    out16[14] = c->fr.prof_flops[1];      // k_diag_block
+    out16[15] = 0.0;
     return 0;
+}
+
+// one application of the factor with a HIP event pair around every level of both sweeps:
+// out[2 L] = forward sweep of level L (ms), out[2 L + 1] = backward sweep of level L; n >= 2 nlevels
+int femo_sweep_profile(femo_ctx* c, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready) return fail(c, "no frontal plan");
+    if (n < 2 * (int64_t)fr.nlevels) return fail(c, "output too small: 2 * nlevels doubles");
+    if (!fr.factored)
+        if (int rc = frontal_factorize(c)) return rc;
+    std::vector<hipEvent_t> ev(2 * fr.nlevels + 2);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->z, 1.0, (int64_t)c->ndof);
+    int rc = 0;
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    for (int L = 0; L < fr.nlevels && !rc; ++L) {
+        rc = frontal_fwd(c, c->z, L, L + 1);
+        HIPCHK(c, hipEventRecord(ev[L + 1], c->stream));
+    }
+    for (int L = fr.nlevels - 1; L >= 0 && !rc; --L) {
+        rc = frontal_bwd(c, c->z, L, L + 1);
+        HIPCHK(c, hipEventRecord(ev[fr.nlevels + 1 + (fr.nlevels - 1 - L)], c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int L = 0; L < fr.nlevels && !rc; ++L) {
+        float f = 0, bw = 0;
+        hipEventElapsedTime(&f, ev[L], ev[L + 1]);
+        const int k = fr.nlevels - 1 - L;
+        hipEventElapsedTime(&bw, ev[fr.nlevels + k], ev[fr.nlevels + k + 1]);
+        out[2 * L] = f; out[2 * L + 1] = bw;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
 }
 
 int femo_frontal_info(const femo_ctx* c, double* out6) {
@@ -1667,9 +1792,7 @@ int femo_load_vec(femo_ctx* c, int32_t dst) {
 
 int femo_factorize_range(femo_ctx* c, int32_t l0, int32_t l1, int assemble) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = frontal_factorize_range(c, l0, l1, assemble != 0)) return rc;
-    if (l1 == c->fr.nlevels) c->diag_dirty = (c->precond != 2);
-    return 0;
+    return frontal_factorize_range(c, l0, l1, assemble != 0);
 }
 
 int femo_frontal_sweep(femo_ctx* c, int32_t vec, int32_t l0, int32_t l1, int backward) {
@@ -1750,7 +1873,7 @@ int femo_field_gradient_vec(femo_ctx* c, const char* functional, const char* arg
 
 // ---- dynamic shell: operator A = aK K + aM M, device-vector building blocks (femo_alpha_amd/dynamic_rm_shell) ----
 int femo_set_operator(femo_ctx* c, double aK, double aM) {
-    if (aK != c->op_aK || aM != c->op_aM) { c->op_aK = aK; c->op_aM = aM; c->diag_dirty = true; c->fr.factored = false; }
+    if (aK != c->op_aK || aM != c->op_aM) { c->op_aK = aK; c->op_aM = aM; operator_changed(c); }
     return 0;
 }
 
@@ -1761,7 +1884,7 @@ int femo_set_strain_quadrature(femo_ctx* c, int32_t nred) {
     Tables T;
     build_tables(true, c->nquad, T, nred);
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
-    c->nred = nred; c->diag_dirty = true; c->fr.factored = false;
+    c->nred = nred; operator_changed(c);
     return 0;
 }
 

@@ -22,11 +22,17 @@ class FacetSet:
 
 
 class RMShellPDE:
-    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=4, device=0):
+    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=4, device=0, solver="direct"):
         self.mesh = mesh
         self.element_wise_material = element_wise_material
         self.elementwise_pressure = elementwise_pressure
         self.ctx = ShellContext(mesh, element_wise_material, elementwise_pressure, nquad=nquad, device=device)
+        # the reference always solves with a sparse direct LU (MUMPS through PETSc, fea/utils_dolfinx.py:466,514-531):
+        # the drop-in surface does the same unless the caller opts out ('jacobi': matrix-free Jacobi-PCG, thick plates only)
+        if solver == "direct":
+            self.ctx.use_direct_solver()
+        elif solver != "jacobi":
+            raise ValueError("solver must be 'direct' or 'jacobi'")
         self.W = FunctionSpace(self.ctx, "W")          # [CG2]^3 x [CG1]^3, linear_shell_model.py:60-65
         self.VT = FunctionSpace(self.ctx, "VT")        # rm_shell_pde.py:37-40
         self.VF = FunctionSpace(self.ctx, "VF")        # :41-44

@@ -189,12 +189,17 @@ def build_plan(mesh, leaf_size=12) -> FrontalPlan:
     """Single-GPU plan: every tree node is a front, levels by height."""
     T = analyse(mesh, leaf_size)
     nV, ndof_u = mesh.nV, mesh.ndof_u
-    dof_lists, npiv = [], []
-    for t in range(T.ntree):
-        pd = _node_dofs(T.piv_nodes[t], nV, ndof_u)
-        bd = _node_dofs(T.bnd_nodes[t], nV, ndof_u)
-        dof_lists.append(np.concatenate([pd, bd]))
-        npiv.append(pd.size)
+    # DOF lists of all fronts from ONE expansion of the concatenated node lists (pivots first, then the boundary)
+    seq = [a for t in range(T.ntree) for a in (T.piv_nodes[t], T.bnd_nodes[t])]
+    lens = np.array([len(a) for a in seq], dtype=np.int64)
+    nodes_all = np.concatenate(seq).astype(np.int64) if seq else np.zeros(0, np.int64)
+    csum = np.concatenate([[0], np.cumsum(np.where(nodes_all < nV, 6, 3))])
+    ends = np.cumsum(lens)
+    ndofs_seg = csum[ends] - csum[ends - lens]
+    dofs_all = _node_dofs(nodes_all, nV, ndof_u)
+    seg_off = np.concatenate([[0], np.cumsum(ndofs_seg)])
+    dof_lists = [dofs_all[seg_off[2 * t]:seg_off[2 * t + 2]] for t in range(T.ntree)]
+    npiv = ndofs_seg[0::2]
     leaf_of_pos = np.zeros(mesh.nel, dtype=np.int64)
     for t in np.nonzero(T.left < 0)[0]:
         leaf_of_pos[T.lo[t]:T.hi[t]] = t

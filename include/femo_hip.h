@@ -104,10 +104,14 @@ int femo_set_frontal_plan(femo_ctx* ctx, int32_t ntree, int32_t nlevels, const i
  * element matrices -> leaf fronts -> batched partial Cholesky level by level.  Replaces ksp.setUp() with
  * PC 'lu' / MUMPS (fea/utils_dolfinx.py:495-531). */
 int femo_factorize(femo_ctx* ctx);
-/* One factorisation with a HIP event pair around every launch; per kernel class (0 unused, 1 panel (diagonal block + rows below),
- * 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): out13[0..5] total ms, out13[6..11] launches;
- * out13[12] algorithmic flops of the trailing updates. */
-int femo_factorize_profile(femo_ctx* ctx, double* out13);
+/* One factorisation with a HIP event pair around every launch; per kernel class (0 rows below the diagonal blocks,
+ * 1 diagonal blocks, 2 trailing rank-k updates, 3 extend_add, 4 front_assemble, 5 memset): out16[0..5] total ms,
+ * out16[6..11] launches; out16[12..14] algorithmic flops (lower triangles only) executed by the launches of classes
+ * 2, 0 and 1 -- counted from each launch's own K and column ranges; out16[15] reserved. */
+int femo_factorize_profile(femo_ctx* ctx, double* out16);
+/* One application of the factor (forward + backward sweep) with a HIP event pair around every tree level:
+ * out[2 L] = forward sweep of level L (ms), out[2 L + 1] = backward sweep; n >= 2 * levels of the plan. */
+int femo_sweep_profile(femo_ctx* ctx, double* out, int64_t n);
 /* out6: [0] front assembly ms, [1] factorisation ms, [2] front storage GB, [3] factor GFLOP,
  *       [4] non-positive pivots repaired, [5] number of fronts. */
 int femo_frontal_info(const femo_ctx* ctx, double* out6);
@@ -115,6 +119,17 @@ int femo_frontal_info(const femo_ctx* ctx, double* out6);
 /* Solver configuration. preconditioner: 0 = Jacobi, 2 = multifrontal Cholesky (needs a frontal plan).
  * check_every: convergence is polled on the host every this many PCG iterations. */
 int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxit, int32_t check_every);
+/* Schedule switches and failure policy of the solvers (they are per context; nothing is read from the environment):
+ *   "strict" (default 1)             a Krylov solve that reaches maxit short of rtol returns 4 with a message -- the reference
+ *                                    solves with a direct LU (fea/utils_dolfinx.py:466,514-531), an unconverged state has no
+ *                                    counterpart there; 0 returns 0 and leaves the judgement to iters / relres
+ *   "allow_pivot_repair" (default 0) 0: a non-positive pivot makes femo_factorize (and the solves that call it) return 5;
+ *                                    1: such pivots are replaced and counted (femo_frontal_info [4])
+ *   "trailing" 0 auto | 1 left-looking | 2 right-looking rank-k updates; "left_min", "left_max" (auto: levels with this
+ *   many fronts are left-looking); "lookahead" 0/1, "lookahead_cnt"; "grid_chunk" (fronts per launch, <= 65535);
+ *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
+ *   "profile_verbose" (per-launch timings of femo_factorize_profile on stderr). */
+int femo_set_option(femo_ctx* ctx, const char* key, double value);
 /* Krylov method for the state / adjoint / linear solves: 0 = conjugate gradients (default; the operator is SPD),
  * 1 = right-preconditioned BiCGStab with the same preconditioner (femo_set_solver).  Stands where the reference
  * chooses its PETSc KSP type (fea/utils_dolfinx.py:495-531). */

@@ -146,25 +146,19 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     the same parity triple as the reference's direct (MUMPS LU) solve.  Levels with few fronts take the wide
     (many workgroups per front) solve kernels by default -- on these small meshes that is every level;
     wide_cnt = 0 sends them through the one-workgroup-per-front kernels instead."""
-    import os
     m, o, c, rng = _pair(kind, ewm=ewm, bc=bc, uhat=uhat)
+    opts = {}
     if kind == "plate24":
-        os.environ["FEMO_WIDE_NP"] = "96"            # wide kernels by pivot-block size: a mix of both paths in one tree
+        opts["wide_np"] = 96                         # wide kernels by pivot-block size: a mix of both paths in one tree
     if wide_cnt is not None:
-        os.environ["FEMO_WIDE_CNT"] = str(wide_cnt)
+        opts["wide_cnt"] = wide_cnt
     if kind in ("plate24", "tri"):
-        os.environ["FEMO_TRAILING"] = "left"         # left-looking rank-k updates (the default on small meshes is right-looking)
+        c.set_option("trailing", 1)                  # left-looking rank-k updates (the default on small meshes is right-looking)
     if kind in ("warped", "plate24"):
-        os.environ["FEMO_GRID_CHUNK"] = "3"          # levels launched three fronts at a time (grid y/z extent limit)
-    try:
-        plan = c.enable_frontal(leaf_size=8)
-        c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
-        info = c.factorize()
-    finally:
-        os.environ.pop("FEMO_WIDE_NP", None)
-        os.environ.pop("FEMO_WIDE_CNT", None)
-        os.environ.pop("FEMO_TRAILING", None)
-        os.environ.pop("FEMO_GRID_CHUNK", None)
+        c.set_option("grid_chunk", 3)                # levels launched three fronts at a time (grid y/z extent limit)
+    plan = c.enable_frontal(leaf_size=8, **opts)
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    info = c.factorize()
     assert plan.ntree > 1
     if kind == "plate24":
         assert plan.npiv.max() > 192
@@ -445,3 +439,65 @@ def test_csr_assembly(kind):
     assert abs(K - Kref).max() < 1e-11 * abs(Kref).max()
     K2 = c.assemble_csr()                                    # repeatable
     assert abs(K2 - K).max() <= 1e-13 * abs(Kref).max()
+
+
+def test_non_convergence_and_indefinite_operators_raise():
+    """The reference solves with a direct LU; here an iteration that stops short of rtol, or a Cholesky that meets a
+    non-positive pivot, must not hand back numbers silently."""
+    from femo_alpha_amd.backend import FemoConvergenceError, FemoNotPositiveDefiniteError
+    m, o, c, rng = _pair("plate")
+    c.set_solver(preconditioner=0, rtol=1e-12, maxit=5, check_every=5)       # starved Jacobi-PCG
+    with pytest.raises(FemoConvergenceError):
+        c.solve_state(zero_guess=True)
+    c.set_option("strict", 0)                                                   # opting out: status 0, the caller judges relres
+    it, rr = c.solve_state(zero_guess=True)
+    assert it == 5 and rr > 1e-12
+    c.set_option("strict", 1)
+    c.use_direct_solver(leaf_size=8)
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 6 and rr <= 1e-12
+    good = c.get_field("thickness")
+    c.set_field("thickness", -good)                  # negative thickness: membrane and shear blocks negative definite
+    with pytest.raises(FemoNotPositiveDefiniteError):
+        c.solve_state(zero_guess=True)
+    with pytest.raises(FemoNotPositiveDefiniteError):
+        c.factorize()
+    c.set_option("allow_pivot_repair", 1)
+    assert c.factorize()["pivots_repaired"] > 0
+    c.set_option("allow_pivot_repair", 0)
+    c.set_field("thickness", good)                   # and the context recovers
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 6 and rel(c.get_state(), o.solve()) < 1e-8
+
+
+def test_switching_preconditioners_after_a_field_change():
+    """Two preconditioners, two staleness flags: a factorisation must not hide a stale Jacobi diagonal and vice versa;
+    the density enters the operator only through the inertia term."""
+    m, o, c, rng = _pair("plate")
+    c.enable_frontal(leaf_size=8)
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    c.solve_state(zero_guess=True)                                   # factor built, Jacobi diagonal never computed
+    h2 = 1.3 * c.get_field("thickness")
+    c.set_field("thickness", h2); o.set_fields(h=h2)
+    w2 = o.solve()
+    c.set_solver(preconditioner=0, rtol=1e-12, maxit=400000, check_every=100)
+    it, rr = c.solve_state(zero_guess=True)                          # needs a fresh diagonal for the new thickness
+    assert np.isfinite(rr) and rel(c.get_state(), w2) < 1e-7
+    h3 = 0.8 * h2
+    c.set_field("thickness", h3); o.set_fields(h=h3)
+    c.solve_state(zero_guess=True)                                   # Jacobi again: clears only its own flag
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
+    it, rr = c.solve_state(zero_guess=True)                          # must re-factorise (h3), not reuse the h2 factor
+    assert it <= 6 and rel(c.get_state(), o.solve()) < 1e-8
+    # density: irrelevant for the static operator (no re-factorisation), part of it once aM != 0
+    f0 = c.frontal_info()["factor_ms"]
+    c.set_field("density", 2.0 * c.get_field("density"))
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 6
+    c.set_operator(0.5, 200.0)
+    x = rng.uniform(-1, 1, m.ndof)
+    c.set_state(x)
+    b1, _, _ = c.solve_linear(x)
+    c.set_field("density", 3.0 * c.get_field("density"))            # operator changed: the factor must follow
+    b2, it2, _ = c.solve_linear(x)
+    assert it2 <= 6 and rel(b1, b2) > 1e-3
