@@ -211,7 +211,6 @@ def test_renumbered_model_answers_in_caller_order():
     model = RMShellModel(mesh, shell_bc_func=root, record=False, renumber=True, mesh_tags=tags)
     assert not np.array_equal(model.vertex_of_new, np.arange(nn))
     ctx = model.shell_pde.ctx
-    ctx.enable_frontal(8)
     ctx.set_solver(preconditioner=2, rtol=1e-12, maxit=50, check_every=1)
     out = model.evaluate(pressure, thickness, E, nu, density)
     recorder.stop()
@@ -248,7 +247,6 @@ def test_thickness_optimisation_loop():
     density = csdl.Variable(value=10.0 * np.ones(nn), name="density")
     model = RMShellModel(mesh, shell_bc_func=ClampedBoundary, record=False)
     ctx = model.shell_pde.ctx
-    ctx.enable_frontal(8)
     ctx.set_solver(preconditioner=2, rtol=1e-11, maxit=50, check_every=1)
     out = model.evaluate(pressure, thickness, E, nu, density)
     J0, m0 = float(out.compliance.value[0]), float(out.mass.value[0])

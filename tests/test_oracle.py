@@ -274,3 +274,46 @@ def test_branching_surface_tee_beam():
     q = 10.0 * (1.0 + 0.5)                                            # the load acts on flange and web area
     eb = -q * 5.0 ** 4 / (8 * 1e9 * I)
     assert abs(tip - eb) < 0.06 * abs(eb), (tip, eb)
+
+
+def test_h_convergence_to_the_beam_value_the_reference_prints():
+    """The only number the reference's text holds for this path is the Euler-Bernoulli tip deflection its examples
+    print next to the FE result (ex_simple_shell.py:38-44 and the literal 0.00868 at :61; ex_simple_shell_opt.py:100-105).
+    With nu = 0 the clamped plate bends cylindrically and the exact Reissner-Mindlin answer is the Timoshenko beam value
+    q b L^4 / (8 E I) + q b L^2 / (2 k G A), k = 0.833 (linear_shell_model.py:146).  The oracle converges to it at second
+    order (rotations are CG1) over four uniform refinements, and the Richardson limit of the sequence hits it to 1e-7:
+    a pin on the whole chain (CLT matrices, strains, quadrature, penalty clamp, load) four orders sharper than a
+    one-mesh band."""
+    E, h, q, b, L = 4.32e8, 0.2, 2.0, 2.0, 10.0
+    I = b * h ** 3 / 12
+    eb = q * b * L ** 4 / (8 * E * I)
+    assert abs(eb - 8.68e-3) < 1e-6                      # the value of ex_simple_shell.py:61
+    exact = eb + q * b * L ** 2 / (2 * 0.833 * (E / 2) * b * h)
+    tips = []
+    for nw, nl in ((1, 5), (2, 10), (4, 20), (8, 40), (16, 80)):
+        m = plate_mesh(b, L, nw, nl)
+        o = ShellOracle(m, penalty_facets=m.penalty_facets(CLAMP))
+        o.set_fields(h=h, E=E, nu=0.0, f=np.tile([0, 0, q], (m.nn, 1)))
+        w = o.solve()
+        edge = np.nonzero(np.abs(m.p2_coords[:, 0] - L) < 1e-9)[0]
+        tips.append(w[3 * edge + 2].mean())
+    err = np.abs(np.array(tips) - exact) / exact
+    rates = np.log2(err[:-1] / err[1:])
+    assert err[0] < 2e-2 and np.all(np.abs(rates - 2.0) < 0.02), (err, rates)       # measured: 2.0000 +- 4e-5
+    richardson = tips[-1] + (tips[-1] - tips[-2]) / 3.0
+    assert abs(richardson - exact) < 1e-7 * exact                                        # measured: 2e-9
+
+
+def test_oracle_reproduces_the_committed_config1_golden(golden_dir):
+    """tests/golden/config1_plate_10x50_nodal.npz (make_fullsize_goldens.py, extended-precision refinement) against a
+    plain oracle run: the plain SuperLU solve is good to a few 1e-9 on the 1e15-penalised system."""
+    import os
+    g = np.load(os.path.join(golden_dir, "config1_plate_10x50_nodal.npz"))
+    m = plate_mesh(2.0, 10.0, int(g["nx"]), int(g["ny"]))
+    o = ShellOracle(m, penalty_facets=m.penalty_facets(CLAMP))
+    o.set_fields(h=g["thickness"], E=1e8, nu=0.3, rho=10.0, f=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
+    w, J, dJ = o.forward_adjoint()
+    assert abs(J - float(g["compliance"])) < 1e-7 * float(g["compliance"])
+    assert abs(o.mass() - 20.0) < 1e-12 and abs(float(g["mass"]) - 20.0) < 1e-12           # rho h b L (SURVEY section 8d)
+    assert np.abs(w[g["w_sample_index"]] - g["w_sample"]).max() < 1e-7 * float(g["w_maxabs"])
+    assert np.abs(dJ - g["dcompliance_dthickness"]).max() < 1e-7 * np.abs(g["dcompliance_dthickness"]).max()
