@@ -31,8 +31,12 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 
 FP64_PEAK_TFLOPS = 78.6
 
 
-def make_workload(name):
+def make_workload(name, renumber=True, timings=None):
+    """(mesh, fields, clamp marker, description).  ``renumber``: cells and vertices reordered for locality at input
+    (ShellMesh.renumbered), as dolfinx reorders every mesh it reads; False keeps the generator's numbering -- for the wing
+    skin a random shuffle of cells and vertices.  ``timings`` receives mesh_s / renumber_s."""
     from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
+    t_start = time.perf_counter()
     if name == "plate250k":      # BASELINE.json configs[1]: flat plate, 250k DOF, thickness design variable
         m = plate_mesh(2.0, 10.0, 58, 290)
         rng = np.random.default_rng(0)
@@ -60,7 +64,8 @@ def make_workload(name):
         desc = "flat plate 2x10, 10x50 quads, 8046 DOF"
     else:
         raise SystemExit(f"unknown workload {name}")
-    if os.environ.get("FEMO_BENCH_KEEP_NUMBERING") is None:
+    t_mesh = time.perf_counter()
+    if renumber:
         # input stage, outside the timed region: cells and vertices reordered for locality, as dolfinx reorders every
         # mesh it reads (the reference maps back through original_cell_index); per-vertex inputs follow the permutation
         m, vperm, _ = m.renumbered()
@@ -69,6 +74,9 @@ def make_workload(name):
             if v.ndim == 2 and v.shape[0] == vperm.size or v.ndim == 1 and v.size == vperm.size:
                 fields[k] = v[vperm]
         desc += "; solver-side numbering: Morton order of the cells (ShellMesh.renumbered)"
+    if timings is not None:
+        timings["mesh_s"] = t_mesh - t_start
+        timings["renumber_s"] = time.perf_counter() - t_mesh
     return m, fields, marker, desc
 
 
@@ -175,6 +183,10 @@ def main():
     ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
     ap.add_argument("--leaf", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-numbering", action="store_true", help="run on the generator's (shuffled) numbering")
+    ap.add_argument("--no-keep-numbering-leg", action="store_true", help="skip the extra forward solve on the shuffled numbering")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: the same 1M-DOF skin split into N element partitions (BASELINE config 4), or N times the span")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,13 +208,22 @@ def main():
     from femo_alpha_amd.backend import ShellContext
     if world > 1:
         return main_distributed(args, rank, local_rank, world, torch, dist)
-    m, fields, marker, desc = make_workload(args.workload)
+    setup = {}
+    m, fields, marker, desc = make_workload(args.workload, renumber=not args.keep_numbering, timings=setup)
+    t0 = time.perf_counter()
     ctx = ShellContext(m, device=local_rank)
     for k, v in fields.items():
         ctx.set_field(k, v)
     ctx.set_penalty_facets(m.penalty_facets(marker))
+    setup["context_s"] = time.perf_counter() - t0
     if args.solver == "frontal":
-        ctx.enable_frontal(args.leaf)                       # symbolic analysis: mesh only, outside the timed region
+        # symbolic analysis (nested dissection, fronts, index maps) and its upload: mesh only, once per mesh, outside the
+        # timed region like MUMPS' analysis phase would be if the reference kept its KSP -- it does not (setUpKSP_MUMPS per
+        # assemble_derivatives, state_operation.py:296), so the numbers are printed beside the headline
+        t0 = time.perf_counter()
+        ctx.enable_frontal(args.leaf)
+        setup["symbolic_s"] = ctx.symbolic_s
+        setup["plan_upload_s"] = time.perf_counter() - t0 - ctx.symbolic_s
         ctx.set_solver(preconditioner=2, rtol=args.rtol, maxit=50, check_every=1)
     else:
         ctx.set_solver(rtol=args.rtol, maxit=400000, check_every=200)
@@ -263,11 +284,49 @@ def main():
         # one instrumented factorisation with a HIP event pair around every launch on the context's stream
         prof = ctx.factorize_profile()
         tr = prof["trailing"]
+        # flops and compulsory bytes are summed over the launches from each launch's own K / column ranges (femo_hip.hip,
+        # count_trailing): lower triangles only, C read + written once, the factor rows of the K panel read once
         tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "k_trailing_mfma<true|false>, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
                 "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic_trailing,
                 "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
+                "algorithmic_bytes_per_launch": prof["trailing_bytes"] / tr["launches"],
                 "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}
+        kernels = {}
+        for cls, fk in (("trailing", "trailing"), ("panel_rows", "panel_rows"), ("panel_diag", "panel_diag")):
+            ms = prof[cls]["ms"]
+            kernels[cls] = {"ms": ms, "launches": prof[cls]["launches"], "gflop": prof[fk + "_flops"] / 1e9,
+                            "tflops": prof[fk + "_flops"] / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                            "compulsory_GB": prof[fk + "_bytes"] / 1e9}
+
+    # true residual of the last forward solve, || F - K w || / || F || evaluated by the matrix-free operator (the
+    # relres_* figures of the Krylov loop are recurrence residuals)
+    ctx.solve_state(zero_guess=True)
+    r_true = ctx.residual()
+    F_load = ctx.load_vector()
+    true_relres = float(np.linalg.norm(r_true) / np.linalg.norm(F_load))
+
+    # the same forward solve on the generator's shuffled numbering (config 3 asks for destroyed locality; the headline
+    # renumbers at input like dolfinx does): one more context, outside the timed region
+    keep = None
+    if args.solver == "frontal" and args.workload.startswith("wing") and not args.keep_numbering and not args.no_keep_numbering_leg and world == 1:
+        m2, fields2, marker2, _ = make_workload(args.workload, renumber=False)
+        c2 = ShellContext(m2, device=local_rank)
+        for k, v in fields2.items():
+            c2.set_field(k, v)
+        c2.set_penalty_facets(m2.penalty_facets(marker2))
+        c2.enable_frontal(args.leaf)
+        c2.set_solver(preconditioner=2, rtol=args.rtol, maxit=50, check_every=1)
+        h2 = c2.get_field("thickness")
+        ts = []
+        for _ in range(4):
+            c2.set_field("thickness", h2)
+            t0 = time.perf_counter()
+            it_k, rr_k = c2.solve_state(zero_guess=True)
+            ts.append(time.perf_counter() - t0)
+        keep = {"forward_ms": float(np.median(ts[1:]) * 1e3), "pcg_iterations": it_k, "apply_ms": c2.bench_kernel("apply", 50),
+                "symbolic_s": c2.symbolic_s}
+        c2.close()
 
     if rank == 0:
         out = {
@@ -286,6 +345,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
+                       "true_relres_forward": true_relres,
                        "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
                                   f"(nested dissection, leaves of <= {args.leaf} cells)" if args.solver == "frontal"
                                   else "Jacobi-PCG, matrix-free element-by-element operator"), "rtol": args.rtol,
@@ -295,9 +355,20 @@ def main():
             "roofline": roof,
             "roofline_spmv": roof_spmv,
             "forward_split_ms": {"assemble_factorise": step.timing["setup_ms"], "pcg": step.timing["krylov_ms"]},
+            # once per mesh, outside the timed region (first solve of a new mesh = these + one step)
+            "setup_s": setup,
         }
+        if keep is not None:
+            out["keep_numbering"] = keep
         if prof is not None:
             out["factorisation_profile_ms"] = {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)}
+            out["factorisation_kernels"] = kernels
+            sw = np.min([ctx.sweep_profile() for _ in range(3)], axis=0)
+            fac_bytes = float(np.sum(ctx.plan.nf.astype(np.float64) * ctx.plan.npiv) * 8)
+            out["preconditioner_apply"] = {"ms": float(sw.sum()), "forward_sweep_ms": float(sw[:, 0].sum()), "backward_sweep_ms": float(sw[:, 1].sum()),
+                                           "factor_GB_per_sweep": fac_bytes / 1e9,
+                                           "achieved_GBs": 2 * fac_bytes / (sw.sum() * 1e-3) / 1e9,
+                                           "frac_of_hbm_peak": 2 * fac_bytes / (sw.sum() * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["frontal"] = {k: (float(v) if not isinstance(v, int) else v) for k, v in ctx.frontal_info().items()}
         if not args.no_cpu_baseline and world == 1:
             from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh

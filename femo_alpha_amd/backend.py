@@ -176,11 +176,12 @@ class ShellContext:
 
     def factorize_profile(self):
         """One factorisation timed per kernel class with HIP events on the context's stream."""
-        t = np.zeros(16)
+        t = np.zeros(32)
         self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)))
-        names = ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset"]
-        out = {n: dict(ms=t[i], launches=int(t[6 + i])) for i, n in enumerate(names)}
-        out["trailing_flops"], out["panel_rows_flops"], out["panel_diag_flops"] = t[12], t[13], t[14]
+        names = ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset", "l11_inverse"]
+        out = {n: dict(ms=t[i], launches=int(t[8 + i])) for i, n in enumerate(names)}
+        out["trailing_flops"], out["panel_rows_flops"], out["panel_diag_flops"] = t[18], t[16], t[17]
+        out["trailing_bytes"], out["panel_rows_bytes"], out["panel_diag_bytes"] = t[26], t[24], t[25]
         return out
 
     def sweep_profile(self):

@@ -36,6 +36,8 @@ struct femo_ctx {
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
+    hipStream_t stream3 = nullptr;           // L11^-1 of a finished level is formed beside the factorisation of the next ones
+    hipEvent_t ev_x[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
     int nghost = 0;
     bool quad = true, ewm = false, ewp = false, has_uhat = false;
@@ -104,18 +106,19 @@ struct femo_ctx {
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr,
             *cinv0 = nullptr, *cinv1 = nullptr;
-        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *spoff = nullptr;
-        double *F = nullptr, *Linv = nullptr, *Sinv = nullptr, *Swork = nullptr;
-        int *sp_front = nullptr, *sp_index = nullptr;
-        int nsp = 0;
-        long long f_doubles = 0, linv_doubles = 0;
+        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
+        double *F = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
+        long long f_doubles = 0, linv_doubles = 0, x_doubles = 0;
         int max_nf = 0;
         double t_factor_ms = 0, t_assemble_ms = 0;
         int pivots_fixed = 0;
         bool profile = false;                 // time every kernel class with HIP events (slower)
-        double prof_ms[6] = {0, 0, 0, 0, 0, 0};   // unused, panel, trailing, extend_add, assemble, memset
-        long long prof_calls[6] = {0, 0, 0, 0, 0, 0};
-        double prof_flops[6] = {0, 0, 0, 0, 0, 0};   // algorithmic flops of what the launches of a class execute (lower triangles only)
+        // kernel classes: 0 rows below the diagonal blocks, 1 diagonal blocks, 2 trailing updates, 3 extend-add, 4 front assembly,
+        // 5 zero fill, 6 inversion of L11 (k_xinv)
+        double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long prof_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double prof_flops[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops of what the launches of a class execute (lower triangles only)
+        double prof_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // compulsory HBM bytes of those launches (every operand entry once, results read + written)
         std::vector<hipEvent_t> pev;
         int cur_level = 0;
     } fr;
@@ -435,7 +438,7 @@ static FrontDev front_dev(const femo_ctx* c) {
     FrontDev fd;
     fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.foff = c->fr.foff; fd.doff = c->fr.doff;
     fd.dofs = c->fr.dofs; fd.upmap = c->fr.upmap; fd.parent = c->fr.parent; fd.child[0] = c->fr.left; fd.child[1] = c->fr.right;
-    fd.linvoff = c->fr.linvoff; fd.spoff = c->fr.spoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv; fd.Sinv = c->fr.Sinv;
+    fd.linvoff = c->fr.linvoff; fd.xoff = c->fr.xoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv; fd.X = c->fr.X; fd.Xtmp = c->fr.Xtmp;
     fd.cinv[0] = c->fr.cinv0; fd.cinv[1] = c->fr.cinv1;
     return fd;
 }
@@ -464,7 +467,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     auto& fr = c->fr;
     if (!fr.ready) return fail(c, "no frontal plan: call femo_set_frontal_plan first");
     if (l0 < 0 || l1 > fr.nlevels || l0 > l1) return fail(c, "bad level range");
-    if (assemble) for (int i = 0; i < 6; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; fr.prof_flops[i] = 0; }
+    if (assemble) for (int i = 0; i < 8; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; fr.prof_flops[i] = 0; fr.prof_bytes[i] = 0; }
+    bool x_pending = false;
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -533,7 +537,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // flops of one k_trailing_mfma launch over this level, with the kernel's own column / K ranges (profiling only)
         auto count_trailing = [&](int C0, int schur) {
             if (!fr.profile) return;
-            double fl = 0;
+            double fl = 0, by = 0;
             for (int i = b; i < e; ++i) {
                 const int t = fr.h_level_nodes[i], np = fr.h_npiv[t], nf = fr.h_nf[t];
                 if (schur != 1 && C0 >= np) continue;
@@ -542,9 +546,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const int col_hi = schur == 0 ? std::min(C0 + NBO, np) : schur == 3 ? std::min(C0 + kw + NBO, nf) : nf;
                 if (kw <= 0 || col_lo >= col_hi) continue;
                 const double ncol = col_hi - col_lo;
-                fl += 2.0 * kw * (ncol * nf - 0.5 * ncol * (col_lo + col_hi - 1.0));
+                const double entries = ncol * nf - 0.5 * ncol * (col_lo + col_hi - 1.0);
+                fl += 2.0 * kw * entries;
+                by += 16.0 * entries + 8.0 * kw * (nf - col_lo);     // C read + written once, the factor rows [col_lo, nf) x kw read once
             }
-            fr.prof_flops[2] += fl;
+            fr.prof_flops[2] += fl; fr.prof_bytes[2] += by;
         };
         // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
         auto count_panel = [&](int C0) {
@@ -555,6 +561,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const double kw = std::min(NBO, np - C0), rows = nf - C0 - kw;
                 fr.prof_flops[1] += kw * kw * kw;
                 fr.prof_flops[0] += rows * kw * (kw + 1.0);
+                fr.prof_bytes[1] += 8.0 * (kw * (kw + 1.0) / 2 + kw * kw);           // block read, factor sub-blocks + inverse written
+                fr.prof_bytes[0] += 16.0 * rows * kw + 4.0 * kw * kw;
             }
         };
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
@@ -632,7 +640,27 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
             }
         }
+        if (wide && max_np > NBO) {
+            // L11^-1 of this level's fronts beyond the diagonal blocks, on its own stream: nothing in the factorisation of the
+            // levels above reads what it reads (the factor columns) or writes (X); only the triangular sweeps need it
+            HIPCHK(c, hipEventRecord(c->ev_x[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_x[0], 0));
+            ProfScope ps(c, 6, c->stream3);
+            for (int bs = NBO; bs < max_np; bs *= 2) {
+                const int npairs = (max_np + 2 * bs - 1) / (2 * bs);
+                const dim3 grid(npairs * (bs / 128) * (bs / 64), 1);
+                FOR_FRONT_CHUNKS(cnt, off, n) {
+                    hipLaunchKernelGGL(k_xinv<0>, dim3(grid.x, n), dim3(256), 0, c->stream3, fd, lev, off, bs);
+                    hipLaunchKernelGGL(k_xinv<1>, dim3(grid.x, n), dim3(256), 0, c->stream3, fd, lev, off, bs);
+                }
+            }
+            x_pending = true;
+        }
         HIPCHK(c, hipGetLastError());
+    }
+    if (x_pending) {
+        HIPCHK(c, hipEventRecord(c->ev_x[1], c->stream3));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_x[1], 0));
     }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int info = 0;
@@ -671,19 +699,25 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
 static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0, c->fr.nlevels, true); }
 
 // v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
+// Wide levels: two matrix-vector products per sweep (X = L11^-1 and L21), accumulated with atomics into entries that the
+// memset at the start of the sweep zeroed; the other levels: one workgroup per front.
 static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
+    if (l0 == 0) HIPCHK(c, hipMemsetAsync(y, 0, (size_t)c->ndof * sizeof(double), c->stream));
     for (int L = l0; L < l1; ++L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnp == 0) continue;
         if (fr.h_level_wide[L]) {
-            for (int c0 = 0; c0 < maxnp; c0 += SP) {
-                const int rows = maxnp + maxnb - c0;              // upper bound of rows below the super panel
-                hipLaunchKernelGGL(k_front_fwd_blk, dim3(std::max(1, (rows + FB_ROWS - 1) / FB_ROWS), cnt), dim3(WT), 0, c->stream, fd, lev, c0, v, y);
-            }
+            const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
+            FOR_FRONT_CHUNKS(cnt, off, n)
+                hipLaunchKernelGGL(k_sweep_gemv_n<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
+            if (maxnb > 0)
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL(k_sweep_gemv_n<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
             const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
             hipLaunchKernelGGL(k_front_fwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
@@ -693,20 +727,26 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
     return 0;
 }
 
-// backward over levels l1-1 ... l0: y (in tmp) is consumed in place (running right-hand side), x lands in v
+// backward over levels l1-1 ... l0: y (in tmp) is consumed in place (running right-hand side), x lands in v.  After the
+// forward sweep nothing in v is alive (every entry is the pivot of a front behind us), so the sweep from the root starts
+// by zeroing it: the wide levels accumulate x with atomics.
 static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
+    if (l1 == fr.nlevels) HIPCHK(c, hipMemsetAsync(v, 0, (size_t)c->ndof * sizeof(double), c->stream));
     for (int L = l1 - 1; L >= l0; --L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnp == 0) continue;
         if (fr.h_level_wide[L]) {
+            const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
             if (maxnb > 0)
-                hipLaunchKernelGGL(k_front_bwd_bnd, dim3((maxnp + BB_COLS - 1) / BB_COLS, cnt), dim3(256), (size_t)maxnb * sizeof(double), c->stream, fd, lev, y, v);
-            for (int c0 = ((maxnp - 1) / SP) * SP; c0 >= 0; c0 -= SP)
-                hipLaunchKernelGGL(k_front_bwd_blk, dim3(std::max(1, (c0 + BB_CB - 1) / BB_CB), cnt), dim3(WT), 0, c->stream, fd, lev, c0, y, v);
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL(k_sweep_gemv_t<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
+            FOR_FRONT_CHUNKS(cnt, off, n)
+                hipLaunchKernelGGL(k_sweep_gemv_t<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
             const size_t shm = (size_t)(maxnp + maxnb + NB) * sizeof(double);
             hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
@@ -914,6 +954,8 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipStreamCreate(&c->stream));
     HIPCHK(c, hipStreamCreate(&c->stream2));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreate(&c->stream3));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     const int nel = c->nel, nvc = c->nvc, npc = c->npc;
     // SoA connectivity
@@ -1067,7 +1109,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv,
-                     c->fr.spoff, c->fr.Sinv, c->fr.Swork, c->fr.sp_front, c->fr.sp_index, c->fr.cinv0, c->fr.cinv1};
+                     c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -1075,6 +1117,9 @@ void femo_destroy(femo_ctx* c) {
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 2; ++i)
         if (c->ev_la[i]) hipEventDestroy(c->ev_la[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
+    if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1622,30 +1667,26 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipMalloc((void**)&fr.linvoff, (ntree + 1) * sizeof(long long)));
     HIPCHK(c, hipMemcpy(fr.linvoff, linvoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
     {
-        std::vector<long long> spoff(ntree + 1, 0);
-        std::vector<int> spf, spi;
-        std::vector<char> wide(ntree, 0);                 // fronts of the levels that take the wide solve kernels
+        // X = L11^-1 of every front of the wide levels (leading dimension ldx_of(npiv)); Xtmp: scratch of the same shape
+        std::vector<long long> xoff(ntree + 1, 0);
+        std::vector<char> wide(ntree, 0);
         for (int L = 0; L < nlevels; ++L)
             if (fr.h_level_wide[L])
                 for (int i = level_off[L]; i < level_off[L + 1]; ++i) wide[level_nodes[i]] = 1;
         for (int t = 0; t < ntree; ++t) {
-            const int n = wide[t] ? (npiv[t] + SP - 1) / SP : 0;
-            spoff[t + 1] = spoff[t] + n;
-            for (int k = 0; k < n; ++k) { spf.push_back(t); spi.push_back(k); }
+            const long long ld = wide[t] ? ldx_of(npiv[t]) : 0;
+            xoff[t + 1] = xoff[t] + ld * ld;
         }
-        fr.nsp = (int)spf.size();
-        HIPCHK(c, hipMalloc((void**)&fr.spoff, (ntree + 1) * sizeof(long long)));
-        HIPCHK(c, hipMemcpy(fr.spoff, spoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMalloc((void**)&fr.sp_front, std::max<size_t>(spf.size(), 1) * sizeof(int)));
-        HIPCHK(c, hipMalloc((void**)&fr.sp_index, std::max<size_t>(spi.size(), 1) * sizeof(int)));
-        HIPCHK(c, hipMemcpy(fr.sp_front, spf.data(), spf.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(fr.sp_index, spi.data(), spi.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMalloc((void**)&fr.Sinv, std::max<size_t>((size_t)fr.nsp, 1) * SP * SP * sizeof(double)));
+        fr.x_doubles = xoff[ntree];
+        HIPCHK(c, hipMalloc((void**)&fr.xoff, (ntree + 1) * sizeof(long long)));
+        HIPCHK(c, hipMemcpy(fr.xoff, xoff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&fr.X, std::max<size_t>((size_t)fr.x_doubles, 1) * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&fr.Xtmp, std::max<size_t>((size_t)fr.x_doubles, 1) * sizeof(double)));
         // scratch for the diagonal-block inverses of the other levels (needed only between k_diag_block and k_panel_rows)
         int max_cnt = 0;
         for (int L = 0; L < nlevels; ++L)
             if (!fr.h_level_wide[L]) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
-        HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SP * SP * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SPD * SPD * sizeof(double)));
     }
     {
         // row maps of the extend-add gather: for every row of a front, the row of each child's front that lands there
@@ -1676,7 +1717,6 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         const int bytes = (int)(max_sweep * sizeof(double));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_bnd, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
@@ -1695,18 +1735,17 @@ int femo_factorize(femo_ctx* c) {
 /* Run one factorisation with a HIP event pair around every kernel launch and report, per kernel class
  * (0 panel rows, 1 diagonal blocks, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
  * also the algorithmic flop counts (lower triangles only) of what the launches of classes 2, 0, 1 execute.
- * out16 = ms[6], calls[6], flops(trailing, rows, diag), 0. */
-int femo_factorize_profile(femo_ctx* c, double* out16) {
+ * out32 = ms[8], calls[8], flops[8], bytes[8], indexed by class (class 6: inversion of L11, 7 unused). */
+int femo_factorize_profile(femo_ctx* c, double* out32) {
     HIPCHK(c, hipSetDevice(c->device));
     c->fr.profile = true;
     int rc = frontal_factorize(c);
     c->fr.profile = false;
     if (rc) return rc;
-    for (int i = 0; i < 6; ++i) { out16[i] = c->fr.prof_ms[i]; out16[6 + i] = (double)c->fr.prof_calls[i]; }
-    out16[12] = c->fr.prof_flops[2];      // what the k_trailing_mfma launches execute (their own K and column ranges)
-    out16[13] = c->fr.prof_flops[0];      // k_panel_rows
-    out16[14] = c->fr.prof_flops[1];      // k_diag_block
-    out16[15] = 0.0;
+    for (int i = 0; i < 8; ++i) {
+        out32[i] = c->fr.prof_ms[i]; out32[8 + i] = (double)c->fr.prof_calls[i];
+        out32[16 + i] = c->fr.prof_flops[i]; out32[24 + i] = c->fr.prof_bytes[i];
+    }
     return 0;
 }
 

@@ -39,11 +39,16 @@ struct FrontDev {
     const int* child[2];        // left / right
     const int* cinv[2];         // per front row: the row of the left / right child's front that lands there, or -1
     const long long* linvoff;   // doubles, [ntree+1]
-    const long long* spoff;     // number of 128-column super panels before front t, [ntree+1]
+    const long long* xoff;      // doubles, [ntree+1]: where the front's X = L11^-1 starts (fronts of the wide levels)
     double* F;
     double* Linv;
-    double* Sinv;               // inverse of every 128 x 128 diagonal block of L11 (SP*SP doubles each)
+    double* X;                  // L11^-1, lower triangle, column-major with leading dimension ldx_of(npiv)
+    double* Xtmp;               // scratch of the same shape (the products C XA of the recursive inversion)
 };
+
+// leading dimension of a front's X (a multiple of the 128-column outer panel, so that k_diag_block can write the
+// inverse of every diagonal block straight into place)
+__device__ __host__ inline int ldx_of(int np) { return (np + SPD - 1) / SPD * SPD; }
 
 // ------------------------------------------------------------------------------------------ assembly
 // one wave per element; lane j evaluates column j of K_e (operator applied to e_j) and adds its
@@ -353,7 +358,10 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     const int nkb = (kw + NB - 1) / NB;
     const int nf = fd.nf[t];
     double* F = fd.F + fd.foff[t];
-    double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    // the inverse of this diagonal block: scratch (levels solved with the one-workgroup-per-front kernels) or the diagonal
+    // block of the front's X (wide levels)
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
     extern __shared__ double lds_raw[];
     blk32* D = reinterpret_cast<blk32*>(lds_raw);              // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
     blk32* Sx = D + nblk * (nblk + 1) / 2;                      // column j of S below its diagonal sub-block
@@ -455,7 +463,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
         const blk32& Sjj = D[j * (j + 1) / 2 + j];
         for (int idx = tid; idx < NB * NB; idx += 256) {
             const int r = idx % NB, c = idx / NB;
-            Sout[(NB * j + r) + (size_t)SPD * (NB * j + c)] = Sjj[r][c];
+            Sout[(NB * j + r) + (size_t)lds_ * (NB * j + c)] = Sjj[r][c];
         }
         for (int i = j + 1; i < nkb; ++i) {
             // W = sum_{k=j}^{i-1} L_ik S_kj
@@ -473,7 +481,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
                 Sx[i - j - 1][r][c] = -x[reg];
-                Sout[(NB * i + r) + (size_t)SPD * (NB * j + c)] = -x[reg];
+                Sout[(NB * i + r) + (size_t)lds_ * (NB * j + c)] = -x[reg];
             }
             __syncthreads();
         }
@@ -500,7 +508,8 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.F + fd.foff[t];
-    const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.Sinv + (size_t)(fd.spoff[t] + C0 / SPD) * SPD * SPD;
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
     // S is shared by the four waves: the 16 rows of S that produce output columns [16 cb, 16 cb + 16) are staged in
     // LDS (k-major, so that the MFMA A operand S[c][k] is a conflict-free read), double-buffered over cb
     __shared__ double sb[2][NBO][16];
@@ -516,7 +525,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     double pre[NBO / 16];
     // stage block 0
 #pragma unroll
-    for (int q = 0; q < 1; ++q) pre[q] = S[sc + (size_t)SPD * (sk0 + 16 * q)];
+    for (int q = 0; q < 1; ++q) pre[q] = S[sc + (size_t)lds_ * (sk0 + 16 * q)];
     sb[0][sk0][sc] = pre[0];
     __syncthreads();
 #pragma unroll
@@ -526,7 +535,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
         const bool more = cb + 1 < NBO / 16 && 16 * (cb + 1) < kw;
         if (more) {
 #pragma unroll
-            for (int q = 0; q < cb + 2; ++q) pre[q] = S[(16 * (cb + 1) + sc) + (size_t)SPD * (sk0 + 16 * q)];
+            for (int q = 0; q < cb + 2; ++q) pre[q] = S[(16 * (cb + 1) + sc) + (size_t)lds_ * (sk0 + 16 * q)];
         }
         mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -760,165 +769,223 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
     for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
 }
 
-// backward, boundary part for the wide levels: s_c = y_c - sum_{r in boundary} L21[r][c] x[r].
-// A workgroup stages the boundary values x[gd[r]] once in LDS and takes BB_COLS pivot columns, four per wave at a
-// time with the lanes along the (contiguous) column -- eight independent loads per lane and iteration.
-constexpr int BB_COLS = 32;
+// ---- wide levels (few fronts, or large pivot blocks): the sweeps are four plain matrix-vector products per level
+//
+//   forward    y_p = X b_p                 (k_sweep_gemv_n<true>)     v_B -= L21 y_p          (k_sweep_gemv_n<false>)
+//   backward   s_p = y_p - L21^T x_B       (k_sweep_gemv_t<false>)    x_p  = X^T s_p          (k_sweep_gemv_t<true>)
+//
+// with X = L11^-1 formed explicitly after the factorisation (k_xinv below).  Substitution through L11 is a chain of one
+// dependent step per 128 pivot columns -- at the top of the tree (pivot blocks of 1000-1500 columns, a handful of
+// fronts) that chain was 10-12 launches of ~9 us per sweep and level with the chip idle; as products with X and L21
+// every sweep is two launches per level whose 128 x 128 tiles spread over the whole chip, and each factor byte is
+// still read exactly once.  Partial sums of a tile are added atomically (the output entries are zeroed by one memset
+// per sweep).
+
+// 128 x 128 tile, 256 threads: thread (row lr, column half ch) keeps 32 loads in flight at a time
+template <bool TRI>
 __global__ void __launch_bounds__(256)
-k_front_bwd_bnd(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ sv, const double* __restrict__ xv) {
-    const int t = level_nodes[blockIdx.y];
+k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
+    const int t = level_nodes[first + blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    const int nb = nf - np;
-    const int c0 = blockIdx.x * BB_COLS;
-    if (c0 >= np || nb == 0) return;
-    extern __shared__ double xs[];                       // nb
-    const int* gd = fd.dofs + fd.doff[t];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int r = tid; r < nb; r += 256) xs[r] = xv[gd[np + r]];
-    __syncthreads();
-    const double* L21 = fd.F + fd.foff[t] + np;          // rows np.., column c at + nf * c
-    for (int g = 0; g < BB_COLS / 16; ++g) {
-        const int cb = c0 + 16 * g + 4 * wv;             // this wave's four columns
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        const double* col[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)nf * min(cb + k, np - 1);
-        int r = lane;
-        for (; r + 64 < nb; r += 128) {
-            const double x0 = xs[r], x1 = xs[r + 64];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0 + col[k][r + 64] * x1;
-        }
-        if (r < nb) {
-            const double x0 = xs[r];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double tot = wave_sum(s[k]);
-            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
-        }
+    if (np == 0) return;
+    const int nct = (np + 127) / 128;
+    int ti, tj;                                              // row tile, column tile
+    if (TRI) {
+        const int lin = blockIdx.x;
+        if (lin >= nct * (nct + 1) / 2) return;
+        ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+        while (ti * (ti + 1) / 2 > lin) --ti;
+        tj = lin - ti * (ti + 1) / 2;
+    } else {
+        const int nrt = (nf - np + 127) / 128;
+        if ((int)blockIdx.x >= nrt * nct) return;
+        ti = blockIdx.x / nct; tj = blockIdx.x % nct;
     }
-}
-
-constexpr int SP = 128;    // columns handled per launch by the wide solve kernels (4 diagonal blocks)
-
-constexpr int WT = 1024;    // threads of the wide solve kernels
-constexpr int FB_ROWS = 128; // rows per workgroup of the wide forward step
-constexpr int BB_CB = 64;    // columns per workgroup of the wide backward step (4 per wave)
-
-// The top levels of the tree are a chain of dependent launches, one per 128 pivot columns and sweep: each kernel is
-// laid out for latency, not throughput -- every thread issues all of its loads at once (32 independent ones) and the
-// partial sums meet in LDS.  The triangular part (y = S v with the stored inverse of the 128 x 128 diagonal block) is
-// recomputed by every workgroup of the step instead of being a launch of its own: 131 KB of S from L2 per workgroup
-// buys one launch less on the chain.
-
-// forward, columns [c0, c0+SP):  y = L11[c0.., c0..]^-1 v[c0..] -> yv ;  v_r -= L[r, c0..c0+W) y for the rows below
-__global__ void __launch_bounds__(WT)
-k_front_fwd_blk(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ v, double* __restrict__ yv) {
-    const int t = level_nodes[blockIdx.y];
-    const int np = fd.npiv[t], nf = fd.nf[t];
-    if (c0 >= np) return;
-    const int W = min(SP, np - c0);
-    const int r0 = c0 + W + blockIdx.x * FB_ROWS;
-    if (blockIdx.x > 0 && r0 >= nf) return;
-    const double* F = fd.F + fd.foff[t];
     const int* gd = fd.dofs + fd.doff[t];
-    const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
-    __shared__ double bs[SP], ys[SP];
-    __shared__ double part[WT / SP][SP];
-    const int tid = threadIdx.x;
-    const int lr = tid & (SP - 1), p = tid >> 7;          // row lr of the block / of the tile, columns 16 p .. 16 p + 15
-    // all loads first: 16 of S (y_r = sum_{m <= r} S[r][m] b[m]), 16 of L (the rows below)
-    double sv[16], lv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int mm = 16 * p + k;
-        sv[k] = (mm <= lr && lr < W) ? S[lr + (size_t)SP * mm] : 0.0;
-    }
+    const int ld = TRI ? ldx_of(np) : nf;
+    const double* M = TRI ? fd.X + fd.xoff[t] : fd.F + fd.foff[t] + np;       // L21 starts at row np
+    const int nrows = TRI ? np : nf - np;
+    const int r0 = 128 * ti, c0 = 128 * tj;
+    __shared__ double xs[128];
+    __shared__ double part[128];
+    const int tid = threadIdx.x, lr = tid & 127, ch = tid >> 7;
+    if (tid < 128) xs[tid] = (c0 + tid < np) ? in[gd[c0 + tid]] : 0.0;
     const int r = r0 + lr;
-    const double* row = F + r + (size_t)nf * (c0 + 16 * p);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lv[k] = (r < nf && 16 * p + k < W) ? row[(size_t)nf * k] : 0.0;
-    if (tid < SP) bs[tid] = tid < W ? v[gd[c0 + tid]] : 0.0;
-    __syncthreads();
+    const double* row = M + r + (size_t)ld * (c0 + 64 * ch);
+    // triangular tiles on the diagonal: only columns <= row
+    const int cmax = min(np - c0 - 64 * ch, 64);             // columns of this half inside the pivot block
+    const int clim = (TRI && ti == tj) ? min(cmax, lr - 64 * ch + 1) : cmax;
+    double a[32];
     double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += sv[k] * bs[16 * p + k];
-    part[p][lr] = s;
     __syncthreads();
-    if (tid < SP) {
-        double y = 0.0;
 #pragma unroll
-        for (int q = 0; q < WT / SP; ++q) y += part[q][tid];
-        ys[tid] = y;
-        if (blockIdx.x == 0 && tid < W) yv[gd[c0 + tid]] = y;
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] = (r < nrows && 32 * h + k < clim) ? row[(size_t)ld * (32 * h + k)] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += a[k] * xs[64 * ch + 32 * h + k];
     }
+    if (ch) part[lr] = s;
     __syncthreads();
-    s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += lv[k] * ys[16 * p + k];
-    part[p][lr] = s;
-    __syncthreads();
-    if (tid < FB_ROWS && r < nf) {
-        s = 0.0;
-#pragma unroll
-        for (int q = 0; q < WT / SP; ++q) s += part[q][tid];
-        if (r < np) v[gd[r]] -= s;
-        else atomicAdd(&v[gd[r]], -s);
+    if (!ch && r < nrows) {
+        s += part[lr];
+        if (TRI) atomicAdd(&out[gd[r]], s);
+        else atomicAdd(&out[gd[np + r]], -s);
     }
 }
 
-// backward, columns [c0, c0+SP):  x = L11[c0.., c0..]^-T s[c0..] -> xv ;  s_j -= L[c0..c0+W, j]^T x for the columns j < c0
-__global__ void __launch_bounds__(WT)
-k_front_bwd_blk(FrontDev fd, const int* __restrict__ level_nodes, int c0, double* __restrict__ sv, double* __restrict__ xv) {
-    const int t = level_nodes[blockIdx.y];
+// transposed products: tile of 128 rows x 128 columns, wave w owns columns 32 w .. 32 w + 31 with its lanes along the
+// (contiguous) rows, 64 loads in flight per lane; per column one wave reduction
+template <bool TRI>
+__global__ void __launch_bounds__(256)
+k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
+    const int t = level_nodes[first + blockIdx.y];
     const int np = fd.npiv[t], nf = fd.nf[t];
-    if (c0 >= np) return;
-    const int W = min(SP, np - c0);
-    const int j0 = blockIdx.x * BB_CB;
-    if (blockIdx.x > 0 && j0 >= c0) return;
-    const double* F = fd.F + fd.foff[t];
+    if (np == 0) return;
+    const int nct = (np + 127) / 128;
+    int ti, tj;
+    if (TRI) {
+        const int lin = blockIdx.x;
+        if (lin >= nct * (nct + 1) / 2) return;
+        ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+        while (ti * (ti + 1) / 2 > lin) --ti;
+        tj = lin - ti * (ti + 1) / 2;
+    } else {
+        const int nrt = (nf - np + 127) / 128;
+        if ((int)blockIdx.x >= nrt * nct) return;
+        ti = blockIdx.x / nct; tj = blockIdx.x % nct;
+    }
     const int* gd = fd.dofs + fd.doff[t];
-    const double* S = fd.Sinv + (size_t)(fd.spoff[t] + c0 / SP) * SP * SP;
-    __shared__ double ss[SP], xs[SP];
+    const int ld = TRI ? ldx_of(np) : nf;
+    const double* M = TRI ? fd.X + fd.xoff[t] : fd.F + fd.foff[t] + np;
+    const int nrows = TRI ? np : nf - np;
+    const int rbase = TRI ? 0 : np;                          // front row of M's row 0
+    const int r0 = 128 * ti, c0 = 128 * tj;
+    __shared__ double xs[128];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // x_c = sum_{r >= c} S[r][c] s[r]: wave wv takes the columns wv, wv + 16, ...; its lanes walk the (contiguous)
-    // column, two rows each.  The columns j of L for the update are loaded in the same breath.
-    double a0[SP / 16], a1[SP / 16], l0[BB_CB / 16], l1[BB_CB / 16];
+    if (tid < 128) xs[tid] = (r0 + tid < nrows) ? in[gd[rbase + r0 + tid]] : 0.0;
+    const int ra = r0 + lane, rb = r0 + lane + 64;
+    double a0[32], a1[32];
 #pragma unroll
-    for (int k = 0; k < SP / 16; ++k) {
-        const int c = wv + 16 * k;
-        const double* col = S + (size_t)SP * c;
-        a0[k] = (lane >= c && lane < W && c < W) ? col[lane] : 0.0;
-        a1[k] = (lane + 64 >= c && lane + 64 < W && c < W) ? col[lane + 64] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < BB_CB / 16; ++k) {
-        const int j = j0 + wv + 16 * k;
-        const double* col = F + c0 + (size_t)nf * j;
-        l0[k] = (j < c0 && lane < W) ? col[lane] : 0.0;
-        l1[k] = (j < c0 && lane + 64 < W) ? col[lane + 64] : 0.0;
-    }
-    if (tid < SP) ss[tid] = tid < W ? sv[gd[c0 + tid]] : 0.0;
-    __syncthreads();
-    const double s0 = ss[lane], s1 = ss[lane + 64];
-#pragma unroll
-    for (int k = 0; k < SP / 16; ++k) {
-        const double x = wave_sum(a0[k] * s0 + a1[k] * s1);
-        if (lane == 0) xs[wv + 16 * k] = x;
+    for (int k = 0; k < 32; ++k) {
+        const int c = c0 + 32 * wv + k;
+        const double* col = M + (size_t)ld * c;
+        // triangular: rows >= column
+        const bool ca = c < np && ra < nrows && (!TRI || ra >= c);
+        const bool cb = c < np && rb < nrows && (!TRI || rb >= c);
+        a0[k] = ca ? col[ra] : 0.0;
+        a1[k] = cb ? col[rb] : 0.0;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid < W) xv[gd[c0 + tid]] = xs[tid];
     const double x0 = xs[lane], x1 = xs[lane + 64];
 #pragma unroll
-    for (int k = 0; k < BB_CB / 16; ++k) {
-        const int j = j0 + wv + 16 * k;
-        const double s = wave_sum(l0[k] * x0 + l1[k] * x1);
-        if (lane == 0 && j < c0) sv[gd[j]] -= s;
+    for (int k = 0; k < 32; ++k) {
+        const double sum = wave_sum(a0[k] * x0 + a1[k] * x1);
+        const int c = c0 + 32 * wv + k;
+        if (lane == 0 && c < np) atomicAdd(&out[gd[c]], TRI ? sum : -sum);
     }
 }
 
-// backward small-level kernel reads s from sv and writes x to xv
+// X = L11^-1 beyond its 128 x 128 diagonal blocks (which k_diag_block leaves in place), by recursive doubling: at block
+// size bs = 128, 256, 512, ... the inverse of every aligned 2 bs block [[A, 0], [C, B]] of L11 is completed from the
+// inverses XA, XB of its halves,  X_BA = -XB (C XA):
+//   PHASE 0:  T = C XA  (into Xtmp, at the place of X_BA);   PHASE 1:  X_BA = -XB T.
+// One workgroup per 128 x 64 tile of the result; fp64 MFMA with the product formed transposed (stores along rows).
+// Entries above the diagonal of X are never read as data: triangular operands are masked while they are staged.
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
+    const int t = level_nodes[first + blockIdx.y];
+    const int np = fd.npiv[t];
+    const int rts = bs / 128, cts = bs / 64;
+    int lin = blockIdx.x;
+    const int ct = lin % cts; lin /= cts;
+    const int rt = lin % rts;
+    const int pair = lin / rts;
+    const int a0 = 2 * pair * bs, b0 = a0 + bs;
+    if (b0 >= np) return;
+    const int mB = min(bs, np - b0);
+    const int r0 = rt * 128;
+    if (r0 >= mB) return;
+    const int c0 = ct * 64;
+    const int nf = fd.nf[t], ldx = ldx_of(np);
+    const double* F = fd.F + fd.foff[t];
+    double* X = fd.X + fd.xoff[t];
+    double* T = fd.Xtmp + fd.xoff[t];
+    // XA is lower triangular: its rows k < c0 vanish in the columns >= c0;  XB likewise: columns k > row vanish
+    const int k_lo = PHASE == 0 ? (c0 & ~15) : 0;
+    const int k_hi = PHASE == 0 ? bs : min(mB, r0 + 128);
+    constexpr int KC = 16, SA = 128 + 16, SB = 64 + 16;
+    __shared__ double sA[2][KC][SA];                      // sA[.][k][r]: the operand whose rows are the result's rows
+    __shared__ double sB[2][KC][SB];                      // sB[.][k][c]: the operand whose columns are the result's columns
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int lr = tid & 127, kq = tid >> 7;              // staging of A: row lr, k = kq + 2 q
+    const int kb = tid & 15, cb = tid >> 4;               // staging of B: k = kb, column cb + 16 q
+    const bool rok = r0 + lr < mB;
+    double pa[8], pb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + kq + 2 * q;
+            if (PHASE == 0) pa[q] = (rok && k < k_hi) ? F[(b0 + r0 + lr) + (size_t)nf * (a0 + k)] : 0.0;
+            else pa[q] = (rok && k < k_hi && k <= r0 + lr) ? X[(b0 + r0 + lr) + (size_t)ldx * (b0 + k)] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + kb, c = c0 + cb + 16 * q;
+            if (PHASE == 0) pb[q] = (k < k_hi && k >= c) ? X[(a0 + k) + (size_t)ldx * (a0 + c)] : 0.0;
+            else pb[q] = (k < k_hi) ? T[(b0 + k) + (size_t)ldx * (a0 + c)] : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sA[buf][kq + 2 * q][lr] = pa[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sB[buf][kb][cb + 16 * q] = pb[q];
+    };
+    mfma_d4 acc[4][2];
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+        for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    fetch(k_lo);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    const int wr = 32 * wv;
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
+        const bool more = k0 + KC < k_hi;
+        if (more) fetch(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double ac[4], br[2];
+#pragma unroll
+            for (int jc = 0; jc < 4; ++jc) ac[jc] = sB[cur][kk + l4][16 * jc + l15];
+#pragma unroll
+            for (int ir = 0; ir < 2; ++ir) br[ir] = sA[cur][kk + l4][wr + 16 * ir + l15];
+#pragma unroll
+            for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+                for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[jc], br[ir], acc[jc][ir], 0, 0, 0);
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double* dst = PHASE == 0 ? T : X;
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+        for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int c = c0 + 16 * jc + l4 + 4 * reg;          // D[i = l4 + 4 reg -> column][j = l15 -> row]
+                const int r = r0 + wr + 16 * ir + l15;
+                if (r < mB) dst[(b0 + r) + (size_t)ldx * (a0 + c)] = PHASE == 0 ? acc[jc][ir][reg] : -acc[jc][ir][reg];
+            }
+}
+
 }  // namespace femo

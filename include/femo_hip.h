@@ -105,10 +105,11 @@ int femo_set_frontal_plan(femo_ctx* ctx, int32_t ntree, int32_t nlevels, const i
  * PC 'lu' / MUMPS (fea/utils_dolfinx.py:495-531). */
 int femo_factorize(femo_ctx* ctx);
 /* One factorisation with a HIP event pair around every launch; per kernel class (0 rows below the diagonal blocks,
- * 1 diagonal blocks, 2 trailing rank-k updates, 3 extend_add, 4 front_assemble, 5 memset): out16[0..5] total ms,
- * out16[6..11] launches; out16[12..14] algorithmic flops (lower triangles only) executed by the launches of classes
- * 2, 0 and 1 -- counted from each launch's own K and column ranges; out16[15] reserved. */
-int femo_factorize_profile(femo_ctx* ctx, double* out16);
+ * 1 diagonal blocks, 2 trailing rank-k updates, 3 extend_add, 4 front_assemble, 5 memset, 6 inversion of L11, 7 unused):
+ * out32[0..7] total ms, out32[8..15] launches, out32[16..23] algorithmic flops (lower triangles only) executed by the
+ * launches of the class -- counted from each launch's own K and column ranges -- and out32[24..31] their compulsory HBM
+ * bytes (every operand entry read once, results read and written once); classes 0, 1, 2, zero otherwise. */
+int femo_factorize_profile(femo_ctx* ctx, double* out32);
 /* One application of the factor (forward + backward sweep) with a HIP event pair around every tree level:
  * out[2 L] = forward sweep of level L (ms), out[2 L + 1] = backward sweep; n >= 2 * levels of the plan. */
 int femo_sweep_profile(femo_ctx* ctx, double* out, int64_t n);

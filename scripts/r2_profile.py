@@ -32,14 +32,14 @@ for line in tmp.read().decode().splitlines():
     mm = re.match(r"prof level (\d+) class (\d+) ([\d.]+) us", line)
     if mm:
         L, cl, us = int(mm[1]), int(mm[2]), float(mm[3])
-        a = lev.setdefault(L, [[0.0, 0] for _ in range(6)])
+        a = lev.setdefault(L, [[0.0, 0] for _ in range(7)])
         a[cl][0] += us; a[cl][1] += 1
-names = ["rows", "diag", "trail", "extend", "assemble", "zero"]
+names = ["rows", "diag", "trail", "extend", "assemble", "zero", "xinv"]
 print("level  cnt  " + " ".join(f"{n:>13s}" for n in names))
 for L in sorted(lev):
     cnt = len(plan.level_nodes[L]) if L < plan.nlevels else 0
     print(f"{L:5d} {cnt:5d} " + " ".join(f"{a[0]:8.0f}/{a[1]:<4d}" for a in lev[L]))
-tot = {n: p[k]["ms"] for n, k in zip(names, ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset"])}
+tot = {n: p[k]["ms"] for n, k in zip(names, ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset", "l11_inverse"])}
 print("class totals (ms):", {k: round(v, 3) for k, v in tot.items()}, "sum", round(sum(tot.values()), 3))
 print("flops: trailing %.1f GF rows %.1f GF diag %.1f GF" % (p["trailing_flops"] / 1e9, p["panel_rows_flops"] / 1e9, p["panel_diag_flops"] / 1e9))
 print("trailing TFLOP/s:", p["trailing_flops"] / (p["trailing"]["ms"] * 1e-3) / 1e12)
