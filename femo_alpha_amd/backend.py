@@ -184,11 +184,13 @@ class ShellContext:
         out["trailing_bytes"], out["panel_rows_bytes"], out["panel_diag_bytes"] = t[26], t[24], t[25]
         return out
 
-    def sweep_profile(self):
-        """(nlevels, 2) array: ms of the forward / backward triangular sweep per tree level."""
-        t = np.zeros(2 * self.plan.nlevels)
+    def sweep_profile(self, detail=False):
+        """(nlevels, 2) array: ms of the forward / backward triangular sweep per tree level (``detail``: (nlevels, 4),
+        the two launches of each sweep separately)."""
+        t = np.zeros(4 * self.plan.nlevels)
         self._chk(self.lib.femo_sweep_profile(self._h, dptr(t), t.size))
-        return t.reshape(-1, 2)
+        t = t.reshape(-1, 4)
+        return t if detail else np.stack([t[:, 0] + t[:, 1], t[:, 2] + t[:, 3]], axis=1)
 
     def frontal_info(self):
         t = np.zeros(6)

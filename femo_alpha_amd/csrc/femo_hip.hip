@@ -89,6 +89,10 @@ struct femo_ctx {
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
         int allow_pivot_repair = 0;   // non-positive pivots: 0 = the factorisation fails, 1 = replace and count
         int profile_verbose = 0;
+        int xinv_small_cnt = 32;      // inversion of L11: levels with at most this many fronts use 64 x 32 tiles
+        // backward sweep, L21^T x: levels whose largest boundary has at least this many rows take the tiled (atomic) kernel.
+        // Measured at 1M DOF: one workgroup per 32 columns wins on every level (43-57 us against 49-115), so the default is never
+        int bnd_tiled_nb = 1 << 30;
     } opt;
     // solver
     int precond = 0;
@@ -100,6 +104,7 @@ struct femo_ctx {
     // multifrontal preconditioner (precond == 2)
     struct Frontal {
         bool ready = false, factored = false;
+        bool x_inflight = false;              // k_xinv launches on stream3 that the main stream has not waited for yet (event ev_x[1])
         int ntree = 0, nlevels = 0;
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
         std::vector<char> h_level_wide;              // level takes the wide solve kernels (and keeps S in Sinv)
@@ -462,6 +467,16 @@ struct ProfScope {
 // (option "grid_chunk" lowers the chunk so that the tests reach this path on small meshes)
 #define FOR_FRONT_CHUNKS(cnt_, off_, n_) for (int off_ = 0, gc_ = std::max(1, c->opt.grid_chunk), n_ = std::min((cnt_), gc_); off_ < (cnt_); off_ += gc_, n_ = std::min((cnt_) - off_, gc_))
 
+// L11^-1 is formed on stream3 beside the factorisation of the levels above and is first needed by a triangular sweep: the
+// main stream joins stream3 lazily (before the first wide level of the next sweep, or before the fronts are rewritten)
+static int join_xinv(femo_ctx* c) {
+    if (c->fr.x_inflight) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_x[1], 0));
+        c->fr.x_inflight = false;
+    }
+    return 0;
+}
+
 // levels [l0, l1) of the elimination tree; assemble != 0 first zeroes the fronts and sums the element matrices in
 static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     auto& fr = c->fr;
@@ -469,6 +484,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     if (l0 < 0 || l1 > fr.nlevels || l0 > l1) return fail(c, "bad level range");
     if (assemble) for (int i = 0; i < 8; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; fr.prof_flops[i] = 0; fr.prof_bytes[i] = 0; }
     bool x_pending = false;
+    if (join_xinv(c)) return 1;             // a previous factorisation's inversion must be done before X is written again
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -646,21 +662,33 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             HIPCHK(c, hipEventRecord(c->ev_x[0], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_x[0], 0));
             ProfScope ps(c, 6, c->stream3);
+            const bool small_tiles = cnt <= c->opt.xinv_small_cnt;      // few fronts: 64 x 32 tiles, four times the workgroups
             for (int bs = NBO; bs < max_np; bs *= 2) {
                 const int npairs = (max_np + 2 * bs - 1) / (2 * bs);
-                const dim3 grid(npairs * (bs / 128) * (bs / 64), 1);
                 FOR_FRONT_CHUNKS(cnt, off, n) {
-                    hipLaunchKernelGGL(k_xinv<0>, dim3(grid.x, n), dim3(256), 0, c->stream3, fd, lev, off, bs);
-                    hipLaunchKernelGGL(k_xinv<1>, dim3(grid.x, n), dim3(256), 0, c->stream3, fd, lev, off, bs);
+                    if (small_tiles) {
+                        const dim3 grid(npairs * (bs / 64) * (bs / 32), n);
+                        hipLaunchKernelGGL((k_xinv<0, 64, 32>), grid, dim3(256), 0, c->stream3, fd, lev, off, bs);
+                        hipLaunchKernelGGL((k_xinv<1, 64, 32>), grid, dim3(256), 0, c->stream3, fd, lev, off, bs);
+                    } else {
+                        const dim3 grid(npairs * (bs / 128) * (bs / 64), n);
+                        hipLaunchKernelGGL((k_xinv<0, 128, 64>), grid, dim3(256), 0, c->stream3, fd, lev, off, bs);
+                        hipLaunchKernelGGL((k_xinv<1, 128, 64>), grid, dim3(256), 0, c->stream3, fd, lev, off, bs);
+                    }
                 }
             }
             x_pending = true;
+            if (fr.profile) {                       // profiling: no overlap, so that every class is timed on an otherwise idle chip
+                HIPCHK(c, hipEventRecord(c->ev_x[1], c->stream3));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_x[1], 0));
+            }
         }
         HIPCHK(c, hipGetLastError());
     }
     if (x_pending) {
         HIPCHK(c, hipEventRecord(c->ev_x[1], c->stream3));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_x[1], 0));
+        fr.x_inflight = true;
+        if (fr.profile && join_xinv(c)) return 1;
     }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int info = 0;
@@ -701,27 +729,33 @@ static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0,
 // v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
 // Wide levels: two matrix-vector products per sweep (X = L11^-1 and L21), accumulated with atomics into entries that the
 // memset at the start of the sweep zeroed; the other levels: one workgroup per front.
-static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
+static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEvent_t>* marks = nullptr) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
+    auto mark = [&]() { if (marks) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); marks->push_back(e); } };
     if (l0 == 0) HIPCHK(c, hipMemsetAsync(y, 0, (size_t)c->ndof * sizeof(double), c->stream));
+    mark();
     for (int L = l0; L < l1; ++L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
         if (fr.h_level_wide[L]) {
+            if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
             FOR_FRONT_CHUNKS(cnt, off, n)
                 hipLaunchKernelGGL(k_sweep_gemv_n<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
+            mark();
             if (maxnb > 0)
                 FOR_FRONT_CHUNKS(cnt, off, n)
                     hipLaunchKernelGGL(k_sweep_gemv_n<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
             const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
             hipLaunchKernelGGL(k_front_fwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
+            mark();
         }
+        mark();
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -730,27 +764,40 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1) {
 // backward over levels l1-1 ... l0: y (in tmp) is consumed in place (running right-hand side), x lands in v.  After the
 // forward sweep nothing in v is alive (every entry is the pivot of a front behind us), so the sweep from the root starts
 // by zeroing it: the wide levels accumulate x with atomics.
-static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1) {
+static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEvent_t>* marks = nullptr) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
+    auto mark = [&]() { if (marks) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); marks->push_back(e); } };
     if (l1 == fr.nlevels) HIPCHK(c, hipMemsetAsync(v, 0, (size_t)c->ndof * sizeof(double), c->stream));
+    mark();
     for (int L = l1 - 1; L >= l0; --L) {
         const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
         if (fr.h_level_wide[L]) {
+            if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
-            if (maxnb > 0)
-                FOR_FRONT_CHUNKS(cnt, off, n)
-                    hipLaunchKernelGGL(k_sweep_gemv_t<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
+            if (maxnb > 0) {
+                if (maxnb >= c->opt.bnd_tiled_nb) {
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        hipLaunchKernelGGL(k_sweep_gemv_t<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
+                } else {
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        hipLaunchKernelGGL(k_sweep_bnd_cols, dim3((maxnp + BB_COLS - 1) / BB_COLS, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream,
+                                           fd, lev, off, y, (const double*)v);
+                }
+            }
+            mark();
             FOR_FRONT_CHUNKS(cnt, off, n)
                 hipLaunchKernelGGL(k_sweep_gemv_t<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
             const size_t shm = (size_t)(maxnp + maxnb + NB) * sizeof(double);
             hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
+            mark();
         }
+        mark();
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1102,6 +1149,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
 void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    hipDeviceSynchronize();                   // stream2 / stream3 may still hold work that reads the buffers freed below
     void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
@@ -1353,6 +1401,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "strict") o.strict = v != 0;
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
+    else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
+    else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;
     else return fail(c, "unknown option '" + k + "'");
     return 0;
 }
@@ -1717,6 +1767,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         const int bytes = (int)(max_sweep * sizeof(double));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
@@ -1749,37 +1800,36 @@ int femo_factorize_profile(femo_ctx* c, double* out32) {
     return 0;
 }
 
-// one application of the factor with a HIP event pair around every level of both sweeps:
-// out[2 L] = forward sweep of level L (ms), out[2 L + 1] = backward sweep of level L; n >= 2 nlevels
+// one application of the factor with HIP events between the launches of both sweeps:
+// out[4 L + 0 / 1] = forward sweep of level L, first / second launch (X b, then L21 y; levels with one workgroup per front
+// have only the first), out[4 L + 2 / 3] = backward sweep (L21^T x, then X^T s).  ms; n >= 4 nlevels
 int femo_sweep_profile(femo_ctx* c, double* out, int64_t n) {
     HIPCHK(c, hipSetDevice(c->device));
     auto& fr = c->fr;
     if (!fr.ready) return fail(c, "no frontal plan");
-    if (n < 2 * (int64_t)fr.nlevels) return fail(c, "output too small: 2 * nlevels doubles");
+    if (n < 4 * (int64_t)fr.nlevels) return fail(c, "output too small: 4 * nlevels doubles");
     if (!fr.factored)
         if (int rc = frontal_factorize(c)) return rc;
-    std::vector<hipEvent_t> ev(2 * fr.nlevels + 2);
-    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->z, 1.0, (int64_t)c->ndof);
-    int rc = 0;
-    HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    for (int L = 0; L < fr.nlevels && !rc; ++L) {
-        rc = frontal_fwd(c, c->z, L, L + 1);
-        HIPCHK(c, hipEventRecord(ev[L + 1], c->stream));
-    }
-    for (int L = fr.nlevels - 1; L >= 0 && !rc; --L) {
-        rc = frontal_bwd(c, c->z, L, L + 1);
-        HIPCHK(c, hipEventRecord(ev[fr.nlevels + 1 + (fr.nlevels - 1 - L)], c->stream));
-    }
+    std::vector<hipEvent_t> mf, mb;
+    int rc = frontal_fwd(c, c->z, 0, fr.nlevels, &mf);
+    if (!rc) rc = frontal_bwd(c, c->z, 0, fr.nlevels, &mb);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int L = 0; L < fr.nlevels && !rc; ++L) {
-        float f = 0, bw = 0;
-        hipEventElapsedTime(&f, ev[L], ev[L + 1]);
-        const int k = fr.nlevels - 1 - L;
-        hipEventElapsedTime(&bw, ev[fr.nlevels + k], ev[fr.nlevels + k + 1]);
-        out[2 * L] = f; out[2 * L + 1] = bw;
+    // marks: one before the first level, then two per level (after the first launch, after the level)
+    if (!rc && (int)mf.size() == 1 + 2 * fr.nlevels && (int)mb.size() == 1 + 2 * fr.nlevels) {
+        for (int L = 0; L < fr.nlevels; ++L) {
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, mf[2 * L], mf[2 * L + 1]); hipEventElapsedTime(&b, mf[2 * L + 1], mf[2 * L + 2]);
+            out[4 * L] = a; out[4 * L + 1] = b;
+            const int k = fr.nlevels - 1 - L;               // the backward sweep visits the levels in reverse
+            hipEventElapsedTime(&a, mb[2 * k], mb[2 * k + 1]); hipEventElapsedTime(&b, mb[2 * k + 1], mb[2 * k + 2]);
+            out[4 * L + 2] = a; out[4 * L + 3] = b;
+        }
+    } else if (!rc) {
+        rc = fail(c, "internal: unexpected number of sweep marks");
     }
-    for (auto& e : ev) hipEventDestroy(e);
+    for (auto e : mf) hipEventDestroy(e);
+    for (auto e : mb) hipEventDestroy(e);
     return rc;
 }
 

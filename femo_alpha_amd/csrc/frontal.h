@@ -888,18 +888,62 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
     }
 }
 
+// s_p = y_p - L21^T x_B with one workgroup per 32 pivot columns and ALL boundary rows of the front (no atomics, fixed
+// summation order): the better shape for the many medium fronts of the middle levels, where a front's L21 is a few
+// hundred rows; the tiled kernel above takes over where one workgroup per 32 columns could not pull the block out of HBM.
+constexpr int BB_COLS = 32;
+__global__ void __launch_bounds__(256)
+k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, double* __restrict__ sv, const double* __restrict__ xv) {
+    const int t = level_nodes[first + blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int nb = nf - np;
+    const int c0 = blockIdx.x * BB_COLS;
+    if (c0 >= np || nb == 0) return;
+    extern __shared__ double xs[];                       // nb
+    const int* gd = fd.dofs + fd.doff[t];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int r = tid; r < nb; r += 256) xs[r] = xv[gd[np + r]];
+    __syncthreads();
+    const double* L21 = fd.F + fd.foff[t] + np;          // rows np.., column c at + nf * c
+    for (int g = 0; g < BB_COLS / 16; ++g) {
+        const int cb = c0 + 16 * g + 4 * wv;             // this wave's four columns
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        const double* col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)nf * min(cb + k, np - 1);
+        int r = lane;
+        for (; r + 64 < nb; r += 128) {
+            const double x0 = xs[r], x1 = xs[r + 64];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0 + col[k][r + 64] * x1;
+        }
+        if (r < nb) {
+            const double x0 = xs[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double tot = wave_sum(s[k]);
+            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
+        }
+    }
+}
+
 // X = L11^-1 beyond its 128 x 128 diagonal blocks (which k_diag_block leaves in place), by recursive doubling: at block
 // size bs = 128, 256, 512, ... the inverse of every aligned 2 bs block [[A, 0], [C, B]] of L11 is completed from the
 // inverses XA, XB of its halves,  X_BA = -XB (C XA):
 //   PHASE 0:  T = C XA  (into Xtmp, at the place of X_BA);   PHASE 1:  X_BA = -XB T.
 // One workgroup per 128 x 64 tile of the result; fp64 MFMA with the product formed transposed (stores along rows).
 // Entries above the diagonal of X are never read as data: triangular operands are masked while they are staged.
-template <int PHASE>
+// Tile TM x TN per workgroup (four waves, 2 x 2): 128 x 64 where a level has many fronts, 64 x 32 at the top of the tree
+// (a handful of fronts: more, shorter workgroups -- the K loop of one tile is the critical path there).
+template <int PHASE, int TM, int TN>
 __global__ void __launch_bounds__(256)
 k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
     const int t = level_nodes[first + blockIdx.y];
     const int np = fd.npiv[t];
-    const int rts = bs / 128, cts = bs / 64;
+    const int rts = bs / TM, cts = bs / TN;
     int lin = blockIdx.x;
     const int ct = lin % cts; lin /= cts;
     const int rt = lin % rts;
@@ -907,34 +951,37 @@ k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
     const int a0 = 2 * pair * bs, b0 = a0 + bs;
     if (b0 >= np) return;
     const int mB = min(bs, np - b0);
-    const int r0 = rt * 128;
+    const int r0 = rt * TM;
     if (r0 >= mB) return;
-    const int c0 = ct * 64;
+    const int c0 = ct * TN;
     const int nf = fd.nf[t], ldx = ldx_of(np);
     const double* F = fd.F + fd.foff[t];
     double* X = fd.X + fd.xoff[t];
     double* T = fd.Xtmp + fd.xoff[t];
     // XA is lower triangular: its rows k < c0 vanish in the columns >= c0;  XB likewise: columns k > row vanish
     const int k_lo = PHASE == 0 ? (c0 & ~15) : 0;
-    const int k_hi = PHASE == 0 ? bs : min(mB, r0 + 128);
-    constexpr int KC = 16, SA = 128 + 16, SB = 64 + 16;
+    const int k_hi = PHASE == 0 ? bs : min(mB, r0 + TM);
+    constexpr int KC = 16, SA = TM + 16, SB = TN + 16;
+    constexpr int GA = 256 / TM, QA = KC / GA;            // staging of A: row lr, k = kq + GA q
+    constexpr int QB = TN / 16;                           // staging of B: k = kb, column cb + 16 q
+    constexpr int MR = TM / 32, NC = TN / 32;             // 16 x 16 MFMA blocks per wave: rows, columns
     __shared__ double sA[2][KC][SA];                      // sA[.][k][r]: the operand whose rows are the result's rows
     __shared__ double sB[2][KC][SB];                      // sB[.][k][c]: the operand whose columns are the result's columns
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int lr = tid & 127, kq = tid >> 7;              // staging of A: row lr, k = kq + 2 q
-    const int kb = tid & 15, cb = tid >> 4;               // staging of B: k = kb, column cb + 16 q
+    const int lr = tid % TM, kq = tid / TM;
+    const int kb = tid & 15, cb = tid >> 4;
     const bool rok = r0 + lr < mB;
-    double pa[8], pb[4];
+    double pa[QA], pb[QB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + kq + 2 * q;
+        for (int q = 0; q < QA; ++q) {
+            const int k = k0 + kq + GA * q;
             if (PHASE == 0) pa[q] = (rok && k < k_hi) ? F[(b0 + r0 + lr) + (size_t)nf * (a0 + k)] : 0.0;
             else pa[q] = (rok && k < k_hi && k <= r0 + lr) ? X[(b0 + r0 + lr) + (size_t)ldx * (b0 + k)] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QB; ++q) {
             const int k = k0 + kb, c = c0 + cb + 16 * q;
             if (PHASE == 0) pb[q] = (k < k_hi && k >= c) ? X[(a0 + k) + (size_t)ldx * (a0 + c)] : 0.0;
             else pb[q] = (k < k_hi) ? T[(b0 + k) + (size_t)ldx * (a0 + c)] : 0.0;
@@ -942,34 +989,34 @@ k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sA[buf][kq + 2 * q][lr] = pa[q];
+        for (int q = 0; q < QA; ++q) sA[buf][kq + GA * q][lr] = pa[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sB[buf][kb][cb + 16 * q] = pb[q];
+        for (int q = 0; q < QB; ++q) sB[buf][kb][cb + 16 * q] = pb[q];
     };
-    mfma_d4 acc[4][2];
+    mfma_d4 acc[NC][MR];
 #pragma unroll
-    for (int jc = 0; jc < 4; ++jc)
+    for (int jc = 0; jc < NC; ++jc)
 #pragma unroll
-        for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        for (int ir = 0; ir < MR; ++ir) acc[jc][ir] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
     fetch(k_lo);
     stash(0);
     __syncthreads();
     int cur = 0;
-    const int wr = 32 * wv;
+    const int wr = (wv & 1) * (TM / 2), wc = (wv >> 1) * (TN / 2);
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
         const bool more = k0 + KC < k_hi;
         if (more) fetch(k0 + KC);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
-            double ac[4], br[2];
+            double ac[NC], br[MR];
 #pragma unroll
-            for (int jc = 0; jc < 4; ++jc) ac[jc] = sB[cur][kk + l4][16 * jc + l15];
+            for (int jc = 0; jc < NC; ++jc) ac[jc] = sB[cur][kk + l4][wc + 16 * jc + l15];
 #pragma unroll
-            for (int ir = 0; ir < 2; ++ir) br[ir] = sA[cur][kk + l4][wr + 16 * ir + l15];
+            for (int ir = 0; ir < MR; ++ir) br[ir] = sA[cur][kk + l4][wr + 16 * ir + l15];
 #pragma unroll
-            for (int jc = 0; jc < 4; ++jc)
+            for (int jc = 0; jc < NC; ++jc)
 #pragma unroll
-                for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[jc], br[ir], acc[jc][ir], 0, 0, 0);
+                for (int ir = 0; ir < MR; ++ir) acc[jc][ir] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[jc], br[ir], acc[jc][ir], 0, 0, 0);
         }
         if (more) stash(cur ^ 1);
         __syncthreads();
@@ -977,12 +1024,12 @@ k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
     }
     double* dst = PHASE == 0 ? T : X;
 #pragma unroll
-    for (int jc = 0; jc < 4; ++jc)
+    for (int jc = 0; jc < NC; ++jc)
 #pragma unroll
-        for (int ir = 0; ir < 2; ++ir)
+        for (int ir = 0; ir < MR; ++ir)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int c = c0 + 16 * jc + l4 + 4 * reg;          // D[i = l4 + 4 reg -> column][j = l15 -> row]
+                const int c = c0 + wc + 16 * jc + l4 + 4 * reg;     // D[i = l4 + 4 reg -> column][j = l15 -> row]
                 const int r = r0 + wr + 16 * ir + l15;
                 if (r < mB) dst[(b0 + r) + (size_t)ldx * (a0 + c)] = PHASE == 0 ? acc[jc][ir][reg] : -acc[jc][ir][reg];
             }

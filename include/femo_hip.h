@@ -110,8 +110,8 @@ int femo_factorize(femo_ctx* ctx);
  * launches of the class -- counted from each launch's own K and column ranges -- and out32[24..31] their compulsory HBM
  * bytes (every operand entry read once, results read and written once); classes 0, 1, 2, zero otherwise. */
 int femo_factorize_profile(femo_ctx* ctx, double* out32);
-/* One application of the factor (forward + backward sweep) with a HIP event pair around every tree level:
- * out[2 L] = forward sweep of level L (ms), out[2 L + 1] = backward sweep; n >= 2 * levels of the plan. */
+/* One application of the factor (forward + backward sweep) with HIP events between the launches, per tree level L:
+ * out[4 L + 0 / 1] forward sweep, first / second launch; out[4 L + 2 / 3] backward sweep (ms); n >= 4 * levels. */
 int femo_sweep_profile(femo_ctx* ctx, double* out, int64_t n);
 /* out6: [0] front assembly ms, [1] factorisation ms, [2] front storage GB, [3] factor GFLOP,
  *       [4] non-positive pivots repaired, [5] number of fronts. */
@@ -129,7 +129,9 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "trailing" 0 auto | 1 left-looking | 2 right-looking rank-k updates; "left_min", "left_max" (auto: levels with this
  *   many fronts are left-looking); "lookahead" 0/1, "lookahead_cnt"; "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
- *   "profile_verbose" (per-launch timings of femo_factorize_profile on stderr). */
+ *   "bnd_tiled_nb" (backward sweep: levels whose largest boundary block has at least this many rows use 128 x 128 tiles
+ *   with atomics for L21^T x, the others one workgroup per 32 columns); "profile_verbose" (per-launch timings of
+ *   femo_factorize_profile on stderr). */
 int femo_set_option(femo_ctx* ctx, const char* key, double value);
 /* Krylov method for the state / adjoint / linear solves: 0 = conjugate gradients (default; the operator is SPD),
  * 1 = right-preconditioned BiCGStab with the same preconditioner (femo_set_solver).  Stands where the reference

@@ -45,12 +45,18 @@ print("flops: trailing %.1f GF rows %.1f GF diag %.1f GF" % (p["trailing_flops"]
 print("trailing TFLOP/s:", p["trailing_flops"] / (p["trailing"]["ms"] * 1e-3) / 1e12)
 info = c.factorize()
 print("factorize:", info)
-sw = np.min([c.sweep_profile() for _ in range(3)], axis=0)
-print("sweeps per level (ms): fwd / bwd")
+for thr in (0, 1 << 30):
+    c.set_option("bnd_tiled_nb", thr)
+    s4 = np.min([c.sweep_profile(detail=True) for _ in range(3)], axis=0)
+    print(f"bnd_tiled_nb {thr}: L21^T x per level (us):", " ".join(f"{x*1e3:.0f}" for x in s4[:, 2]), " total apply ms", s4.sum())
+c.set_option("bnd_tiled_nb", 1 << 30)
+sw4 = np.min([c.sweep_profile(detail=True) for _ in range(3)], axis=0)
+sw = np.stack([sw4[:, 0] + sw4[:, 1], sw4[:, 2] + sw4[:, 3]], axis=1)
+print("sweeps per level (us): fwd (X b | L21 y)  bwd (L21^T x | X^T s)")
 for L in range(plan.nlevels):
     nf, npv = plan.nf[plan.level_nodes[L]].astype(float), plan.npiv[plan.level_nodes[L]].astype(float)
     gb = (nf * npv).sum() * 8 / 1e9
-    print(f"{L:5d} cnt {len(nf):5d} maxnp {int(npv.max()):5d} factor {gb:6.3f} GB  fwd {sw[L,0]*1e3:8.1f} us  bwd {sw[L,1]*1e3:8.1f} us   {2*gb/(sw[L].sum()*1e-3)/1e3:6.2f} TB/s")
+    print(f"{L:5d} cnt {len(nf):5d} maxnp {int(npv.max()):5d} factor {gb:6.3f} GB  fwd {sw4[L,0]*1e3:7.1f} {sw4[L,1]*1e3:7.1f}  bwd {sw4[L,2]*1e3:7.1f} {sw4[L,3]*1e3:7.1f}   {2*gb/(sw[L].sum()*1e-3)/1e3:6.2f} TB/s")
 print("sweep total ms", sw.sum(), "fwd", sw[:, 0].sum(), "bwd", sw[:, 1].sum())
 it, rr = c.solve_state(True)
 print("solve", it, rr, c.last_timing())

@@ -1,0 +1,63 @@
+"""The C++/OpenMP restatement behind bench.py's ``cpu_baseline`` leg (oracle/cpu_kernels.cpp, oracle/cpu_baseline.py)
+against the numpy oracle it restates: element matrices, CSR assembly, dR/dfield, and the CPU multifrontal Cholesky."""
+import numpy as np
+import pytest
+
+from femo_alpha_amd.mesh import plate_mesh, quads_to_triangles, wing_skin_mesh
+from femo_alpha_amd.solver.symbolic import build_plan
+from oracle import cpu_baseline as cb
+from oracle.rm_shell_oracle import ShellOracle
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
+
+
+@pytest.fixture(scope="module")
+def warped():
+    m = wing_skin_mesh(6, 14, shuffle=True)
+    rng = np.random.default_rng(0)
+    o = ShellOracle(m, penalty_facets=m.penalty_facets(lambda x: np.less(x[1], 1e-12)))
+    o.set_fields(h=0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)), E=3e7 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)),
+                 nu=0.3 + 0.05 * rng.uniform(-1, 1, m.nn), f=rng.uniform(-1, 1, (m.nn, 3)), uhat=0.02 * rng.uniform(-1, 1, (m.nn, 3)))
+    return m, o, cb.CpuShell(o), rng
+
+
+def test_element_matrices_and_csr_assembly(warped):
+    m, o, cs, rng = warped
+    assert rel(cs.element_matrices(0, 2), o.element_matrices()) < 1e-13
+    K1, K0 = cs.assemble_K(2), o.assemble_K()
+    assert abs(K1 - K0).max() < 1e-13 * abs(K0).max()
+    mt = quads_to_triangles(wing_skin_mesh(5, 9, shuffle=True))
+    ot = ShellOracle(mt)
+    ot.set_fields(h=0.05, E=3e7, nu=0.3)
+    assert rel(cb.CpuShell(ot).element_matrices(0, 2), ot.element_matrices()) < 1e-12
+
+
+def test_derivative_matrices(warped):
+    m, o, cs, rng = warped
+    w, lam = rng.uniform(-1, 1, m.ndof) * 1e-3, rng.uniform(-1, 1, m.ndof)
+    for name in ("h", "E", "nu"):
+        A = cs.assemble_drdfield(name, w, 2)
+        assert A.shape == (m.ndof, m.nn)
+        assert rel(A.T @ lam, o.dRdfield_T(name, w, lam)) < 1e-12
+
+
+def test_cpu_multifrontal_solves_the_oracle_system(warped):
+    m, o, cs, rng = warped
+    mf = cb.CpuMultifrontal(cs, build_plan(m, 8), 2)
+    mf.factorize()
+    K, b = o.assemble_K(), o.load_vector()
+    x = mf.solve(b)
+    x += mf.solve(b - K @ x)
+    assert rel(x, o.solve()) < 1e-8
+
+
+def test_measure_protocol_on_a_small_plate():
+    m = plate_mesh(2.0, 10.0, 6, 30)
+    o = ShellOracle(m, penalty_facets=m.penalty_facets(lambda x: np.less(x[0], 3e-16)))
+    o.set_fields(h=0.1, E=1e8, nu=0.3, rho=10.0, f=np.tile([0, 0, 5.0], (m.nn, 1)))
+    r = cb.measure(o, build_plan(m, 12), cores=2, repeats=1)
+    assert r["mf_relres"] < 1e-5 and r["superlu_vs_mf"] < 1e-7
+    assert r["as_reference"]["forward_s"] > r["best_effort_superlu"]["forward_s"] > 0
+    assert r["best_effort"]["dof_per_s"] > 0
