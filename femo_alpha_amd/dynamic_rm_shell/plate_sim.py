@@ -82,8 +82,13 @@ class PlateSim:
     def _sync(self):
         self.torch.cuda.synchronize()
 
-    def solve_dynamic_problem(self, residual=None, saving_outputs=False, PATH=None, timing=False):
-        """March from zero initial conditions; returns the (fe_dofs, time_levels) history."""
+    def solve_dynamic_problem(self, residual=None, saving_outputs=False, PATH=None, timing=False, reassemble_every_step=False):
+        """March from zero initial conditions; returns the (fe_dofs, time_levels) history.
+
+        ``reassemble_every_step``: rebuild and re-factorise the step operator before every solve, as the reference does
+        (``solveNonlinear_mod`` assembles the Jacobian and runs a fresh LU per step, nonlinear_utils.py:210-233 from
+        plate_sim.py:319).  The operator does not change along the march, so the default factorises once per thickness;
+        the flag exists so that BASELINE config 5 can be timed as written ("re-assembly per step")."""
         ctx, v, torch = self.ctx, self._v, self.torch
         W = self.W = torch.zeros((self.time_levels, self.fe_dofs), dtype=torch.float64, device=v["state"].device)
         wdot = torch.zeros_like(v["state"])
@@ -100,11 +105,36 @@ class PlateSim:
             v["b"].add_(v["Ap"]).add_(v["z"], alpha=-0.5)
             self._sync()
             ctx.vec_mask_zero("b")
+            if reassemble_every_step:
+                ctx.set_field("thickness", self.t)                       # marks the factorisation stale: next solve re-assembles
             self.solve_info.append(ctx.solve_vec("b", "state", zero_guess=True))
             W[i].copy_(v["state"])
             wdot = self.b * (W[i] - w_old) - wdot                        # plate_sim.py:243-244, 333
         self._sync()
         return W.T.cpu().numpy().copy(order="F")
+
+    def energy_audit(self):
+        """Discrete energy balance of the last march.  The midpoint rule with the force at the new level satisfies
+            (T_i + U_i) - (T_{i-1} + U_{i-1}) = F_i . (w_i - w_{i-1})        exactly,
+        T = 1/2 wdot^T M wdot, U = 1/2 w^T K w (multiply the step equation by w_i - w_{i-1} = dt (wdot_i + wdot_{i-1}) / 2).
+        Returns (U, T, work) as arrays over the time levels, evaluated by the matrix-free operator on the device history --
+        a size-independent check of the whole step (operator, inertia, solve, Dirichlet rows)."""
+        ctx, v, torch = self.ctx, self._v, self.torch
+        W = self.W
+        U, T, work = np.zeros(self.time_levels), np.zeros(self.time_levels), np.zeros(self.time_levels)
+        wdot = torch.zeros_like(v["state"])
+        for i in range(1, self.time_levels):
+            wdot = self.b * (W[i] - W[i - 1]) - wdot
+            v["p"].copy_(W[i]); v["adjoint"].copy_(wdot)
+            self._sync()
+            ctx.op_apply_vec2("p", "z", 1.0, 0.0, False)                # K w_i
+            ctx.op_apply_vec2("adjoint", "Ap", 0.0, 1.0, False)         # M wdot_i
+            ctx.set_field("F_solid", self._force_at(i))
+            ctx.load_vec("b")
+            U[i] = 0.5 * float(torch.dot(W[i], v["z"]))
+            T[i] = 0.5 * float(torch.dot(wdot, v["Ap"]))
+            work[i] = float(torch.dot(v["b"], W[i] - W[i - 1]))
+        return U, T, work
 
     # ------------------------------------------------------------------ outputs on one level
     def assembleStrainEnergy(self, w):

@@ -7,8 +7,9 @@
 * ``read_msh`` — Gmsh ASCII 2.2 / 4.1 surface meshes (what the reference's advanced examples feed to CADDEE's
   ``import_shell_mesh``), with the physical groups returned as ``mesh_tags`` for ``RMShellModel``.
 
-XDMF heavy data: inline XML (``Format="XML"``) is read and written natively; ``Format="HDF"`` needs ``h5py``, which
-is imported on demand and reported clearly when absent.
+XDMF heavy data: inline XML (``Format="XML"``) is read and written natively; ``Format="HDF"`` -- the format of every
+mesh the reference ships (fea/utils_dolfinx.py:34-50: ``XDMFFile(...).read_mesh(name="Grid")``) -- is read through the
+library-free HDF5 parser in ``hdf5_min.py`` (h5py is not part of this image).
 """
 from __future__ import annotations
 
@@ -29,14 +30,11 @@ def _read_dataitem(item, base_dir):
     if fmt == "XML":
         data = np.array(item.text.split(), dtype=np.int64 if is_int else np.float64)
     elif fmt == "HDF":
+        # dolfinx keeps the arrays of every mesh it writes in an HDF5 file next to the XML ("mesh.h5:/Mesh/Grid/topology");
+        # they are plain contiguous datasets, read here without h5py / libhdf5 (femo_alpha_amd/hdf5_min.py)
+        from .hdf5_min import read_dataset
         fname, _, path = item.text.strip().partition(":")
-        try:
-            import h5py
-        except ImportError as e:
-            raise ImportError("this XDMF file keeps its arrays in HDF5 and h5py is not installed; "
-                              "re-export the mesh with inline XML data (format='XML')") from e
-        with h5py.File(os.path.join(base_dir, fname), "r") as h5:
-            data = np.asarray(h5[path])
+        data = read_dataset(os.path.join(base_dir, fname), path)
     else:
         raise ValueError(f"unsupported XDMF DataItem format '{fmt}'")
     return data.reshape(dims)

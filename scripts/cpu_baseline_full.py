@@ -33,7 +33,8 @@ def main():
     plan = build_plan(m, 12)
     symbolic_s = time.perf_counter() - t0
     ncores = cb.host_cores()
-    rec = dict(workload=f"{which}: {desc}", cpu_model=cb.cpu_model_name(), host_cores=ncores, symbolic_s=symbolic_s,
+    rec = dict(workload=f"{which}: {desc}", cpu_model=cb.cpu_model_name(), host_cores=ncores,
+               cores_visible=len(os.sched_getaffinity(0)), symbolic_s=symbolic_s,
                kind="port", protocol="1 warm-up + median of N repeats per phase; SuperLU factorisation timed once per core count")
     print(f"{which}: {m.ndof} DOF, {ncores} host cores ({rec['cpu_model']}), symbolic analysis {symbolic_s:.1f} s", flush=True)
     for cores in (1, ncores):

@@ -119,3 +119,35 @@ def test_read_msh_41(tmp_path):
     assert mesh.nel == 3 and mesh.nn == 5 and mesh.cells.shape[1] == 3
     assert tags == {"skin": [0, 1]}
     assert mesh.ndof == 3 * (mesh.nn + mesh.edges.shape[0]) + 3 * mesh.nn
+
+
+@pytest.mark.parametrize("flavour", ["", "_chunked", "_latest"])
+def test_hdf5_backed_xdmf_like_the_reference_meshes(flavour, golden_dir):
+    """``readFEAMesh`` on an XDMF + HDF5 pair in dolfinx's layout (reference fea/utils_dolfinx.py:34-50; every mesh the
+    reference ships is such a pair).  The fixture regenerates examples/advanced_examples/simple_shell_opt/plate_meshes/
+    plate_2_10_quad_4_20 from its name; its default flavour has the 10 592 bytes the reference's git-LFS stub declares
+    for the .h5 file.  Three HDF5 flavours: old-style groups + contiguous data, chunked data, and libver-latest headers."""
+    import os
+    from femo_alpha_amd.mesh import plate_mesh
+    from femo_alpha_amd.mesh_io import readFEAMesh
+    stem = os.path.join(golden_dir, "plate_2_10_quad_4_20" + flavour)
+    if flavour == "":
+        assert os.path.getsize(stem + ".h5") == 10592
+    m = readFEAMesh(stem + ".xdmf")
+    exp = np.load(os.path.join(golden_dir, "plate_2_10_quad_4_20_expected.npz"))
+    assert m.is_quad and m.nel == 80 and m.nn == 105
+    assert np.array_equal(m.nodes, exp["nodes"]) and np.array_equal(m.cells, exp["cells"])
+    # the same plate as the generator, in the file's (shuffled) vertex numbering
+    ref = plate_mesh(2.0, 10.0, 4, 20)
+    assert np.isclose(m.cell_diameters().max(), ref.cell_diameters().max())
+    assert np.allclose(np.sort(m.nodes, axis=0), np.sort(ref.nodes, axis=0))
+    clamp = lambda x: np.less(x[0], 3e-16)
+    assert len(m.penalty_facets(clamp)) == len(ref.penalty_facets(clamp)) == 4
+
+
+def test_hdf5_reader_reports_what_it_cannot_read(tmp_path):
+    from femo_alpha_amd.hdf5_min import HDF5FormatError, read_dataset
+    p = tmp_path / "not_hdf5.h5"
+    p.write_bytes(b"this is not an hdf5 file" * 40)
+    with pytest.raises(HDF5FormatError):
+        read_dataset(str(p), "/Mesh/Grid/topology")
