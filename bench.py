@@ -136,16 +136,20 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0):
 
 
 def main_distributed(args, rank, local_rank, world, torch, dist):
-    """N > 1: weak scaling of the wing skin -- N times the span, N times the cells, one element partition
-    (one subtree of the nested-dissection tree) per GPU; collectives over RCCL (backend nccl)."""
+    """N > 1.  ``--scaling strong`` (default; BASELINE config 4 as written): the SAME 1 015 470-DOF wing skin split into N
+    element partitions (the N subtrees at depth log2 N of the nested-dissection tree), one per GPU.  ``--scaling weak``: N
+    times the span, N times the cells.  Collectives over RCCL (backend nccl): one all-reduce of the replicated separator
+    entries per operator / preconditioner application, one packed scalar all-reduce per dot, one all-gather of the
+    subtree roots' Schur complements (packed lower triangles) per factorisation."""
     from femo_alpha_amd.mesh import wing_skin_mesh
     from femo_alpha_amd.parallel import Comm, DistributedShell
     if world & (world - 1):
         raise SystemExit("the element partition needs a power-of-two number of GPUs")
     if args.workload != "wing1m":
         raise SystemExit("the multi-GPU bench runs the wing-skin workload")
-    ns = int(os.environ.get("FEMO_BENCH_NS", "580"))               # spanwise cells per GPU (580 = the 1M-DOF config)
-    m = wing_skin_mesh(116, ns * world, span=6.0 * world * ns / 580.0).renumbered()[0]
+    ns = int(os.environ.get("FEMO_BENCH_NS", "580"))               # spanwise cells (580 = the 1M-DOF config); rehearsals shrink it
+    mult = world if args.scaling == "weak" else 1
+    m = wing_skin_mesh(116, ns * mult, span=6.0 * mult * ns / 580.0).renumbered()[0]
     marker = lambda x: np.less(x[1], 1e-9)
     comm = Comm(dist)
     shared_gpu = torch.cuda.device_count() < world                 # rehearsal: several ranks on one card
@@ -190,10 +194,12 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
             "metric": "DOF/s (assembly+solve), forward solve of the RM shell; adjoint-gradient wallclock in adjoint_ms",
             "value": m.ndof * args.steps / t_fwd, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_total / args.steps * 1e3, "forward_ms": t_fwd / args.steps * 1e3,
-            "adjoint_ms": t_adj / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "adjoint_ms": t_adj / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"wing1m x{world}: synthetic wing skin 116x{ns * world} quads (span x{world}), {m.ndof} DOF, "
-                                   f"one element partition of {ds.sub.nel} cells per GPU",
+            "config": {"workload": (f"wing1m, strong scaling: the 116x{ns} wing skin ({m.ndof} DOF) in {world} element partitions of "
+                                    f"{ds.sub.nel} cells" if args.scaling == "strong" else
+                                    f"wing1m x{world}, weak scaling: synthetic wing skin 116x{ns * world} quads (span x{world}), {m.ndof} DOF, "
+                                    f"one element partition of {ds.sub.nel} cells per GPU"),
                        "ndof": m.ndof, "cells": m.nel, "ndof_per_gpu": ds.sub.ndof,
                        "replicated_separator_dofs": ds.info["n_top"],
                        "solver": "PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "

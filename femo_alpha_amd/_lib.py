@@ -70,6 +70,7 @@ SIGNATURES = {
     "femo_bench_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _c_double_p]),
     "femo_vec_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "femo_sync": (C.c_int, [C.c_void_p]),
+    "femo_stream_ptr": (C.c_void_p, [C.c_void_p]),
     "femo_op_apply_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "femo_load_vec": (C.c_int, [C.c_void_p, C.c_int32]),
     "femo_factorize_range": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int]),
@@ -95,6 +96,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: the PyTorch wheel ships its own libamdhip64.  If this library initialised /opt/rocm's copy
+    # first, a later ``import torch`` would bring a second runtime that finds no device ("No HIP GPUs are available").  With
+    # torch imported first, libfemo_hip's dependency resolves to the copy already loaded.  torch is only plumbing here
+    # (device tensors over the context's buffers, torch.distributed); the library itself does not need it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     from . import _build
     if _build.needs_build():
         # missing, or compiled from other sources than the ones beside it (content digest): rebuild, or refuse

@@ -330,6 +330,12 @@ class ShellContext:
     def sync(self):
         self._chk(self.lib.femo_sync(self._h))
 
+    def torch_stream(self):
+        """The context's HIP stream as a ``torch.cuda.ExternalStream``: with it as torch's current stream, tensor ops on the
+        zero-copy views and the collectives issued from Python are ordered with the library's kernels by the stream itself."""
+        import torch
+        return torch.cuda.ExternalStream(int(self.lib.femo_stream_ptr(self._h)), device=torch.device("cuda", self.device))
+
     def op_apply_vec(self, src, dst):
         self._chk(self.lib.femo_op_apply_vec(self._h, self.VEC_IDS[src], self.VEC_IDS[dst]))
 

@@ -1854,6 +1854,8 @@ static double* vec_by_id(femo_ctx* c, int id) {
 
 void* femo_vec_ptr(femo_ctx* c, int32_t id) { return vec_by_id(c, id); }
 
+void* femo_stream_ptr(femo_ctx* c) { return (void*)c->stream; }
+
 int femo_sync(femo_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));

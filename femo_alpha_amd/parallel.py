@@ -52,16 +52,18 @@ class Comm:
         return t
 
     def allgather(self, t):
+        """(size, len(t)) tensor of every rank's ``t`` (equal lengths): one ``all_gather_into_tensor`` over RCCL; gloo (the
+        CPU tests and rehearsals, which stage device tensors through the host) has no such call and gathers a list."""
         if self.dist is None:
-            return [t]
+            return t.reshape(1, -1)
         import torch
-        if self._stage and t.is_cuda:
-            h = t.cpu()
-            out = [torch.empty_like(h) for _ in range(self.size)]
-            self.dist.all_gather(out, h)
-            return [o.to(t.device) for o in out]
-        out = [torch.empty_like(t) for _ in range(self.size)]
-        self.dist.all_gather(out, t)
+        if self._stage:
+            h = t.cpu() if t.is_cuda else t
+            parts = [torch.empty_like(h) for _ in range(self.size)]
+            self.dist.all_gather(parts, h)
+            return torch.stack(parts).to(t.device)
+        out = torch.empty((self.size, t.numel()), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
         return out
 
 
@@ -78,6 +80,10 @@ class HipEngine:
         self.device = torch.device("cuda", device)
         self.nvec = self.ctx.ndof
         self._views = {}
+        # torch's tensor ops and collectives run on the context's own stream: every library call is synchronous on return and
+        # everything torch enqueues afterwards is ordered behind it, so no device-wide synchronisation is needed in between
+        self.stream = self.ctx.torch_stream()
+        torch.cuda.set_stream(self.stream)
 
     def vec(self, name):
         if name not in self._views:
@@ -88,7 +94,7 @@ class HipEngine:
         return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
 
     def _sync(self):
-        self.torch.cuda.synchronize(self.device)
+        pass            # same stream on both sides (see __init__); kept as the seam where a two-stream engine would wait
 
     def set_field(self, name, values):
         self.ctx.set_field(name, values)
@@ -188,15 +194,34 @@ class DistributedShell:
         eng, info = self.eng, self.info
         eng.factor(0, self.nl, True)
         if self.comm.size > 1:
+            # the Schur complements of the subtree roots travel as packed lower triangles (they are symmetric and only the
+            # lower triangle of a front is ever read), padded to the largest one: ONE all_gather_into_tensor
             sizes = info["schur_sizes"]
-            cap = max(sizes) ** 2
+            n_me = sizes[self.comm.rank]
+            full = eng.new_tensor(max(n_me * n_me, 1))
+            eng.schur_get(info["root_front"], full)
+            cap = max(n * (n + 1) // 2 for n in sizes)
             mine = eng.new_tensor(cap)
-            eng.schur_get(info["root_front"], mine)
-            for q, blk in enumerate(self.comm.allgather(mine)):
+            il = self._tril(n_me)
+            mine[: il.numel()] = full[il]
+            gathered = self.comm.allgather(mine)
+            for q in range(self.comm.size):
                 if q != self.comm.rank:
-                    eng.block_set(info["stub_fronts"][q], blk[: sizes[q] ** 2].contiguous())
+                    n = sizes[q]
+                    iq = self._tril(n)
+                    blk = eng.new_tensor(n * n)
+                    blk[iq] = gathered[q, : iq.numel()]
+                    eng.block_set(info["stub_fronts"][q], blk)
         eng.factor(self.nl, self.nlev, False)
         self.factored = True
+
+    def _tril(self, n):
+        """Flat (column-major) indices of the lower triangle of an n x n block, cached per size."""
+        cache = self.__dict__.setdefault("_tril_cache", {})
+        if n not in cache:
+            r, c = np.tril_indices(n)
+            cache[n] = self.torch.as_tensor(np.sort(r + n * c), dtype=self.torch.int64, device=self.eng.vec("r").device)
+        return cache[n]
 
     def precondition(self, name):
         """name <- (L L^T)^-1 name; replicated entries must agree on all ranks on entry."""

@@ -223,6 +223,9 @@ int femo_bench_kernel(femo_ctx* ctx, const char* name, int32_t reps, double* avg
  * Vector ids: 0 state, 1 adjoint, 2 r, 3 z, 4 p, 5 Ap, 6 b. */
 void* femo_vec_ptr(femo_ctx* ctx, int32_t id);                 /* device pointer, femo_ndof doubles */
 int femo_sync(femo_ctx* ctx);                                  /* wait for the context's stream */
+void* femo_stream_ptr(femo_ctx* ctx);                          /* the context's hipStream_t: the multi-GPU driver makes it torch's
+                                                                  current stream, so that its tensor ops and collectives are
+                                                                  ordered with the library's launches without device-wide syncs */
 int femo_op_apply_vec(femo_ctx* ctx, int32_t src, int32_t dst);   /* dst = K_local src (no Dirichlet mask) */
 int femo_load_vec(femo_ctx* ctx, int32_t dst);                 /* dst = local load vector */
 int femo_factorize_range(femo_ctx* ctx, int32_t l0, int32_t l1, int assemble);   /* tree levels [l0, l1) */

@@ -96,8 +96,10 @@ class NumpyEngine:
         out[: S.size] = self.torch.as_tensor(S.ravel())
 
     def block_set(self, front, src):
+        # the driver hands over one triangle of the (symmetric) Schur complement; this engine works on full matrices
         n = self.plan.nf[front]
-        self.F[front] = src.numpy()[: n * n].reshape(n, n).copy()
+        A = src.numpy()[: n * n].reshape(n, n)
+        self.F[front] = np.tril(A) + np.tril(A, -1).T if np.abs(np.triu(A, 1)).max() == 0 else np.triu(A) + np.triu(A, 1).T
 
     def sweep(self, vec, l0, l1, backward):
         p = self.plan
