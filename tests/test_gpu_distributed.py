@@ -39,10 +39,9 @@ def test_hip_partitioned_solve_matches_oracle(world):
 
 def test_partitions_agree_with_the_single_rank_run():
     """SURVEY.md section 8e "correctness check": the P-rank result against the 1-rank result of the SAME driver --
-    identical PCG iteration counts; displacement, compliance and gradient agree to the level two converged solves of
-    this operator can (rtol 1e-12 on the residual; the forward error of either run is eps * kappa of the thin shell with
-    its 1e15 penalty, ~1e-10: the 1e-12 the survey hoped for is below that floor).  Also exercises the packed
-    lower-triangle exchange of the subtree Schur complements."""
+    displacement <= 1e-12 relative, identical PCG iteration counts (measured: 4e-15 on displacement, 4e-16 on the
+    compliance, 8e-16 on the gradient for 2 and 4 ranks).  Also exercises the packed lower-triangle exchange of the
+    subtree Schur complements."""
     res = {}
     for world in (1, 2, 4):
         with tempfile.TemporaryDirectory() as tmp:
@@ -58,5 +57,5 @@ def test_partitions_agree_with_the_single_rank_run():
         print(f"world {world} vs 1: iterations {int(r['it'])}/{int(r['it2'])} vs {int(one['it'])}/{int(one['it2'])}, "
               f"displacement {ew:.2e}, compliance {eJ:.2e}, gradient {eg:.2e}")
         assert int(r["it"]) == int(one["it"]) and int(r["it2"]) == int(one["it2"])
-        assert ew < 1e-9 and eJ < 1e-9 and eg < 1e-9
+        assert ew < 1e-12 and eJ < 1e-12 and eg < 1e-12
         assert int(r["ntop"]) > 0
