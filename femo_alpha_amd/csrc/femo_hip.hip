@@ -89,6 +89,7 @@ struct femo_ctx {
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
         int allow_pivot_repair = 0;   // non-positive pivots: 0 = the factorisation fails, 1 = replace and count
         int profile_verbose = 0;
+        int swork_slots = 8192;       // cap of the diagonal-block scratch (1 GB); larger levels are factorised in chunks (read at plan upload)
         int xinv_small_cnt = 32;      // inversion of L11: levels with at most this many fronts use 64 x 32 tiles
         // backward sweep, L21^T x: levels whose largest boundary has at least this many rows take the tiled (atomic) kernel.
         // Measured at 1M DOF: one workgroup per 32 columns wins on every level (43-57 us against 49-115), so the default is never
@@ -114,6 +115,7 @@ struct femo_ctx {
         long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
         double *F = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
         long long f_doubles = 0, linv_doubles = 0, x_doubles = 0;
+        int swork_slots = 1;                  // 128 x 128 scratch blocks for the diagonal-block inverses of the non-wide levels
         int max_nf = 0;
         double t_factor_ms = 0, t_assemble_ms = 0;
         int pivots_fixed = 0;
@@ -534,11 +536,22 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
               FOR_FRONT_CHUNKS(cnt, off, n)
                   hipLaunchKernelGGL(k_extend_gather, dim3(grid.x, n), dim3(256), 0, c->stream, fd, lev, off, mask); }
         }
+        const bool wide = fr.h_level_wide[L];                      // these levels keep S (inside X) for the triangular solves
+        const int cnt_level = cnt, max_np_level = max_np;
+        const int* lev_level = lev;
+        // the other levels park the inverse of a diagonal block in Swork between k_diag_block and k_panel_rows, one 128 x 128
+        // slot per front: levels with more fronts than Swork has slots are factorised in chunks of that many fronts
+        const int chunk_cap = wide ? cnt_level : std::min(cnt_level, fr.swork_slots);
+        for (int chunk_b = b; chunk_b < fr.h_level_off[L + 1]; chunk_b += chunk_cap) {
+        const int b = chunk_b, e = std::min(chunk_b + chunk_cap, fr.h_level_off[L + 1]);
+        const int cnt = e - b;
+        const int* lev = fr.level_nodes + b;
+        int max_np = 0;
+        for (int i = b; i < e; ++i) max_np = std::max(max_np, fr.h_npiv[fr.h_level_nodes[i]]);
         int max_nf = 0;
         for (int i = b; i < e; ++i) max_nf = std::max(max_nf, fr.h_nf[fr.h_level_nodes[i]]);
         // outer panels of NBO columns, three launches each: the diagonal block (factor + inverse, one workgroup per
         // front), the rows below it (one GEMM against the inverse), the trailing update
-        const bool wide = fr.h_level_wide[L];                      // these levels keep S for the triangular solves
         int max_nb = 0;
         for (int i = b; i < e; ++i) max_nb = std::max(max_nb, fr.h_nf[fr.h_level_nodes[i]] - fr.h_npiv[fr.h_level_nodes[i]]);
         // Rank-k updates, two schedules (option "trailing": 0 auto, 1 left, 2 right):
@@ -547,8 +560,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         //                    the Schur complement is updated once with K = npiv (each entry read and written once).
         // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
-        const bool right_looking = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt < c->opt.left_min || cnt > c->opt.left_max);
-        const bool lookahead = right_looking && cnt < c->opt.lookahead_cnt && c->opt.lookahead != 0;
+        const bool right_looking = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt_level < c->opt.left_min || cnt_level > c->opt.left_max);
+        const bool lookahead = right_looking && cnt_level < c->opt.lookahead_cnt && c->opt.lookahead != 0;
         bool bulk_pending = false;
         // flops of one k_trailing_mfma launch over this level, with the kernel's own column / K ranges (profiling only)
         auto count_trailing = [&](int C0, int schur) {
@@ -656,7 +669,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
             }
         }
-        if (wide && max_np > NBO) {
+        }   // chunks of the level
+        if (wide && max_np_level > NBO) {
+            const int max_np = max_np_level, cnt = cnt_level;
+            const int* lev = lev_level;
             // L11^-1 of this level's fronts beyond the diagonal blocks, on its own stream: nothing in the factorisation of the
             // levels above reads what it reads (the factor columns) or writes (X); only the triangular sweeps need it
             HIPCHK(c, hipEventRecord(c->ev_x[0], c->stream));
@@ -826,7 +842,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
         return 0;
     };
     if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
-    double bb = 0, rr = 0, rz = 0, rz_new = 0, pAp = 0;
+    double bb = 0, rr = 0, pAp = 0;
     if (dot(b, b, &bb)) return 1;
     // r = b - A x
     if (zero_guess) {
@@ -840,29 +856,27 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
         hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -1.0, c->Ap, 1.0, n);
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->r, mask, n);
     }
-    if (dot(c->r, c->r, &rr)) return 1;
+    if (zero_guess) rr = bb;                       // r = b
+    else if (dot(c->r, c->r, &rr)) return 1;
     int k = 0, napply = 0;
     const double target = c->rtol * c->rtol * bb;
+    // device scalars: [0] r.z of the previous iteration, [1] r.z, [2] p.Ap, [3] r.r -- one host synchronisation per iteration
     while (bb > 0 && rr > target && k < c->maxit) {
+        HIPCHK(c, hipMemsetAsync(c->scal + 1, 0, 3 * sizeof(double), c->stream));
         HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (frontal_solve(c, c->z)) return 1;
-        if (dot(c->r, c->z, &rz_new)) return 1;
-        if (k == 0) {
-            HIPCHK(c, hipMemcpyAsync(c->p, c->z, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        } else {
-            hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, c->z, rz_new / rz, n);   // p = z + beta p
-        }
-        rz = rz_new;
+        hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, c->r, c->z, n, c->scal + 1);
+        hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->scal, k == 0 ? 1 : 0, n);
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
         if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
         ++napply;
         if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->Ap, mask, n);
-        if (dot(c->p, c->Ap, &pAp)) return 1;
+        hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, c->p, c->Ap, n, c->scal + 2);
+        hipLaunchKernelGGL(k_pcgf_update, dim3(red_grid(n)), dim3(256), 0, c->stream, x, c->r, c->p, c->Ap, c->scal, n);
+        HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        pAp = c->scal_host[2]; rr = c->scal_host[3];
         if (!(pAp > 0)) return fail(c, "PCG broke down: p.Ap <= 0 (preconditioner or operator not positive definite)");
-        const double alpha = rz / pAp;
-        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, x, alpha, c->p, 1.0, n);
-        hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -alpha, c->Ap, 1.0, n);
-        if (dot(c->r, c->r, &rr)) return 1;
         if (!(rr == rr)) return fail(c, "PCG broke down (NaN residual)");
         ++k;
     }
@@ -1402,6 +1416,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
+    else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
     else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;
     else return fail(c, "unknown option '" + k + "'");
     return 0;
@@ -1736,7 +1751,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         int max_cnt = 0;
         for (int L = 0; L < nlevels; ++L)
             if (!fr.h_level_wide[L]) max_cnt = std::max(max_cnt, level_off[L + 1] - level_off[L]);
-        HIPCHK(c, hipMalloc((void**)&fr.Swork, std::max<size_t>((size_t)max_cnt, 1) * SPD * SPD * sizeof(double)));
+        fr.swork_slots = std::max(1, std::min(max_cnt, std::max(1, c->opt.swork_slots)));
+        HIPCHK(c, hipMalloc((void**)&fr.Swork, (size_t)fr.swork_slots * SPD * SPD * sizeof(double)));
     }
     {
         // row maps of the extend-add gather: for every row of a front, the row of each child's front that lands there

@@ -1359,6 +1359,28 @@ __global__ void k_mul(double* __restrict__ y, const double* __restrict__ d, int6
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] *= d[i];
 }
 
+// PCG with the multifrontal preconditioner: the two vector updates read their coefficients from device scalars
+// (scal[0] = r.z of the previous iteration, [1] = r.z, [2] = p.Ap, [3] = r.r), so that an iteration needs ONE host
+// synchronisation (the convergence test) instead of one per dot product
+__global__ void k_pcgf_direction(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ scal, int first, int64_t n) {
+    const double beta = first ? 0.0 : scal[1] / scal[0];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = first ? z[i] : z[i] + beta * p[i];
+}
+__global__ void k_pcgf_update(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ Ap,
+                              double* __restrict__ scal, int64_t n) {
+    const double alpha = scal[1] / scal[2];
+    double local = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        r[i] = ri;
+        local += ri * ri;
+    }
+    block_accumulate(local, scal + 3);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = scal[1];       // nobody reads slot 0 in this kernel
+}
+
 __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* slot) {
     // four independent partial sums: a thread has 4 pairs of loads in flight per trip of the grid-stride loop
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;

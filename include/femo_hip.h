@@ -129,6 +129,8 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "trailing" 0 auto | 1 left-looking | 2 right-looking rank-k updates; "left_min", "left_max" (auto: levels with this
  *   many fronts are left-looking); "lookahead" 0/1, "lookahead_cnt"; "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
+ *   "swork_slots" (default 8192; before femo_set_frontal_plan): 128 x 128 scratch blocks for the diagonal-block inverses of
+ *   the levels solved with one workgroup per front -- levels with more fronts are factorised in chunks of that many;
  *   "bnd_tiled_nb" (backward sweep: levels whose largest boundary block has at least this many rows use 128 x 128 tiles
  *   with atomics for L21^T x, the others one workgroup per 32 columns); "profile_verbose" (per-launch timings of
  *   femo_factorize_profile on stderr). */

@@ -152,6 +152,8 @@ def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
         opts["wide_np"] = 96                         # wide kernels by pivot-block size: a mix of both paths in one tree
     if wide_cnt is not None:
         opts["wide_cnt"] = wide_cnt
+    if kind in ("tee", "tri") and wide_cnt == 0:
+        opts["swork_slots"] = 2                      # levels with more fronts than scratch slots are factorised in chunks
     if kind in ("plate24", "tri"):
         c.set_option("trailing", 1)                  # left-looking rank-k updates (the default on small meshes is right-looking)
     if kind in ("warped", "plate24"):
