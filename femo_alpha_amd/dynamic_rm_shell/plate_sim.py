@@ -37,8 +37,9 @@ class PlateSim:
         self.nn, self.nel = mesh.nn, mesh.nel
         self.element_wise_thickness = element_wise_thickness
         self.add_self_weight, self.g_factor, self.quad_deg = add_self_weight, g_factor, quad_deg
-        if add_self_weight and element_wise_thickness:
-            raise NotImplementedError("self weight is applied through the nodal pressure field")
+        # self weight f_d = (0, 0, rho t g) (plate_sim.py:203-214): with nodal thickness it rides on the nodal pressure field;
+        # with element-wise thickness it is a cell-wise constant pressure, applied as its consistent P2 nodal loads
+        self._sw_weights = mesh.p2_integrals() if (add_self_weight and element_wise_thickness) else None
         ctx = self.ctx = ShellContext(mesh, element_wise_material=element_wise_thickness, device=device)
         ctx.set_field("E", [E]); ctx.set_field("nu", [nu]); ctx.set_field("density", [rho])
         marker = custom_bc_func if custom_bc_func is not None else (lambda x: np.isclose(x[0], 0.0, atol=1e-6))
@@ -71,12 +72,21 @@ class PlateSim:
     def update_nsteps(self, Nsteps):
         self.Nsteps, self.time_levels = Nsteps, Nsteps + 1
 
+    def _gravity(self):
+        return (-1.0 if self.g_factor is None else self.g_factor) * 9.81
+
     def _force_at(self, i):
         f = self.f_history[min(i, self.f_history.shape[0] - 1)].reshape(-1, 3).copy()
-        if self.add_self_weight:
-            g = (-1.0 if self.g_factor is None else self.g_factor) * 9.81
-            f[:, 2] += self.rho * self.t * g                             # f_d = (0, 0, rho t g), plate_sim.py:204-211
+        if self.add_self_weight and self._sw_weights is None:
+            f[:, 2] += self.rho * self.t * self._gravity()               # f_d = (0, 0, rho t g), plate_sim.py:204-211
         return f
+
+    def _self_weight_load(self):
+        """Device vector of the self-weight load for element-wise thickness: F[3 p + 2] += rho t_e g int N2_a dS."""
+        F = np.zeros(self.fe_dofs)
+        np.add.at(F, 3 * self.mesh.cell_p2.ravel() + 2, (self._sw_weights * (self.rho * self._gravity() * self.t)[:, None]).ravel())
+        F[self.bc_dofs] = 0.0
+        return self.torch.as_tensor(F, device=self._v["state"].device)
 
     # ------------------------------------------------------------------ forward march
     def _sync(self):
@@ -93,10 +103,13 @@ class PlateSim:
         W = self.W = torch.zeros((self.time_levels, self.fe_dofs), dtype=torch.float64, device=v["state"].device)
         wdot = torch.zeros_like(v["state"])
         self.solve_info = []
+        F_sw = self._self_weight_load() if self._sw_weights is not None else None
         for i in range(1, self.time_levels):
             w_old = W[i - 1]
             ctx.set_field("F_solid", self._force_at(i))
             ctx.load_vec("b")                                            # F_i with BC rows zeroed
+            if F_sw is not None:
+                v["b"].add_(F_sw)
             v["p"].copy_(w_old).mul_(self.a).add_(wdot, alpha=self.b)    # 2/dt^2 w_old + 2/dt wdot_old
             v["adjoint"].copy_(w_old)
             self._sync()
@@ -135,6 +148,35 @@ class PlateSim:
             T[i] = 0.5 * float(torch.dot(wdot, v["Ap"]))
             work[i] = float(torch.dot(v["b"], W[i] - W[i - 1]))
         return U, T, work
+
+    # ------------------------------------------------------------------ post-processing the gust examples call
+    def _level_state(self, level):
+        if level is not None:
+            self.ctx.set_state(self.W[level].cpu().numpy())
+
+    def pnorm_stress(self, m=1e-6, rho=100, alpha=None, regularization=False, level=None):
+        """1/alpha int (m vm_top)^rho dx over the degree-4 measure (plate_sim.py:427-444) for the state of time level
+        ``level`` (default: the state the context holds, i.e. the last level solved -- the reference's ``self.w``)."""
+        if regularization or alpha is not None:
+            raise NotImplementedError("only the reference's default call pattern (alpha=None, regularization=False) is provided")
+        self._level_state(level)
+        self.ctx.set_stress_params(m, rho)
+        return self.ctx.functional("pnorm_stress")
+
+    def von_Mises_stress(self, level=None):
+        """Top-surface von Mises stress of one time level as a DG1 field, nvc values per cell (plate_sim.py:446-450)."""
+        self._level_state(level)
+        return self.ctx.field_output("stress")
+
+    def construct_force_to_pressure_map(self):
+        """Consistent mass matrix of the pressure space [CG1]^3 (plate_sim.py:452-468)."""
+        from ..rm_shell.rm_shell_pde import force_to_pressure_map
+        return force_to_pressure_map(self.mesh)
+
+    def construct_nodal_disp_map(self):
+        """Sparse (3 nn x fe_dofs) map history level -> [ux; uy; uz] at the mesh vertices (plate_sim.py:470-480)."""
+        from ..rm_shell.rm_shell_pde import nodal_disp_map
+        return nodal_disp_map(self.mesh)
 
     # ------------------------------------------------------------------ outputs on one level
     def assembleStrainEnergy(self, w):
@@ -202,10 +244,14 @@ class PlateSim:
             self._sync()
             ctx.grad_add("K", "p", "adjoint", 0.5)                       # 1/2 lam^T K' (w_i + w_{i-1})
             ctx.grad_add("M", "z", "adjoint", 1.0)                       # lam^T M' (a (w_i - w_{i-1}) - b wdot_{i-1})
-            dfi = ctx.dRdarg_T("F_solid", Lam[i].cpu().numpy())
+            lam_i = Lam[i].cpu().numpy()
+            dfi = ctx.dRdarg_T("F_solid", lam_i)
             dF[i] = dfi
-            if self.add_self_weight:
-                g = (-1.0 if self.g_factor is None else self.g_factor) * 9.81
-                g_sw += dfi.reshape(-1, 3)[:, 2] * self.rho * g
+            if self.add_self_weight and self._sw_weights is None:
+                g_sw += dfi.reshape(-1, 3)[:, 2] * self.rho * self._gravity()
+            elif self.add_self_weight:
+                # R_i = ... - F_sw(t):  (dR_i/dt_e)^T lam = -rho g sum_a lam_z(p_a) int N2_a dS   (BC rows carry no load)
+                lz = lam_i.copy(); lz[self.bc_dofs] = 0.0
+                g_sw -= self.rho * self._gravity() * (self._sw_weights * lz[3 * self.mesh.cell_p2 + 2]).sum(axis=1)
             wdot = self.b * (W[i] - W[i - 1]) - wdot
         return ctx.grad_get() + g_sw, dF

@@ -126,6 +126,27 @@ class ShellMesh:
         t = (self.ndof_u + 3 * self.cells[:, :, None] + np.arange(3)[None, None, :]).reshape(self.nel, -1)
         return np.hstack([u, t]).astype(np.int32)
 
+    def p2_integrals(self, nquad=4):
+        """(nel, npc): int N2_a dS over every cell, N2 the P2 basis of the mid-surface displacement in ``cell_p2`` order --
+        the consistent nodal loads of a unit pressure (nquad x nquad Gauss on quads, the rule of the device load vector; on
+        triangles the vertex functions integrate to zero and every edge function to a third of the area)."""
+        X = self.nodes[self.cells]
+        if not self.is_quad:
+            area = 0.5 * np.linalg.norm(np.cross(X[:, 1] - X[:, 0], X[:, 2] - X[:, 0]), axis=1)
+            return np.concatenate([np.zeros((self.nel, 3)), np.repeat(area[:, None] / 3.0, 3, axis=1)], axis=1)
+        g, w = np.polynomial.legendre.leggauss(nquad)
+        lag2 = lambda t: np.stack([0.5 * t * (t - 1.0), 1.0 - t * t, 0.5 * t * (t + 1.0)], axis=1)       # nodes -1, 0, 1
+        q2 = [(0, 0), (2, 0), (2, 2), (0, 2), (1, 0), (2, 1), (1, 2), (0, 1), (1, 1)]                      # cell_p2 order
+        xi, eta = np.repeat(g, nquad), np.tile(g, nquad)
+        wq = np.repeat(w, nquad) * np.tile(w, nquad)
+        a, b = lag2(xi), lag2(eta)
+        N2 = np.stack([a[:, i] * b[:, j] for i, j in q2], axis=1)                                         # (points, 9 nodes)
+        sx, sy = np.array([-1, 1, 1, -1.0]), np.array([-1, -1, 1, 1.0])
+        dN = np.stack([0.25 * sx[None] * (1 + sy[None] * eta[:, None]), 0.25 * sy[None] * (1 + sx[None] * xi[:, None])], axis=-1)
+        J = np.einsum("ebi,qbk->eqik", X, dN)
+        det = np.linalg.norm(np.cross(J[..., 0], J[..., 1]), axis=-1)
+        return np.einsum("q,eq,qa->ea", wq, det, N2)
+
     def cell_diameters(self):
         """UFL ``CellDiameter``: largest distance between two vertices of the cell
         (used at linear_shell_model.py:285,325,339)."""

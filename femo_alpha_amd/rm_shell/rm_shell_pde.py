@@ -107,40 +107,51 @@ class RMShellPDE:
     # ------------------------------------------------------------------ maps
     def construct_force_to_pressure_map(self):
         """Consistent mass matrix of the pressure space VF = [CG1]^3, a = int Pv . w dx
-        (rm_shell_pde.py:194-209), node-major xyz ordering like ``F_solid``.  Host-side set-up map (3x3 Gauss on
-        quads, 6-point rule on triangles; exact for the bilinear / linear basis on affine cells)."""
+        (rm_shell_pde.py:194-209), node-major xyz ordering like ``F_solid``."""
         if self.elementwise_pressure:
             raise NotImplementedError("force -> pressure conversion is defined for nodal pressures")
-        m = self.mesh
-        X = m.nodes[m.cells]
-        if m.is_quad:
-            g = np.array([-np.sqrt(0.6), 0.0, np.sqrt(0.6)]); w = np.array([5.0, 8.0, 5.0]) / 9.0
-            P = np.array([(a, b) for a in g for b in g]); Wq = np.array([wa * wb for wa in w for wb in w])
-            sx, sy = np.array([-1, 1, 1, -1.0]), np.array([-1, -1, 1, 1.0])
-            N = 0.25 * (1 + sx[None] * P[:, :1]) * (1 + sy[None] * P[:, 1:])
-            dN = np.stack([0.25 * sx[None] * (1 + sy[None] * P[:, 1:]), 0.25 * sy[None] * (1 + sx[None] * P[:, :1])], axis=-1)
-        else:
-            P = np.array([[1 / 6, 1 / 6], [2 / 3, 1 / 6], [1 / 6, 2 / 3]]); Wq = np.full(3, 1 / 6)
-            N = np.stack([1 - P[:, 0] - P[:, 1], P[:, 0], P[:, 1]], axis=1)
-            dN = np.broadcast_to(np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]]), (3, 3, 2))
-        J = np.einsum("ebi,qbk->eqik", X, dN)
-        det = np.linalg.norm(np.cross(J[..., 0], J[..., 1]), axis=-1)
-        Me = np.einsum("q,eq,qa,qb->eab", Wq, det, N, N)
-        nv = m.nvc
-        rows = np.repeat(m.cells, nv, axis=1).ravel()
-        cols = np.tile(m.cells, (1, nv)).ravel()
-        Ms = sp.coo_matrix((Me.ravel(), (rows, cols)), shape=(m.nn, m.nn)).tocsr()
-        return sp.kron(Ms, sp.identity(3), format="csr")
+        return force_to_pressure_map(self.mesh)
 
     def construct_nodal_disp_map(self):
-        """Sparse (3 nn x ndof) map state -> [ux; uy; uz] at the mesh vertices, the stacking the
-        reference builds from P2 basis evaluations (rm_shell_pde.py:212-221); vertices are P2 nodes
-        here, so every row holds a single 1."""
-        nn, ndof = self.mesh.nn, self.mesh.ndof
-        rows = np.arange(3 * nn)
-        cols = (3 * np.arange(nn)[None, :] + np.arange(3)[:, None]).ravel()
-        return sp.csr_matrix((np.ones(3 * nn), (rows, cols)), shape=(3 * nn, ndof))
+        """Sparse (3 nn x ndof) map state -> [ux; uy; uz] at the mesh vertices (rm_shell_pde.py:212-221)."""
+        return nodal_disp_map(self.mesh)
 
     def compute_nodal_disp(self, func: Function):
         u = func.get()[: 3 * self.mesh.nn].reshape(-1, 3)
         return u[:, 0].copy(), u[:, 1].copy(), u[:, 2].copy()
+
+
+def force_to_pressure_map(mesh):
+    """Consistent mass matrix of [CG1]^3 on ``mesh``, node-major xyz ordering (rm_shell_pde.py:194-209;
+    dynamic_rm_shell/plate_sim.py:452-468).  Host-side set-up map (3x3 Gauss on quads, 3-point rule on triangles; exact
+    for the bilinear / linear basis on affine cells)."""
+    m = mesh
+    X = m.nodes[m.cells]
+    if m.is_quad:
+        g = np.array([-np.sqrt(0.6), 0.0, np.sqrt(0.6)]); w = np.array([5.0, 8.0, 5.0]) / 9.0
+        P = np.array([(a, b) for a in g for b in g]); Wq = np.array([wa * wb for wa in w for wb in w])
+        sx, sy = np.array([-1, 1, 1, -1.0]), np.array([-1, -1, 1, 1.0])
+        N = 0.25 * (1 + sx[None] * P[:, :1]) * (1 + sy[None] * P[:, 1:])
+        dN = np.stack([0.25 * sx[None] * (1 + sy[None] * P[:, 1:]), 0.25 * sy[None] * (1 + sx[None] * P[:, :1])], axis=-1)
+    else:
+        P = np.array([[1 / 6, 1 / 6], [2 / 3, 1 / 6], [1 / 6, 2 / 3]]); Wq = np.full(3, 1 / 6)
+        N = np.stack([1 - P[:, 0] - P[:, 1], P[:, 0], P[:, 1]], axis=1)
+        dN = np.broadcast_to(np.array([[-1.0, -1.0], [1.0, 0.0], [0.0, 1.0]]), (3, 3, 2))
+    J = np.einsum("ebi,qbk->eqik", X, dN)
+    det = np.linalg.norm(np.cross(J[..., 0], J[..., 1]), axis=-1)
+    Me = np.einsum("q,eq,qa,qb->eab", Wq, det, N, N)
+    nv = m.nvc
+    rows = np.repeat(m.cells, nv, axis=1).ravel()
+    cols = np.tile(m.cells, (1, nv)).ravel()
+    Ms = sp.coo_matrix((Me.ravel(), (rows, cols)), shape=(m.nn, m.nn)).tocsr()
+    return sp.kron(Ms, sp.identity(3), format="csr")
+
+
+def nodal_disp_map(mesh):
+    """Sparse (3 nn x ndof) map state -> [ux; uy; uz] at the mesh vertices, the stacking the reference builds from P2 basis
+    evaluations (rm_shell_pde.py:212-221; dynamic_rm_shell/plate_sim.py:470-480); vertices are P2 nodes here, so every
+    row holds a single 1."""
+    nn, ndof = mesh.nn, mesh.ndof
+    rows = np.arange(3 * nn)
+    cols = (3 * np.arange(nn)[None, :] + np.arange(3)[:, None]).ravel()
+    return sp.csr_matrix((np.ones(3 * nn), (rows, cols)), shape=(3 * nn, ndof))

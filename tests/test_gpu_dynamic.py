@@ -82,3 +82,53 @@ def test_march_and_adjoint(ewt):
     Fm = F.copy(); Fm[k, 3 * node + 2] -= 1e-3
     fd = (JF(Fp) - JF(Fm)) / 2e-3
     assert abs(gF[k, 3 * node + 2] - fd) < 1e-5 * np.abs(gF).max()
+
+
+def test_self_weight_with_elementwise_thickness_and_postprocessing():
+    """Self weight f_d = (0, 0, rho t g) (reference plate_sim.py:203-214) with element-wise thickness -- a cell-wise
+    constant pressure applied as consistent P2 loads -- against the nodal-thickness path on a uniform plate (identical
+    loads, so identical histories), its thickness gradient against finite differences of the march, and the
+    post-processing calls of the gust examples (plate_sim.py:427-480)."""
+    from femo_alpha_amd.dynamic_rm_shell.plate_sim import PlateSim
+    mesh = plate_mesh(2.0, 10.0, 4, 12)
+    E, nu, rho, dt, N = 1e8, 0.3, 10.0, 0.01, 8
+    F = np.zeros((N + 1, 3 * mesh.nn))
+    hist = {}
+    for ewt in (False, True):
+        ps = PlateSim(mesh, E, nu, rho, dt, N, element_wise_thickness=ewt, add_self_weight=True, quad_deg=3, leaf_size=8)
+        ps.update_f_history(F)
+        ps.update_t(np.full(mesh.nel if ewt else mesh.nn, 0.1))
+        hist[ewt] = ps.solve_dynamic_problem()
+        sims = ps if ewt else None
+    assert np.abs(hist[False]).max() > 0
+    assert np.abs(hist[True] - hist[False]).max() < 1e-10 * np.abs(hist[False]).max()
+    # thickness gradient of J = sum_i U_i with the self weight depending on t, element-wise
+    ps = sims
+    rng = np.random.default_rng(1)
+    t0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, mesh.nel))
+
+    def J(t):
+        ps.update_t(t)
+        ps.solve_dynamic_problem()
+        return ps.energy_audit()[0].sum()
+    J(t0)
+    G = np.zeros((mesh.ndof, N + 1)); g_exp = np.zeros(mesh.nel)
+    for i in range(N + 1):
+        gt, gw = ps.strain_energy_gradients(ps.W[i].cpu().numpy())
+        g_exp += gt; G[:, i] = gw
+    g = g_exp - ps.residual_T_products(ps.adjoint_history(G))[0]
+    d = rng.uniform(0, 1, mesh.nel)
+    eps = 1e-6
+    fd = (J(t0 + eps * d) - J(t0 - eps * d)) / (2 * eps)
+    assert abs(g @ d - fd) < 2e-6 * abs(fd)
+    # post-processing of a time level
+    ps.update_t(t0); ps.solve_dynamic_problem()
+    p_last, p_mid = ps.pnorm_stress(), ps.pnorm_stress(level=N // 2)
+    assert p_last > 0 and p_mid > 0 and p_last != p_mid
+    vm = ps.von_Mises_stress(level=N)
+    assert vm.shape == (4 * mesh.nel,) and vm.max() > 0 and vm.mean() > 0      # an L2 projection onto DG1: vertex values may undershoot
+    A = ps.construct_force_to_pressure_map()
+    assert A.shape == (3 * mesh.nn, 3 * mesh.nn) and abs(A.sum() - 3 * 20.0) < 1e-10        # three components x plate area
+    D = ps.construct_nodal_disp_map()
+    w_last = ps.W[N].cpu().numpy()
+    assert np.array_equal(D @ w_last, np.concatenate([w_last[c:3 * mesh.nn:3] for c in range(3)]))
