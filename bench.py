@@ -97,7 +97,7 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0):
     plan = build_plan(m, leaf)
     cs = cb.CpuShell(o)
     ncores = cb.host_cores()
-    b = o.load_vector()
+    b = cs.load_vector(ncores)
 
     def forward(cores):
         mf = cb.CpuMultifrontal(cs, plan, cores) if forward.mf.get(cores) is None else forward.mf[cores]

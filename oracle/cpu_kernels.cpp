@@ -317,6 +317,46 @@ int cpu_assemble_drdfield(int nel, int nvc, int npc, int nq, const double* nodes
     return 0;
 }
 
+// load vector F_a = int f . N2_a J det dS (oracle load_vector, linear_shell_model.py:320): the vector assembly that stands
+// for one residual evaluation of the reference's Newton loop
+int cpu_load_vector(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
+                    const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* N2, const double* w,
+                    const double* f, int ewp, int quad, double* F, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, w};
+    if (3 * npc + 3 * nvc > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel for schedule(static, 64) num_threads(nthreads)
+    for (int e = 0; e < nel; ++e) {
+        double X[4][3], U[4][3], fe[4][3], B[9][MAXLD];
+        bool has_u = false;
+        for (int b = 0; b < nvc; ++b) {
+            const int v = cells[(size_t)e * nvc + b];
+            for (int i = 0; i < 3; ++i) {
+                X[b][i] = nodes[3 * (size_t)v + i];
+                U[b][i] = uhat ? uhat[3 * (size_t)v + i] : 0.0;
+                has_u = has_u || U[b][i] != 0.0;
+                fe[b][i] = f[3 * (size_t)(ewp ? e : v) + i];
+            }
+        }
+        double Fe[9][3] = {{0}};
+        for (int q = 0; q < nq; ++q) {
+            QP g;
+            qp_B(T, q, X, has_u ? U : nullptr, quad != 0, B, g);          // (only det and Ju are needed here)
+            double fq[3] = {0, 0, 0};
+            for (int b = 0; b < nvc; ++b)
+                for (int i = 0; i < 3; ++i) fq[i] += (ewp ? (b == 0 ? 1.0 : 0.0) : N1[(size_t)q * nvc + b]) * fe[b][i];
+            const double wj = w[q] * g.det * g.Ju;
+            for (int a = 0; a < npc; ++a)
+                for (int i = 0; i < 3; ++i) Fe[a][i] += wj * N2[(size_t)q * npc + a] * fq[i];
+        }
+        for (int a = 0; a < npc; ++a)
+            for (int i = 0; i < 3; ++i) {
+#pragma omp atomic
+                F[3 * (size_t)cell_p2[(size_t)e * npc + a] + i] += Fe[a][i];
+            }
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ multifrontal numeric phase
 typedef void (*dpotrf_t)(const char*, const int*, double*, const int*, int*);
 typedef void (*dtrsm_t)(const char*, const char*, const char*, const char*, const int*, const int*, const double*, const double*,

@@ -28,6 +28,7 @@ def test_element_matrices_and_csr_assembly(warped):
     assert rel(cs.element_matrices(0, 2), o.element_matrices()) < 1e-13
     K1, K0 = cs.assemble_K(2), o.assemble_K()
     assert abs(K1 - K0).max() < 1e-13 * abs(K0).max()
+    assert rel(cs.load_vector(2), o.load_vector()) < 1e-13
     mt = quads_to_triangles(wing_skin_mesh(5, 9, shuffle=True))
     ot = ShellOracle(mt)
     ot.set_fields(h=0.05, E=3e7, nu=0.3)
