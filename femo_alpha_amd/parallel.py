@@ -178,12 +178,17 @@ class DistributedShell:
         self.comm.allreduce_(buf)
         v.index_copy_(0, self.top_idx, buf)
 
-    def dot(self, a, b):
+    def dot_t(self, a, b):
+        """a . b over the global vector as a 0-dim device tensor (no host synchronisation): interior entries summed over the
+        ranks by one scalar all-reduce, replicated entries counted once."""
         va, vb = self.eng.vec(a), self.eng.vec(b)
         loc = (va.index_select(0, self.int_idx) * vb.index_select(0, self.int_idx)).sum().reshape(1)
         top = (va.index_select(0, self.top_idx) * vb.index_select(0, self.top_idx)).sum()
         self.comm.allreduce_(loc)
-        return float(loc[0] + top)
+        return loc[0] + top
+
+    def dot(self, a, b):
+        return float(self.dot_t(a, b))
 
     # ------------------------------------------------------------------ operator, preconditioner
     def apply(self, src, dst):
@@ -246,24 +251,26 @@ class DistributedShell:
         vx.zero_()
         vr.copy_(vb)
         bb = self.dot(b, b)
-        rr, k, rz = bb, 0, 0.0
+        rr, k, rz = bb, 0, None
+        # the scalars of an iteration (r.z, p.Ap, alpha, beta) stay on the device; one host read per iteration: (r.r, p.Ap)
         while bb > 0 and rr > self.rtol ** 2 * bb and k < self.maxit:
             vz.copy_(vr)
             self.precondition("z")
-            rz_new = self.dot("r", "z")
+            rz_new = self.dot_t("r", "z")
             if k == 0:
                 vp.copy_(vz)
             else:
                 vp.mul_(rz_new / rz).add_(vz)
             rz = rz_new
             self.apply("p", "Ap")
-            pAp = self.dot("p", "Ap")
-            if not pAp > 0:
-                raise RuntimeError("PCG broke down: p.Ap <= 0")
+            pAp = self.dot_t("p", "Ap")
             alpha = rz / pAp
-            vx.add_(vp, alpha=alpha)
-            vr.add_(vAp, alpha=-alpha)
-            rr = self.dot("r", "r")
+            vx.addcmul_(vp, alpha)
+            vr.addcmul_(vAp, -alpha)
+            rr_t = self.dot_t("r", "r")
+            rr, pAp_h = self.torch.stack([rr_t, pAp]).tolist()
+            if not pAp_h > 0:
+                raise RuntimeError("PCG broke down: p.Ap <= 0")
             k += 1
         return k, (rr / bb) ** 0.5 if bb > 0 else 0.0
 
