@@ -112,9 +112,10 @@ struct femo_ctx {
         int *nf = nullptr, *npiv = nullptr, *dofs = nullptr, *upmap = nullptr, *parent = nullptr, *left = nullptr,
             *right = nullptr, *level_nodes = nullptr, *elem_front = nullptr, *elem_map = nullptr, *info = nullptr,
             *cinv0 = nullptr, *cinv1 = nullptr;
-        long long *foff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
-        double *F = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
-        long long f_doubles = 0, linv_doubles = 0, x_doubles = 0;
+        long long *poff = nullptr, *soff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
+        double *P = nullptr, *S = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
+        std::vector<long long> h_soff;        // host copy of the Schur offsets (femo_front_schur_get / block_set)
+        long long p_doubles = 0, s_doubles = 0, linv_doubles = 0, x_doubles = 0;
         int swork_slots = 1;                  // 128 x 128 scratch blocks for the diagonal-block inverses of the non-wide levels
         int max_nf = 0;
         double t_factor_ms = 0, t_assemble_ms = 0;
@@ -443,9 +444,9 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
 // ------------------------------------------------------------------------------------------ multifrontal driver
 static FrontDev front_dev(const femo_ctx* c) {
     FrontDev fd;
-    fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.foff = c->fr.foff; fd.doff = c->fr.doff;
+    fd.ntree = c->fr.ntree; fd.nf = c->fr.nf; fd.npiv = c->fr.npiv; fd.poff = c->fr.poff; fd.soff = c->fr.soff; fd.doff = c->fr.doff;
     fd.dofs = c->fr.dofs; fd.upmap = c->fr.upmap; fd.parent = c->fr.parent; fd.child[0] = c->fr.left; fd.child[1] = c->fr.right;
-    fd.linvoff = c->fr.linvoff; fd.xoff = c->fr.xoff; fd.F = c->fr.F; fd.Linv = c->fr.Linv; fd.X = c->fr.X; fd.Xtmp = c->fr.Xtmp;
+    fd.linvoff = c->fr.linvoff; fd.xoff = c->fr.xoff; fd.P = c->fr.P; fd.S = c->fr.S; fd.Linv = c->fr.Linv; fd.X = c->fr.X; fd.Xtmp = c->fr.Xtmp;
     fd.cinv[0] = c->fr.cinv0; fd.cinv[1] = c->fr.cinv1;
     return fd;
 }
@@ -1170,7 +1171,7 @@ void femo_destroy(femo_ctx* c) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
-                     c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.foff, c->fr.doff, c->fr.linvoff, c->fr.F, c->fr.Linv,
+                     c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.poff, c->fr.soff, c->fr.doff, c->fr.linvoff, c->fr.P, c->fr.S, c->fr.Linv,
                      c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1};
     for (void* p : fptrs)
         if (p) hipFree(p);
@@ -1718,15 +1719,64 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     fr.h_level_wide.assign(nlevels, 0);
     for (int L = 0; L < nlevels; ++L)
         fr.h_level_wide[L] = fr.h_level_maxnp[L] > WIDE_NP || level_off[L + 1] - level_off[L] <= WIDE_CNT;
-    fr.f_doubles = front_off[ntree];
+    // Storage of the fronts.  Pivot columns (the factor): one nf x npiv panel per front, for good.  Schur complements: an
+    // arena.  The block of front t is written at t's level and read once, by the extend-add at its parent's level; all
+    // blocks whose parents share a level form one region, alive from the lowest level of its fronts to that parent level,
+    // and regions are placed first-fit so that two regions alive at the same time never overlap.
+    std::vector<long long> poff(ntree + 1, 0), soff(ntree, 0);
+    {
+        std::vector<int> level_of(ntree, 0);
+        for (int L = 0; L < nlevels; ++L)
+            for (int i = level_off[L]; i < level_off[L + 1]; ++i) level_of[level_nodes[i]] = L;
+        for (int t = 0; t < ntree; ++t) poff[t + 1] = poff[t] + (long long)nf[t] * npiv[t];
+        std::vector<long long> rsize(nlevels + 1, 0);                 // region nlevels: fronts without a parent (never read)
+        std::vector<int> rstart(nlevels + 1, nlevels);
+        auto region_of = [&](int t) { return parent[t] >= 0 ? level_of[parent[t]] : nlevels; };
+        for (int t = 0; t < ntree; ++t) {
+            const long long nb = nf[t] - npiv[t];
+            const int R = region_of(t);
+            if (parent[t] >= 0 && level_of[parent[t]] <= level_of[t]) return fail(c, "inconsistent frontal plan (a parent is not above its child)");
+            soff[t] = rsize[R];
+            rsize[R] += nb * nb;
+            rstart[R] = std::min(rstart[R], level_of[t]);
+        }
+        std::vector<long long> rbase(nlevels + 1, 0);
+        std::vector<int> order;
+        for (int R = 0; R <= nlevels; ++R)
+            if (rsize[R] > 0) order.push_back(R);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return rstart[a] != rstart[b] ? rstart[a] < rstart[b] : a < b; });
+        std::vector<int> placed;
+        long long arena = 0;
+        for (int R : order) {
+            // lifetimes: [rstart[R], R]; busy address intervals of the placed regions whose lifetime overlaps this one
+            std::vector<std::pair<long long, long long>> busy;
+            for (int Q : placed)
+                if (rstart[Q] <= R && rstart[R] <= Q) busy.push_back({rbase[Q], rbase[Q] + rsize[Q]});
+            std::sort(busy.begin(), busy.end());
+            long long at = 0;
+            for (auto& iv : busy) {
+                if (at + rsize[R] <= iv.first) break;
+                at = std::max(at, iv.second);
+            }
+            rbase[R] = at;
+            arena = std::max(arena, at + rsize[R]);
+            placed.push_back(R);
+        }
+        for (int t = 0; t < ntree; ++t) soff[t] += rbase[region_of(t)];
+        fr.p_doubles = poff[ntree];
+        fr.s_doubles = arena;
+        fr.h_soff = soff;
+    }
     fr.linv_doubles = linvoff[ntree];
 #define UPI(dst, src, n) do { HIPCHK(c, hipMalloc((void**)&dst, std::max<size_t>((size_t)(n), 1) * sizeof(*dst))); \
         HIPCHK(c, hipMemcpy(dst, src, (size_t)(n) * sizeof(*dst), hipMemcpyHostToDevice)); } while (0)
     UPI(fr.nf, nf, ntree); UPI(fr.npiv, npiv, ntree); UPI(fr.parent, parent, ntree); UPI(fr.left, left, ntree);
     UPI(fr.right, right, ntree); UPI(fr.level_nodes, level_nodes, ntree); UPI(fr.dofs, front_dofs, ndofs_total);
     UPI(fr.upmap, up_map, ndofs_total); UPI(fr.elem_front, elem_front, c->nel); UPI(fr.elem_map, elem_map, (size_t)c->nel * c->ld);
-    HIPCHK(c, hipMalloc((void**)&fr.foff, (ntree + 1) * sizeof(long long)));
-    HIPCHK(c, hipMemcpy(fr.foff, front_off, (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&fr.poff, (ntree + 1) * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(fr.poff, poff.data(), (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&fr.soff, std::max(ntree, 1) * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(fr.soff, soff.data(), ntree * sizeof(long long), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&fr.doff, (ntree + 1) * sizeof(long long)));
     HIPCHK(c, hipMemcpy(fr.doff, dof_off, (ntree + 1) * sizeof(long long), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc((void**)&fr.linvoff, (ntree + 1) * sizeof(long long)));
@@ -1770,8 +1820,9 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         }
         UPI(fr.cinv0, inv0.data(), ndofs_total); UPI(fr.cinv1, inv1.data(), ndofs_total);
     }
-    HIPCHK(c, hipMalloc((void**)&fr.F, (size_t)fr.f_doubles * sizeof(double)));
-    HIPCHK(c, hipMemset(fr.F, 0, (size_t)fr.f_doubles * sizeof(double)));      // once: the upper triangles are never written
+    HIPCHK(c, hipMalloc((void**)&fr.P, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));
+    HIPCHK(c, hipMemset(fr.P, 0, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));   // once: the upper triangles of L11 are never written
+    HIPCHK(c, hipMalloc((void**)&fr.S, (size_t)std::max<long long>(fr.s_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
     // dynamic LDS of the one-workgroup-per-front sweeps: forward maxnp + NB, backward maxnp + maxnb + NB doubles, where
@@ -1856,7 +1907,7 @@ int femo_frontal_info(const femo_ctx* c, double* out6) {
         const double p = fr.h_npiv[t], n = fr.h_nf[t];
         fl += p * n * n - p * p * n + p * p * p / 3.0;
     }
-    out6[0] = fr.t_assemble_ms; out6[1] = fr.t_factor_ms; out6[2] = fr.f_doubles * 8.0 / 1e9; out6[3] = fl / 1e9;
+    out6[0] = fr.t_assemble_ms; out6[1] = fr.t_factor_ms; out6[2] = (fr.p_doubles + fr.s_doubles) * 8.0 / 1e9; out6[3] = fl / 1e9;
     out6[4] = fr.pivots_fixed; out6[5] = fr.ntree;
     return 0;
 }
@@ -1912,7 +1963,7 @@ int femo_frontal_sweep(femo_ctx* c, int32_t vec, int32_t l0, int32_t l1, int bac
     return 0;
 }
 
-// contiguous copy of the Schur complement (trailing nb x nb block, column-major) of one front
+// contiguous copy of the Schur complement (trailing nb x nb block, column-major; the lower triangle is what is maintained)
 int femo_front_schur_get(femo_ctx* c, int32_t front, void* dst_dev, int64_t capacity_doubles) {
     HIPCHK(c, hipSetDevice(c->device));
     auto& fr = c->fr;
@@ -1920,11 +1971,7 @@ int femo_front_schur_get(femo_ctx* c, int32_t front, void* dst_dev, int64_t capa
     const int nf = fr.h_nf[front], np = fr.h_npiv[front], nb = nf - np;
     if ((int64_t)nb * nb > capacity_doubles) return fail(c, "destination too small for the Schur complement");
     if (nb == 0) return 0;
-    std::vector<long long> off(1);
-    HIPCHK(c, hipMemcpy(off.data(), fr.foff + front, sizeof(long long), hipMemcpyDeviceToHost));
-    const double* src = fr.F + off[0] + (size_t)np + (size_t)nf * np;
-    HIPCHK(c, hipMemcpy2DAsync(dst_dev, (size_t)nb * sizeof(double), src, (size_t)nf * sizeof(double), (size_t)nb * sizeof(double), nb,
-                               hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dst_dev, fr.S + fr.h_soff[front], (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1936,9 +1983,7 @@ int femo_front_block_set(femo_ctx* c, int32_t front, const void* src_dev) {
     if (!fr.ready || front < 0 || front >= fr.ntree) return fail(c, "bad front id");
     if (fr.h_npiv[front] != 0) return fail(c, "only fronts without pivots can be overwritten");
     const int nf = fr.h_nf[front];
-    std::vector<long long> off(1);
-    HIPCHK(c, hipMemcpy(off.data(), fr.foff + front, sizeof(long long), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpyAsync(fr.F + off[0], src_dev, (size_t)nf * nf * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fr.S + fr.h_soff[front], src_dev, (size_t)nf * nf * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
