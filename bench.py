@@ -50,8 +50,8 @@ def make_workload(name, renumber=True, timings=None):
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
         desc = "synthetic wing skin 116x580 quads (cambered, tapered, twisted, jittered, renumbered), 1015470 DOF"
-    elif name in ("wing4m", "wing8m"):   # beyond BASELINE: 4x / 8x the span on one GPU (fronts: ~60 / ~125 GB of the 288 GB)
-        mult = 4 if name == "wing4m" else 8
+    elif name in ("wing4m", "wing8m", "wing16m", "wing32m"):   # beyond BASELINE: 4x .. 32x the span on one GPU (fronts ~5.4 GB per 1M DOF)
+        mult = int(name[4:-1])
         m = wing_skin_mesh(116, 580 * mult, span=6.0 * mult)
         fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
