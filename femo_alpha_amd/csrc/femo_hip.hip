@@ -631,7 +631,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     hipLaunchKernelGGL(k_panel_rows, dim3(tiles, n), dim3(256), 0, c->stream, fd, lev, off, C0, sw);
             }
             if (right_looking && max_nf > C0 + 1) {
-                const int ntr = (max_nf - (C0 + 1) + TS - 1) / TS;
+                const int ntr = (max_nf - C0 + TS - 1) / TS;     // tiles are anchored at an even column, at most one before the first updated one
                 if (!lookahead) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
@@ -664,7 +664,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
             count_trailing(0, 1);
-            const int ntr = (max_nb + TS - 1) / TS;
+            const int ntr = (max_nb + 1 + TS - 1) / TS;          // + 1: even tile anchor
             FOR_FRONT_CHUNKS(cnt, off, n) {
                 if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
                 else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
@@ -1728,7 +1728,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         std::vector<int> level_of(ntree, 0);
         for (int L = 0; L < nlevels; ++L)
             for (int i = level_off[L]; i < level_off[L + 1]; ++i) level_of[level_nodes[i]] = L;
-        for (int t = 0; t < ntree; ++t) poff[t + 1] = poff[t] + (long long)nf[t] * npiv[t];
+        for (int t = 0; t < ntree; ++t) poff[t + 1] = poff[t] + (long long)ldp_of(nf[t]) * npiv[t];   // even leading dimension: 16-byte loads of row pairs
         std::vector<long long> rsize(nlevels + 1, 0);                 // region nlevels: fronts without a parent (never read)
         std::vector<int> rstart(nlevels + 1, nlevels);
         auto region_of = [&](int t) { return parent[t] >= 0 ? level_of[parent[t]] : nlevels; };

@@ -52,12 +52,16 @@ struct FrontDev {
 };
 
 // entries of one front by FRONT row and column (r >= c): pivot columns in the panel store, the rest in the Schur arena
+// leading dimension of the pivot columns in the panel store: nf rounded up to even, so that every column starts on a
+// 16-byte boundary and the rank-k update can stage two rows of a factor column per load (the pad row stays zero)
+__device__ __host__ inline int ldp_of(int nf) { return (nf + 1) & ~1; }
+
 struct FrontView {
     double* P;
     double* S;
     int nf, np;
     __device__ __forceinline__ double* col(int c) const {
-        return c < np ? P + (size_t)nf * c : S + (size_t)(nf - np) * (c - np) - np;     // then [r], r >= c
+        return c < np ? P + (size_t)ldp_of(nf) * c : S + (size_t)(nf - np) * (c - np) - np;     // then [r], r >= c
     }
 };
 __device__ __forceinline__ FrontView front_view(const FrontDev& fd, int t) {
@@ -179,7 +183,7 @@ __global__ void k_front_mask_diag(FrontDev fd, const unsigned char* __restrict__
     double* P = fd.P + fd.poff[t];
     const int* gd = fd.dofs + fd.doff[t];
     for (int p = threadIdx.x; p < np; p += blockDim.x)
-        if (mask[gd[p]]) P[p + (size_t)nf * p] = 1.0;
+        if (mask[gd[p]]) P[p + (size_t)ldp_of(nf) * p] = 1.0;
 }
 
 // lower triangle of every front of a level := 0 (the leaf fronts before the element matrices are added)
@@ -332,6 +336,7 @@ __device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane)
 // result.  v_mfma_f64_16x16x4_f64: a lane supplies A[i = lane & 15][k = lane >> 4] and B[k = lane >> 4][j = lane & 15]
 // and holds D[i = (lane >> 4) + 4 reg][j = lane & 15].
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double blk32[NB][NB + 1];
 
 // acc += A(32 x 32) * B(32 x 32) restricted to this wave's sub-block; TA / TB: the operand is stored transposed
@@ -375,7 +380,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     if (C0 >= np) return;
     const int kw = min(NBO, np - C0);
     const int nkb = (kw + NB - 1) / NB;
-    const int nf = fd.nf[t];
+    const int ldp = ldp_of(fd.nf[t]);
     double* F = fd.P + fd.poff[t];                             // pivot columns only
     // the inverse of this diagonal block: scratch (levels solved with the one-workgroup-per-front kernels) or the diagonal
     // block of the front's X (wide levels)
@@ -402,7 +407,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
                 const int r = idx % NB, c = idx / NB;
                 const int gr = NB * bi + r, gc = NB * bj + c;
                 v[b][q] = (gr == gc) ? 1.0 : 0.0;
-                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)nf * (C0 + gc)];
+                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
             }
         }
 #pragma unroll
@@ -459,7 +464,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
                     const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
                     Dij[r][c] = acc[i - 1][reg];
                     const int gr = NB * (j + i) + r, gc = NB * j + c;
-                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)nf * (C0 + gc)] = acc[i - 1][reg];
+                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)ldp * (C0 + gc)] = acc[i - 1][reg];
                 }
             }
             __syncthreads();
@@ -527,6 +532,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.P + fd.poff[t];                             // pivot columns only
+    const int ldp = ldp_of(nf);
     const int lds_ = Swork ? SPD : ldx_of(np);
     const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
     // S is shared by the four waves: the 16 rows of S that produce output columns [16 cb, 16 cb + 16) are staged in
@@ -538,7 +544,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
 #pragma unroll
     for (int kk = 0; kk < NBO / 4; ++kk) {
         const int k = 4 * kk + l4;
-        a[kk] = (rok && k < kw) ? F[row + (size_t)nf * (C0 + k)] : 0.0;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
     }
     const int sc = tid & 15, sk0 = tid >> 4;              // staging: column sc of the block, rows sk0, sk0 + 16, ...
     double pre[NBO / 16];
@@ -563,7 +569,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int c = 16 * cb + l4 + 4 * reg;
-            if (rok && c < kw) F[row + (size_t)nf * (C0 + c)] = acc[reg];
+            if (rok && c < kw) F[row + (size_t)ldp * (C0 + c)] = acc[reg];
         }
         if (more) {
 #pragma unroll
@@ -596,8 +602,10 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
     if (schur != 1 && C0 >= np) return;
     const int kc0 = schur >= 2 ? C0 : 0;
     const int kw = schur >= 2 ? min(NBO, np - C0) : (schur ? np : C0);
-    const int col_lo = schur >= 2 ? C0 + kw + (schur == 4 ? NBO : 0) : (schur ? np : C0);
-    const int col_hi = schur == 0 ? min(C0 + NBO, np) : schur == 3 ? min(C0 + kw + NBO, nf) : nf;
+    // the look-ahead split (3 | 4) sits 128 columns behind the even anchor of the first updated column
+    const int split = ((C0 + kw) & ~1) + NBO;
+    const int col_lo = schur >= 2 ? (schur == 4 ? split : C0 + kw) : (schur ? np : C0);
+    const int col_hi = schur == 0 ? min(C0 + NBO, np) : schur == 3 ? min(split, nf) : nf;
     if (kw == 0) return;
     // tile from the linear block index: consecutive workgroups go to different XCDs, so a (row tile, column tile)
     // grid whose x extent is a multiple of 8 would pin every row-tile offset to one XCD -- and the lower triangle has
@@ -612,7 +620,9 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         while (ti * (ti + 1) / 2 > lin) --ti;
         by = lin - ti * (ti + 1) / 2; bx = ti - by;                 // column tile by, row tile by + bx
     }
-    const int cj = col_lo + by * TS;
+    // tiles are anchored at an even column: with the even leading dimension of the panel store every pair of rows
+    // (2 rp, 2 rp + 1) of a tile is then one aligned 16-byte load (+8..12 % on this kernel against 8-byte loads)
+    const int cj = (col_lo & ~1) + by * TS;
     if (cj >= col_hi) return;
     const int ri = cj + bx * TS;                   // row tiles start at the column tile (lower triangle)
     if (ri >= nf) return;
@@ -620,21 +630,23 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
     const double* F = fv.P;                        // the K panel: always pivot columns
     // 16 factor columns per stage, two LDS buffers (20 KB each): the next stage travels global -> registers while the
     // matrix cores work on the current one, and one barrier per stage suffices
-    constexpr int KC = 16, NQ = KC / 4;
-    __shared__ double si[2][KC][LSTR];             // rows of the tile:    si[.][k][r] = L[ri + r][kc0 + k0 + k]
-    __shared__ double sj[2][KC][LSTR];             // columns of the tile: sj[.][k][c] = L[cj + c][kc0 + k0 + k]
+    constexpr int KC = 16, NQ = KC / 8;
+    __shared__ __attribute__((aligned(16))) double si[2][KC][LSTR];   // rows of the tile:    si[.][k][r] = L[ri + r][kc0 + k0 + k]
+    __shared__ __attribute__((aligned(16))) double sj[2][KC][LSTR];   // columns of the tile: sj[.][k][c] = L[cj + c][kc0 + k0 + k]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;     // this wave's quarter: rows wr.., columns wc..
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int lr = tid % TS, lc = tid / TS;                // staging: row lr of the tile, columns lc, lc + 4, ...
-    const bool iok = ri + lr < nf, jok = cj + lr < nf;
-    double pi[NQ], pj[NQ];
+    const int rp = tid & 31, cg = tid >> 5;                // staging: rows 2 rp, 2 rp + 1 of the tile, columns cg, cg + 8
+    const int ldp = ldp_of(nf);                            // a pair may end on the pad row nf (nf odd): its products are never stored
+    const bool iok = ri + 2 * rp < nf, jok = cj + 2 * rp < nf;
+    d2 pi[NQ], pj[NQ];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int c = lc + 4 * q;
-            pi[q] = (iok && k0 + c < kw) ? F[(ri + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
-            pj[q] = (jok && k0 + c < kw) ? F[(cj + lr) + (size_t)nf * (kc0 + k0 + c)] : 0.0;
+            const int c = cg + 8 * q;
+            const d2 z = {0.0, 0.0};
+            pi[q] = (iok && k0 + c < kw) ? *reinterpret_cast<const d2*>(F + (ri + 2 * rp) + (size_t)ldp * (kc0 + k0 + c)) : z;
+            pj[q] = (jok && k0 + c < kw) ? *reinterpret_cast<const d2*>(F + (cj + 2 * rp) + (size_t)ldp * (kc0 + k0 + c)) : z;
         }
     };
     fetch(0);
@@ -650,7 +662,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                cpre[a][b][reg] = (PRE && r < nf && cc < col_hi && r >= cc) ? fv.col(cc)[r] : 0.0;
+                cpre[a][b][reg] = (PRE && r < nf && cc >= col_lo && cc < col_hi && r >= cc) ? fv.col(cc)[r] : 0.0;
             }
     mfma_d4 acc[2][2];
 #pragma unroll
@@ -658,7 +670,10 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { si[0][lc + 4 * q][lr] = pi[q]; sj[0][lc + 4 * q][lr] = pj[q]; }
+    for (int q = 0; q < NQ; ++q) {
+        *reinterpret_cast<d2*>(&si[0][cg + 8 * q][2 * rp]) = pi[q];
+        *reinterpret_cast<d2*>(&sj[0][cg + 8 * q][2 * rp]) = pj[q];
+    }
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < kw; k0 += KC) {
@@ -676,7 +691,10 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         }
         if (more) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) { si[cur ^ 1][lc + 4 * q][lr] = pi[q]; sj[cur ^ 1][lc + 4 * q][lr] = pj[q]; }
+            for (int q = 0; q < NQ; ++q) {
+                *reinterpret_cast<d2*>(&si[cur ^ 1][cg + 8 * q][2 * rp]) = pi[q];
+                *reinterpret_cast<d2*>(&sj[cur ^ 1][cg + 8 * q][2 * rp]) = pj[q];
+            }
         }
         __syncthreads();
         cur ^= 1;
@@ -689,7 +707,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (r < nf && cc < col_hi && r >= cc) {
+                if (r < nf && cc >= col_lo && cc < col_hi && r >= cc) {
                     double* p = fv.col(cc) + r;
                     *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
                 }
@@ -712,6 +730,7 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
     const int np = fd.npiv[t], nf = fd.nf[t];
     if (np == 0) return;
     const double* F = fd.P + fd.poff[t];                       // the factor columns [L11; L21]
+    const int ldp = ldp_of(nf);
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
     double* y = sh;            // np
@@ -733,9 +752,9 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
         if (threadIdx.x < wb) y[c0 + threadIdx.x] = yk[threadIdx.x];
         for (int r = c0 + wb + threadIdx.x; r < np; r += blockDim.x) {
             double s = 0.0;
-            const double* row = F + r + (size_t)nf * c0;
+            const double* row = F + r + (size_t)ldp * c0;
 #pragma unroll 8
-            for (int mm = 0; mm < wb; ++mm) s += row[(size_t)nf * mm] * yk[mm];
+            for (int mm = 0; mm < wb; ++mm) s += row[(size_t)ldp * mm] * yk[mm];
             y[r] -= s;
         }
         __syncthreads();
@@ -745,7 +764,7 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
         double s = 0.0;
         const double* row = F + r;
 #pragma unroll 8
-        for (int c = 0; c < np; ++c) s += row[(size_t)nf * c] * y[c];
+        for (int c = 0; c < np; ++c) s += row[(size_t)ldp * c] * y[c];
         atomicAdd(&v[gd[r]], -s);
     }
 }
@@ -757,6 +776,7 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
     const int np = fd.npiv[t], nf = fd.nf[t];
     if (np == 0) return;
     const double* F = fd.P + fd.poff[t];                       // the factor columns [L11; L21]
+    const int ldp = ldp_of(nf);
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
     double* x = sh;            // nf
@@ -770,7 +790,7 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
         const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
         for (int c = wid; c < wb; c += nw) {
             double s = 0.0;
-            const double* col = F + (size_t)nf * (c0 + c);
+            const double* col = F + (size_t)ldp * (c0 + c);
 #pragma unroll 4
             for (int r = c0 + wb + lane; r < nf; r += 64) s += col[r] * x[r];
             s = wave_sum(s);
@@ -823,7 +843,7 @@ k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
         ti = blockIdx.x / nct; tj = blockIdx.x % nct;
     }
     const int* gd = fd.dofs + fd.doff[t];
-    const int ld = TRI ? ldx_of(np) : nf;
+    const int ld = TRI ? ldx_of(np) : ldp_of(nf);
     const double* M = TRI ? fd.X + fd.xoff[t] : fd.P + fd.poff[t] + np;       // L21 starts at row np of the pivot columns
     const int nrows = TRI ? np : nf - np;
     const int r0 = 128 * ti, c0 = 128 * tj;
@@ -878,7 +898,7 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
         ti = blockIdx.x / nct; tj = blockIdx.x % nct;
     }
     const int* gd = fd.dofs + fd.doff[t];
-    const int ld = TRI ? ldx_of(np) : nf;
+    const int ld = TRI ? ldx_of(np) : ldp_of(nf);
     const double* M = TRI ? fd.X + fd.xoff[t] : fd.P + fd.poff[t] + np;
     const int nrows = TRI ? np : nf - np;
     const int rbase = TRI ? 0 : np;                          // front row of M's row 0
@@ -930,7 +950,7 @@ k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, do
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         const double* col[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)nf * min(cb + k, np - 1);
+        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)ldp_of(nf) * min(cb + k, np - 1);
         int r = lane;
         for (; r + 64 < nb; r += 128) {
             const double x0 = xs[r], x1 = xs[r + 64];
@@ -997,7 +1017,7 @@ k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             const int k = k0 + kq + GA * q;
-            if (PHASE == 0) pa[q] = (rok && k < k_hi) ? F[(b0 + r0 + lr) + (size_t)nf * (a0 + k)] : 0.0;
+            if (PHASE == 0) pa[q] = (rok && k < k_hi) ? F[(b0 + r0 + lr) + (size_t)ldp_of(nf) * (a0 + k)] : 0.0;
             else pa[q] = (rok && k < k_hi && k <= r0 + lr) ? X[(b0 + r0 + lr) + (size_t)ldx * (b0 + k)] : 0.0;
         }
 #pragma unroll

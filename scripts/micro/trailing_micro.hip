@@ -442,6 +442,94 @@ k_db2(double* Fall, int nf, int kc0, int kw) {
             }
 }
 
+// k_db with 16-byte staging loads: a thread moves two consecutive rows of a factor column per load (needs an even leading
+// dimension and even tile origins) -- half the global-load and half the LDS-store instructions per stage
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <bool PRE>
+__global__ void __launch_bounds__(256)
+k_db16(double* Fall, int nf, int kc0, int kw) {
+    constexpr int KC = 16;
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    __shared__ __attribute__((aligned(16))) double si[2][KC][LSTR];
+    __shared__ __attribute__((aligned(16))) double sj[2][KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int rp = tid & 31, cg = tid >> 5;                  // rows 2 rp, 2 rp + 1; columns cg, cg + 8
+    d2 pi[2], pj[2];
+    const bool iok = ri + 2 * rp + 1 < nf, jok = cj + 2 * rp + 1 < nf;      // (micro: nf even, tiles never cut a pair)
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = cg + 8 * q;
+            const d2 z = {0.0, 0.0};
+            pi[q] = (iok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[(ri + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
+            pj[q] = (jok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[(cj + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
+        }
+    };
+    fetch(0);
+    double cpre[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                cpre[a][b][reg] = (PRE && r < nf && cc < nf && r >= cc) ? F[r + (size_t)nf * cc] : 0.0;
+            }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<d2*>(&si[0][cg + 8 * q][2 * rp]) = pi[q];
+        *reinterpret_cast<d2*>(&sj[0][cg + 8 * q][2 * rp]) = pj[q];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const bool more = k0 + KC < kw;
+        if (more) fetch(k0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = sj[cur][kk + l4][wc + l15], a1 = sj[cur][kk + l4][wc + 16 + l15];
+            const double b0 = si[cur][kk + l4][wr + l15], b1 = si[cur][kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<d2*>(&si[cur ^ 1][cg + 8 * q][2 * rp]) = pi[q];
+                *reinterpret_cast<d2*>(&sj[cur ^ 1][cg + 8 * q][2 * rp]) = pj[q];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) {
+                    double* p = &F[r + (size_t)nf * cc];
+                    *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
+                }
+            }
+}
+
 int main(int argc, char** argv) {
     const int nfr = argc > 1 ? atoi(argv[1]) : 8, nf = argc > 2 ? atoi(argv[2]) : 3200, kw = argc > 3 ? atoi(argv[3]) : 128;
     double* F; CK(hipMalloc(&F, sizeof(double) * (size_t)nfr * nf * nf));
@@ -449,7 +537,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nt = (nf - kw + TS - 1) / TS;
     const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
-    for (int mode = 0; mode < 20; ++mode)
+    for (int mode = 0; mode < 22; ++mode)
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
@@ -472,6 +560,8 @@ int main(int argc, char** argv) {
             if (mode == 17) hipLaunchKernelGGL((k_rect<false>), dim3((nf - kw + 127) / 128, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 18) hipLaunchKernelGGL((k_db2<true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 19) hipLaunchKernelGGL((k_db2<false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 20) hipLaunchKernelGGL((k_db16<true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 21) hipLaunchKernelGGL((k_db16<false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
