@@ -84,6 +84,7 @@ struct femo_ctx {
         int trailing = 0;             // rank-k update schedule: 0 auto, 1 left-looking, 2 right-looking
         int left_min = 16, left_max = 2048;   // auto: levels with this many fronts are left-looking
         int lookahead = 1, lookahead_cnt = 16;
+        int super_panel = 0, super_panel_cnt = 32;
         int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
         int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
@@ -562,18 +563,17 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
         const bool right_looking = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt_level < c->opt.left_min || cnt_level > c->opt.left_max);
-        const bool lookahead = right_looking && cnt_level < c->opt.lookahead_cnt && c->opt.lookahead != 0;
+        const bool use_sp = right_looking && c->opt.super_panel > NBO && cnt_level <= c->opt.super_panel_cnt && max_np_level > NBO;
+        const bool lookahead = right_looking && !use_sp && cnt_level < c->opt.lookahead_cnt && c->opt.lookahead != 0;
         bool bulk_pending = false;
         // flops of one k_trailing_mfma launch over this level, with the kernel's own column / K ranges (profiling only)
-        auto count_trailing = [&](int C0, int schur) {
+        auto count_trailing = [&](int C0, int schur, int K0 = 0, int KW = NBO) {
             if (!fr.profile) return;
             double fl = 0, by = 0;
             for (int i = b; i < e; ++i) {
                 const int t = fr.h_level_nodes[i], np = fr.h_npiv[t], nf = fr.h_nf[t];
-                if (schur != 1 && C0 >= np) continue;
-                const int kw = schur >= 2 ? std::min(NBO, np - C0) : (schur ? np : C0);
-                const int col_lo = schur >= 2 ? C0 + kw + (schur == 4 ? NBO : 0) : (schur ? np : C0);
-                const int col_hi = schur == 0 ? std::min(C0 + NBO, np) : schur == 3 ? std::min(C0 + kw + NBO, nf) : nf;
+                const TrailRange tr = trail_range(schur, C0, K0, KW, np, nf);
+                const int kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
                 if (kw <= 0 || col_lo >= col_hi) continue;
                 const double ncol = col_hi - col_lo;
                 const double entries = ncol * nf - 0.5 * ncol * (col_lo + col_hi - 1.0);
@@ -595,15 +595,21 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 fr.prof_bytes[0] += 16.0 * rows * kw + 4.0 * kw * kw;
             }
         };
+        // right-looking levels with few, large fronts work in super-panels of SP columns: inside one the panels are
+        // updated left-looking with the super-panel's earlier columns only, and everything behind it is updated once,
+        // with K = SP -- the K = 128 update of the whole trailing matrix is HBM-bound (16 flop per byte moved)
+        const int SP = use_sp ? c->opt.super_panel / NBO * NBO : NBO;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
-            if (C0 > 0 && !right_looking) {
-                // left-looking update of this panel's columns with all factor columns to their left
+            const int S0 = C0 / SP * SP;                 // start of this panel's super-panel (== C0 when SP == NBO)
+            const int K0 = right_looking ? S0 : 0;
+            if (C0 > K0) {
+                // left-looking update of this panel's columns with the factor columns [K0, C0) to their left
                 ProfScope ps(c, 2);
-                count_trailing(C0, 0);
+                count_trailing(C0, 0, K0);
                 const int ntr = (max_nf - C0 + TS - 1) / TS;
                 FOR_FRONT_CHUNKS(cnt, off, n)
-                    hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0);
+                    hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO);
             }
             count_panel(C0);
             { ProfScope ps(c, 1);
@@ -630,13 +636,29 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 FOR_FRONT_CHUNKS(cnt, off, n)
                     hipLaunchKernelGGL(k_panel_rows, dim3(tiles, n), dim3(256), 0, c->stream, fd, lev, off, C0, sw);
             }
-            if (right_looking && max_nf > C0 + 1) {
+            if (right_looking && SP > NBO) {
+                if (C0 + NBO >= S0 + SP || C0 + NBO >= max_np) {
+                    // the super-panel is complete: one update of everything behind it
+                    int kend = max_nf;                  // first updated column, the smallest over the fronts that take part
+                    for (int i = b; i < e; ++i) {
+                        const int np = fr.h_npiv[fr.h_level_nodes[i]];
+                        if (np > S0) kend = std::min(kend, std::min(S0 + SP, np));
+                    }
+                    const int ntr = (max_nf - (kend & ~1) + TS - 1) / TS;
+                    if (ntr > 0) {
+                        ProfScope ps(c, 2);
+                        count_trailing(S0, 2, 0, SP);
+                        FOR_FRONT_CHUNKS(cnt, off, n)
+                            hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, S0, 2, 0, SP);
+                    }
+                }
+            } else if (right_looking && max_nf > C0 + 1) {
                 const int ntr = (max_nf - C0 + TS - 1) / TS;     // tiles are anchored at an even column, at most one before the first updated one
                 if (!lookahead) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
                     FOR_FRONT_CHUNKS(cnt, off, n)
-                        hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2);
+                        hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO);
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
                     // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
@@ -645,14 +667,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
                     { ProfScope ps(c, 2);
                       count_trailing(C0, 3);
-                      hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3); }
+                      hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO); }
                     const int ntb = ntr - NBO / TS;
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
                           count_trailing(C0, 4);
-                          hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4); }
+                          hipLaunchKernelGGL(k_trailing_mfma, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4, 0, NBO); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
@@ -665,10 +687,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             ProfScope ps(c, 2);
             count_trailing(0, 1);
             const int ntr = (max_nb + 1 + TS - 1) / TS;          // + 1: even tile anchor
-            FOR_FRONT_CHUNKS(cnt, off, n) {
-                if (max_np >= 256) hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
-                else hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1);
-            }
+            FOR_FRONT_CHUNKS(cnt, off, n)
+                hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO);
         }
         }   // chunks of the level
         if (wide && max_np_level > NBO) {
@@ -1407,6 +1427,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "left_max") o.left_max = v;
     else if (k == "lookahead") o.lookahead = v != 0;
     else if (k == "lookahead_cnt") o.lookahead_cnt = v;
+    else if (k == "super_panel") o.super_panel = v;
+    else if (k == "super_panel_cnt") o.super_panel_cnt = v;
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {
         if (c->fr.ready) return fail(c, "wide_np / wide_cnt shape the plan: set them before femo_set_frontal_plan");

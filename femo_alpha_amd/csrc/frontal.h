@@ -587,26 +587,36 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
 // LDS rows are padded to 80 doubles so that the four 16-lane groups of a ds_read_b64 hit disjoint banks.
 constexpr int LSTR = TS + 16;
 
-template <bool PRE>
+// The K range and the updated columns of one front in one k_trailing_mfma launch (shared with the host's flop count).
+//   schur 0  left-looking: the 128 pivot columns at C0 receive the updates of the factor columns [K0, C0) right
+//            before they are factorised (K0 = 0: all earlier columns; K0 = start of the super-panel: see below);
+//   schur 1  the Schur complement is updated once, after the last panel, with K = npiv.  Every entry of the front is
+//            then read and written once per factorisation instead of once per 128 factor columns;
+//   schur 2  right-looking: everything behind the factor columns [C0, C0 + KW) is updated with those columns
+//            (KW = 128: after every outer panel; KW = 256, 512: after a super-panel whose own panels were updated
+//            with schur 0 / K0 = C0 -- the Schur complement then moves through HBM once per KW columns);
+//   schur 3, 4  the look-ahead split of 2: only the next 128 columns | everything behind those.
+struct TrailRange { int kc0, kw, col_lo, col_hi; };
+__device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int KW, int np, int nf) {
+    TrailRange r{0, 0, 0, 0};
+    if (schur != 1 && C0 >= np) return r;
+    r.kc0 = schur >= 2 ? C0 : (schur ? 0 : K0);
+    r.kw = schur >= 2 ? (KW < np - C0 ? KW : np - C0) : (schur ? np : C0 - K0);
+    // the look-ahead split (3 | 4) sits 128 columns behind the even anchor of the first updated column
+    const int split = ((C0 + r.kw) & ~1) + NBO;
+    r.col_lo = schur >= 2 ? (schur == 4 ? split : C0 + r.kw) : (schur ? np : C0);
+    r.col_hi = schur == 0 ? (C0 + NBO < np ? C0 + NBO : np) : schur == 3 ? (split < nf ? split : nf) : nf;
+    return r;
+}
+
 __global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
-k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur) {
+k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW) {
     const int t = level_nodes[first + blockIdx.z];
     const int np = fd.npiv[t];
     const int nf = fd.nf[t];
-    // left-looking: the 128 pivot columns of an outer panel receive the updates of ALL earlier factor columns right
-    // before they are factorised (schur == 0: columns [C0, C0+128) of the pivot block, K = [0, C0)); the Schur
-    // complement is updated once, after the last panel, with K = npiv (schur == 1).  Every entry of the front is then
-    // read and written once per factorisation instead of once per 128 factor columns.
-    // schur >= 2: right-looking -- everything behind the outer panel at C0 is updated with that panel's columns
-    // (2: all of it; 3: only the next panel's 128 columns; 4: everything behind those -- the look-ahead split)
-    if (schur != 1 && C0 >= np) return;
-    const int kc0 = schur >= 2 ? C0 : 0;
-    const int kw = schur >= 2 ? min(NBO, np - C0) : (schur ? np : C0);
-    // the look-ahead split (3 | 4) sits 128 columns behind the even anchor of the first updated column
-    const int split = ((C0 + kw) & ~1) + NBO;
-    const int col_lo = schur >= 2 ? (schur == 4 ? split : C0 + kw) : (schur ? np : C0);
-    const int col_hi = schur == 0 ? min(C0 + NBO, np) : schur == 3 ? min(split, nf) : nf;
-    if (kw == 0) return;
+    const TrailRange tr = trail_range(schur, C0, K0, KW, np, nf);
+    const int kc0 = tr.kc0, kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
+    if (kw <= 0) return;
     // tile from the linear block index: consecutive workgroups go to different XCDs, so a (row tile, column tile)
     // grid whose x extent is a multiple of 8 would pin every row-tile offset to one XCD -- and the lower triangle has
     // 8x more tiles at offset 0 than at offset 7.  The linear order spreads them evenly (measured: up to 2.2x).
@@ -621,64 +631,65 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         by = lin - ti * (ti + 1) / 2; bx = ti - by;                 // column tile by, row tile by + bx
     }
     // tiles are anchored at an even column: with the even leading dimension of the panel store every pair of rows
-    // (2 rp, 2 rp + 1) of a tile is then one aligned 16-byte load (+8..12 % on this kernel against 8-byte loads)
+    // (2 rp, 2 rp + 1) of a tile is then one aligned 16-byte load
     const int cj = (col_lo & ~1) + by * TS;
     if (cj >= col_hi) return;
     const int ri = cj + bx * TS;                   // row tiles start at the column tile (lower triangle)
     if (ri >= nf) return;
     const FrontView fv = front_view(fd, t);
-    const double* F = fv.P;                        // the K panel: always pivot columns
     // 16 factor columns per stage, two LDS buffers (20 KB each): the next stage travels global -> registers while the
     // matrix cores work on the current one, and one barrier per stage suffices
-    constexpr int KC = 16, NQ = KC / 8;
+    constexpr int KC = 16;
     __shared__ __attribute__((aligned(16))) double si[2][KC][LSTR];   // rows of the tile:    si[.][k][r] = L[ri + r][kc0 + k0 + k]
     __shared__ __attribute__((aligned(16))) double sj[2][KC][LSTR];   // columns of the tile: sj[.][k][c] = L[cj + c][kc0 + k0 + k]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;     // this wave's quarter: rows wr.., columns wc..
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int rp = tid & 31, cg = tid >> 5;                // staging: rows 2 rp, 2 rp + 1 of the tile, columns cg, cg + 8
-    const int ldp = ldp_of(nf);                            // a pair may end on the pad row nf (nf odd): its products are never stored
-    const bool iok = ri + 2 * rp < nf, jok = cj + 2 * rp < nf;
-    d2 pi[NQ], pj[NQ];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int c = cg + 8 * q;
-            const d2 z = {0.0, 0.0};
-            pi[q] = (iok && k0 + c < kw) ? *reinterpret_cast<const d2*>(F + (ri + 2 * rp) + (size_t)ldp * (kc0 + k0 + c)) : z;
-            pj[q] = (jok && k0 + c < kw) ? *reinterpret_cast<const d2*>(F + (cj + 2 * rp) + (size_t)ldp * (kc0 + k0 + c)) : z;
-        }
+    // Staging with as little vector arithmetic as possible -- the vector ALU shares its issue slots with the matrix
+    // cores, and address / mask arithmetic per load costs this kernel a fifth of its rate (micro-benchmark: 49 -> 60
+    // TFLOP/s at K = 512, 32 -> 41 at K = 128).  The stage pointer is uniform; a thread keeps four constant 32-bit byte
+    // offsets (rows 2 rp, 2 rp + 1 of the tile's row and column blocks, factor columns cg and cg + 8).  Rows past the
+    // front are clamped to its last row pair (their products are never stored); only the last, partial stage is masked.
+    const int rp = tid & 31, cg = tid >> 5;
+    const int ldp = ldp_of(nf);
+    const int rowi = min(ri + 2 * rp, ldp - 2), rowj = min(cj + 2 * rp, ldp - 2);
+    const unsigned obi0 = 8u * (unsigned)(rowi + ldp * cg), obi1 = 8u * (unsigned)(rowi + ldp * (cg + 8));
+    const unsigned obj0 = 8u * (unsigned)(rowj + ldp * cg), obj1 = 8u * (unsigned)(rowj + ldp * (cg + 8));
+    const char* base = reinterpret_cast<const char*>(fv.P + (size_t)ldp * kc0);      // the K panel: always pivot columns
+    const size_t stage_bytes = (size_t)ldp * KC * 8;
+    d2 pi[2], pj[2];
+    auto fetch = [&](const char* b) {
+        pi[0] = *reinterpret_cast<const d2*>(b + obi0); pi[1] = *reinterpret_cast<const d2*>(b + obi1);
+        pj[0] = *reinterpret_cast<const d2*>(b + obj0); pj[1] = *reinterpret_cast<const d2*>(b + obj1);
     };
-    fetch(0);
-    // the tile of C is read up front as well (PRE): its latency hides behind the whole K loop instead of ending the
-    // kernel.  Long K loops (Schur updates with K = npiv >= 256) do better without: 32 registers less, one more wave per SIMD.
-    // D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
-    double cpre[2][2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
-                const int r = ri + wr + 16 * b + l15;
-                cpre[a][b][reg] = (PRE && r < nf && cc >= col_lo && cc < col_hi && r >= cc) ? fv.col(cc)[r] : 0.0;
-            }
+    auto fetch_tail = [&](const char* b, int left) {       // left = factor columns this stage still has (1..15)
+        const d2 z = {0.0, 0.0};
+        const unsigned a0 = 8u * (unsigned)(ldp * min(cg, left - 1)), a1 = 8u * (unsigned)(ldp * min(cg + 8, left - 1));
+        const d2 vi0 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowi + a0), vi1 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowi + a1);
+        const d2 vj0 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowj + a0), vj1 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowj + a1);
+        pi[0] = cg < left ? vi0 : z; pi[1] = cg + 8 < left ? vi1 : z;
+        pj[0] = cg < left ? vj0 : z; pj[1] = cg + 8 < left ? vj1 : z;
+    };
+    if (kw >= KC) fetch(base); else fetch_tail(base, kw);
+    base += stage_bytes;
     mfma_d4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < 2; ++q) {
         *reinterpret_cast<d2*>(&si[0][cg + 8 * q][2 * rp]) = pi[q];
         *reinterpret_cast<d2*>(&sj[0][cg + 8 * q][2 * rp]) = pj[q];
     }
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < kw; k0 += KC) {
-        const bool more = k0 + KC < kw;
-        if (more) fetch(k0 + KC);
+        const int left = kw - k0 - KC;             // factor columns behind this stage
+        if (left > 0) {
+            if (left >= KC) fetch(base); else fetch_tail(base, left);
+            base += stage_bytes;
+        }
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             // A: tile columns (index i), B: tile rows (index j); k = kk + (lane >> 4)
@@ -689,9 +700,9 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) {
+        if (left > 0) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 *reinterpret_cast<d2*>(&si[cur ^ 1][cg + 8 * q][2 * rp]) = pi[q];
                 *reinterpret_cast<d2*>(&sj[cur ^ 1][cg + 8 * q][2 * rp]) = pj[q];
             }
@@ -699,6 +710,19 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         __syncthreads();
         cur ^= 1;
     }
+    // C -= D with all of the tile's loads in flight at once (entries outside the tile's part of the lower triangle load
+    // from a safe address and are not stored).  D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
+    double* cp[2][4];
+    bool cok[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+            cok[a][reg] = cc >= col_lo && cc < col_hi;
+            cp[a][reg] = cok[a][reg] ? fv.col(cc) : fv.P - (nf - 1);          // safe: [r] below stays inside the panel store
+        }
+    double cv[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -707,10 +731,18 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (r < nf && cc >= col_lo && cc < col_hi && r >= cc) {
-                    double* p = fv.col(cc) + r;
-                    *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
-                }
+                const bool ok = cok[a][reg] && r < nf && r >= cc;
+                cv[a][b][reg] = cp[a][reg][ok ? r : nf - 1];
+            }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (cok[a][reg] && r < nf && r >= cc) cp[a][reg][r] = cv[a][b][reg] - acc[a][b][reg];
             }
 }
 

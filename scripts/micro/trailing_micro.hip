@@ -445,7 +445,9 @@ k_db2(double* Fall, int nf, int kc0, int kw) {
 // k_db with 16-byte staging loads: a thread moves two consecutive rows of a factor column per load (needs an even leading
 // dimension and even tile origins) -- half the global-load and half the LDS-store instructions per stage
 typedef double d2 __attribute__((ext_vector_type(2)));
-template <bool PRE>
+// VAR 1: later stages are loaded but not written to LDS; VAR 2: every workgroup loads the rows of tile (0, 0) (cache-hot);
+// VAR 3: batched epilogue loads (no serial read-modify-write chain)
+template <bool PRE, int VAR = 0>
 __global__ void __launch_bounds__(256)
 k_db16(double* Fall, int nf, int kc0, int kw) {
     constexpr int KC = 16;
@@ -470,10 +472,11 @@ k_db16(double* Fall, int nf, int kc0, int kw) {
         for (int q = 0; q < 2; ++q) {
             const int c = cg + 8 * q;
             const d2 z = {0.0, 0.0};
-            pi[q] = (iok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[(ri + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
-            pj[q] = (jok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[(cj + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
+            pi[q] = (iok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[((VAR == 2 ? col_lo : ri) + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
+            pj[q] = (jok && k0 + c < kw) ? *reinterpret_cast<const d2*>(&F[((VAR == 2 ? col_lo : cj) + 2 * rp) + (size_t)nf * (kc0 + k0 + c)]) : z;
         }
     };
+    double dummy = 0.0;
     fetch(0);
     double cpre[2][2][4];
 #pragma unroll
@@ -506,10 +509,15 @@ k_db16(double* Fall, int nf, int kc0, int kw) {
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (more) {
+            if (VAR == 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dummy += pi[q].x + pi[q].y + pj[q].x + pj[q].y;
+            } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 *reinterpret_cast<d2*>(&si[cur ^ 1][cg + 8 * q][2 * rp]) = pi[q];
                 *reinterpret_cast<d2*>(&sj[cur ^ 1][cg + 8 * q][2 * rp]) = pj[q];
+            }
             }
         }
         __syncthreads();
@@ -523,10 +531,134 @@ k_db16(double* Fall, int nf, int kc0, int kw) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
+                if (VAR == 3) continue;
                 if (r < nf && cc < nf && r >= cc) {
                     double* p = &F[r + (size_t)nf * cc];
                     *p = (PRE ? cpre[a][b][reg] : *p) - acc[a][b][reg];
                 }
+            }
+    if (VAR == 1 && dummy == 1.2345) F[0] = dummy;
+    if (VAR == 3) {
+        double cv[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const bool ok = r < nf && cc < nf && r >= cc;
+                    cv[a][b][reg] = F[ok ? r + (size_t)nf * cc : 0];          // unconditional load from a safe address
+                }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] = cv[a][b][reg] - acc[a][b][reg];
+                }
+    }
+}
+
+// scalar-base staging: the stage pointer is uniform (SGPR), every thread keeps four constant 32-bit byte offsets, so a
+// stage costs four global_load_dwordx4 with saddr and no vector address arithmetic; rows beyond the front are clamped
+// (their products are never stored), only the last partial K stage is masked; batched epilogue.
+template <int TAILMODE>
+__global__ void __launch_bounds__(256, 4)
+k_sg(double* Fall, int nf, int kc0, int kw) {
+    constexpr int KC = 16;
+    double* F = Fall + (size_t)blockIdx.z * nf * nf;
+    const int col_lo = kc0 + kw;
+    const int cj = col_lo + blockIdx.y * TS;
+    if (cj >= nf) return;
+    const int ri = cj + blockIdx.x * TS;
+    if (ri >= nf) return;
+    __shared__ __attribute__((aligned(16))) double si[2][KC][LSTR];
+    __shared__ __attribute__((aligned(16))) double sj[2][KC][LSTR];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int rp = tid & 31, cg = tid >> 5;
+    const int rowi = min(ri + 2 * rp, nf - 2), rowj = min(cj + 2 * rp, nf - 2);
+    const unsigned obi0 = 8u * (unsigned)(rowi + nf * cg), obi1 = 8u * (unsigned)(rowi + nf * (cg + 8));
+    const unsigned obj0 = 8u * (unsigned)(rowj + nf * cg), obj1 = 8u * (unsigned)(rowj + nf * (cg + 8));
+    const char* base = reinterpret_cast<const char*>(F + (size_t)nf * kc0);
+    const size_t stage_bytes = (size_t)nf * KC * 8;
+    d2 pi[2], pj[2];
+    auto fetch = [&](const char* b) {
+        pi[0] = *reinterpret_cast<const d2*>(b + obi0); pi[1] = *reinterpret_cast<const d2*>(b + obi1);
+        pj[0] = *reinterpret_cast<const d2*>(b + obj0); pj[1] = *reinterpret_cast<const d2*>(b + obj1);
+    };
+    auto fetch_tail = [&](const char* b, int left) {          // left = columns of this stage that exist (1..15)
+        const d2 z = {0.0, 0.0};
+        const unsigned c0 = min(cg, left - 1), c1 = min(cg + 8, left - 1);
+        const unsigned a0 = 8u * (unsigned)(nf * c0), a1 = 8u * (unsigned)(nf * c1);
+        const d2 vi0 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowi + a0), vi1 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowi + a1);
+        const d2 vj0 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowj + a0), vj1 = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowj + a1);
+        pi[0] = cg < left ? vi0 : z; pi[1] = cg + 8 < left ? vi1 : z;
+        pj[0] = cg < left ? vj0 : z; pj[1] = cg + 8 < left ? vj1 : z;
+    };
+    if (kw >= KC) fetch(base); else fetch_tail(base, kw);
+    base += stage_bytes;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<d2*>(&si[0][cg + 8 * q][2 * rp]) = pi[q];
+        *reinterpret_cast<d2*>(&sj[0][cg + 8 * q][2 * rp]) = pj[q];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const int left = kw - k0 - KC;                  // columns behind this stage
+        if (left > 0) {
+            if (left >= KC) fetch(base); else fetch_tail(base, left);
+            base += stage_bytes;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = sj[cur][kk + l4][wc + l15], a1 = sj[cur][kk + l4][wc + 16 + l15];
+            const double b0 = si[cur][kk + l4][wr + l15], b1 = si[cur][kk + l4][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (left > 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                *reinterpret_cast<d2*>(&si[cur ^ 1][cg + 8 * q][2 * rp]) = pi[q];
+                *reinterpret_cast<d2*>(&sj[cur ^ 1][cg + 8 * q][2 * rp]) = pj[q];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    double cv[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                const bool ok = r < nf && cc < nf && r >= cc;
+                cv[a][b][reg] = F[ok ? r + (size_t)nf * cc : 0];
+            }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (r < nf && cc < nf && r >= cc) F[r + (size_t)nf * cc] = cv[a][b][reg] - acc[a][b][reg];
             }
 }
 
@@ -537,7 +669,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int nt = (nf - kw + TS - 1) / TS;
     const double flops = (double)nfr * nt * (nt + 1) / 2 * 64.0 * 64.0 * kw * 2.0;
-    for (int mode = 0; mode < 22; ++mode)
+    for (int mode = 0; mode < 26; ++mode)
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_var<0>, dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
@@ -562,6 +694,10 @@ int main(int argc, char** argv) {
             if (mode == 19) hipLaunchKernelGGL((k_db2<false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 20) hipLaunchKernelGGL((k_db16<true>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 21) hipLaunchKernelGGL((k_db16<false>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 22) hipLaunchKernelGGL((k_db16<false, 1>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 23) hipLaunchKernelGGL((k_db16<false, 2>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 24) hipLaunchKernelGGL((k_db16<false, 3>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
+            if (mode == 25) hipLaunchKernelGGL((k_sg<0>), dim3(nt, nt, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             if (mode == 9) hipLaunchKernelGGL((k_big<true>), dim3(nb, nb, nfr), dim3(256), 0, 0, F, nf, 0, kw);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));

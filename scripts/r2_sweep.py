@@ -34,11 +34,14 @@ def run(leaf, opts):
 
 
 base = dict()
-cases = [(12, {}), (8, {}), (16, {}), (24, {}),
+cases = [(12, {}), (12, dict(super_panel=256)), (12, dict(super_panel=512)), (12, dict(super_panel=256, super_panel_cnt=15)), (12, dict(super_panel=512, super_panel_cnt=15)),
+         (12, dict(super_panel=512, super_panel_cnt=64, left_min=64)), (12, dict(super_panel=384)), (12, dict(super_panel=1024))]
+if len(sys.argv) > 2 and sys.argv[2] == "all":
+    cases += [(8, {}), (16, {}), (24, {}),
          (12, dict(left_max=8192)), (12, dict(left_max=100000)), (12, dict(left_min=8)), (12, dict(left_min=32)),
          (12, dict(lookahead_cnt=8)), (12, dict(lookahead_cnt=32)), (12, dict(lookahead=0)),
          (12, dict(wide_cnt=1024)), (12, dict(wide_cnt=256)), (12, dict(wide_cnt=2048)), (12, dict(wide_cnt=4096)),
          (12, dict(xinv_small_cnt=8)), (12, dict(xinv_small_cnt=128))]
 for leaf, opts in cases:
     f, su, kr, ad, sw, its = run(leaf, opts)
-    print(f"leaf {leaf:3d} {str(opts):32s} forward {f:7.2f} ms (factor {su:6.2f} + pcg {kr:5.2f}, {its} it)  adjoint {ad:6.2f} ms  apply {sw:5.2f} ms", flush=True)
+    print(f"leaf {leaf:3d} {str(opts):60s} forward {f:7.2f} ms (factor {su:6.2f} + pcg {kr:5.2f}, {its} it)  adjoint {ad:6.2f} ms  apply {sw:5.2f} ms", flush=True)
