@@ -36,6 +36,7 @@ struct femo_ctx {
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
+    hipEvent_t ev_sp[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;           // L11^-1 of a finished level is formed beside the factorisation of the next ones
     hipEvent_t ev_x[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
@@ -82,9 +83,9 @@ struct femo_ctx {
     // schedule switches and failure policy (femo_set_option); never read from the environment
     struct Options {
         int trailing = 0;             // rank-k update schedule: 0 auto, 1 left-looking, 2 right-looking
-        int left_min = 16, left_max = 2048;   // auto: levels with this many fronts are left-looking
+        int left_min = 64, left_max = 2048;   // auto: levels with this many fronts are left-looking
         int lookahead = 1, lookahead_cnt = 16;
-        int super_panel = 0, super_panel_cnt = 32;
+        int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
         int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
         int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
@@ -582,6 +583,17 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             fr.prof_flops[2] += fl; fr.prof_bytes[2] += by;
         };
+        // 64-row tiles a k_trailing_mfma launch needs from its even column anchor down: the largest extent over the chunk's
+        // fronts (a grid sized by the largest front alone launches mostly idle workgroups on levels of small fronts)
+        auto trail_tiles = [&](int C0, int schur, int K0 = 0, int KW = NBO) {
+            int need = 0;
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i], nf = fr.h_nf[t];
+                const TrailRange tr = trail_range(schur, C0, K0, KW, fr.h_npiv[t], nf);
+                if (tr.kw > 0 && tr.col_lo < tr.col_hi) need = std::max(need, nf - (tr.col_lo & ~1));
+            }
+            return (need + TS - 1) / TS;
+        };
         // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
         auto count_panel = [&](int C0) {
             if (!fr.profile) return;
@@ -596,18 +608,29 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
         };
         // right-looking levels with few, large fronts work in super-panels of SP columns: inside one the panels are
-        // updated left-looking with the super-panel's earlier columns only, and everything behind it is updated once,
-        // with K = SP -- the K = 128 update of the whole trailing matrix is HBM-bound (16 flop per byte moved)
+        // updated left-looking, and everything behind it is updated once, with K = SP -- the K = 128 update of the whole
+        // trailing matrix is HBM-bound (16 flop per byte moved).  With "super_panel_ahead" that bulk update runs on the second
+        // stream beside the NEXT super-panel's chain (diagonal block -> rows -> narrow update, latency-bound at the top
+        // of the tree): it leaves the next super-panel's pivot columns out (schur 5), and those columns take the factor
+        // columns of both super-panels in their own narrow updates (K0 = start of the previous super-panel).  Measured at
+        // 1M DOF: slower than the plain super-panel schedule (19.0 against 18.4 ms) -- the one-workgroup-per-front
+        // diagonal-block kernels lose more to sharing their CUs with the bulk update than the overlap gains; off by default.
         const int SP = use_sp ? c->opt.super_panel / NBO * NBO : NBO;
+        const bool sp_ahead = use_sp && c->opt.super_panel_ahead != 0;
+        int sp_bulks = 0;                                // bulk updates of this chunk issued on stream2 so far
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             const int S0 = C0 / SP * SP;                 // start of this panel's super-panel (== C0 when SP == NBO)
-            const int K0 = right_looking ? S0 : 0;
+            const int K0 = !right_looking ? 0 : sp_ahead ? std::max(0, S0 - SP) : S0;
+            if (sp_ahead && C0 == S0 && sp_bulks >= 2)
+                // the bulk update two super-panels back wrote this super-panel's columns
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sp[sp_bulks & 1], 0));
             if (C0 > K0) {
                 // left-looking update of this panel's columns with the factor columns [K0, C0) to their left
                 ProfScope ps(c, 2);
                 count_trailing(C0, 0, K0);
-                const int ntr = (max_nf - C0 + TS - 1) / TS;
+                const int ntr = trail_tiles(C0, 0, K0);
+                if (ntr > 0)
                 FOR_FRONT_CHUNKS(cnt, off, n)
                     hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO);
             }
@@ -630,7 +653,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                                          fd, lev, start, nblk, C0, sw, fr.info);
                   start = end;
               } }
-            const int tiles = (std::max(0, max_nf - C0 - 1) + TS - 1) / TS;
+            int rows_below = 0;                          // rows under the diagonal block, the most over the chunk's fronts
+            for (int i = b; i < e; ++i) {
+                const int t = fr.h_level_nodes[i], np = fr.h_npiv[t];
+                if (np > C0) rows_below = std::max(rows_below, fr.h_nf[t] - C0 - std::min(NBO, np - C0));
+            }
+            const int tiles = (rows_below + TS - 1) / TS;
             if (tiles > 0) {
                 ProfScope ps(c, 0);
                 FOR_FRONT_CHUNKS(cnt, off, n)
@@ -639,21 +667,26 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             if (right_looking && SP > NBO) {
                 if (C0 + NBO >= S0 + SP || C0 + NBO >= max_np) {
                     // the super-panel is complete: one update of everything behind it
-                    int kend = max_nf;                  // first updated column, the smallest over the fronts that take part
-                    for (int i = b; i < e; ++i) {
-                        const int np = fr.h_npiv[fr.h_level_nodes[i]];
-                        if (np > S0) kend = std::min(kend, std::min(S0 + SP, np));
-                    }
-                    const int ntr = (max_nf - (kend & ~1) + TS - 1) / TS;
+                    const int mode = sp_ahead ? 5 : 2;
+                    const int ntr = trail_tiles(S0, mode, 0, SP);
                     if (ntr > 0) {
-                        ProfScope ps(c, 2);
-                        count_trailing(S0, 2, 0, SP);
-                        FOR_FRONT_CHUNKS(cnt, off, n)
-                            hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, S0, 2, 0, SP);
+                        hipStream_t bs = sp_ahead ? c->stream2 : c->stream;
+                        if (sp_ahead) {
+                            HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
+                            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
+                        }
+                        { ProfScope ps(c, 2, bs);
+                          count_trailing(S0, mode, 0, SP);
+                          FOR_FRONT_CHUNKS(cnt, off, n)
+                              hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP); }
+                        if (sp_ahead) {
+                            HIPCHK(c, hipEventRecord(c->ev_sp[sp_bulks & 1], c->stream2));
+                            ++sp_bulks;
+                        }
                     }
                 }
-            } else if (right_looking && max_nf > C0 + 1) {
-                const int ntr = (max_nf - C0 + TS - 1) / TS;     // tiles are anchored at an even column, at most one before the first updated one
+            } else if (right_looking && trail_tiles(C0, 2) > 0) {
+                const int ntr = trail_tiles(C0, 2);              // tiles are anchored at an even column, at most one before the first updated one
                 if (!lookahead) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
@@ -668,7 +701,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     { ProfScope ps(c, 2);
                       count_trailing(C0, 3);
                       hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO); }
-                    const int ntb = ntr - NBO / TS;
+                    const int ntb = trail_tiles(C0, 4);
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
@@ -682,11 +715,13 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
         }
         if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
+        if (sp_bulks > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sp[(sp_bulks - 1) & 1], 0));     // stream2 runs its launches in order
         if (max_nb > 0 && !right_looking) {
             // Schur complement: one update with all npiv factor columns
             ProfScope ps(c, 2);
             count_trailing(0, 1);
-            const int ntr = (max_nb + 1 + TS - 1) / TS;          // + 1: even tile anchor
+            const int ntr = trail_tiles(0, 1);
+            if (ntr > 0)
             FOR_FRONT_CHUNKS(cnt, off, n)
                 hipLaunchKernelGGL(k_trailing_mfma, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO);
         }
@@ -1036,6 +1071,7 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipStreamCreate(&c->stream));
     HIPCHK(c, hipStreamCreate(&c->stream2));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_la[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sp[i], hipEventDisableTiming));
     HIPCHK(c, hipStreamCreate(&c->stream3));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
@@ -1198,8 +1234,10 @@ void femo_destroy(femo_ctx* c) {
     if (c->scal_host) hipHostFree(c->scal_host);
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (c->ev_la[i]) hipEventDestroy(c->ev_la[i]);
+        if (c->ev_sp[i]) hipEventDestroy(c->ev_sp[i]);
+    }
     for (int i = 0; i < 2; ++i)
         if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
     if (c->stream3) hipStreamDestroy(c->stream3);
@@ -1429,6 +1467,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "lookahead_cnt") o.lookahead_cnt = v;
     else if (k == "super_panel") o.super_panel = v;
     else if (k == "super_panel_cnt") o.super_panel_cnt = v;
+    else if (k == "super_panel_ahead") o.super_panel_ahead = v != 0;
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {
         if (c->fr.ready) return fail(c, "wide_np / wide_cnt shape the plan: set them before femo_set_frontal_plan");

@@ -595,7 +595,10 @@ constexpr int LSTR = TS + 16;
 //   schur 2  right-looking: everything behind the factor columns [C0, C0 + KW) is updated with those columns
 //            (KW = 128: after every outer panel; KW = 256, 512: after a super-panel whose own panels were updated
 //            with schur 0 / K0 = C0 -- the Schur complement then moves through HBM once per KW columns);
-//   schur 3, 4  the look-ahead split of 2: only the next 128 columns | everything behind those.
+//   schur 3, 4  the look-ahead split of 2: only the next 128 columns | everything behind those;
+//   schur 5  as 2, but the pivot columns of the NEXT super-panel are left out (columns from min(C0 + 2 KW, npiv)): those
+//            get this super-panel's columns through their own schur 0 updates (K0 = C0), so that this launch can run on
+//            a second stream beside the next super-panel's chain of panels.
 struct TrailRange { int kc0, kw, col_lo, col_hi; };
 __device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int KW, int np, int nf) {
     TrailRange r{0, 0, 0, 0};
@@ -604,7 +607,7 @@ __device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int
     r.kw = schur >= 2 ? (KW < np - C0 ? KW : np - C0) : (schur ? np : C0 - K0);
     // the look-ahead split (3 | 4) sits 128 columns behind the even anchor of the first updated column
     const int split = ((C0 + r.kw) & ~1) + NBO;
-    r.col_lo = schur >= 2 ? (schur == 4 ? split : C0 + r.kw) : (schur ? np : C0);
+    r.col_lo = schur >= 2 ? (schur == 4 ? split : schur == 5 ? (C0 + 2 * KW < np ? C0 + 2 * KW : np) : C0 + r.kw) : (schur ? np : C0);
     r.col_hi = schur == 0 ? (C0 + NBO < np ? C0 + NBO : np) : schur == 3 ? (split < nf ? split : nf) : nf;
     return r;
 }
