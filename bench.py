@@ -329,7 +329,7 @@ def main():
         # flops and compulsory bytes are summed over the launches from each launch's own K / column ranges (femo_hip.hip,
         # count_trailing): lower triangles only, C read + written once, the factor rows of the K panel read once
         tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "k_trailing_mfma<true|false>, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
+        roof = {"bound": "mfma", "kernel": "k_trailing_mfma, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
                 "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic_trailing,
                 "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
                 "algorithmic_bytes_per_launch": prof["trailing_bytes"] / tr["launches"],
