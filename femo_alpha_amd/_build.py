@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mun
 def dependencies():
     """Every file the library is compiled from: the translation units, all headers next to them, the C ABI header."""
     deps = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
-                  + glob.glob(os.path.join(INCLUDE, "*.h")))
+                  + [os.path.join(INCLUDE, "femo_hip.h")])
     return deps
 
 
@@ -68,5 +68,47 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# ---- libfemo_symbolic.so: the analysis phase, host C++ (g++, OpenMP); same content-digest rule
+SYM_LIB = os.path.join(CSRC, "libfemo_symbolic.so")
+SYM_HASHFILE = os.path.join(CSRC, "libfemo_symbolic.srchash")
+SYM_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp"]
+
+
+def symbolic_digest() -> str:
+    h = hashlib.sha256(" ".join(SYM_FLAGS).encode())
+    for d in (os.path.join(CSRC, "symbolic.cpp"), os.path.join(INCLUDE, "femo_symbolic.h")):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def symbolic_needs_build() -> bool:
+    if not os.path.exists(SYM_LIB) or not os.path.exists(SYM_HASHFILE):
+        return True
+    with open(SYM_HASHFILE) as fh:
+        return fh.read().strip() != symbolic_digest()
+
+
+def build_symbolic(force: bool = False) -> str:
+    if not force and not symbolic_needs_build():
+        return SYM_LIB
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("g++ not found: libfemo_symbolic.so cannot be built")
+    digest = symbolic_digest()
+    tmp = SYM_LIB + ".tmp"
+    res = subprocess.run([gxx, *SYM_FLAGS, "-o", tmp, "symbolic.cpp"], cwd=CSRC, capture_output=True, text=True)
+    if res.returncode:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError("g++ failed building libfemo_symbolic.so:\n" + res.stderr[-4000:])
+    os.replace(tmp, SYM_LIB)
+    with open(SYM_HASHFILE, "w") as fh:
+        fh.write(digest + "\n")
+    return SYM_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_symbolic(force=True))

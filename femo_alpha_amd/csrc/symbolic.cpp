@@ -1,0 +1,291 @@
+// Symbolic analysis of the multifrontal Cholesky factorisation -- host code, no GPU involved (include/femo_symbolic.h).
+//
+// The reference hands its assembled Jacobian to MUMPS through PETSc (reference femo_alpha/fea/utils_dolfinx.py:466,
+// 495-531); the analysis phase of that solver (ordering + elimination tree + front structure) is what this file
+// replaces, driven by the mesh instead of a sparse matrix:
+//   1. nested dissection of the ELEMENTS by recursive coordinate bisection (stable sort along the longest extent of the
+//      centroids, split in the middle) down to leaves of <= leaf_size cells;
+//   2. every P2 node is eliminated at the deepest tree node whose element interval holds all its elements;
+//   3. front of a tree node = the DOFs of its own nodes (pivots) + the DOFs of the ancestor-owned nodes its subtree
+//      touches (boundary), children's boundaries merged upwards;
+//   4. index maps: boundary row of a child -> row of its parent, element DOF -> row of its leaf front; levels by height.
+// The host-side Python module femo_alpha_amd/solver/symbolic.py states the same algorithm in numpy and is kept as the
+// cross-check (tests/test_symbolic_native.py compares every array).  The tree shape depends on the element count only, so
+// it is laid out first; the sorts of one depth are independent and run in parallel (OpenMP).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/femo_symbolic.h"
+
+namespace {
+
+struct Plan {
+    std::map<std::string, std::vector<int32_t>> i32;
+    std::map<std::string, std::vector<int64_t>> i64;
+    std::string error;
+};
+
+thread_local std::string g_error;
+
+template <class T>
+std::vector<T>& put(std::map<std::string, std::vector<T>>& m, const char* name) { return m[name]; }
+
+}   // namespace
+
+struct femo_plan : Plan {};
+
+extern "C" {
+
+const char* femo_plan_last_error(void) { return g_error.c_str(); }
+
+void femo_plan_free(femo_plan* p) { delete p; }
+
+int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                    const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth) {
+    if (!out || nel < 1 || nP2 < 1 || nV < 1 || npc < 1 || ndpc < 1 || !cell_p2 || !cent || !cell_dofs || leaf_size < 1 || min_depth < 0) {
+        g_error = "femo_plan_build: bad arguments";
+        return 1;
+    }
+    const int64_t ndof_u = 3 * (int64_t)nP2;
+    // ---- 1a. shape of the bisection tree (same creation order as a stack-driven recursion: children of the node
+    //          popped last come first)
+    std::vector<int32_t> lo{0}, hi{nel}, left{-1}, right{-1}, parent{-1}, depth{0};
+    {
+        std::vector<int32_t> stack{0};
+        while (!stack.empty()) {
+            const int32_t t = stack.back(); stack.pop_back();
+            const int32_t a = lo[t], b = hi[t];
+            if (b - a <= leaf_size && depth[t] >= min_depth) continue;
+            if (b - a < 2) { g_error = "mesh too small for the requested number of partitions"; return 2; }
+            const int32_t mid = a + (b - a) / 2;
+            for (int side = 0; side < 2; ++side) {
+                const int32_t id = (int32_t)lo.size();
+                lo.push_back(side ? mid : a); hi.push_back(side ? b : mid); left.push_back(-1); right.push_back(-1);
+                parent.push_back(t); depth.push_back(depth[t] + 1);
+                (side ? right : left)[t] = id;
+                stack.push_back(id);
+            }
+        }
+    }
+    const int32_t ntree = (int32_t)lo.size();
+    int32_t maxdepth = 0;
+    for (int32_t t = 0; t < ntree; ++t) maxdepth = std::max(maxdepth, depth[t]);
+    // ---- 1b. the sorts, depth by depth
+    std::vector<int32_t> eorder(nel);
+    std::iota(eorder.begin(), eorder.end(), 0);
+    {
+        std::vector<std::vector<int32_t>> by_depth(maxdepth + 1);
+        for (int32_t t = 0; t < ntree; ++t)
+            if (left[t] >= 0) by_depth[depth[t]].push_back(t);
+        for (int32_t d = 0; d <= maxdepth; ++d) {
+            const auto& nodes = by_depth[d];
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t k = 0; k < (int64_t)nodes.size(); ++k) {
+                const int32_t t = nodes[k], a = lo[t], b = hi[t];
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int32_t i = a; i < b; ++i)
+                    for (int c = 0; c < 3; ++c) {
+                        const double v = cent[3 * (int64_t)eorder[i] + c];
+                        mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v);
+                    }
+                int ax = 0;
+                for (int c = 1; c < 3; ++c)
+                    if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;          // first of equal extents, as numpy's argmax
+                std::stable_sort(eorder.begin() + a, eorder.begin() + b,
+                                 [&](int32_t x, int32_t y) { return cent[3 * (int64_t)x + ax] < cent[3 * (int64_t)y + ax]; });
+            }
+        }
+    }
+    std::vector<int32_t> epos(nel);
+    for (int32_t i = 0; i < nel; ++i) epos[eorder[i]] = i;
+    // ---- 2. owners
+    std::vector<int32_t> amin(nP2, nel), amax(nP2, -1);
+    for (int32_t e = 0; e < nel; ++e)
+        for (int a = 0; a < npc; ++a) {
+            const int32_t n = cell_p2[(int64_t)e * npc + a];
+            if (n < 0 || n >= nP2) { g_error = "cell_p2 entry out of range"; return 3; }
+            amin[n] = std::min(amin[n], epos[e]); amax[n] = std::max(amax[n], epos[e]);
+        }
+    std::vector<int32_t> owner(nP2, 0);
+#pragma omp parallel for schedule(static)
+    for (int32_t n = 0; n < nP2; ++n) {
+        int32_t t = 0;
+        while (left[t] >= 0) {
+            const int32_t mid = lo[right[t]];
+            if (amax[n] < mid) t = left[t];
+            else if (amin[n] >= mid) t = right[t];
+            else break;
+        }
+        owner[n] = t;
+    }
+    std::vector<int32_t> height(ntree, 0);
+    for (int32_t t = ntree - 1; t >= 0; --t)                                    // children have larger ids than their parent
+        if (left[t] >= 0) height[t] = 1 + std::max(height[left[t]], height[right[t]]);
+    // pivot nodes per tree node: ascending node id
+    std::vector<int64_t> piv_off(ntree + 1, 0);
+    for (int32_t n = 0; n < nP2; ++n) ++piv_off[owner[n] + 1];
+    for (int32_t t = 0; t < ntree; ++t) piv_off[t + 1] += piv_off[t];
+    std::vector<int32_t> piv_nodes(nP2);
+    {
+        std::vector<int64_t> fill(piv_off.begin(), piv_off.end() - 1);
+        for (int32_t n = 0; n < nP2; ++n) piv_nodes[fill[owner[n]]++] = n;
+    }
+    // ---- 3. boundary nodes, bottom-up (sorted ascending; union of the children's lists minus the node's own)
+    std::vector<std::vector<int32_t>> bnd(ntree);
+    {
+        std::vector<std::vector<int32_t>> by_depth(maxdepth + 1);
+        for (int32_t t = 0; t < ntree; ++t) by_depth[depth[t]].push_back(t);
+        for (int32_t d = maxdepth; d >= 0; --d) {
+            const auto& nodes = by_depth[d];
+#pragma omp parallel for schedule(dynamic, 16)
+            for (int64_t k = 0; k < (int64_t)nodes.size(); ++k) {
+                const int32_t t = nodes[k];
+                std::vector<int32_t> u;
+                if (left[t] < 0) {
+                    for (int32_t i = lo[t]; i < hi[t]; ++i)
+                        for (int a = 0; a < npc; ++a) u.push_back(cell_p2[(int64_t)eorder[i] * npc + a]);
+                    std::sort(u.begin(), u.end());
+                    u.erase(std::unique(u.begin(), u.end()), u.end());
+                } else {
+                    const auto &x = bnd[left[t]], &y = bnd[right[t]];
+                    u.resize(x.size() + y.size());
+                    u.erase(std::set_union(x.begin(), x.end(), y.begin(), y.end(), u.begin()), u.end());
+                }
+                auto& b = bnd[t];
+                b.reserve(u.size());
+                for (int32_t n : u)
+                    if (owner[n] != t) b.push_back(n);
+            }
+        }
+    }
+    std::vector<int64_t> bnd_off(ntree + 1, 0);
+    for (int32_t t = 0; t < ntree; ++t) bnd_off[t + 1] = bnd_off[t] + (int64_t)bnd[t].size();
+    std::vector<int32_t> bnd_nodes(bnd_off[ntree]);
+    for (int32_t t = 0; t < ntree; ++t) std::copy(bnd[t].begin(), bnd[t].end(), bnd_nodes.begin() + bnd_off[t]);
+    // ---- front DOF lists: pivots first, then the boundary; a vertex node carries u and theta (6 DOFs), the others u (3)
+    auto ndofs_of = [&](int32_t n) { return n < nV ? 6 : 3; };
+    std::vector<int32_t> npiv(ntree), nf(ntree);
+    std::vector<int64_t> dof_off(ntree + 1, 0);
+    for (int32_t t = 0; t < ntree; ++t) {
+        int64_t a = 0, b = 0;
+        for (int64_t i = piv_off[t]; i < piv_off[t + 1]; ++i) a += ndofs_of(piv_nodes[i]);
+        for (int32_t n : bnd[t]) b += ndofs_of(n);
+        if (a + b > INT32_MAX) { g_error = "front too large"; return 4; }
+        npiv[t] = (int32_t)a; nf[t] = (int32_t)(a + b);
+        dof_off[t + 1] = dof_off[t] + a + b;
+    }
+    if (ndof_u + 3 * (int64_t)nV > INT32_MAX) { g_error = "more than 2^31 DOFs"; return 4; }
+    std::vector<int32_t> front_dofs(dof_off[ntree]);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int32_t t = 0; t < ntree; ++t) {
+        int64_t w = dof_off[t];
+        auto emit = [&](int32_t n) {
+            for (int c = 0; c < 3; ++c) front_dofs[w++] = 3 * n + c;
+            if (n < nV)
+                for (int c = 0; c < 3; ++c) front_dofs[w++] = (int32_t)(ndof_u + 3 * (int64_t)n + c);
+        };
+        for (int64_t i = piv_off[t]; i < piv_off[t + 1]; ++i) emit(piv_nodes[i]);
+        for (int32_t n : bnd[t]) emit(n);
+    }
+    // ---- 4. index maps.  Position of a DOF inside a front: sorted copy of the front's list + binary search
+    //         (fronts are independent: parallel over parents / leaves)
+    std::vector<int32_t> up_map(dof_off[ntree], -1);
+    std::vector<int32_t> leaf_of_pos(nel, 0);
+    for (int32_t t = 0; t < ntree; ++t)
+        if (left[t] < 0)
+            for (int32_t i = lo[t]; i < hi[t]; ++i) leaf_of_pos[i] = t;
+    std::vector<int32_t> elem_front(nel);
+    for (int32_t e = 0; e < nel; ++e) elem_front[e] = leaf_of_pos[epos[e]];
+    std::vector<int32_t> elem_map((int64_t)nel * ndpc);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+    for (int32_t t = 0; t < ntree; ++t) {
+        const int32_t n = nf[t];
+        const int32_t* fd = front_dofs.data() + dof_off[t];
+        std::vector<std::pair<int32_t, int32_t>> srt(n);
+        for (int32_t i = 0; i < n; ++i) srt[i] = {fd[i], i};
+        std::sort(srt.begin(), srt.end());
+        auto find = [&](int32_t dof) {
+            auto it = std::lower_bound(srt.begin(), srt.end(), std::make_pair(dof, (int32_t)-1));
+            if (it == srt.end() || it->first != dof) { bad |= 1; return -1; }
+            return it->second;
+        };
+        if (left[t] >= 0) {
+            for (int32_t ch : {left[t], right[t]})
+                for (int64_t i = dof_off[ch] + npiv[ch]; i < dof_off[ch + 1]; ++i) up_map[i] = find(front_dofs[i]);
+        } else {
+            for (int32_t i = lo[t]; i < hi[t]; ++i) {
+                const int32_t e = eorder[i];
+                for (int k = 0; k < ndpc; ++k) elem_map[(int64_t)e * ndpc + k] = find(cell_dofs[(int64_t)e * ndpc + k]);
+            }
+        }
+    }
+    if (bad) { g_error = "a boundary or element DOF is missing from the front that should hold it"; return 5; }
+    // levels by height; inside a level the largest fronts first (stable)
+    int32_t nlevels = 0;
+    for (int32_t t = 0; t < ntree; ++t) nlevels = std::max(nlevels, height[t] + 1);
+    std::vector<int64_t> level_off(nlevels + 1, 0);
+    for (int32_t t = 0; t < ntree; ++t) ++level_off[height[t] + 1];
+    for (int32_t h = 0; h < nlevels; ++h) level_off[h + 1] += level_off[h];
+    std::vector<int32_t> level_nodes(ntree);
+    {
+        std::vector<int64_t> fill(level_off.begin(), level_off.end() - 1);
+        for (int32_t t = 0; t < ntree; ++t) level_nodes[fill[height[t]]++] = t;
+        for (int32_t h = 0; h < nlevels; ++h)
+            std::stable_sort(level_nodes.begin() + level_off[h], level_nodes.begin() + level_off[h + 1],
+                             [&](int32_t a, int32_t b) { return nf[a] > nf[b]; });
+    }
+    femo_plan* p = new femo_plan;
+    p->i32["lo"] = std::move(lo); p->i32["hi"] = std::move(hi); p->i32["left"] = std::move(left); p->i32["right"] = std::move(right);
+    p->i32["parent"] = std::move(parent); p->i32["depth"] = std::move(depth); p->i32["height"] = std::move(height);
+    p->i32["eorder"] = std::move(eorder); p->i32["epos"] = std::move(epos); p->i32["owner"] = std::move(owner);
+    p->i32["piv_nodes"] = std::move(piv_nodes); p->i64["piv_off"] = std::move(piv_off);
+    p->i32["bnd_nodes"] = std::move(bnd_nodes); p->i64["bnd_off"] = std::move(bnd_off);
+    p->i32["npiv"] = std::move(npiv); p->i32["nf"] = std::move(nf); p->i64["dof_off"] = std::move(dof_off);
+    p->i32["front_dofs"] = std::move(front_dofs); p->i32["up_map"] = std::move(up_map);
+    p->i32["elem_front"] = std::move(elem_front); p->i32["elem_map"] = std::move(elem_map);
+    p->i32["level_nodes"] = std::move(level_nodes); p->i64["level_off"] = std::move(level_off);
+    *out = p;
+    return 0;
+}
+
+int64_t femo_plan_size(const femo_plan* p, const char* name) {
+    if (!p || !name) return -1;
+    auto a = p->i32.find(name);
+    if (a != p->i32.end()) return (int64_t)a->second.size();
+    auto b = p->i64.find(name);
+    if (b != p->i64.end()) return (int64_t)b->second.size();
+    return -1;
+}
+
+int femo_plan_itemsize(const femo_plan* p, const char* name) {
+    if (!p || !name) return 0;
+    if (p->i32.count(name)) return 4;
+    if (p->i64.count(name)) return 8;
+    return 0;
+}
+
+int femo_plan_get(const femo_plan* p, const char* name, void* dst, int64_t nbytes) {
+    if (!p || !name || !dst) { g_error = "femo_plan_get: bad arguments"; return 1; }
+    auto a = p->i32.find(name);
+    if (a != p->i32.end()) {
+        if (nbytes != (int64_t)a->second.size() * 4) { g_error = std::string("femo_plan_get: wrong size for ") + name; return 2; }
+        std::memcpy(dst, a->second.data(), nbytes);
+        return 0;
+    }
+    auto b = p->i64.find(name);
+    if (b != p->i64.end()) {
+        if (nbytes != (int64_t)b->second.size() * 8) { g_error = std::string("femo_plan_get: wrong size for ") + name; return 2; }
+        std::memcpy(dst, b->second.data(), nbytes);
+        return 0;
+    }
+    g_error = std::string("femo_plan_get: no array named ") + name;
+    return 3;
+}
+
+}   // extern "C"

@@ -122,9 +122,13 @@ class ShellMesh:
 
     def cell_dofs(self):
         """(nel, ldof) global DOF numbers, element-local order [u_a xyz ..., theta_b xyz ...]."""
-        u = (3 * self.cell_p2[:, :, None] + np.arange(3)[None, None, :]).reshape(self.nel, -1)
-        t = (self.ndof_u + 3 * self.cells[:, :, None] + np.arange(3)[None, None, :]).reshape(self.nel, -1)
-        return np.hstack([u, t]).astype(np.int32)
+        npc, nvc = self.cell_p2.shape[1], self.cells.shape[1]
+        out = np.empty((self.nel, 3 * npc + 3 * nvc), dtype=np.int32)
+        p3, v3 = 3 * self.cell_p2.astype(np.int32), np.int32(self.ndof_u) + 3 * self.cells.astype(np.int32)
+        for c in range(3):
+            out[:, c:3 * npc:3] = p3 + np.int32(c)
+            out[:, 3 * npc + c::3] = v3 + np.int32(c)
+        return out
 
     def p2_integrals(self, nquad=4):
         """(nel, npc): int N2_a dS over every cell, N2 the P2 basis of the mid-surface displacement in ``cell_p2`` order --

@@ -1,0 +1,64 @@
+"""ctypes binding of libfemo_symbolic.so (include/femo_symbolic.h): the analysis phase in host C++."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _build
+
+_lib = None
+_i32p = C.POINTER(C.c_int32)
+
+SIGNATURES = {
+    "femo_plan_build": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p,
+                                  C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32]),
+    "femo_plan_size": (C.c_int64, [C.c_void_p, C.c_char_p]),
+    "femo_plan_itemsize": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "femo_plan_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "femo_plan_free": (None, [C.c_void_p]),
+    "femo_plan_last_error": (C.c_char_p, []),
+}
+
+ARRAYS = ("lo", "hi", "left", "right", "parent", "depth", "height", "eorder", "epos", "owner", "piv_nodes", "piv_off",
+          "bnd_nodes", "bnd_off", "npiv", "nf", "dof_off", "front_dofs", "up_map", "elem_front", "elem_map", "level_nodes",
+          "level_off")
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = _build.build_symbolic() if _build.symbolic_needs_build() else _build.SYM_LIB
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def plan_arrays(mesh, leaf_size, min_depth=0):
+    """All arrays of include/femo_symbolic.h for ``mesh`` as a dict of numpy arrays."""
+    lib = load()
+    cell_p2 = np.ascontiguousarray(mesh.cell_p2, dtype=np.int32)
+    cent = np.ascontiguousarray(mesh.nodes[mesh.cells].mean(axis=1), dtype=np.float64)
+    cell_dofs = np.ascontiguousarray(mesh.cell_dofs(), dtype=np.int32)
+    h = C.c_void_p()
+    rc = lib.femo_plan_build(C.byref(h), mesh.nel, mesh.nP2, mesh.nV, cell_p2.shape[1], cell_dofs.shape[1],
+                             cell_p2.ctypes.data_as(_i32p), cent.ctypes.data_as(C.POINTER(C.c_double)),
+                             cell_dofs.ctypes.data_as(_i32p), int(leaf_size), int(min_depth))
+    if rc:
+        msg = lib.femo_plan_last_error().decode()
+        raise ValueError(msg) if rc == 2 else RuntimeError(msg)
+    try:
+        out = {}
+        for name in ARRAYS:
+            n, isz = lib.femo_plan_size(h, name.encode()), lib.femo_plan_itemsize(h, name.encode())
+            a = np.empty(n, dtype=np.int32 if isz == 4 else np.int64)
+            if lib.femo_plan_get(h, name.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes):
+                raise RuntimeError(lib.femo_plan_last_error().decode())
+            out[name] = a
+    finally:
+        lib.femo_plan_free(h)
+    out["elem_map"] = out["elem_map"].reshape(mesh.nel, -1)
+    return out

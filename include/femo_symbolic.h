@@ -1,0 +1,48 @@
+/* femo_symbolic.h -- C ABI of libfemo_symbolic.so: the analysis phase of the multifrontal Cholesky factorisation
+ * (host code only; the numeric phase is libfemo_hip.so, femo_hip.h: femo_set_frontal_plan takes the arrays built here).
+ *
+ * Replaces the analysis MUMPS runs inside the reference's `setUpKSP_MUMPS` / `solveNonlinear` LU solves
+ * (reference femo_alpha/fea/utils_dolfinx.py:466, 495-531), driven by the mesh instead of an assembled matrix:
+ * nested dissection of the elements by coordinate bisection, elimination tree, front structure and index maps.
+ *
+ * Arrays are read back by name with femo_plan_size / femo_plan_itemsize / femo_plan_get:
+ *   tree (one entry per tree node, ids in creation order, children > parent):
+ *     "lo", "hi"        element interval [lo, hi) of the node in "eorder"        int32
+ *     "left", "right", "parent", "depth", "height"                               int32
+ *   elements:  "eorder" (bisection order -> cell), "epos" (cell -> position)     int32
+ *              "elem_front" (cell -> leaf front), "elem_map" (nel x ndpc: row of every element DOF in its leaf front)
+ *   nodes:     "owner" (P2 node -> tree node that eliminates it)                  int32
+ *              "piv_nodes" / "piv_off", "bnd_nodes" / "bnd_off": per tree node its own nodes and the ancestor-owned
+ *              nodes its subtree touches, ascending (CSR; offsets int64)
+ *   fronts:    "npiv", "nf" (pivot DOFs, all DOFs), "dof_off" (int64), "front_dofs" (pivots first),
+ *              "up_map" (row of every boundary DOF in the parent front, -1 on pivots)
+ *   schedule:  "level_nodes" / "level_off": fronts by height, largest first inside a level
+ */
+#ifndef FEMO_SYMBOLIC_H
+#define FEMO_SYMBOLIC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct femo_plan femo_plan;
+
+/* Build the plan.  cell_p2: nel x npc P2 node ids (row-major); cent: nel x 3 cell centroids; cell_dofs: nel x ndpc global
+ * DOF numbers in element-local order (u of the P2 nodes, then theta of the vertices); P2 nodes < nV are vertices and carry
+ * 6 DOFs (u: 3 n + c, theta: 3 nP2 + 3 n + c), the others 3.  leaf_size: cells per leaf; min_depth: every branch is split
+ * at least that deep (2^d subtrees for d-level element partitions).  Returns 0, or an error code with
+ * femo_plan_last_error() set. */
+int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                    const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth);
+/* number of entries of a named array (-1: no such array); 4 or 8 bytes per entry (0: no such array) */
+int64_t femo_plan_size(const femo_plan* p, const char* name);
+int femo_plan_itemsize(const femo_plan* p, const char* name);
+/* copy a named array out; nbytes must be size * itemsize */
+int femo_plan_get(const femo_plan* p, const char* name, void* dst, int64_t nbytes);
+void femo_plan_free(femo_plan* p);
+const char* femo_plan_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

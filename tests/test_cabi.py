@@ -26,6 +26,20 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.femo_version() >= 100
 
 
+def test_symbolic_library_builds_and_exports_every_declared_symbol():
+    from femo_alpha_amd import _build
+    from femo_alpha_amd.solver import _native
+    _build.build_symbolic()
+    lib = _native.load()
+    text = open(os.path.join(ROOT, "include", "femo_symbolic.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(femo_plan_[a-z_A-Z0-9]+)\s*\(", text)))
+    assert len(syms) == 6
+    for s in syms:
+        assert hasattr(lib, s), f"libfemo_symbolic.so does not export {s}"
+    assert sorted(_native.SIGNATURES) == syms, "ctypes SIGNATURES and include/femo_symbolic.h disagree"
+
+
 def test_product_path_fails_loudly_without_a_gpu():
     from femo_alpha_amd import _lib
     from femo_alpha_amd.backend import ShellContext

@@ -1,0 +1,71 @@
+"""The analysis phase in host C++ (csrc/symbolic.cpp, include/femo_symbolic.h) against the numpy statement of the same
+algorithm (solver/symbolic.py, impl="python"): every array of the plan and of the tree, entry by entry, on quads,
+triangles, a branching surface, shuffled numberings, one-cell meshes and forced partition depths."""
+import numpy as np
+import pytest
+
+from femo_alpha_amd.mesh import plate_mesh, quads_to_triangles, tee_beam_mesh, wing_skin_mesh
+from femo_alpha_amd.solver import symbolic
+
+MESHES = {
+    "plate": lambda: plate_mesh(2.0, 10.0, 10, 50),
+    "wing": lambda: wing_skin_mesh(12, 30, shuffle=True),
+    "tri": lambda: quads_to_triangles(wing_skin_mesh(7, 11, shuffle=True)),
+    "tee": lambda: tee_beam_mesh(1.0, 0.5, 5.0, 4, 2, 10),
+    "one_cell": lambda: plate_mesh(1.0, 1.0, 1, 1),
+    "renumbered": lambda: wing_skin_mesh(9, 17, shuffle=True).renumbered()[0],
+}
+PLAN_ARRAYS = ("npiv", "nf", "parent", "left", "right", "front_dofs", "up_map", "elem_front", "elem_map", "height", "eorder",
+               "dof_off", "front_off")
+
+
+def _same_plan(a, b):
+    for k in ("ntree", "nlevels", "nleaves"):
+        assert getattr(a, k) == getattr(b, k), k
+    for k in PLAN_ARRAYS:
+        x, y = np.asarray(getattr(a, k)), np.asarray(getattr(b, k))
+        assert x.shape == y.shape and np.array_equal(x, y), k
+    assert len(a.level_nodes) == len(b.level_nodes)
+    for x, y in zip(a.level_nodes, b.level_nodes):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name", sorted(MESHES))
+@pytest.mark.parametrize("leaf", [1, 5, 12])
+def test_native_plan_equals_the_numpy_plan(name, leaf):
+    m = MESHES[name]()
+    _same_plan(symbolic.build_plan(m, leaf, impl="python"), symbolic.build_plan(m, leaf))
+
+
+@pytest.mark.parametrize("name,depth", [("plate", 2), ("wing", 3), ("tri", 1)])
+def test_native_tree_equals_the_numpy_tree(name, depth):
+    m = MESHES[name]()
+    a = symbolic.analyse(m, 6, min_depth=depth, impl="python")
+    b = symbolic.analyse(m, 6, min_depth=depth)
+    assert a.ntree == b.ntree
+    for k in ("lo", "hi", "left", "right", "parent", "depth", "height", "eorder", "epos", "owner"):
+        assert np.array_equal(np.asarray(getattr(a, k)), np.asarray(getattr(b, k))), k
+    for t in range(a.ntree):
+        assert np.array_equal(a.piv_nodes[t], b.piv_nodes[t])
+        assert np.array_equal(a.bnd_nodes[t], b.bnd_nodes[t])
+
+
+def test_every_dof_is_eliminated_exactly_once_and_maps_are_consistent():
+    m = MESHES["wing"]()
+    p = symbolic.build_plan(m, 8)
+    piv = np.concatenate([p.front_dofs[p.dof_off[t]:p.dof_off[t] + p.npiv[t]] for t in range(p.ntree)])
+    assert np.array_equal(np.sort(piv), np.arange(m.ndof))
+    for t in range(p.ntree):
+        par = p.parent[t]
+        if par >= 0:
+            rows = p.up_map[p.dof_off[t] + p.npiv[t]:p.dof_off[t + 1]]
+            assert np.array_equal(p.front_dofs[p.dof_off[par] + rows], p.front_dofs[p.dof_off[t] + p.npiv[t]:p.dof_off[t + 1]])
+    cd = m.cell_dofs()
+    for e in range(0, m.nel, 7):
+        t = p.elem_front[e]
+        assert np.array_equal(p.front_dofs[p.dof_off[t] + p.elem_map[e]], cd[e])
+
+
+def test_too_few_cells_for_the_requested_depth_is_an_error():
+    with pytest.raises(ValueError):
+        symbolic.analyse(plate_mesh(1.0, 1.0, 1, 2), 1, min_depth=3)
