@@ -823,7 +823,7 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
                 FOR_FRONT_CHUNKS(cnt, off, n)
                     hipLaunchKernelGGL(k_sweep_gemv_n<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
-            const size_t shm = (size_t)(maxnp + NB) * sizeof(double);
+            const size_t shm = (size_t)(maxnp + SMALL_PART) * sizeof(double);
             hipLaunchKernelGGL(k_front_fwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, v, y);
             mark();
         }
@@ -865,7 +865,7 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
             FOR_FRONT_CHUNKS(cnt, off, n)
                 hipLaunchKernelGGL(k_sweep_gemv_t<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
-            const size_t shm = (size_t)(maxnp + maxnb + NB) * sizeof(double);
+            const size_t shm = (size_t)(maxnp + maxnb + SMALL_PART) * sizeof(double);
             hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
             mark();
         }
@@ -1886,10 +1886,10 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipMalloc((void**)&fr.S, (size_t)std::max<long long>(fr.s_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
-    // dynamic LDS of the one-workgroup-per-front sweeps: forward maxnp + NB, backward maxnp + maxnb + NB doubles, where
-    // the two maxima of a level may come from different fronts
-    int max_sweep = fr.max_nf + NB;
-    for (int L = 0; L < nlevels; ++L) max_sweep = std::max(max_sweep, fr.h_level_maxnp[L] + fr.h_level_maxnb[L] + NB);
+    // dynamic LDS of the one-workgroup-per-front sweeps: forward maxnp + SMALL_PART, backward maxnp + maxnb + SMALL_PART
+    // doubles, where the two maxima of a level may come from different fronts
+    int max_sweep = fr.max_nf + SMALL_PART;
+    for (int L = 0; L < nlevels; ++L) max_sweep = std::max(max_sweep, fr.h_level_maxnp[L] + fr.h_level_maxnb[L] + SMALL_PART);
     if ((size_t)max_sweep * sizeof(double) > 150 * 1024) return fail(c, "largest front does not fit the LDS solve kernels");
     if ((size_t)max_sweep * sizeof(double) > 48 * 1024) {
         const int bytes = (int)(max_sweep * sizeof(double));

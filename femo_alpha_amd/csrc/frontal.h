@@ -758,8 +758,14 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
 // ---- small fronts (tree levels whose largest pivot block is <= WIDE_NP): one workgroup per front does the
 // whole sweep of that front; inner loops are unrolled so that many loads are in flight per thread.
 
+// Both kernels are latency-bound per workgroup (a front is 100-300 KB, a level has one to a few rounds of workgroups):
+// every phase spreads its loads over all 256 threads -- lanes along the rows of the column-major factor, thread groups
+// along the columns, partial sums joined through LDS -- so that a phase is one or two batches of loads in flight, not a
+// loop of dependent batches on 32 or 100 active threads (measured at 1M DOF: levels 1-3 70-89 -> see DESIGN.md).
+constexpr int SMALL_PART = 512;      // doubles of LDS for the partial sums of a phase
+
 // forward: y_p = L11^-1 v_p -> yv ; v_B -= L21 y_p
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v, double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -768,44 +774,85 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
     const int ldp = ldp_of(nf);
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
-    double* y = sh;            // np
-    double* yk = sh + np;      // NB
-    for (int p = threadIdx.x; p < np; p += blockDim.x) y[p] = v[gd[p]];
+    double* y = sh;              // np
+    double* part = sh + np;      // SMALL_PART
+    const int tid = threadIdx.x;
+    for (int p = tid; p < np; p += 256) y[p] = v[gd[p]];
     __syncthreads();
     const int npan = (np + NB - 1) / NB;
     for (int k = 0; k < npan; ++k) {
         const int c0 = k * NB, wb = min(NB, np - c0);
         const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-        if (threadIdx.x < wb) {
-            const int r = threadIdx.x;
+        {   // y_k = Linv_k y[c0 .. c0 + wb): thread (row r, group g) takes the columns g, g + 8, g + 16, g + 24 that are <= r
+            const int r = tid & 31, g = tid >> 5;
+            double a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int mm = g + 8 * q; a[q] = (mm <= r && r < wb) ? Li[r + NB * mm] : 0.0; }
             double s = 0.0;
-#pragma unroll 8
-            for (int mm = 0; mm <= r; ++mm) s += Li[r + NB * mm] * y[c0 + mm];
-            yk[r] = s;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int mm = g + 8 * q; s += a[q] * y[c0 + min(mm, wb - 1)]; }
+            part[32 * g + r] = s;
         }
         __syncthreads();
-        if (threadIdx.x < wb) y[c0 + threadIdx.x] = yk[threadIdx.x];
-        for (int r = c0 + wb + threadIdx.x; r < np; r += blockDim.x) {
+        if (tid < 32) {
             double s = 0.0;
-            const double* row = F + r + (size_t)ldp * c0;
-#pragma unroll 8
-            for (int mm = 0; mm < wb; ++mm) s += row[(size_t)ldp * mm] * yk[mm];
-            y[r] -= s;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += part[32 * g + tid];
+            part[256 + tid] = s;                               // y_k, read by the update below
+            if (tid < wb) y[c0 + tid] = s;
         }
         __syncthreads();
+        // the pivot rows below the panel: y[r] -= L11[r][c0 .. c0 + wb) y_k; thread (row slot tid & 127, half tid >> 7)
+        const int r1 = c0 + wb;
+        if (r1 < np) {
+            const int h = tid >> 7;
+            for (int rb = r1; rb < np; rb += 128) {
+                const int r = rb + (tid & 127);
+                double a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const int mm = 16 * h + q; a[q] = (r < np && mm < wb) ? F[r + (size_t)ldp * (c0 + mm)] : 0.0; }
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += a[q] * part[256 + 16 * h + q];
+                if (h) part[tid & 127] = s;
+                __syncthreads();
+                if (!h && r < np) y[r] -= s + part[tid & 127];
+                __syncthreads();
+            }
+        }
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) yv[gd[p]] = y[p];
-    for (int r = np + threadIdx.x; r < nf; r += blockDim.x) {
-        double s = 0.0;
-        const double* row = F + r;
-#pragma unroll 8
-        for (int c = 0; c < np; ++c) s += row[(size_t)ldp * c] * y[c];
-        atomicAdd(&v[gd[r]], -s);
+    for (int p = tid; p < np; p += 256) yv[gd[p]] = y[p];
+    // v_B -= L21 y: row slots of 64, 128 or 256 and 4, 2 or 1 column groups, 16 loads in flight per thread
+    const int nb = nf - np;
+    if (nb > 0) {
+        const int slots = nb <= 64 ? 64 : nb <= 128 ? 128 : 256, G = 256 / slots;
+        const int rs = tid % slots, g = tid / slots;
+        const int cper = (np + G - 1) / G, cbeg = g * cper, cend = min(np, cbeg + cper);
+        for (int rb = 0; rb < nb; rb += slots) {
+            const int r = rb + rs;
+            const double* row = F + np + min(r, nb - 1);
+            double s = 0.0;
+            for (int cb = cbeg; cb < cend; cb += 16) {
+                double a[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = cb + q < cend ? row[(size_t)ldp * (cb + q)] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += a[q] * y[min(cb + q, np - 1)];
+            }
+            if (G > 1) {
+                if (g) part[slots * (g - 1) + rs] = s;
+                __syncthreads();
+                if (!g)
+                    for (int gg = 1; gg < G; ++gg) s += part[slots * (gg - 1) + rs];
+            }
+            if (!g && r < nb) atomicAdd(&v[gd[np + r]], -s);
+            if (G > 1) __syncthreads();
+        }
     }
 }
 
 // backward: x_p = L11^-T (y_p - L21^T x_B)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -814,34 +861,93 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
     const int ldp = ldp_of(nf);
     const int* gd = fd.dofs + fd.doff[t];
     extern __shared__ double sh[];
-    double* x = sh;            // nf
-    double* sk = sh + nf;      // NB
-    for (int p = threadIdx.x; p < nf; p += blockDim.x) x[p] = p < np ? sv[gd[p]] : xv[gd[p]];
+    double* x = sh;              // nf: s_p (then x_p) in [0, np), x_B behind
+    double* part = sh + nf;      // SMALL_PART
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int p = tid; p < nf; p += 256) x[p] = p < np ? sv[gd[p]] : xv[gd[p]];
     __syncthreads();
-    const int npan = (np + NB - 1) / NB;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int k = npan - 1; k >= 0; --k) {
-        const int c0 = k * NB, wb = min(NB, np - c0);
-        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
-        for (int c = wid; c < wb; c += nw) {
-            double s = 0.0;
-            const double* col = F + (size_t)ldp * (c0 + c);
-#pragma unroll 4
-            for (int r = c0 + wb + lane; r < nf; r += 64) s += col[r] * x[r];
-            s = wave_sum(s);
-            if (lane == 0) sk[c] = x[c0 + c] - s;
-        }
-        __syncthreads();
-        if (threadIdx.x < wb) {
-            const int c = threadIdx.x;
-            double s = 0.0;
-#pragma unroll 8
-            for (int r = c; r < wb; ++r) s += Li[r + NB * c] * sk[r];
-            x[c0 + c] = s;
+    // s_p -= L21^T x_B: a wave takes eight columns at a time, lanes along the rows, up to four row chunks: 32 loads in
+    // flight per lane, then eight wave reductions
+    const int nb = nf - np;
+    if (nb > 0) {
+        for (int cb = 8 * wid; cb < np; cb += 32) {
+            double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int rb = 0; rb < nb; rb += 256) {
+                double a[8][4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double* col = F + np + (size_t)ldp * min(cb + q, np - 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int r = rb + lane + 64 * u; a[q][u] = r < nb ? col[r] : 0.0; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rb + lane + 64 * u;
+                    const double xr = x[np + min(r, nb - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s[q] += a[q][u] * xr;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double tot = wave_sum(s[q]);
+                if (lane == 0 && cb + q < np) x[cb + q] -= tot;              // a column belongs to one wave
+            }
         }
         __syncthreads();
     }
-    for (int p = threadIdx.x; p < np; p += blockDim.x) xv[gd[p]] = x[p];
+    const int npan = (np + NB - 1) / NB;
+    for (int k = npan - 1; k >= 0; --k) {
+        const int c0 = k * NB, wb = min(NB, np - c0);
+        const double* Li = fd.Linv + fd.linvoff[t] + (size_t)k * NB * NB;
+        // s_k -= L11[r1 .., panel]^T x[r1 ..): the pivot rows below the panel (solved already); wave = eight columns
+        const int r1 = c0 + wb, nr = np - r1;
+        if (nr > 0) {
+            const int cb = 8 * wid;
+            double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int rb = 0; rb < nr; rb += 256) {
+                double a[8][4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double* col = F + r1 + (size_t)ldp * (c0 + min(cb + q, wb - 1));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int r = rb + lane + 64 * u; a[q][u] = r < nr ? col[r] : 0.0; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rb + lane + 64 * u;
+                    const double xr = x[r1 + min(r, nr - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s[q] += a[q][u] * xr;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double tot = wave_sum(s[q]);
+                if (lane == 0 && cb + q < wb) x[c0 + cb + q] -= tot;
+            }
+            __syncthreads();
+        }
+        {   // x_k = Linv_k^T s_k: thread (column c, group g) takes the rows c + g, c + g + 8, ... < wb
+            const int c = tid & 31, g = tid >> 5;
+            double a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int r = c + g + 8 * q; a[q] = (r < wb && c < wb) ? Li[r + NB * c] : 0.0; }
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int r = c + g + 8 * q; s += a[q] * x[c0 + min(r, wb - 1)]; }
+            part[32 * g + c] = s;
+        }
+        __syncthreads();
+        if (tid < wb) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += part[32 * g + tid];
+            x[c0 + tid] = s;
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < np; p += 256) xv[gd[p]] = x[p];
 }
 
 // ---- wide levels (few fronts, or large pivot blocks): the sweeps are four plain matrix-vector products per level
