@@ -1069,10 +1069,10 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
     }
 }
 
-// s_p = y_p - L21^T x_B with one workgroup per 32 pivot columns and ALL boundary rows of the front (no atomics, fixed
+// s_p = y_p - L21^T x_B with one workgroup per 16 pivot columns and ALL boundary rows of the front (no atomics, fixed
 // summation order): the better shape for the many medium fronts of the middle levels, where a front's L21 is a few
 // hundred rows; the tiled kernel above takes over where one workgroup per 32 columns could not pull the block out of HBM.
-constexpr int BB_COLS = 32;
+constexpr int BB_COLS = 16;
 __global__ void __launch_bounds__(256)
 k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[first + blockIdx.y];
@@ -1085,29 +1085,32 @@ k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, do
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int r = tid; r < nb; r += 256) xs[r] = xv[gd[np + r]];
     __syncthreads();
-    const double* L21 = fd.P + fd.poff[t] + np;          // rows np.., column c at + nf * c
-    for (int g = 0; g < BB_COLS / 16; ++g) {
-        const int cb = c0 + 16 * g + 4 * wv;             // this wave's four columns
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        const double* col[4];
+    // a wave owns four columns; 4 columns x 8 row chunks = 32 loads in flight per lane (the upper levels have only one
+    // or two workgroups per CU: what is in flight per wave is what pulls the block out of HBM)
+    const int ldp = ldp_of(nf);
+    const double* L21 = fd.P + fd.poff[t] + np;          // rows np.., column c at + ldp * c
+    const int cb = c0 + 4 * wv;
+    const double* col[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)ldp_of(nf) * min(cb + k, np - 1);
-        int r = lane;
-        for (; r + 64 < nb; r += 128) {
-            const double x0 = xs[r], x1 = xs[r + 64];
+    for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)ldp * min(cb + k, np - 1);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rb = 0; rb < nb; rb += 512) {
+        double a[4][8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0 + col[k][r + 64] * x1;
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int r = rb + lane + 64 * u; a[k][u] = r < nb ? col[k][r] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double xr = xs[min(rb + lane + 64 * u, nb - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += a[k][u] * xr;
         }
-        if (r < nb) {
-            const double x0 = xs[r];
+    }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] += col[k][r] * x0;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double tot = wave_sum(s[k]);
-            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
-        }
+    for (int k = 0; k < 4; ++k) {
+        const double tot = wave_sum(s[k]);
+        if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
     }
 }
 
