@@ -374,6 +374,7 @@ __device__ __host__ inline int diag_block_lds_blocks(int nblk) { return nblk * (
 __global__ void __launch_bounds__(256)
 k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
              int* __restrict__ info) {
+    STAMP(31);
     const int slot = first + blockIdx.x;                       // position of the front in its level
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];

@@ -15,24 +15,35 @@ template <class T> T* up(const std::vector<T>& h) {
 
 int main(int argc, char** argv) {
     const int nfr = argc > 1 ? atoi(argv[1]) : 8, nf = argc > 2 ? atoi(argv[2]) : 3200, np = argc > 3 ? atoi(argv[3]) : 1024;
+    const int nb = nf - np, ldp = ldp_of(nf);
     std::vector<int> h_nf(nfr, nf), h_np(nfr, np), lev(nfr);
-    std::vector<long long> foff(nfr + 1), linvoff(nfr + 1);
-    for (int i = 0; i <= nfr; ++i) { foff[i] = (long long)i * nf * nf; linvoff[i] = (long long)i * ((np + NB - 1) / NB) * NB * NB; }
-    for (int i = 0; i < nfr; ++i) lev[i] = i;
+    std::vector<long long> poff(nfr + 1), soff(nfr), linvoff(nfr + 1);
+    for (int i = 0; i <= nfr; ++i) { poff[i] = (long long)i * ldp * np; linvoff[i] = (long long)i * ((np + NB - 1) / NB) * NB * NB; }
+    for (int i = 0; i < nfr; ++i) { soff[i] = (long long)i * nb * nb; lev[i] = i; }
     std::vector<double> A((size_t)nf * nf);
     srand(1);
     for (int c = 0; c < nf; ++c) for (int r = c; r < nf; ++r) A[r + (size_t)nf * c] = (r == c) ? nf + 1.0 : (rand() / (double)RAND_MAX - 0.5);
+    std::vector<double> hP((size_t)ldp * np, 0.0), hS((size_t)std::max(nb, 1) * std::max(nb, 1), 0.0);
+    for (int c = 0; c < nf; ++c)
+        for (int r = c; r < nf; ++r) {
+            if (c < np) hP[r + (size_t)ldp * c] = A[r + (size_t)nf * c];
+            else hS[(r - np) + (size_t)nb * (c - np)] = A[r + (size_t)nf * c];
+        }
     FrontDev fd{};
-    fd.ntree = nfr; fd.nf = up(h_nf); fd.npiv = up(h_np); fd.foff = up(foff); fd.linvoff = up(linvoff);
-    double* F; CK(hipMalloc(&F, sizeof(double) * foff[nfr]));
-    double* Li; CK(hipMalloc(&Li, sizeof(double) * linvoff[nfr]));
-    fd.F = F; fd.Linv = Li;
+    fd.ntree = nfr; fd.nf = up(h_nf); fd.npiv = up(h_np); fd.poff = up(poff); fd.soff = up(soff); fd.linvoff = up(linvoff);
+    double *P, *S, *Li;
+    CK(hipMalloc(&P, sizeof(double) * poff[nfr])); CK(hipMalloc(&S, sizeof(double) * std::max<long long>(1, (long long)nfr * nb * nb)));
+    CK(hipMalloc(&Li, sizeof(double) * linvoff[nfr]));
+    fd.P = P; fd.S = S; fd.Linv = Li;
     double* Sw; CK(hipMalloc(&Sw, sizeof(double) * (size_t)nfr * SPD * SPD));
     CK(hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(diag_block_lds_blocks(4) * sizeof(blk32))));
     int* dlev = up(lev); int* info; CK(hipMalloc(&info, 4)); CK(hipMemset(info, 0, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
-        for (int i = 0; i < nfr; ++i) CK(hipMemcpy(F + foff[i], A.data(), sizeof(double) * nf * nf, hipMemcpyHostToDevice));
+        for (int i = 0; i < nfr; ++i) {
+            CK(hipMemcpy(P + poff[i], hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
+            if (nb > 0) CK(hipMemcpy(S + soff[i], hS.data(), sizeof(double) * (size_t)nb * nb, hipMemcpyHostToDevice));
+        }
         double tp = 0, tt = 0;
         for (int C0 = 0; C0 < np; C0 += NBO) {
             const int kw = std::min(NBO, np - C0);
@@ -52,16 +63,16 @@ int main(int argc, char** argv) {
                 if (rep == 1) printf("C0=%4d: diag block %6.1f us, rows (%d tiles) %6.1f us\n", C0, ms * 1e3, tiles, ms2 * 1e3);
                 if (rep == 1 && C0 == 0) {
                     long long st[32]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
-                    printf("   load %.2f zero-S %.2f |", (st[0] - st[0]) * 0.01, (st[1] - st[0]) * 0.01);
+                    printf("   (us, 100 MHz clock) load+store-to-LDS %.2f sync %.2f |", (st[0] - st[31]) * 0.01, (st[1] - st[0]) * 0.01);
                     for (int j = 0; j < 4; ++j) printf(" step%d: chol %.2f trsm %.2f upd %.2f |", j, (st[3 + 4 * j] - st[2 + 4 * j]) * 0.01,
                                                        j < 3 ? (st[4 + 4 * j] - st[3 + 4 * j]) * 0.01 : 0.0, j < 3 ? (st[2 + 4 * (j + 1)] - st[4 + 4 * j]) * 0.01 : 0.0);
-                    printf(" S-phase %.2f\n", (st[21] - st[20]) * 0.01);
+                    printf(" S-phase %.2f | whole kernel %.2f\n", (st[21] - st[20]) * 0.01, (st[21] - st[31]) * 0.01);
                 }
             }
-            const int nt = (nf - C0 - kw + TS - 1) / TS;
+            const int nt = (nf - C0 - kw + 1 + TS - 1) / TS;
             if (nt > 0) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, 2);
+                hipLaunchKernelGGL(k_trailing_mfma, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, 2, 0, NBO);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt += ms;
                 if (rep == 1) printf("  trailing C0=%4d nt=%3d: %7.1f us\n", C0, nt, ms * 1e3);
