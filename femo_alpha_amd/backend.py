@@ -59,7 +59,8 @@ class ShellContext:
 
     def set_option(self, key, value):
         """Schedule switches and failure policy (femo_set_option): 'strict', 'allow_pivot_repair', 'trailing',
-        'left_min', 'left_max', 'lookahead', 'lookahead_cnt', 'grid_chunk', 'wide_np', 'wide_cnt', 'profile_verbose'."""
+        'left_min', 'left_max', 'super_panel', 'super_panel_cnt', 'super_panel_ahead', 'lookahead', 'lookahead_cnt', 'grid_chunk',
+        'wide_np', 'wide_cnt', 'profile_verbose'."""
         self._chk(self.lib.femo_set_option(self._h, key.encode(), float(value)))
 
     def close(self):

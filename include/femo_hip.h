@@ -127,12 +127,16 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "allow_pivot_repair" (default 0) 0: a non-positive pivot makes femo_factorize (and the solves that call it) return 5;
  *                                    1: such pivots are replaced and counted (femo_frontal_info [4])
  *   "trailing" 0 auto | 1 left-looking | 2 right-looking rank-k updates; "left_min", "left_max" (auto: levels with this
- *   many fronts are left-looking); "lookahead" 0/1, "lookahead_cnt"; "grid_chunk" (fronts per launch, <= 65535);
+ *   many fronts are left-looking; defaults 64, 2048); "super_panel" (default 512; 0 = off), "super_panel_cnt" (default 64):
+ *   right-looking levels of at most that many fronts update the trailing matrix once per super-panel of that many factor
+ *   columns instead of once per 128; "super_panel_ahead" (default 0): that update on a second stream beside the next
+ *   super-panel's panels; "lookahead" 0/1, "lookahead_cnt": the same for the 128-column schedule;
+ *   "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
  *   "swork_slots" (default 8192; before femo_set_frontal_plan): 128 x 128 scratch blocks for the diagonal-block inverses of
  *   the levels solved with one workgroup per front -- levels with more fronts are factorised in chunks of that many;
  *   "bnd_tiled_nb" (backward sweep: levels whose largest boundary block has at least this many rows use 128 x 128 tiles
- *   with atomics for L21^T x, the others one workgroup per 32 columns); "profile_verbose" (per-launch timings of
+ *   with atomics for L21^T x, the others one workgroup per 16 columns); "profile_verbose" (per-launch timings of
  *   femo_factorize_profile on stderr). */
 int femo_set_option(femo_ctx* ctx, const char* key, double value);
 /* Krylov method for the state / adjoint / linear solves: 0 = conjugate gradients (default; the operator is SPD),
