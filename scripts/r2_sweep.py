@@ -34,10 +34,8 @@ def run(leaf, opts):
 
 
 base = dict()
-cases = [(12, {}), (12, dict(lookahead=0)), (12, dict(super_panel=512)), (12, dict(super_panel=512, left_min=64)), (12, dict(super_panel=256, left_min=64)),
-         (12, dict(super_panel=512, left_min=128, super_panel_cnt=64)), (12, dict(super_panel=384, left_min=64)),
-         (16, {}), (16, dict(super_panel=512, left_min=64)), (20, dict(super_panel=512, left_min=64)), (10, dict(super_panel=512, left_min=64)),
-         (12, dict(super_panel=512, left_min=64, left_max=4096)), (12, dict(super_panel=512, left_min=64, left_max=1024))]
+cases = [(12, {}), (12, dict(wide_cnt=256)), (12, dict(wide_cnt=128)), (12, dict(wide_cnt=64)), (12, dict(wide_cnt=32)), (12, dict(wide_cnt=1024)),
+         (12, dict(wide_cnt=2048)), (12, dict(wide_cnt=128, wide_np=1024)), (12, dict(wide_cnt=16, wide_np=2048))]
 if len(sys.argv) > 2 and sys.argv[2] == "all":
     cases += [(8, {}), (16, {}), (24, {}),
          (12, dict(left_max=8192)), (12, dict(left_max=100000)), (12, dict(left_min=8)), (12, dict(left_min=32)),
