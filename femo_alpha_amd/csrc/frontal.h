@@ -210,7 +210,7 @@ k_zero_fronts(FrontDev fd, const int* __restrict__ level_nodes, int first) {
 // Schur complements that land there (row maps cinv) -- written once, never read: no zero fill of the parent, no
 // read-modify-write, one launch per level for both children.  Masked (strong-BC) pivots get their unit diagonal here.
 __global__ void __launch_bounds__(256)
-k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, const unsigned char* __restrict__ mask) {
+k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, const unsigned char* __restrict__ mask, int skip_schur) {
     const int p = level_nodes[first + blockIdx.y];
     const int ch0 = fd.child[0][p], ch1 = fd.child[1][p];
     if (ch0 < 0 && ch1 < 0) return;                      // nothing below: the front keeps what it was given
@@ -223,6 +223,10 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, con
     while (ti * (ti + 1) / 2 > lin) --ti;
     const int tj = lin - ti * (ti + 1) / 2;
     const int r0 = ti * TS, c0 = tj * TS;
+    // skip_schur: the Schur-complement columns of this level's fronts are not filled here -- their one rank-k update
+    // gathers them from the children itself (k_trailing_mfma<true>); fronts without pivots have no such update
+    const int c_end = (skip_schur && npp > 0) ? npp : nfp;
+    if (c0 >= c_end) return;
     __shared__ int rmap[2][TS], cmap[2][TS];
     const long long dp = fd.doff[p];
     for (int i = threadIdx.x; i < 4 * TS; i += blockDim.x) {
@@ -245,7 +249,7 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, con
     for (int k = 0; k < TS / 4; ++k) {
         const int lc = lc0 + 4 * k, cc = c0 + lc;
         double x = 0.0;
-        if (r < nfp && cc <= r) {
+        if (r < nfp && cc <= r && cc < c_end) {
             const int b0 = cmap[0][lc], b1 = cmap[1][lc];
             if (ra0 >= 0 && b0 >= 0) x += f0.col(min(ra0, b0))[max(ra0, b0)];
             if (ra1 >= 0 && b1 >= 0) x += f1.col(min(ra1, b1))[max(ra1, b1)];
@@ -255,7 +259,7 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, con
 #pragma unroll
     for (int k = 0; k < TS / 4; ++k) {
         const int cc = c0 + lc0 + 4 * k;
-        if (r < nfp && cc <= r) {
+        if (r < nfp && cc <= r && cc < c_end) {
             double x = v[k];
             if (mask && r == cc && r < npp && mask[gd[r]]) x = 1.0;
             fp.col(cc)[r] = x;
@@ -613,6 +617,10 @@ __device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int
     return r;
 }
 
+// GATHER (schur == 1 on levels above the leaves): the tile of C does not exist yet -- it is the sum of the children's
+// Schur-complement entries that land there (the extend-add of these columns, left out of k_extend_gather), gathered here
+// and written once: the parent's Schur complement is never read back and never written twice.
+template <bool GATHER>
 __global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
 k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW) {
     // Which (front, tile) this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in
@@ -741,17 +749,78 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             cp[a][reg] = cok[a][reg] ? fv.col(cc) : fv.P - (nf - 1);          // safe: [r] below stays inside the panel store
         }
     double cv[2][2][4];
+    if (!GATHER) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const bool ok = cok[a][reg] && r < nf && r >= cc;
+                    cv[a][b][reg] = cp[a][reg][ok ? r : nf - 1];
+                }
+    } else {
+        // rows of the two children's fronts that land on this lane's two rows and eight columns (-1: none): boundary rows
+        // of the children (>= their pivot count), so every entry sits in a child's Schur block S_c[(hi - np_c) + nb_c (lo - np_c)]
+        const long long dp = fd.doff[t];
+        int rr[2][2], cr[2][2][4];
+        const double* Sc[2];
+        int npc[2], nbc[2];
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int ch = fd.child[sd][t];
+            const int chs = ch >= 0 ? ch : t;
+            npc[sd] = fd.npiv[chs]; nbc[sd] = fd.nf[chs] - npc[sd];
+            Sc[sd] = fd.S + fd.soff[chs];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
                 const int r = ri + wr + 16 * b + l15;
-                const bool ok = cok[a][reg] && r < nf && r >= cc;
-                cv[a][b][reg] = cp[a][reg][ok ? r : nf - 1];
+                rr[sd][b] = fd.cinv[sd][dp + min(r, nf - 1)];
+                if (ch < 0 || r >= nf) rr[sd][b] = -1;
             }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    cr[sd][a][reg] = fd.cinv[sd][dp + min(cc, nf - 1)];
+                    if (ch < 0 || !cok[a][reg]) cr[sd][a][reg] = -1;
+                }
+        }
+        double g0[2][2][4], g1[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const bool tri = r >= cc;
+                    {
+                        const int x = rr[0][b], y = cr[0][a][reg];
+                        const bool ok = tri && x >= 0 && y >= 0;
+                        const int lo = min(x, y) - npc[0], hi = max(x, y) - npc[0];
+                        g0[a][b][reg] = Sc[0][ok ? hi + (size_t)nbc[0] * lo : 0];
+                        if (!ok) g0[a][b][reg] = 0.0;
+                    }
+                    {
+                        const int x = rr[1][b], y = cr[1][a][reg];
+                        const bool ok = tri && x >= 0 && y >= 0;
+                        const int lo = min(x, y) - npc[1], hi = max(x, y) - npc[1];
+                        g1[a][b][reg] = Sc[1][ok ? hi + (size_t)nbc[1] * lo : 0];
+                        if (!ok) g1[a][b][reg] = 0.0;
+                    }
+                }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) cv[a][b][reg] = g0[a][b][reg] + g1[a][b][reg];
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
