@@ -532,8 +532,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // the extend-add fills the pivot columns only (option "fused_schur").  Measured at 1M DOF: extend-add 3.3 -> 2.3 ms,
         // rank-k updates 8.4 -> 8.7 ms.
         const bool left_level = !(c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt < c->opt.left_min || cnt > c->opt.left_max));
+        const bool sp_level = !left_level && c->opt.super_panel > NBO && cnt <= c->opt.super_panel_cnt && max_np > NBO && !c->opt.super_panel_ahead;
         const bool single_update = left_level || (max_np <= NBO && !(cnt < c->opt.lookahead_cnt && c->opt.lookahead != 0));
-        const bool fused_schur = L > 0 && single_update && c->opt.fused_schur != 0;
+        // super-panel levels: the FIRST update behind a super-panel reaches every Schur complement of the level: it gathers,
+        // the later ones read and write what it stored
+        const bool fused_schur = L > 0 && (single_update || sp_level) && c->opt.fused_schur != 0;
         if (L > 0) {
             // children Schur complements into the parents of this level
             int max_nb = 0;
@@ -685,8 +688,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                         }
                         { ProfScope ps(c, 2, bs);
                           count_trailing(S0, mode, 0, SP);
-                          FOR_FRONT_CHUNKS(cnt, off, n)
-                              hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP); }
+                          FOR_FRONT_CHUNKS(cnt, off, n) {
+                              if (fused_schur && S0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP);
+                              else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP);
+                          } }
                         if (sp_ahead) {
                             HIPCHK(c, hipEventRecord(c->ev_sp[sp_bulks & 1], c->stream2));
                             ++sp_bulks;

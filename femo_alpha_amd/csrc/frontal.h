@@ -799,16 +799,21 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
                     const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                     const int r = ri + wr + 16 * b + l15;
                     const bool tri = r >= cc;
+                    // pivot columns of the front inside the tile (the first update of a super-panel schedule reaches them
+                    // too) were filled by the extend-add: plain read-modify-write
+                    const bool piv = cc < np;
                     {
                         const int x = rr[0][b], y = cr[0][a][reg];
-                        const bool ok = tri && x >= 0 && y >= 0;
+                        const bool ok = tri && x >= 0 && y >= 0 && !piv;
+                        const bool okp = piv && cok[a][reg] && r < nf && tri;
                         const int lo = min(x, y) - npc[0], hi = max(x, y) - npc[0];
-                        g0[a][b][reg] = Sc[0][ok ? hi + (size_t)nbc[0] * lo : 0];
-                        if (!ok) g0[a][b][reg] = 0.0;
+                        const double* src = okp ? cp[a][reg] + r : Sc[0] + (ok ? hi + (size_t)nbc[0] * lo : 0);
+                        g0[a][b][reg] = *src;
+                        if (!ok && !okp) g0[a][b][reg] = 0.0;
                     }
                     {
                         const int x = rr[1][b], y = cr[1][a][reg];
-                        const bool ok = tri && x >= 0 && y >= 0;
+                        const bool ok = tri && x >= 0 && y >= 0 && !piv;
                         const int lo = min(x, y) - npc[1], hi = max(x, y) - npc[1];
                         g1[a][b][reg] = Sc[1][ok ? hi + (size_t)nbc[1] * lo : 0];
                         if (!ok) g1[a][b][reg] = 0.0;
