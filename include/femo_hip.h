@@ -131,6 +131,8 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   right-looking levels of at most that many fronts update the trailing matrix once per super-panel of that many factor
  *   columns instead of once per 128; "super_panel_ahead" (default 0): that update on a second stream beside the next
  *   super-panel's panels; "lookahead" 0/1, "lookahead_cnt": the same for the 128-column schedule;
+ *   "fused_schur" (default 1): Schur complements are gathered from the children by the rank-k update that touches them
+ *   first instead of by the extend-add;
  *   "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
  *   "swork_slots" (default 8192; before femo_set_frontal_plan): 128 x 128 scratch blocks for the diagonal-block inverses of
