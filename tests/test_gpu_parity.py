@@ -203,6 +203,7 @@ def test_super_panel_schedule_gives_the_same_factor(sp, force_right, ahead):
             c.set_field(k, v)
         c.set_penalty_facets(pf, 1e15)
         c.set_option("super_panel", super_panel)
+        c.set_option("fused_schur", 1 if super_panel else 0)      # the reference run also fills the Schur columns in the extend-add
         c.set_option("super_panel_cnt", 64)
         c.set_option("super_panel_ahead", ahead)
         if force_right:
