@@ -641,9 +641,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 ProfScope ps(c, 2);
                 count_trailing(C0, 0, K0);
                 const int ntr = trail_tiles(C0, 0, K0);
+                // fused levels: these pivot columns are touched here for the first time (left-looking: every panel behind
+                // the first; super-panel schedule: the panels of the first super-panel) -- gathered from the children
+                const bool gather_panel = fused_schur && K0 == 0;
                 if (ntr > 0)
-                FOR_FRONT_CHUNKS(cnt, off, n)
-                    hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO);
+                FOR_FRONT_CHUNKS(cnt, off, n) {
+                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask);
+                    else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask);
+                }
             }
             count_panel(C0);
             { ProfScope ps(c, 1);
@@ -689,8 +694,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                         { ProfScope ps(c, 2, bs);
                           count_trailing(S0, mode, 0, SP);
                           FOR_FRONT_CHUNKS(cnt, off, n) {
-                              if (fused_schur && S0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP);
-                              else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP);
+                              if (fused_schur && S0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP, mask);
+                              else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP, mask);
                           } }
                         if (sp_ahead) {
                             HIPCHK(c, hipEventRecord(c->ev_sp[sp_bulks & 1], c->stream2));
@@ -704,8 +709,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
                     FOR_FRONT_CHUNKS(cnt, off, n) {
-                        if (fused_schur && !left_level) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO);
-                        else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO);
+                        if (fused_schur && !left_level) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
+                        else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
                     }
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
@@ -715,14 +720,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
                     { ProfScope ps(c, 2);
                       count_trailing(C0, 3);
-                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO); }
+                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO, mask); }
                     const int ntb = trail_tiles(C0, 4);
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
                           count_trailing(C0, 4);
-                          hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4, 0, NBO); }
+                          hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4, 0, NBO, mask); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
@@ -738,8 +743,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             const int ntr = trail_tiles(0, 1);
             if (ntr > 0)
             FOR_FRONT_CHUNKS(cnt, off, n) {
-                if (fused_schur) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO);
-                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO);
+                if (fused_schur) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO, mask);
+                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO, mask);
             }
         }
         }   // chunks of the level

@@ -223,9 +223,10 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, con
     while (ti * (ti + 1) / 2 > lin) --ti;
     const int tj = lin - ti * (ti + 1) / 2;
     const int r0 = ti * TS, c0 = tj * TS;
-    // skip_schur: the Schur-complement columns of this level's fronts are not filled here -- their one rank-k update
-    // gathers them from the children itself (k_trailing_mfma<true>); fronts without pivots have no such update
-    const int c_end = (skip_schur && npp > 0) ? npp : nfp;
+    // skip_schur: only the first outer panel's columns are filled here -- every other column of this level's fronts is
+    // gathered from the children by the rank-k update that touches it first (k_trailing_mfma<true>); fronts without
+    // pivots have no such update
+    const int c_end = (skip_schur && npp > 0) ? min(npp, NBO) : nfp;
     if (c0 >= c_end) return;
     __shared__ int rmap[2][TS], cmap[2][TS];
     const long long dp = fd.doff[p];
@@ -617,12 +618,13 @@ __device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int
     return r;
 }
 
-// GATHER (schur == 1 on levels above the leaves): the tile of C does not exist yet -- it is the sum of the children's
-// Schur-complement entries that land there (the extend-add of these columns, left out of k_extend_gather), gathered here
-// and written once: the parent's Schur complement is never read back and never written twice.
+// GATHER (levels above the leaves, the launch that touches its columns first): the tile of C does not exist yet -- it is
+// the sum of the children's Schur-complement entries that land there (the extend-add of these columns, left out of
+// k_extend_gather), gathered here and written once.  `mask`: strong-BC pivots get their unit diagonal, as in the extend-add.
 template <bool GATHER>
 __global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
-k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW) {
+k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW,
+                const unsigned char* __restrict__ mask) {
     // Which (front, tile) this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in
     // launch order, x fastest; the two or three tiles of a small front read the same rows of its factor panel.  On levels
     // of many fronts (a multiple of 8, at least 256) XCD x therefore takes the fronts x, x + 8, ... whole, tile after tile:
@@ -738,7 +740,6 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
     }
     // C -= D with all of the tile's loads in flight at once (entries outside the tile's part of the lower triangle load
     // from a safe address and are not stored).  D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
-    double* cp[2][4];
     bool cok[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -746,10 +747,18 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         for (int reg = 0; reg < 4; ++reg) {
             const int cc = cj + wc + 16 * a + l4 + 4 * reg;
             cok[a][reg] = cc >= col_lo && cc < col_hi;
-            cp[a][reg] = cok[a][reg] ? fv.col(cc) : fv.P - (nf - 1);          // safe: [r] below stays inside the panel store
         }
+    auto col_ptr = [&](int a, int reg) {                       // safe: [r] below stays inside the panel store
+        const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+        return cok[a][reg] ? fv.col(cc) : fv.P - (nf - 1);
+    };
     double cv[2][2][4];
     if (!GATHER) {
+        double* cp[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cp[a][reg] = col_ptr(a, reg);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -799,21 +808,16 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
                     const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                     const int r = ri + wr + 16 * b + l15;
                     const bool tri = r >= cc;
-                    // pivot columns of the front inside the tile (the first update of a super-panel schedule reaches them
-                    // too) were filled by the extend-add: plain read-modify-write
-                    const bool piv = cc < np;
                     {
                         const int x = rr[0][b], y = cr[0][a][reg];
-                        const bool ok = tri && x >= 0 && y >= 0 && !piv;
-                        const bool okp = piv && cok[a][reg] && r < nf && tri;
+                        const bool ok = tri && x >= 0 && y >= 0;
                         const int lo = min(x, y) - npc[0], hi = max(x, y) - npc[0];
-                        const double* src = okp ? cp[a][reg] + r : Sc[0] + (ok ? hi + (size_t)nbc[0] * lo : 0);
-                        g0[a][b][reg] = *src;
-                        if (!ok && !okp) g0[a][b][reg] = 0.0;
+                        g0[a][b][reg] = Sc[0][ok ? hi + (size_t)nbc[0] * lo : 0];
+                        if (!ok) g0[a][b][reg] = 0.0;
                     }
                     {
                         const int x = rr[1][b], y = cr[1][a][reg];
-                        const bool ok = tri && x >= 0 && y >= 0 && !piv;
+                        const bool ok = tri && x >= 0 && y >= 0;
                         const int lo = min(x, y) - npc[1], hi = max(x, y) - npc[1];
                         g1[a][b][reg] = Sc[1][ok ? hi + (size_t)nbc[1] * lo : 0];
                         if (!ok) g1[a][b][reg] = 0.0;
@@ -825,6 +829,19 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) cv[a][b][reg] = g0[a][b][reg] + g1[a][b][reg];
+        if (mask && bx == 0) {                                // diagonal entries exist only in the tiles on the diagonal
+            const int* gd = fd.dofs + dp;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                        const int r = ri + wr + 16 * b + l15;
+                        if (r == cc && cok[a][reg] && cc < np && mask[gd[r]]) cv[a][b][reg] = 1.0;
+                    }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -834,7 +851,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = cj + wc + 16 * a + l4 + 4 * reg;
                 const int r = ri + wr + 16 * b + l15;
-                if (cok[a][reg] && r < nf && r >= cc) cp[a][reg][r] = cv[a][b][reg] - acc[a][b][reg];
+                if (cok[a][reg] && r < nf && r >= cc) col_ptr(a, reg)[r] = cv[a][b][reg] - acc[a][b][reg];
             }
 }
 
