@@ -140,7 +140,8 @@ def test_errors_are_loud():
 @pytest.mark.parametrize("kind,ewm,bc,uhat,wide_cnt", [("plate", False, "penalty", False, None), ("warped", True, "strong", False, 0),
                                                        ("warped", False, "penalty", True, None), ("tri", False, "penalty", False, 0),
                                                        ("plate24", False, "penalty", False, 0), ("plate", False, "strong", False, 0),
-                                                       ("tee", False, "penalty", False, None), ("tee", True, "strong", True, 0)])
+                                                       ("tee", False, "penalty", False, None), ("tee", True, "strong", True, 0),
+                                                       ("plate24", False, "strong", False, None)])
 def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
     the same parity triple as the reference's direct (MUMPS LU) solve.  Levels with few fronts take the wide
