@@ -1,4 +1,4 @@
-"""world_size 2 and 4 under gloo on the CPU: the element-partitioned driver (femo_alpha_amd/parallel.py)
+"""world_size 2, 4 and 8 under gloo on the CPU: the element-partitioned driver (femo_alpha_amd/parallel.py)
 with the numpy stand-in engine reproduces the single-domain oracle solution, compliance, mass and
 d compliance / d thickness.  Covers the N > 1 path of bench.py by construction."""
 import os
@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (2, "plate")])
+@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (8, "wing"), (2, "plate")])
 def test_partitioned_solve_matches_single_domain(world, kind):
     m, marker, fields = H.make_case(kind)
     w0, J0, dJ0, M0 = H.reference_solution(m, marker, fields)
