@@ -300,10 +300,15 @@ class DistributedShell:
         it, rel = self._pcg("b", "adjoint")
         self.last["adjoint"] = (it, rel)
         g_loc = self.eng.field_gradient_vec(functional, arg, "adjoint")
-        n_glob = self.mesh.nel if self.ewm else self.mesh.nn
-        g = self.eng.new_tensor(n_glob)
-        sel = self.info["cells"] if self.ewm else self.info["vertices"]
-        g[self.torch.as_tensor(sel, dtype=self.torch.int64, device=g.device)] = self.torch.as_tensor(g_loc).to(g.device)
+        # the global gradient buffer and the index of this rank's entries in it live on the device for the life of the driver
+        if getattr(self, "_grad_buf", None) is None:
+            n_glob = self.mesh.nel if self.ewm else self.mesh.nn
+            sel = self.info["cells"] if self.ewm else self.info["vertices"]
+            self._grad_buf = self.eng.new_tensor(n_glob)
+            self._grad_sel = self.torch.as_tensor(np.asarray(sel), dtype=self.torch.int64, device=self._grad_buf.device)
+        g = self._grad_buf
+        g.zero_()
+        g[self._grad_sel] = self.torch.as_tensor(g_loc).to(g.device)
         self.comm.allreduce_(g)
         return g.cpu().numpy(), it, rel
 
