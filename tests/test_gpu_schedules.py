@@ -1,0 +1,56 @@
+"""Random combinations of the factorisation / sweep schedule options (left- / right-looking thresholds, super-panels with
+and without the second-stream update, look-ahead, fused extend-add, launch chunking, wide-level thresholds, scratch chunking,
+leaf size): whatever the schedule, the factor is the same -- same iteration count, same displacement and gradient as the
+plainest schedule.  (scripts/fuzz_schedules.py runs the same check over hundreds of combinations.)"""
+import numpy as np
+import pytest
+
+from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(m, marker, strong, leaf, pre, post):
+    from femo_alpha_amd.backend import ShellContext
+    c = ShellContext(m)
+    r = np.random.default_rng(1)
+    c.set_field("thickness", 0.02 * (1 + 0.3 * r.uniform(-1, 1, m.nn)))
+    for k, v in (("E", [7e10]), ("nu", [0.3]), ("density", [2700.0])):
+        c.set_field(k, v)
+    c.set_field("F_solid", r.uniform(-1, 1, (m.nn, 3)))
+    if strong:
+        c.set_strong_dofs(m.locate_dofs_geometrical(marker))
+    else:
+        c.set_penalty_facets(m.penalty_facets(marker))
+    for k, v in post.items():
+        c.set_option(k, v)
+    c.enable_frontal(leaf, **pre)
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=30, check_every=1)
+    c.factorize(); c.factorize()                     # twice: stream order must also hold across factorisations
+    it, _ = c.solve_state(True)
+    w = c.get_state()
+    g, _, _ = c.total_gradient("compliance", "thickness")
+    c.close()
+    return it, w, g
+
+
+@pytest.mark.parametrize("case,seed", [("plate", 11), ("wing_strong", 12)])
+def test_random_schedules_give_the_same_solution(case, seed):
+    if case == "plate":
+        m, marker, strong = plate_mesh(2.0, 5.0, 64, 64), (lambda x: np.less(x[0], 3e-16)), False
+    else:
+        m, marker, strong = wing_skin_mesh(32, 96, shuffle=True).renumbered()[0], (lambda x: np.less(x[1], 1e-9)), True
+    it0, w0, g0 = _solve(m, marker, strong, 8, {}, dict(super_panel=0, fused_schur=0, lookahead=0))
+    rng = np.random.default_rng(seed)
+    for _ in range(8):
+        post = dict(trailing=int(rng.integers(0, 3)), left_min=int(rng.choice([1, 8, 64, 4096])), left_max=int(rng.choice([16, 2048, 100000])),
+                    super_panel=int(rng.choice([0, 256, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
+                    super_panel_ahead=int(rng.integers(0, 2)), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
+                    fused_schur=int(rng.integers(0, 2)), grid_chunk=int(rng.choice([3, 17, 65535])), xinv_small_cnt=int(rng.choice([0, 32, 100000])))
+        pre = dict(wide_cnt=int(rng.choice([0, 8, 512, 100000])), wide_np=int(rng.choice([64, 512])), swork_slots=int(rng.choice([2, 100, 8192])))
+        leaf = int(rng.choice([4, 8, 12, 20]))
+        it, w, g = _solve(m, marker, strong, leaf, pre, post)
+        what = f"leaf {leaf} {pre} {post}"
+        assert it <= it0 + 1, what
+        assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max(), what
+        assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max(), what
