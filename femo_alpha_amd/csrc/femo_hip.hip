@@ -1804,7 +1804,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     for (int L = 0; L < nlevels; ++L)
         fr.h_level_wide[L] = fr.h_level_maxnp[L] > WIDE_NP || level_off[L + 1] - level_off[L] <= WIDE_CNT;
     // Storage of the fronts.  Pivot columns (the factor): one nf x npiv panel per front, for good.  Schur complements: an
-    // arena.  The block of front t is written at t's level and read once, by the extend-add at its parent's level; all
+    // arena.  The block of front t is written at t's level and read once, at its parent's level (by the extend-add or by
+    // the rank-k updates that gather their columns from the children, any time during that level); all
     // blocks whose parents share a level form one region, alive from the lowest level of its fronts to that parent level,
     // and regions are placed first-fit so that two regions alive at the same time never overlap.
     std::vector<long long> poff(ntree + 1, 0), soff(ntree, 0);
