@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
                 float ms2 = 0;
                 if (tiles > 0) {
                     CK(hipEventRecord(e0));
-                    hipLaunchKernelGGL(k_panel_rows<false>, dim3(tiles, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, Sw);
+                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, Sw);
                     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                     CK(hipEventElapsedTime(&ms2, e0, e1)); tp += ms2;
                 }
