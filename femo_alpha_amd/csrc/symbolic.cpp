@@ -12,6 +12,8 @@
 // The host-side Python module femo_alpha_amd/solver/symbolic.py states the same algorithm in numpy and is kept as the
 // cross-check (tests/test_symbolic_native.py compares every array).  The tree shape depends on the element count only, so
 // it is laid out first; the sorts of one depth are independent and run in parallel (OpenMP).
+#include <omp.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -51,6 +53,8 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
         g_error = "femo_plan_build: bad arguments";
         return 1;
     }
+    // at most 16 threads: several ranks of a multi-GPU job run this at the same time on one host
+    const int nthreads = std::max(1, std::min(omp_get_max_threads(), 16));
     const int64_t ndof_u = 3 * (int64_t)nP2;
     // ---- 1a. shape of the bisection tree (same creation order as a stack-driven recursion: children of the node
     //          popped last come first)
@@ -84,7 +88,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
             if (left[t] >= 0) by_depth[depth[t]].push_back(t);
         for (int32_t d = 0; d <= maxdepth; ++d) {
             const auto& nodes = by_depth[d];
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
             for (int64_t k = 0; k < (int64_t)nodes.size(); ++k) {
                 const int32_t t = nodes[k], a = lo[t], b = hi[t];
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
@@ -112,7 +116,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
             amin[n] = std::min(amin[n], epos[e]); amax[n] = std::max(amax[n], epos[e]);
         }
     std::vector<int32_t> owner(nP2, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int32_t n = 0; n < nP2; ++n) {
         int32_t t = 0;
         while (left[t] >= 0) {
@@ -142,7 +146,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
         for (int32_t t = 0; t < ntree; ++t) by_depth[depth[t]].push_back(t);
         for (int32_t d = maxdepth; d >= 0; --d) {
             const auto& nodes = by_depth[d];
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 16)
             for (int64_t k = 0; k < (int64_t)nodes.size(); ++k) {
                 const int32_t t = nodes[k];
                 std::vector<int32_t> u;
@@ -181,7 +185,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
     }
     if (ndof_u + 3 * (int64_t)nV > INT32_MAX) { g_error = "more than 2^31 DOFs"; return 4; }
     std::vector<int32_t> front_dofs(dof_off[ntree]);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
     for (int32_t t = 0; t < ntree; ++t) {
         int64_t w = dof_off[t];
         auto emit = [&](int32_t n) {
@@ -203,7 +207,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
     for (int32_t e = 0; e < nel; ++e) elem_front[e] = leaf_of_pos[epos[e]];
     std::vector<int32_t> elem_map((int64_t)nel * ndpc);
     int bad = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 16) reduction(| : bad)
     for (int32_t t = 0; t < ntree; ++t) {
         const int32_t n = nf[t];
         const int32_t* fd = front_dofs.data() + dof_off[t];
