@@ -34,8 +34,8 @@ def run(leaf, opts):
 
 
 base = dict()
-cases = [(12, {}), (12, dict(wide_cnt=256)), (12, dict(wide_cnt=128)), (12, dict(wide_cnt=64)), (12, dict(wide_cnt=32)), (12, dict(wide_cnt=1024)),
-         (12, dict(wide_cnt=2048)), (12, dict(wide_cnt=128, wide_np=1024)), (12, dict(wide_cnt=16, wide_np=2048))]
+cases = [(12, {}), (12, dict(left_min=32)), (12, dict(left_min=128)), (12, dict(left_min=256, super_panel_cnt=256)), (12, dict(super_panel=256)), (12, dict(super_panel=384)),
+         (12, dict(super_panel=768)), (12, dict(left_max=4096)), (12, dict(left_max=1024)), (10, {}), (14, {}), (16, {}), (12, dict(fused_schur=0))]
 if len(sys.argv) > 2 and sys.argv[2] == "all":
     cases += [(8, {}), (16, {}), (24, {}),
          (12, dict(left_max=8192)), (12, dict(left_max=100000)), (12, dict(left_min=8)), (12, dict(left_min=32)),
