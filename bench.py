@@ -382,7 +382,7 @@ def main():
             "forward_ms": t_fwd / args.steps * 1e3,
             "adjoint_ms": t_adj / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
