@@ -153,6 +153,11 @@ class DistributedShell:
         is_top[self.info["top_local"]] = True
         self.top_idx = torch.as_tensor(self.info["top_local"], dtype=torch.int64, device=dev)
         self.int_idx = torch.as_tensor(np.nonzero(~is_top)[0], dtype=torch.int64, device=dev)
+        # weights of the global dot product: 1 on the entries only this rank holds, 1 / size on the replicated ones (the number
+        # of ranks is a power of two, so the weight is exact and the replicated entries add up to one copy in the all-reduce)
+        wd = np.ones(is_top.size)
+        wd[is_top] = 1.0 / comm.size
+        self.wdot = torch.as_tensor(wd, dtype=torch.float64, device=dev) if comm.size > 1 else None
         self.nl, self.nlev = self.info["n_local_levels"], self.plan.nlevels
         self.rtol, self.maxit = 1e-10, 50
         self.factored = False
@@ -179,13 +184,14 @@ class DistributedShell:
         v.index_copy_(0, self.top_idx, buf)
 
     def dot_t(self, a, b):
-        """a . b over the global vector as a 0-dim device tensor (no host synchronisation): interior entries summed over the
-        ranks by one scalar all-reduce, replicated entries counted once."""
+        """a . b over the global vector as a 0-dim device tensor (no host synchronisation): one weighted local dot and one
+        scalar all-reduce; replicated entries carry the weight 1 / size, so they are counted once."""
         va, vb = self.eng.vec(a), self.eng.vec(b)
-        loc = (va.index_select(0, self.int_idx) * vb.index_select(0, self.int_idx)).sum().reshape(1)
-        top = (va.index_select(0, self.top_idx) * vb.index_select(0, self.top_idx)).sum()
+        if self.wdot is None:
+            return self.torch.dot(va, vb)
+        loc = self.torch.dot(va * self.wdot, vb).reshape(1)
         self.comm.allreduce_(loc)
-        return loc[0] + top
+        return loc[0]
 
     def dot(self, a, b):
         return float(self.dot_t(a, b))
