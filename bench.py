@@ -29,6 +29,61 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 
 # fp64 peak: the guide lists FP32 vector/matrix = 157.3 TFLOP/s (64 FLOP/clk/SIMD); CDNA4 runs fp64 FMA and
 # v_mfma_f64_16x16x4_f64 at half that rate -> 78.6 TFLOP/s (MI355X datasheet: FP64 vector = FP64 matrix = 78.6)
 FP64_PEAK_TFLOPS = 78.6
+# fp64 operations k_apply4 executes per quadrature point of a quad cell without mesh motion, counted from the kernel's loop body
+# (femo_alpha_amd/csrc/shell_device.h; an FMA = 2, a divide / square root = 1): geometry + derivative of the normal 176,
+# three field interpolations 24, constitutive coefficients 32, strains_q (two 2x2 derivative maps of 13 nodes, six reduced
+# 3-vectors, nine strains) 390, stress_of 21, strains_T_q 382  ->  1025; per cell 16 points + the DPP quad reduction and the
+# p.Ap partial (390).  k_gather_sum adds 2 flops per (cell, local DOF).
+APPLY_FLOPS_PER_QP = 1025.0
+APPLY_FLOPS_PER_CELL_EXTRA = 390.0 + 2.0 * 39.0
+
+
+def apply_flops(nel, nq=16):
+    return nel * (nq * APPLY_FLOPS_PER_QP + APPLY_FLOPS_PER_CELL_EXTRA)
+
+
+def spmv_roofline(apply_ms, ndof, nel, traffic, where=""):
+    """The north star's SpMV (k_apply4 + k_gather_sum) against BOTH roofs: HBM on the algorithmic bytes of SURVEY.md section 8d
+    (B_spmv,ebe = 16 B/DOF + 340 B/cell) and the fp64 vector ALU on the counted flops.  Counter traffic equals the algorithmic
+    bytes, so the HBM fraction is not what binds; the VALU fraction is the achieved share of the binding roof."""
+    alg_bytes = 16.0 * ndof + 340.0 * nel
+    gbs = alg_bytes / (apply_ms * 1e-3) / 1e9
+    fl = apply_flops(nel)
+    tf = fl / (apply_ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": "k_apply4 (matrix-free CG2xCG1 shell operator)" + where,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms,
+            "algorithmic_flops_per_launch": fl, "achieved_fp64_valu_TFLOPs": tf, "frac_fp64_valu": tf / FP64_PEAK_TFLOPS,
+            "binding": "fp64 vector ALU latency at two waves per SIMD (242 VGPRs); neither roof is reached"}
+
+
+def trailing_roofline(prof, traffic):
+    """The dominant kernel of the step: the rank-k updates of the multifrontal Cholesky (fp64 MFMA).  Flops and compulsory
+    bytes are summed over the launches from each launch's own K / column ranges (femo_hip.hip, count_trailing): lower
+    triangles only, C read + written once, the factor rows of the K panel read once."""
+    tr = prof["trailing"]
+    tf = prof["trailing_flops"] / (tr["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_trailing_mfma, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
+            "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+            "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
+            "algorithmic_bytes_per_launch": prof["trailing_bytes"] / tr["launches"],
+            "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 counter passes (scripts/aggregate_pmc.py; separate FETCH_SIZE and
+    WRITE_SIZE runs, gfx950 correction 2*FETCH+WRITE) -- counters cannot be read from inside bench.py.  Accepted only when the
+    file carries the digest of the library sources that produced it: after a kernel change the committed bytes are stale."""
+    from femo_alpha_amd import _build
+    pmc = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
+    if not os.path.exists(pmc):
+        return None, None
+    pj = json.load(open(pmc))
+    if pj.get("source_digest") != _build.source_digest():
+        print(f"warning: {os.path.relpath(pmc, ROOT)} was measured on other kernel sources (digest mismatch): roofline.traffic = null; "
+              "re-run scripts/r3_rocprof.sh", file=sys.stderr)
+        return None, None
+    return pj.get("apply_hbm_bytes_per_launch"), pj.get("trailing_hbm_bytes_per_launch")
 
 
 def make_workload(name, renumber=True, timings=None):
@@ -80,7 +135,7 @@ def make_workload(name, renumber=True, timings=None):
     return m, fields, marker, desc
 
 
-def cpu_baseline(m, fields, marker, leaf, budget_s=25.0):
+def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m"):
     """The "reference CPU path" timed on this box's host cores (rank 0, N = 1 only): kind "port" -- the reference itself
     needs FEniCSx/PETSc and cannot run here, so this is oracle/cpu_baseline.py, the repository's float64 restatement of
     its algorithm: C++/OpenMP element assembly + a multifrontal Cholesky on dense fronts with LAPACK/BLAS (what MUMPS is
@@ -105,8 +160,10 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0):
         t0 = time.perf_counter()
         asm, fac = mf.factorize()
         w = mf.solve(b)
+        for _ in range(2):                           # two refinement steps on the true residual: three solves, all executed
+            w = w + mf.solve(b - cs.apply_K(w, cores))
         t1 = time.perf_counter()
-        return t1 - t0 + 2 * (t1 - t0 - asm - fac), asm, fac, w, mf          # two more solves: refinement on the true residual
+        return t1 - t0, asm, fac, w, mf
     forward.mf = {}
     forward(ncores)                                                             # warm-up (page faults of the 15 GB of fronts)
     runs = []
@@ -114,24 +171,32 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0):
         runs.append(forward(ncores))
     runs.sort(key=lambda r: r[0])
     tot, asm, fac, w, mf = runs[len(runs) // 2]
-    t0 = time.perf_counter()
-    rhs = o.dcompliance_du(w)
-    lam = mf.solve(rhs)
-    g = o.dcompliance_dh(w) - cs.assemble_drdfield("h", w, ncores).T @ lam
-    adj = time.perf_counter() - t0
+
+    def adjoint():
+        # best effort, like the forward leg: quadrature sweeps in C++/OpenMP (no assembled dR/dh), the factor reused, the
+        # triangular sweeps level-parallel; one refinement step on the true residual, as the GPU path does (2 PCG iterations)
+        t0 = time.perf_counter()
+        rhs, dJdh = cs.dcompliance(w, ncores)
+        lam = mf.solve(rhs)
+        lam = lam + mf.solve(rhs - cs.apply_K(lam, ncores))
+        g = cs.drdfield_T("h", w, lam, ncores, scale=-1.0, out=dJdh)
+        return time.perf_counter() - t0, g
+    adjoint()
+    adj = float(np.median([adjoint()[0] for _ in range(3)]))
     out = dict(value=m.ndof / tot, unit="DOF/s", cores=ncores, kind="port", cpu_model=cb.cpu_model_name(),
                sample=f"the workload itself ({m.ndof} DOF): C++/OpenMP front assembly {asm:.2f} s + multifrontal Cholesky (LAPACK/BLAS) "
-                      f"{fac:.2f} s + 3 triangular solves = {tot:.2f} s, median of {len(runs)} after 1 warm-up, {ncores} threads; "
-                      f"adjoint gradient with the same factor {adj:.2f} s",
+                      f"{fac:.2f} s + 3 level-parallel triangular solves with 2 matrix-free residuals (all executed) = {tot:.2f} s, "
+                      f"median of {len(runs)} after 1 warm-up, {ncores} threads; adjoint gradient with the same factor "
+                      f"(C++/OpenMP quadrature of dJ/du, dJ/dh and (dR/dh)^T lambda, 2 solves + 1 residual) {adj:.3f} s, median of 3",
                forward_s=tot, adjoint_ms=adj * 1e3)
     if time.perf_counter() - t_begin + 1.2 * ncores * tot < budget_s + 30.0:    # one single-core run, if it fits (same, already touched, fronts)
         mf.nthreads = 1
         forward.mf[1] = mf
         t1, a1, f1, _, _ = forward(1)
         out["single_core"] = dict(value=m.ndof / t1, forward_s=t1, assemble_s=a1, factor_s=f1, cores=1)
-    full = os.path.join(ROOT, "profiles", "r2_cpu_baseline_wing1m.json")
-    if os.path.exists(full):
-        out["full_protocol"] = "profiles/r2_cpu_baseline_wing1m.json"
+    full = os.path.join("profiles", f"r2_cpu_baseline_{workload}.json")
+    if os.path.exists(os.path.join(ROOT, full)):
+        out["full_protocol"] = full
     return out
 
 
@@ -186,9 +251,16 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
     tt = torch.tensor([t_total, sum(r[0] for r in rows), sum(r[1] for r in rows)], device="cuda", dtype=torch.float64)
     comm.allreduce_(tt, op="max")
     t_total, t_fwd, t_adj = tt.tolist()
-    apply_ms = ds.eng.ctx.bench_kernel("apply", 50)
-    alg_bytes = 16.0 * ds.sub.ndof + 340.0 * ds.sub.nel
-    achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
+    # the same two roofline objects as the N = 1 line, measured on rank 0's partition: the rank-k updates of ITS factorisation
+    # (its subtree + the replicated top of the tree; one instrumented factorisation, HIP event pairs on the context's stream --
+    # every rank takes part, the Schur all-gather sits in the middle) and its element operator
+    ctx0 = ds.eng.ctx
+    ctx0.set_option("profile", 1)
+    with ds.eng.on_stream():
+        ds.factorize()
+    ctx0.set_option("profile", 0)
+    prof = ctx0.factorize_profile(run=False)
+    apply_ms = ctx0.bench_kernel("apply", 50)
     if rank == 0:
         out = {
             "metric": "DOF/s (assembly+solve), forward solve of the RM shell; adjoint-gradient wallclock in adjoint_ms",
@@ -207,19 +279,43 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
                        "rtol": args.rtol, "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
                        "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],
                        "parallelism": f"element partition over {world} GPUs, RCCL all-reduce of separator DOFs"},
-            "roofline": {"bound": "hbm", "kernel": "k_apply4 (matrix-free CG2xCG1 shell operator), rank 0",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms},
+            "roofline": dict(trailing_roofline(prof, None), where=f"rank 0 of {world}: its subtree + the replicated top of the tree"),
+            "roofline_spmv": spmv_roofline(apply_ms, ds.sub.ndof, ds.sub.nel, None, where=f", rank 0 of {world}"),
+            "factorisation_profile_ms": {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)},
         }
         print(json.dumps(out))
     dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: this process parses the arguments, touches no GPU API and starts the N
+    ranks itself (``torch.distributed.run`` as a child process, rendezvous on 127.0.0.1); rank 0's JSON line goes straight to
+    this process's stdout, the exit code is the children's.  Under torchrun (WORLD_SIZE set) bench.py is a rank and never
+    comes here.  No process that has initialised the GPU is ever replaced by another."""
+    import socket
+    import subprocess
+    import torch                                   # counting devices does not initialise the GPU
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        if not args.share_gpu:
+            raise SystemExit(f"--gpus {args.gpus} but {ndev} device(s) visible (a rehearsal on fewer cards: --share-gpu)")
+        env.setdefault("FEMO_BENCH_BACKEND", "gloo")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    res = subprocess.run(cmd, env=env)
+    if res.returncode:
+        raise SystemExit(res.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=80, help="default: a timed region of ~2 s at 1 M DOF")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "wing1m"))
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
@@ -229,7 +325,11 @@ def main():
     ap.add_argument("--no-keep-numbering-leg", action="store_true", help="skip the extra forward solve on the shuffled numbering")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: the same 1M-DOF skin split into N element partitions (BASELINE config 4), or N times the span")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: allow --gpus N on a box with fewer cards (the ranks share them; collectives over gloo)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -306,34 +406,15 @@ def main():
 
     # the matrix-free element operator (the SpMV of the north star), HIP events around back-to-back launches
     apply_ms = ctx.bench_kernel("apply", 100)
-    alg_bytes = 16.0 * m.ndof + 340.0 * m.nel          # SURVEY.md section 8d, B_spmv,ebe per launch
-    achieved = alg_bytes / (apply_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 counter passes (scripts/aggregate_pmc.py; separate
-    # FETCH_SIZE and WRITE_SIZE runs, gfx950 correction 2*FETCH+WRITE) -- counters cannot be read from inside bench.py
-    traffic = traffic_trailing = None
-    pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-    if os.path.exists(pmc):
-        pj = json.load(open(pmc))
-        traffic = pj.get("apply_hbm_bytes_per_launch")
-        traffic_trailing = pj.get("trailing_hbm_bytes_per_launch")
-    roof_spmv = {"bound": "hbm", "kernel": "k_apply4 (matrix-free CG2xCG1 shell operator)",
-                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": apply_ms}
+    traffic, traffic_trailing = pmc_traffic(args.workload)
+    roof_spmv = spmv_roofline(apply_ms, m.ndof, m.nel, traffic)
     roof = roof_spmv
     prof = None
     if args.solver == "frontal":
-        # dominant kernel of the frontal path: the trailing update of the partial Cholesky (fp64 rank-32 updates);
+        # dominant kernel of the frontal path: the trailing update of the partial Cholesky (fp64 rank-k updates);
         # one instrumented factorisation with a HIP event pair around every launch on the context's stream
         prof = ctx.factorize_profile()
-        tr = prof["trailing"]
-        # flops and compulsory bytes are summed over the launches from each launch's own K / column ranges (femo_hip.hip,
-        # count_trailing): lower triangles only, C read + written once, the factor rows of the K panel read once
-        tf = prof["trailing_flops"] / tr["launches"] / (tr["ms"] / tr["launches"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "k_trailing_mfma, all launches (fp64 rank-k updates of the multifrontal Cholesky)",
-                "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": traffic_trailing,
-                "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
-                "algorithmic_bytes_per_launch": prof["trailing_bytes"] / tr["launches"],
-                "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"]}
+        roof = trailing_roofline(prof, traffic_trailing)
         kernels = {}
         for cls, fk in (("trailing", "trailing"), ("panel_rows", "panel_rows"), ("panel_diag", "panel_diag")):
             ms = prof[cls]["ms"]
@@ -414,7 +495,7 @@ def main():
             out["frontal"] = {k: (float(v) if not isinstance(v, int) else v) for k, v in ctx.frontal_info().items()}
         if not args.no_cpu_baseline and world == 1:
             ctx.close()                                   # the CPU leg wants the host memory bandwidth to itself
-            out["cpu_baseline"] = cpu_baseline(m, fields, marker, args.leaf)
+            out["cpu_baseline"] = cpu_baseline(m, fields, marker, args.leaf, workload=args.workload)
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

@@ -6,6 +6,8 @@ from (csrc/*.hip, csrc/*.h, include/*.h) and of the compiler flags is stored bes
 when hipcc is there) a library whose digest does not match the sources it sits next to."""
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import glob
 import hashlib
 import os
@@ -37,6 +39,27 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
+@contextlib.contextmanager
+def _build_lock(path):
+    """Exclusive lock for one library's build: every rank of a torchrun / mp.spawn job calls ``load()`` at the same time and
+    would otherwise link into the same file while another rank dlopens it.  The first to take the lock builds; the others
+    wait, re-check the digest under the lock and find the library fresh."""
+    fd = os.open(path + ".lock", os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
+def _write_atomic(path, text):
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as fh:
+        fh.write(text)
+    os.replace(tmp, path)
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(HASHFILE):
         return True
@@ -51,20 +74,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libfemo_hip.so cannot be built (there is no CPU fallback)")
-    digest = source_digest()
-    tmp = LIB + ".tmp"
-    cmd = [hipcc, *FLAGS, "-o", tmp, *SOURCES]
-    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    if verbose or res.returncode:
-        print(" ".join(cmd))
-        print(res.stdout, res.stderr)
-    if res.returncode:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed building libfemo_hip.so:\n" + res.stderr[-4000:])
-    os.replace(tmp, LIB)
-    with open(HASHFILE, "w") as fh:
-        fh.write(digest + "\n")
+    with _build_lock(LIB):
+        if not force and not needs_build():          # another process built it while this one waited for the lock
+            return LIB
+        digest = source_digest()
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        cmd = [hipcc, *FLAGS, "-o", tmp, *SOURCES]
+        res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        if verbose or res.returncode:
+            print(" ".join(cmd))
+            print(res.stdout, res.stderr)
+        if res.returncode:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("hipcc failed building libfemo_hip.so:\n" + res.stderr[-4000:])
+        os.replace(tmp, LIB)
+        _write_atomic(HASHFILE, digest + "\n")
     return LIB
 
 
@@ -96,16 +121,18 @@ def build_symbolic(force: bool = False) -> str:
     gxx = shutil.which("g++")
     if not gxx:
         raise RuntimeError("g++ not found: libfemo_symbolic.so cannot be built")
-    digest = symbolic_digest()
-    tmp = SYM_LIB + ".tmp"
-    res = subprocess.run([gxx, *SYM_FLAGS, "-o", tmp, "symbolic.cpp"], cwd=CSRC, capture_output=True, text=True)
-    if res.returncode:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("g++ failed building libfemo_symbolic.so:\n" + res.stderr[-4000:])
-    os.replace(tmp, SYM_LIB)
-    with open(SYM_HASHFILE, "w") as fh:
-        fh.write(digest + "\n")
+    with _build_lock(SYM_LIB):
+        if not force and not symbolic_needs_build():
+            return SYM_LIB
+        digest = symbolic_digest()
+        tmp = f"{SYM_LIB}.{os.getpid()}.tmp"
+        res = subprocess.run([gxx, *SYM_FLAGS, "-o", tmp, "symbolic.cpp"], cwd=CSRC, capture_output=True, text=True)
+        if res.returncode:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("g++ failed building libfemo_symbolic.so:\n" + res.stderr[-4000:])
+        os.replace(tmp, SYM_LIB)
+        _write_atomic(SYM_HASHFILE, digest + "\n")
     return SYM_LIB
 
 

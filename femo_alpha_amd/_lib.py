@@ -80,6 +80,20 @@ SIGNATURES = {
     "femo_functionals_partial": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_dfunctional_vec": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "femo_field_gradient_vec": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, _c_double_p, C.c_int64]),
+    "femo_dist_setup": (C.c_int, [C.c_void_p, C.c_int32, _c_int32_p, C.c_int32, C.c_int32, C.c_int32, _c_int32_p]),
+    "femo_dist_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "femo_dist_pack": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_dist_unpack": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_dist_pcg_start": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "femo_dist_precond_fwd": (C.c_int, [C.c_void_p]),
+    "femo_dist_read": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_dist_precond_rest": (C.c_int, [C.c_void_p]),
+    "femo_dist_direction_apply": (C.c_int, [C.c_void_p, C.c_int]),
+    "femo_dist_update": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_dist_gradient": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "femo_front_schur_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "femo_front_block_unpack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "femo_factorize_profile_get": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
 }
 

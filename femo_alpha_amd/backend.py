@@ -175,10 +175,11 @@ class ShellContext:
         self._chk(self.lib.femo_factorize(self._h))
         return self.frontal_info()
 
-    def factorize_profile(self):
-        """One factorisation timed per kernel class with HIP events on the context's stream."""
+    def factorize_profile(self, run=True):
+        """One factorisation timed per kernel class with HIP events on the context's stream.  ``run=False``: only read what
+        the factorisations since the last assembly recorded while option "profile" was on (the partitioned driver)."""
         t = np.zeros(32)
-        self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)))
+        self._chk(self.lib.femo_factorize_profile(self._h, dptr(t)) if run else self.lib.femo_factorize_profile_get(self._h, dptr(t)))
         names = ["panel_rows", "panel_diag", "trailing", "extend_add", "front_assemble", "memset", "l11_inverse"]
         out = {n: dict(ms=t[i], launches=int(t[8 + i])) for i, n in enumerate(names)}
         out["trailing_flops"], out["panel_rows_flops"], out["panel_diag_flops"] = t[18], t[16], t[17]
@@ -368,6 +369,65 @@ class ShellContext:
         self._chk(self.lib.femo_field_gradient_vec(self._h, functional.encode(), arg.encode(), self.VEC_IDS[lam],
                                                    dptr(out), out.size))
         return out
+
+    # ---- the partitioned PCG (femo_dist_*): every call enqueues on the context's stream; collectives are the caller's
+    def dist_setup(self, top_idx, nranks, n_local_levels, sel):
+        ti = np.ascontiguousarray(top_idx, dtype=np.int32)
+        se = np.ascontiguousarray(sel, dtype=np.int32)
+        self._chk(self.lib.femo_dist_setup(self._h, ti.size, iptr(ti), int(nranks), int(n_local_levels), se.size, iptr(se)))
+        self._ntop = ti.size
+
+    def _dev_tensor(self, ptr, n):
+        import torch
+
+        class _Arr:
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(int(ptr), False), version=2)
+        t = torch.as_tensor(a, device=f"cuda:{self.device}")
+        t._femo_owner = self
+        return t
+
+    def dist_tensors(self):
+        """Zero-copy torch views of the two buffers the collectives run on: (ntop + 1 packed entries, 8 device scalars)."""
+        return (self._dev_tensor(self.lib.femo_dist_ptr(self._h, 0), self._ntop + 1),
+                self._dev_tensor(self.lib.femo_dist_ptr(self._h, 1), 8))
+
+    def dist_pack(self, vec):
+        self._chk(self.lib.femo_dist_pack(self._h, self.VEC_IDS[vec]))
+
+    def dist_unpack(self, vec):
+        self._chk(self.lib.femo_dist_unpack(self._h, self.VEC_IDS[vec]))
+
+    def dist_pcg_start(self, b, x):
+        self._chk(self.lib.femo_dist_pcg_start(self._h, self.VEC_IDS[b], self.VEC_IDS[x]))
+
+    def dist_precond_fwd(self):
+        self._chk(self.lib.femo_dist_precond_fwd(self._h))
+
+    def dist_read(self):
+        t = np.zeros(2)
+        self._chk(self.lib.femo_dist_read(self._h, dptr(t)))
+        return float(t[0]), float(t[1])
+
+    def dist_precond_rest(self):
+        self._chk(self.lib.femo_dist_precond_rest(self._h))
+
+    def dist_direction_apply(self, first):
+        self._chk(self.lib.femo_dist_direction_apply(self._h, int(first)))
+
+    def dist_update(self, x):
+        self._chk(self.lib.femo_dist_update(self._h, self.VEC_IDS[x]))
+
+    def dist_gradient(self, functional, arg, lam, gglob_tensor):
+        self._chk(self.lib.femo_dist_gradient(self._h, functional.encode(), arg.encode(), self.VEC_IDS[lam],
+                                              C.c_void_p(gglob_tensor.data_ptr()), gglob_tensor.numel()))
+
+    def front_schur_pack(self, front, dst_tensor):
+        self._chk(self.lib.femo_front_schur_pack(self._h, int(front), C.c_void_p(dst_tensor.data_ptr()), dst_tensor.numel()))
+
+    def front_block_unpack(self, front, src_tensor):
+        self._chk(self.lib.femo_front_block_unpack(self._h, int(front), C.c_void_p(src_tensor.data_ptr())))
 
     def last_timing(self):
         t = np.zeros(5)

@@ -58,6 +58,13 @@ struct femo_ctx {
     int csel = -1, ntags = 0;
     std::vector<double> alpha_tag;           // reference area of every sub-domain (frozen at first use, like stress_alpha)
     double* gradbuf = nullptr;
+    // element-partitioned driver (femo_dist_*): replicated separator entries, dot weights, gradient scatter map
+    struct Dist {
+        bool ready = false;
+        int ntop = 0, nranks = 1, nl = 0, nsel = 0;
+        int *top_idx = nullptr, *sel = nullptr;
+        double *wdot = nullptr, *topbuf = nullptr, *topsave = nullptr, *gloc = nullptr;
+    } di;
     // CSR assembly
     long long csr_ncontrib = 0; int csr_nnz = 0;
     int *csr_perm = nullptr, *csr_dest = nullptr;
@@ -532,7 +539,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // the extend-add fills the pivot columns only (option "fused_schur").  Measured at 1M DOF: extend-add 3.3 -> 2.3 ms,
         // rank-k updates 8.4 -> 8.7 ms.
         const bool left_level = !(c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt < c->opt.left_min || cnt > c->opt.left_max));
-        const bool sp_level = !left_level && c->opt.super_panel > NBO && cnt <= c->opt.super_panel_cnt && max_np > NBO && !c->opt.super_panel_ahead;
+        // the super-panel width the schedule really uses (whole outer panels): every decision below tests THIS value, so an
+        // option between two multiples of 128 cannot switch the gathering update on while the super-panel branch stays off
+        const int SP_opt = c->opt.super_panel / NBO * NBO;
+        const bool sp_level = !left_level && SP_opt > NBO && cnt <= c->opt.super_panel_cnt && max_np > NBO && !c->opt.super_panel_ahead;
         const bool single_update = left_level || (max_np <= NBO && !(cnt < c->opt.lookahead_cnt && c->opt.lookahead != 0));
         // super-panel levels: the FIRST update behind a super-panel reaches every Schur complement of the level: it gathers,
         // the later ones read and write what it stored
@@ -575,7 +585,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // Left-looking wins where a level has enough fronts to fill the chip with the narrow panel updates (measured at
         // 1M DOF: levels of 16..2048 fronts), right-looking at the top of the tree and on the single-panel leaves.
         const bool right_looking = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt_level < c->opt.left_min || cnt_level > c->opt.left_max);
-        const bool use_sp = right_looking && c->opt.super_panel > NBO && cnt_level <= c->opt.super_panel_cnt && max_np_level > NBO;
+        const bool use_sp = right_looking && SP_opt > NBO && cnt_level <= c->opt.super_panel_cnt && max_np_level > NBO;
         const bool lookahead = right_looking && !use_sp && cnt_level < c->opt.lookahead_cnt && c->opt.lookahead != 0;
         bool bulk_pending = false;
         // flops of one k_trailing_mfma launch over this level, with the kernel's own column / K ranges (profiling only)
@@ -626,7 +636,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // columns of both super-panels in their own narrow updates (K0 = start of the previous super-panel).  Measured at
         // 1M DOF: slower than the plain super-panel schedule (19.0 against 18.4 ms) -- the one-workgroup-per-front
         // diagonal-block kernels lose more to sharing their CUs with the bulk update than the overlap gains; off by default.
-        const int SP = use_sp ? c->opt.super_panel / NBO * NBO : NBO;
+        const int SP = use_sp ? SP_opt : NBO;
         const bool sp_ahead = use_sp && c->opt.super_panel_ahead != 0;
         int sp_bulks = 0;                                // bulk updates of this chunk issued on stream2 so far
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
@@ -709,7 +719,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
                     FOR_FRONT_CHUNKS(cnt, off, n) {
-                        if (fused_schur && !left_level) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
+                        // only the FIRST update behind the pivot columns may gather: a later one would overwrite the earlier panels' updates
+                        if (fused_schur && !left_level && C0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
                         else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
                     }
                 } else {
@@ -1243,6 +1254,9 @@ void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();                   // stream2 / stream3 may still hold work that reads the buffers freed below
+    void* dptrs[] = {c->di.top_idx, c->di.sel, c->di.wdot, c->di.topbuf, c->di.topsave, c->di.gloc};
+    for (void* p : dptrs)
+        if (p) hipFree(p);
     void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
@@ -1487,7 +1501,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "left_max") o.left_max = v;
     else if (k == "lookahead") o.lookahead = v != 0;
     else if (k == "lookahead_cnt") o.lookahead_cnt = v;
-    else if (k == "super_panel") o.super_panel = v;
+    else if (k == "super_panel") { if (v < 0) return fail(c, "super_panel: a column count (rounded down to whole 128-column panels; < 256 switches it off)"); o.super_panel = v; }
     else if (k == "super_panel_cnt") o.super_panel_cnt = v;
     else if (k == "super_panel_ahead") o.super_panel_ahead = v != 0;
     else if (k == "fused_schur") o.fused_schur = v != 0;
@@ -1500,6 +1514,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "strict") o.strict = v != 0;
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
+    else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
     else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;
@@ -1907,7 +1922,9 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     }
     HIPCHK(c, hipMalloc((void**)&fr.P, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMemset(fr.P, 0, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));   // once: the upper triangles of L11 are never written
-    HIPCHK(c, hipMalloc((void**)&fr.S, (size_t)std::max<long long>(fr.s_doubles, 1) * sizeof(double)));
+    // two doubles of padding: the gathering updates read Sc[0] of a child without a Schur block (or of the front itself when a
+    // child is missing) as their "safe address", which may be the very end of the arena
+    HIPCHK(c, hipMalloc((void**)&fr.S, (size_t)(std::max<long long>(fr.s_doubles, 1) + 2) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.Linv, (size_t)std::max<long long>(fr.linv_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMalloc((void**)&fr.info, sizeof(int)));
     // dynamic LDS of the one-workgroup-per-front sweeps: forward maxnp + SMALL_PART, backward maxnp + maxnb + SMALL_PART
@@ -2107,6 +2124,201 @@ int femo_field_gradient_vec(femo_ctx* c, const char* functional, const char* arg
     return rc;
 }
 
+
+
+// ---- element-partitioned PCG: everything between two collectives is ONE call that only enqueues work on the context's
+// stream (no host synchronisation); the caller issues the all-reduce on femo_dist_ptr(ctx, 0) / (ctx, 1) on the same stream.
+// Per iteration: precond_fwd -> all-reduce(topbuf[0 .. ntop]) -> read -> precond_rest -> all-reduce(scal[1]) ->
+// direction_apply -> all-reduce(topbuf[0 .. ntop]) -> update.  topbuf[ntop] carries the scalar that rides along with the
+// replicated entries: this rank's share of r.r (first collective) or of p.Ap (second).
+int femo_dist_setup(femo_ctx* c, int32_t ntop, const int32_t* top_idx, int32_t nranks, int32_t n_local_levels, int32_t nsel,
+                    const int32_t* sel) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& d = c->di;
+    if (d.ready) return fail(c, "femo_dist_setup was already called for this context");
+    if (ntop < 0 || nranks < 1 || nsel < 0 || (ntop > 0 && !top_idx) || (nsel > 0 && !sel)) return fail(c, "bad arguments");
+    if (!c->fr.ready || n_local_levels < 0 || n_local_levels > c->fr.nlevels) return fail(c, "n_local_levels outside the frontal plan");
+    for (int i = 0; i < ntop; ++i)
+        if (top_idx[i] < 0 || top_idx[i] >= c->ndof) return fail(c, "replicated entry outside the vector");
+    d.ntop = ntop; d.nranks = nranks; d.nl = n_local_levels; d.nsel = nsel;
+    std::vector<double> w((size_t)c->ndof, 1.0);
+    for (int i = 0; i < ntop; ++i) w[top_idx[i]] = 1.0 / nranks;
+    HIPCHK(c, hipMalloc((void**)&d.wdot, (size_t)c->ndof * sizeof(double)));
+    HIPCHK(c, hipMemcpy(d.wdot, w.data(), (size_t)c->ndof * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&d.top_idx, (size_t)std::max(ntop, 1) * sizeof(int)));
+    if (ntop) HIPCHK(c, hipMemcpy(d.top_idx, top_idx, (size_t)ntop * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&d.topbuf, (size_t)(ntop + 2) * sizeof(double)));
+    HIPCHK(c, hipMemset(d.topbuf, 0, (size_t)(ntop + 2) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&d.topsave, (size_t)std::max(ntop, 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&d.sel, (size_t)std::max(nsel, 1) * sizeof(int)));
+    if (nsel) HIPCHK(c, hipMemcpy(d.sel, sel, (size_t)nsel * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc((void**)&d.gloc, (size_t)std::max<int64_t>(std::max<int64_t>(c->nT, 3 * c->nF), 1) * sizeof(double)));
+    d.ready = true;
+    return 0;
+}
+
+void* femo_dist_ptr(femo_ctx* c, int32_t which) { return which == 0 ? (void*)c->di.topbuf : which == 1 ? (void*)c->scal : nullptr; }
+
+#define DIST_READY(c) do { HIPCHK(c, hipSetDevice((c)->device)); if (!(c)->di.ready) return fail(c, "call femo_dist_setup first"); } while (0)
+
+int femo_dist_pack(femo_ctx* c, int32_t vec) {
+    DIST_READY(c);
+    double* v = vec_by_id(c, vec);
+    if (!v) return fail(c, "bad vector id");
+    if (c->di.ntop) hipLaunchKernelGGL(k_gather_idx, dim3(nblk(c->di.ntop, 256)), dim3(256), 0, c->stream, c->di.topbuf, (const double*)v, (const int*)c->di.top_idx, c->di.ntop);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int femo_dist_unpack(femo_ctx* c, int32_t vec) {
+    DIST_READY(c);
+    double* v = vec_by_id(c, vec);
+    if (!v) return fail(c, "bad vector id");
+    if (c->di.ntop) hipLaunchKernelGGL(k_scatter_idx, dim3(nblk(c->di.ntop, 256)), dim3(256), 0, c->stream, v, (const double*)c->di.topbuf, (const int*)c->di.top_idx, c->di.ntop);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// x = 0, r = b; this rank's share of b.b goes into scal[3] (it travels with the first collective of the first iteration)
+int femo_dist_pcg_start(femo_ctx* c, int32_t b, int32_t x) {
+    DIST_READY(c);
+    double *vb = vec_by_id(c, b), *vx = vec_by_id(c, x);
+    if (!vb || !vx || vb == vx || vb == c->r || vb == c->z || vb == c->p || vb == c->Ap || vx == c->r || vx == c->z || vx == c->p || vx == c->Ap)
+        return fail(c, "bad vector ids (2..5 are the solver's work space)");
+    const int64_t n = c->ndof;
+    HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(vx, 0, n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->r, vb, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_wdot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)vb, (const double*)vb, (const double*)c->di.wdot, n, c->scal + 3);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// z = r; forward sweep over this rank's subtree; topbuf = what it added to the replicated entries, topbuf[ntop] = share of r.r
+int femo_dist_precond_fwd(femo_ctx* c) {
+    DIST_READY(c);
+    auto& d = c->di;
+    if (!c->fr.factored) return fail(c, "the factorisation is stale");
+    const int64_t n = c->ndof;
+    HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (d.ntop) hipLaunchKernelGGL(k_gather_idx, dim3(nblk(d.ntop, 256)), dim3(256), 0, c->stream, d.topsave, (const double*)c->z, (const int*)d.top_idx, d.ntop);
+    if (int rc = frontal_fwd(c, c->z, 0, d.nl)) return rc;
+    if (d.ntop) hipLaunchKernelGGL(k_top_delta, dim3(nblk(d.ntop, 256)), dim3(256), 0, c->stream, d.topbuf, (const double*)c->z, (const double*)d.topsave, (const int*)d.top_idx, d.ntop);
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(64), 0, c->stream, d.topbuf + d.ntop, (const double*)(c->scal + 3));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// after the collective: out2 = { global r.r, global p.Ap of the previous iteration }  (the one host synchronisation per iteration)
+int femo_dist_read(femo_ctx* c, double* out2) {
+    DIST_READY(c);
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->di.topbuf + c->di.ntop, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->scal_host + 1, c->scal + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out2[0] = c->scal_host[0]; out2[1] = c->scal_host[1];
+    return 0;
+}
+
+// replicated entries of z <- saved + summed delta; the replicated top of the tree forward and backward; this rank's subtree
+// backward; scal[1] = share of r.z
+int femo_dist_precond_rest(femo_ctx* c) {
+    DIST_READY(c);
+    auto& d = c->di;
+    const int64_t n = c->ndof;
+    if (d.ntop) hipLaunchKernelGGL(k_top_restore, dim3(nblk(d.ntop, 256)), dim3(256), 0, c->stream, c->z, (const double*)d.topsave, (const double*)d.topbuf, (const int*)d.top_idx, d.ntop);
+    if (int rc = frontal_fwd(c, c->z, d.nl, c->fr.nlevels)) return rc;
+    if (int rc = frontal_bwd(c, c->z, d.nl, c->fr.nlevels)) return rc;
+    if (int rc = frontal_bwd(c, c->z, 0, d.nl)) return rc;
+    HIPCHK(c, hipMemsetAsync(c->scal + 1, 0, 3 * sizeof(double), c->stream));
+    hipLaunchKernelGGL(k_wdot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)c->r, (const double*)c->z, (const double*)d.wdot, n, c->scal + 1);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// p = z + (r.z / previous r.z) p; Ap = (local operator) p; topbuf = Ap on the replicated entries, topbuf[ntop] = p . Ap_local
+// (p^T A p is the sum over the ranks of p^T A_local p: the scalar needs no collective of its own)
+int femo_dist_direction_apply(femo_ctx* c, int first) {
+    DIST_READY(c);
+    auto& d = c->di;
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, (const double*)c->z, (const double*)c->scal, first ? 1 : 0, n);
+    HIPCHK(c, hipMemsetAsync(c->Ap, 0, n * sizeof(double), c->stream));
+    if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
+    if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->Ap, c->mask, n);
+    hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)c->p, (const double*)c->Ap, n, c->scal + 2);
+    if (d.ntop) hipLaunchKernelGGL(k_gather_idx, dim3(nblk(d.ntop, 256)), dim3(256), 0, c->stream, d.topbuf, (const double*)c->Ap, (const int*)d.top_idx, d.ntop);
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(64), 0, c->stream, d.topbuf + d.ntop, (const double*)(c->scal + 2));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// after the collective: Ap's replicated entries and the global p.Ap are in topbuf; x += alpha p, r -= alpha Ap, scal[3] = share of r.r
+int femo_dist_update(femo_ctx* c, int32_t x) {
+    DIST_READY(c);
+    auto& d = c->di;
+    double* vx = vec_by_id(c, x);
+    if (!vx) return fail(c, "bad vector id");
+    const int64_t n = c->ndof;
+    if (d.ntop) hipLaunchKernelGGL(k_scatter_idx, dim3(nblk(d.ntop, 256)), dim3(256), 0, c->stream, c->Ap, (const double*)d.topbuf, (const int*)d.top_idx, d.ntop);
+    hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(64), 0, c->stream, c->scal + 2, (const double*)(d.topbuf + d.ntop));
+    hipLaunchKernelGGL(k_pcgf_update_w, dim3(red_grid(n)), dim3(256), 0, c->stream, vx, c->r, (const double*)c->p, (const double*)c->Ap, (const double*)d.wdot, c->scal, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// gglob (device, nglob doubles, zeroed by the caller) [sel] = - (dR/d arg)^T lambda + d functional / d arg over this rank's cells
+int femo_dist_gradient(femo_ctx* c, const char* functional, const char* arg, int32_t lam, void* gglob, int64_t nglob) {
+    DIST_READY(c);
+    auto& d = c->di;
+    double* l = vec_by_id(c, lam);
+    if (!l) return fail(c, "bad vector id");
+    int64_t len;
+    if (!field_ptr(c, arg ? arg : "", &len)) return fail(c, "unknown argument");
+    if (len != d.nsel) return fail(c, "the gradient scatter map was set up for a field of another length");
+    int rc = dfunctional_dev(c, functional ? functional : "", arg, d.gloc, len);
+    if (!rc) rc = dRdarg_T_dev(c, arg, l, -1.0, d.gloc, len);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scatter_idx, dim3(nblk(d.nsel, 256)), dim3(256), 0, c->stream, (double*)gglob, (const double*)d.gloc, (const int*)d.sel, d.nsel);
+    HIPCHK(c, hipGetLastError());
+    (void)nglob;
+    return 0;
+}
+
+// packed lower triangle of a front's Schur complement (what the all-gather of the subtree roots carries), and back into a
+// pivot-free stand-in front; both asynchronous on the context's stream
+int femo_front_schur_pack(femo_ctx* c, int32_t front, void* dst_dev, int64_t capacity_doubles) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready || front < 0 || front >= fr.ntree) return fail(c, "bad front id");
+    const int nb = fr.h_nf[front] - fr.h_npiv[front];
+    if ((int64_t)nb * (nb + 1) / 2 > capacity_doubles) return fail(c, "destination too small for the packed Schur complement");
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(k_tril_pack, dim3(std::min(8, nblk(nb, 256)), nb), dim3(256), 0, c->stream, (double*)dst_dev, (const double*)(fr.S + fr.h_soff[front]), nb);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int femo_front_block_unpack(femo_ctx* c, int32_t front, const void* src_dev) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready || front < 0 || front >= fr.ntree) return fail(c, "bad front id");
+    if (fr.h_npiv[front] != 0) return fail(c, "only fronts without pivots can be overwritten");
+    const int nf = fr.h_nf[front];
+    if (nf == 0) return 0;
+    hipLaunchKernelGGL(k_tril_unpack, dim3(std::min(8, nblk(nf, 256)), nf), dim3(256), 0, c->stream, fr.S + fr.h_soff[front], (const double*)src_dev, nf);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// results of the instrumented factorisation(s) since the last assembly (option "profile"): same layout as femo_factorize_profile
+int femo_factorize_profile_get(femo_ctx* c, double* out32) {
+    for (int i = 0; i < 8; ++i) {
+        out32[i] = c->fr.prof_ms[i]; out32[8 + i] = (double)c->fr.prof_calls[i];
+        out32[16 + i] = c->fr.prof_flops[i]; out32[24 + i] = c->fr.prof_bytes[i];
+    }
+    return 0;
+}
 
 // ---- dynamic shell: operator A = aK K + aM M, device-vector building blocks (femo_alpha_amd/dynamic_rm_shell) ----
 int femo_set_operator(femo_ctx* c, double aK, double aM) {

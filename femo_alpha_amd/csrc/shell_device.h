@@ -1394,6 +1394,68 @@ __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b
     block_accumulate((s0 + s1) + (s2 + s3), slot);
 }
 
+// ---- element-partitioned (multi-GPU) driver: the replicated separator entries of a vector are packed into one
+// contiguous buffer for the all-reduce and written back; global dot products weigh every entry by 1 / (ranks holding it)
+__global__ void k_gather_idx(double* __restrict__ out, const double* __restrict__ v, const int* __restrict__ idx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[idx[i]];
+}
+__global__ void k_scatter_idx(double* __restrict__ v, const double* __restrict__ in, const int* __restrict__ idx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[idx[i]] = in[i];
+}
+// out = v[idx] - save   (what the local forward sweep added to the replicated entries)
+__global__ void k_top_delta(double* __restrict__ out, const double* __restrict__ v, const double* __restrict__ save,
+                            const int* __restrict__ idx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[idx[i]] - save[i];
+}
+// v[idx] = save + delta   (delta summed over the ranks)
+__global__ void k_top_restore(double* __restrict__ v, const double* __restrict__ save, const double* __restrict__ delta,
+                              const int* __restrict__ idx, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[idx[i]] = save[i] + delta[i];
+}
+// slot += sum_i w_i a_i b_i
+__global__ void k_wdot(const double* __restrict__ a, const double* __restrict__ b, const double* __restrict__ w, int64_t n, double* slot) {
+    double s0 = 0.0, s1 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) { s0 += w[i] * a[i] * b[i]; s1 += w[i + stride] * a[i + stride] * b[i + stride]; }
+    for (; i < n; i += stride) s0 += w[i] * a[i] * b[i];
+    block_accumulate(s0 + s1, slot);
+}
+// k_pcgf_update of the partitioned driver: r.r weighted as above (scal[3] then holds this rank's share of the global r.r)
+__global__ void k_pcgf_update_w(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p, const double* __restrict__ Ap,
+                                const double* __restrict__ w, double* __restrict__ scal, int64_t n) {
+    const double alpha = scal[1] / scal[2];
+    double local = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        r[i] = ri;
+        local += w[i] * ri * ri;
+    }
+    block_accumulate(local, scal + 3);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[0] = scal[1];
+}
+__global__ void k_copy_scalar(double* __restrict__ dst, const double* __restrict__ src) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst = *src;
+}
+// lower triangle (column by column) of a column-major n x n block <-> packed n (n + 1) / 2 doubles
+__global__ void k_tril_pack(double* __restrict__ packed, const double* __restrict__ full, int n) {
+    const int c = blockIdx.y;
+    const long long base = (long long)c * n - (long long)c * (c - 1) / 2;           // entries of the columns before c
+    for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+        packed[base + (r - c)] = full[r + (size_t)n * c];
+}
+__global__ void k_tril_unpack(double* __restrict__ full, const double* __restrict__ packed, int n) {
+    const int c = blockIdx.y;
+    const long long base = (long long)c * n - (long long)c * (c - 1) / 2;
+    for (int r = c + blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+        full[r + (size_t)n * c] = packed[base + (r - c)];
+}
+
 // r = b - Ap (or r = b when Ap == null); masked rows zero; z = dinv r; p = z; Ap = 0; rz[0] += r.z; rr[0] += r.r
 __global__ void k_pcg_init(const double* __restrict__ b, double* __restrict__ Ap, const double* __restrict__ dinv,
                            const unsigned char* __restrict__ mask, double* __restrict__ r, double* __restrict__ z,

@@ -16,9 +16,17 @@ femo_alpha/fea/utils_dolfinx.py:41,45); this is the build's own design (SURVEY.m
 * **dots** -- interior entries summed over ranks (one packed scalar all-reduce), replicated entries
   counted once.
 
-PCG then converges in the same 2-3 iterations as on one GPU.  The Krylov loop lives here, in Python,
-on zero-copy torch views of the context's device vectors: a solve is a handful of collectives and
-kernel launches, so host orchestration costs microseconds against milliseconds of device work.
+PCG then converges in the same 2-3 iterations as on one GPU.  The arithmetic of the Krylov loop is the
+library's (``femo_dist_*``, include/femo_hip.h): fused vector kernels with device-resident scalars, the
+replicated-index list and the dot weights resident in the context; every library call between two
+collectives only enqueues work on the context's HIP stream.  Python keeps what only it can do -- the
+collectives (``torch.distributed``; issued on that same stream, on zero-copy views of two small device
+buffers) and the one convergence test per iteration.  Three collectives per iteration:
+
+    precond_fwd     -> all-reduce(replicated entries of z after the local forward sweep  +  r.r)
+    precond_rest    -> all-reduce(r.z)                                      [one scalar]
+    direction_apply -> all-reduce(replicated entries of A p  +  p.A p)      [p^T A p = sum over ranks of p^T A_local p]
+    update
 """
 from __future__ import annotations
 
@@ -80,10 +88,14 @@ class HipEngine:
         self.device = torch.device("cuda", device)
         self.nvec = self.ctx.ndof
         self._views = {}
-        # torch's tensor ops and collectives run on the context's own stream: every library call is synchronous on return and
-        # everything torch enqueues afterwards is ordered behind it, so no device-wide synchronisation is needed in between
+        # torch's collectives and the few tensor ops of the driver run on the context's own stream (``on_stream``): ordered
+        # with the library's launches by the stream itself, no device-wide synchronisation in between.  The stream is made
+        # current only inside ``on_stream`` -- a second engine or a caller that uses torch's default stream is not affected.
         self.stream = self.ctx.torch_stream()
-        torch.cuda.set_stream(self.stream)
+        self.topbuf = self.scal = None
+
+    def on_stream(self):
+        return self.torch.cuda.stream(self.stream)
 
     def vec(self, name):
         if name not in self._views:
@@ -93,8 +105,9 @@ class HipEngine:
     def new_tensor(self, n):
         return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
 
-    def _sync(self):
-        pass            # same stream on both sides (see __init__); kept as the seam where a two-stream engine would wait
+    def dist_setup(self, top_local, nranks, n_local_levels, sel):
+        self.ctx.dist_setup(top_local, nranks, n_local_levels, sel)
+        self.topbuf, self.scal = self.ctx.dist_tensors()
 
     def set_field(self, name, values):
         self.ctx.set_field(name, values)
@@ -102,32 +115,50 @@ class HipEngine:
     def set_penalty_facets(self, pairs, beta):
         self.ctx.set_penalty_facets(pairs, beta)
 
-    def apply(self, src, dst):
-        self._sync(); self.ctx.op_apply_vec(src, dst)
-
     def load(self, dst):
-        self._sync(); self.ctx.load_vec(dst)
+        self.ctx.load_vec(dst)
+
+    def pack(self, vec):
+        self.ctx.dist_pack(vec)
+
+    def unpack(self, vec):
+        self.ctx.dist_unpack(vec)
 
     def factor(self, l0, l1, assemble):
-        self._sync(); self.ctx.factorize_range(l0, l1, assemble); self.ctx.sync()
+        self.ctx.factorize_range(l0, l1, assemble)
 
-    def schur_get(self, front, out):
-        self._sync(); self.ctx.front_schur_get(front, out)
+    def schur_pack(self, front, out):
+        self.ctx.front_schur_pack(front, out)
 
-    def block_set(self, front, src):
-        self._sync(); self.ctx.front_block_set(front, src)
+    def block_unpack(self, front, src):
+        self.ctx.front_block_unpack(front, src)
 
-    def sweep(self, vec, l0, l1, backward):
-        self._sync(); self.ctx.frontal_sweep(vec, l0, l1, backward)
+    def pcg_start(self, b, x):
+        self.ctx.dist_pcg_start(b, x)
+
+    def precond_fwd(self):
+        self.ctx.dist_precond_fwd()
+
+    def read(self):
+        return self.ctx.dist_read()
+
+    def precond_rest(self):
+        self.ctx.dist_precond_rest()
+
+    def direction_apply(self, first):
+        self.ctx.dist_direction_apply(first)
+
+    def update(self, x):
+        self.ctx.dist_update(x)
 
     def functionals_partial(self):
-        self._sync(); return self.ctx.functionals_partial()
+        return self.ctx.functionals_partial()
 
     def dfunctional_vec(self, name, dst):
-        self._sync(); self.ctx.dfunctional_vec(name, dst)
+        self.ctx.dfunctional_vec(name, dst)
 
-    def field_gradient_vec(self, functional, arg, lam):
-        self._sync(); return self.ctx.field_gradient_vec(functional, arg, lam)
+    def gradient(self, functional, arg, lam, gglob):
+        self.ctx.dist_gradient(functional, arg, lam, gglob)
 
 
 class DistributedShell:
@@ -147,21 +178,17 @@ class DistributedShell:
         self.eng = factory(self.sub, self.plan, self.info)
         if bc_marker is not None:
             self.eng.set_penalty_facets(self.sub.penalty_facets(bc_marker), beta)
-        nvec = self.sub.ndof + self.info["nghost"]
-        dev = self.eng.vec("r").device
-        is_top = np.zeros(nvec, dtype=bool)
-        is_top[self.info["top_local"]] = True
-        self.top_idx = torch.as_tensor(self.info["top_local"], dtype=torch.int64, device=dev)
-        self.int_idx = torch.as_tensor(np.nonzero(~is_top)[0], dtype=torch.int64, device=dev)
-        # weights of the global dot product: 1 on the entries only this rank holds, 1 / size on the replicated ones (the number
-        # of ranks is a power of two, so the weight is exact and the replicated entries add up to one copy in the all-reduce)
-        wd = np.ones(is_top.size)
-        wd[is_top] = 1.0 / comm.size
-        self.wdot = torch.as_tensor(wd, dtype=torch.float64, device=dev) if comm.size > 1 else None
         self.nl, self.nlev = self.info["n_local_levels"], self.plan.nlevels
+        self.ntop = int(self.info["n_top"])
+        sel = self.info["cells"] if self.ewm else self.info["vertices"]
+        # resident in the engine: the replicated entries (same global order on every rank), the dot weights (1 on the entries
+        # only this rank holds, 1 / size on the replicated ones -- size is a power of two, so the weight is exact and the
+        # replicated entries add up to one copy in the all-reduce), the place of this rank's field entries in the global field
+        self.eng.dist_setup(self.info["top_local"], comm.size, self.nl, sel)
         self.rtol, self.maxit = 1e-10, 50
         self.factored = False
         self.last = {}
+        self._grad_buf = None
 
     # ------------------------------------------------------------------ inputs
     def set_fields(self, thickness=None, E=None, nu=None, density=None, F_solid=None):
@@ -178,29 +205,14 @@ class DistributedShell:
 
     # ------------------------------------------------------------------ collectives on replicated entries
     def _sum_top(self, name):
-        v = self.eng.vec(name)
-        buf = v.index_select(0, self.top_idx)
-        self.comm.allreduce_(buf)
-        v.index_copy_(0, self.top_idx, buf)
+        """Sum a vector's replicated entries over the ranks (after a local operator application)."""
+        if self.comm.size == 1:
+            return
+        self.eng.pack(name)
+        self.comm.allreduce_(self.eng.topbuf[: self.ntop])
+        self.eng.unpack(name)
 
-    def dot_t(self, a, b):
-        """a . b over the global vector as a 0-dim device tensor (no host synchronisation): one weighted local dot and one
-        scalar all-reduce; replicated entries carry the weight 1 / size, so they are counted once."""
-        va, vb = self.eng.vec(a), self.eng.vec(b)
-        if self.wdot is None:
-            return self.torch.dot(va, vb)
-        loc = self.torch.dot(va * self.wdot, vb).reshape(1)
-        self.comm.allreduce_(loc)
-        return loc[0]
-
-    def dot(self, a, b):
-        return float(self.dot_t(a, b))
-
-    # ------------------------------------------------------------------ operator, preconditioner
-    def apply(self, src, dst):
-        self.eng.apply(src, dst)
-        self._sum_top(dst)
-
+    # ------------------------------------------------------------------ preconditioner set-up
     def factorize(self):
         eng, info = self.eng, self.info
         eng.factor(0, self.nl, True)
@@ -208,125 +220,101 @@ class DistributedShell:
             # the Schur complements of the subtree roots travel as packed lower triangles (they are symmetric and only the
             # lower triangle of a front is ever read), padded to the largest one: ONE all_gather_into_tensor
             sizes = info["schur_sizes"]
-            n_me = sizes[self.comm.rank]
-            full = eng.new_tensor(max(n_me * n_me, 1))
-            eng.schur_get(info["root_front"], full)
             cap = max(n * (n + 1) // 2 for n in sizes)
-            mine = eng.new_tensor(cap)
-            il = self._tril(n_me)
-            mine[: il.numel()] = full[il]
-            gathered = self.comm.allgather(mine)
+            if getattr(self, "_schur_mine", None) is None:
+                self._schur_mine = eng.new_tensor(max(cap, 1))
+            eng.schur_pack(info["root_front"], self._schur_mine)
+            gathered = self.comm.allgather(self._schur_mine)
             for q in range(self.comm.size):
                 if q != self.comm.rank:
-                    n = sizes[q]
-                    iq = self._tril(n)
-                    blk = eng.new_tensor(n * n)
-                    blk[iq] = gathered[q, : iq.numel()]
-                    eng.block_set(info["stub_fronts"][q], blk)
+                    eng.block_unpack(info["stub_fronts"][q], gathered[q])
+            self._schur_keep = gathered            # alive until the unpack kernels have run (the next factorisation at the latest)
         eng.factor(self.nl, self.nlev, False)
         self.factored = True
 
-    def _tril(self, n):
-        """Flat (column-major) indices of the lower triangle of an n x n block, cached per size."""
-        cache = self.__dict__.setdefault("_tril_cache", {})
-        if n not in cache:
-            r, c = np.tril_indices(n)
-            cache[n] = self.torch.as_tensor(np.sort(r + n * c), dtype=self.torch.int64, device=self.eng.vec("r").device)
-        return cache[n]
-
-    def precondition(self, name):
-        """name <- (L L^T)^-1 name; replicated entries must agree on all ranks on entry."""
-        eng = self.eng
-        v = eng.vec(name)
-        before = v.index_select(0, self.top_idx)
-        eng.sweep(name, 0, self.nl, False)
-        if self.comm.size > 1:
-            delta = v.index_select(0, self.top_idx) - before
-            self.comm.allreduce_(delta)
-            v.index_copy_(0, self.top_idx, before + delta)
-        eng.sweep(name, self.nl, self.nlev, False)
-        eng.sweep(name, self.nl, self.nlev, True)
-        eng.sweep(name, 0, self.nl, True)
-
     # ------------------------------------------------------------------ PCG
     def _pcg(self, b, x):
-        eng = self.eng
-        if not self.factored:
-            self.factorize()
-        vb, vx, vr, vz, vp, vAp = (eng.vec(n) for n in (b, x, "r", "z", "p", "Ap"))
-        vx.zero_()
-        vr.copy_(vb)
-        bb = self.dot(b, b)
-        rr, k, rz = bb, 0, None
-        # the scalars of an iteration (r.z, p.Ap, alpha, beta) stay on the device; one host read per iteration: (r.r, p.Ap)
-        while bb > 0 and rr > self.rtol ** 2 * bb and k < self.maxit:
-            vz.copy_(vr)
-            self.precondition("z")
-            rz_new = self.dot_t("r", "z")
-            if k == 0:
-                vp.copy_(vz)
-            else:
-                vp.mul_(rz_new / rz).add_(vz)
-            rz = rz_new
-            self.apply("p", "Ap")
-            pAp = self.dot_t("p", "Ap")
-            alpha = rz / pAp
-            vx.addcmul_(vp, alpha)
-            vr.addcmul_(vAp, -alpha)
-            rr_t = self.dot_t("r", "r")
-            rr, pAp_h = self.torch.stack([rr_t, pAp]).tolist()
-            if not pAp_h > 0:
-                raise RuntimeError("PCG broke down: p.Ap <= 0")
-            k += 1
+        eng, comm, ntop = self.eng, self.comm, self.ntop
+        with eng.on_stream():
+            if not self.factored:
+                self.factorize()
+            eng.pcg_start(b, x)
+            k, bb, rr = 0, None, None
+            while True:
+                # z = r and the forward sweep over the rank's subtree; its contributions to the replicated entries and the
+                # rank's share of r.r travel together
+                eng.precond_fwd()
+                if comm.size > 1:
+                    comm.allreduce_(eng.topbuf)
+                rr, pAp = eng.read()                      # the one host synchronisation of the iteration
+                if bb is None:
+                    bb = rr                               # r = b before the first iteration
+                if not rr == rr:
+                    raise RuntimeError("PCG broke down (NaN residual)")
+                if k > 0 and not pAp > 0:
+                    raise RuntimeError("PCG broke down: p.Ap <= 0 (preconditioner or operator not positive definite)")
+                if bb == 0 or rr <= self.rtol ** 2 * bb or k >= self.maxit:
+                    break
+                eng.precond_rest()                        # top of the tree, backward sweeps, share of r.z
+                if comm.size > 1:
+                    comm.allreduce_(eng.scal[1:2])
+                eng.direction_apply(k == 0)               # p, A_local p; replicated entries of A p + p.A_local p
+                if comm.size > 1:
+                    comm.allreduce_(eng.topbuf)
+                eng.update(x)
+                k += 1
         return k, (rr / bb) ** 0.5 if bb > 0 else 0.0
 
     def solve_state(self):
         """Forward solve K w = F (cold start); the state stays on the devices."""
-        self.eng.load("b")
-        self._sum_top("b")
+        with self.eng.on_stream():
+            self.eng.load("b")
+            self._sum_top("b")
         it, rel = self._pcg("b", "state")
         self.last["forward"] = (it, rel)
         return it, rel
 
     def functional(self, name):
         uu, reg, mass = self.eng.functionals_partial()
-        t = self.eng.new_tensor(2)
-        t.copy_(self.torch.tensor([uu + reg, mass], dtype=self.torch.float64))
-        self.comm.allreduce_(t)
+        with self.eng.on_stream():
+            t = self.eng.new_tensor(2)
+            t.copy_(self.torch.tensor([uu + reg, mass], dtype=self.torch.float64))
+            self.comm.allreduce_(t)
+            vals = t.tolist()
         if name == "compliance":
-            return float(t[0])
+            return vals[0]
         if name == "mass":
-            return float(t[1])
+            return vals[1]
         raise ValueError(name)
 
     def total_gradient(self, functional="compliance", arg="thickness"):
         """d functional / d arg on the caller's global numbering (summed over ranks)."""
-        self.eng.dfunctional_vec(functional, "b")
-        self._sum_top("b")
+        with self.eng.on_stream():
+            self.eng.dfunctional_vec(functional, "b")
+            self._sum_top("b")
         it, rel = self._pcg("b", "adjoint")
         self.last["adjoint"] = (it, rel)
-        g_loc = self.eng.field_gradient_vec(functional, arg, "adjoint")
-        # the global gradient buffer and the index of this rank's entries in it live on the device for the life of the driver
-        if getattr(self, "_grad_buf", None) is None:
-            n_glob = self.mesh.nel if self.ewm else self.mesh.nn
-            sel = self.info["cells"] if self.ewm else self.info["vertices"]
-            self._grad_buf = self.eng.new_tensor(n_glob)
-            self._grad_sel = self.torch.as_tensor(np.asarray(sel), dtype=self.torch.int64, device=self._grad_buf.device)
-        g = self._grad_buf
-        g.zero_()
-        g[self._grad_sel] = self.torch.as_tensor(g_loc).to(g.device)
-        self.comm.allreduce_(g)
-        return g.cpu().numpy(), it, rel
+        with self.eng.on_stream():
+            # the global gradient lives on the device: the rank's quadrature sweep scatters into its own entries, one all-reduce
+            if self._grad_buf is None:
+                self._grad_buf = self.eng.new_tensor(self.mesh.nel if self.ewm else self.mesh.nn)
+            g = self._grad_buf
+            g.zero_()
+            self.eng.gradient(functional, arg, "adjoint", g)
+            self.comm.allreduce_(g)
+            out = g.cpu().numpy()
+        return out, it, rel
 
     def gather_state(self):
         """Global state vector on every rank (tests / post-processing)."""
-        w = self.eng.vec("state")
-        out = self.eng.new_tensor(self.mesh.ndof)
-        cnt = self.eng.new_tensor(self.mesh.ndof)
-        l2g = self.torch.as_tensor(self.info["l2g_dof"], dtype=self.torch.int64, device=out.device)
-        # interior entries are unique to this rank; replicated entries are taken from every rank and averaged
-        out[l2g] = w
-        cnt[l2g] = 1.0
-        self.comm.allreduce_(out)
-        self.comm.allreduce_(cnt)
-        return (out / cnt.clamp(min=1.0)).cpu().numpy()
+        with self.eng.on_stream():
+            w = self.eng.vec("state")
+            out = self.eng.new_tensor(self.mesh.ndof)
+            cnt = self.eng.new_tensor(self.mesh.ndof)
+            l2g = self.torch.as_tensor(self.info["l2g_dof"], dtype=self.torch.int64, device=out.device)
+            # interior entries are unique to this rank; replicated entries are taken from every rank and averaged
+            out[l2g] = w
+            cnt[l2g] = 1.0
+            self.comm.allreduce_(out)
+            self.comm.allreduce_(cnt)
+            return (out / cnt.clamp(min=1.0)).cpu().numpy()

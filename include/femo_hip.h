@@ -244,6 +244,36 @@ int femo_functionals_partial(femo_ctx* ctx, double* out3);     /* { int u.u J dx
 int femo_dfunctional_vec(femo_ctx* ctx, const char* name, int32_t dst);
 int femo_field_gradient_vec(femo_ctx* ctx, const char* functional, const char* arg, int32_t lam, double* out, int64_t n);
 
+/* The partitioned PCG itself (the counterpart of the reference's KSP solve, fea/utils_dolfinx.py:501-531, on an element
+ * partition the reference does not have).  The replicated separator entries ("top", local indices top_idx, the same global
+ * order on every rank), the weights of the global dot product (1 / nranks on replicated entries) and the scatter map of the
+ * gradient (sel: position of this rank's field entries in the global field) stay resident in the context.  Every call
+ * below only ENQUEUES work on the context's stream; the caller issues the collective named in the comment on the same
+ * stream (torch.distributed over RCCL) and is the only party that talks to other ranks.
+ *   buffer 0 = ntop + 1 doubles: packed replicated entries + one scalar that rides along;   buffer 1 = the 8 device
+ *   scalars, [1] = r.z. */
+int femo_dist_setup(femo_ctx* ctx, int32_t ntop, const int32_t* top_idx, int32_t nranks, int32_t n_local_levels,
+                    int32_t nsel, const int32_t* sel);
+void* femo_dist_ptr(femo_ctx* ctx, int32_t which);
+int femo_dist_pack(femo_ctx* ctx, int32_t vec);                /* buffer 0 = vec[top]            -> all-reduce(buffer 0[0..ntop)) */
+int femo_dist_unpack(femo_ctx* ctx, int32_t vec);              /* vec[top] = buffer 0 */
+int femo_dist_pcg_start(femo_ctx* ctx, int32_t b, int32_t x);  /* x = 0, r = b, share of b.b */
+int femo_dist_precond_fwd(femo_ctx* ctx);                      /* z = r, local forward sweep      -> all-reduce(buffer 0[0..ntop]) */
+int femo_dist_read(femo_ctx* ctx, double* out2);               /* host: { r.r, previous p.Ap } (the one synchronisation per iteration) */
+int femo_dist_precond_rest(femo_ctx* ctx);                     /* top sweeps, local backward sweep -> all-reduce(buffer 1[1]) */
+int femo_dist_direction_apply(femo_ctx* ctx, int first);       /* p, Ap = A_local p               -> all-reduce(buffer 0[0..ntop]) */
+int femo_dist_update(femo_ctx* ctx, int32_t x);                /* x += alpha p, r -= alpha Ap */
+/* gglob[sel] = d functional / d arg - (dR/d arg)^T lambda(vector id) over this rank's cells; gglob: device, zeroed by the
+ * caller, summed over the ranks by the caller                                                      -> all-reduce(gglob) */
+int femo_dist_gradient(femo_ctx* ctx, const char* functional, const char* arg, int32_t lam, void* gglob_dev, int64_t nglob);
+/* packed lower triangle (column by column) of a front's Schur complement, and back into a pivot-free stand-in front: what
+ * the all-gather of the subtree roots carries.  Asynchronous on the context's stream. */
+int femo_front_schur_pack(femo_ctx* ctx, int32_t front, void* dst_dev, int64_t capacity_doubles);
+int femo_front_block_unpack(femo_ctx* ctx, int32_t front, const void* src_dev);
+/* per-class times / launches / flops / bytes of the factorisation launches since the last assembly while option
+ * "profile" is on (same layout as femo_factorize_profile): the partitioned driver factorises in two ranges */
+int femo_factorize_profile_get(femo_ctx* ctx, double* out32);
+
 /* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")
  * for zero-copy wrapping by the caller (e.g. torch.from_dlpack-free ctypes views). */
 void* femo_device_ptr(femo_ctx* ctx, const char* name);

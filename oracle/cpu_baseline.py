@@ -48,10 +48,14 @@ def build(force=False):
     stamp = LIB + ".srchash"
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB
-    res = subprocess.run(["g++", *FLAGS, "-o", LIB, SRC], capture_output=True, text=True)
+    tmp = f"{LIB}.{os.getpid()}.tmp"             # several ranks may build at once: link privately, publish atomically
+    res = subprocess.run(["g++", *FLAGS, "-o", tmp, SRC], capture_output=True, text=True)
     if res.returncode:
         raise RuntimeError("g++ failed on oracle/cpu_kernels.cpp:\n" + res.stderr[-3000:])
-    open(stamp, "w").write(digest + "\n")
+    os.replace(tmp, LIB)
+    with open(f"{stamp}.{os.getpid()}.tmp", "w") as fh:
+        fh.write(digest + "\n")
+    os.replace(f"{stamp}.{os.getpid()}.tmp", stamp)
     return LIB
 
 
@@ -169,6 +173,47 @@ class CpuShell:
             F[o.strong_dofs] = 0.0
         return F
 
+    def apply_K(self, x, nthreads=1):
+        """y = (K_elastic + penalty) x, matrix-free (C++/OpenMP element sweep; the penalty blocks as one small sparse matrix)."""
+        m, o = self.mesh, self.o
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(m.ndof)
+        rc = self.lib.cpu_apply_K(*self._common(), _i(self.cell_p2), m.ndof_u, self._u(), *self._tables(), *self._fields(),
+                                  _d(x), _d(y), int(nthreads))
+        assert rc == 0
+        if o.penalty_facets.shape[0]:
+            if getattr(self, "_P", None) is None:
+                r, c_, v = [], [], []
+                for d, blk in o._penalty_blocks():
+                    r.append(np.repeat(d, d.size)); c_.append(np.tile(d, d.size)); v.append(blk.ravel())
+                self._P = sp.csr_matrix((np.concatenate(v), (np.concatenate(r), np.concatenate(c_))), shape=(m.ndof, m.ndof))
+            y += self._P @ x
+        return y
+
+    def drdfield_T(self, name, state, lam, nthreads=1, scale=1.0, out=None):
+        """out += scale * (dR/d field)^T lam at ``state`` by quadrature -- no matrix is assembled."""
+        m, o = self.mesh, self.o
+        out = np.zeros(o.h.size) if out is None else out
+        st, lm = (np.ascontiguousarray(a, dtype=np.float64) for a in (state, lam))
+        rc = self.lib.cpu_drdfield_T(*self._common(), _i(self.cell_p2), m.ndof_u, self._u(), *self._tables(), *self._fields(),
+                                     {"h": 1, "E": 2, "nu": 3}[name], _d(st), _d(lm), C.c_double(scale), _d(out), int(nthreads))
+        assert rc == 0
+        return out
+
+    def dcompliance(self, state, nthreads=1):
+        """(d compliance / d u, d compliance / d h) in one sweep: 2 int N2 u J dx and the regularisation's thickness gradient."""
+        from oracle.rm_shell_oracle import REG_ALPHA1
+        m, o = self.mesh, self.o
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        du, dh = np.zeros(m.ndof), np.zeros(o.h.size)
+        N2 = np.ascontiguousarray(o.N2)
+        hh = np.ascontiguousarray(o.h, dtype=np.float64)
+        rc = self.lib.cpu_dcompliance(*self._common(), _i(self.cell_p2), self._u(), _d(self.N1), _d(self.dN1), _d(self.dN2), _d(N2),
+                                      _d(self.w), _d(hh), int(o.ewm), C.c_double(REG_ALPHA1), int(m.is_quad), _d(st), _d(du), _d(dh),
+                                      int(nthreads))
+        assert rc == 0
+        return du, dh
+
     def assemble_drdfield(self, name, state, nthreads=1):
         """Sparse ndof x n_field matrix dR/d(field) at ``state`` (field in h, E, nu)."""
         m, o = self.mesh, self.o
@@ -208,6 +253,7 @@ class CpuMultifrontal:
         self.elem_start = np.searchsorted(p.elem_front[order], np.arange(p.ntree + 1)).astype(np.int32)
         self.levels = [c(l, dtype=np.int32) for l in p.level_nodes]
         self.order = c(np.concatenate(self.levels), dtype=np.int32)
+        self.level_off = c(np.concatenate([[0], np.cumsum([l.size for l in self.levels])]), dtype=np.int32)
         self.F = np.empty(int(p.front_off[-1]))
         self.leaves = c(np.nonzero(p.left < 0)[0], dtype=np.int32)
 
@@ -250,9 +296,17 @@ class CpuMultifrontal:
         if o.strong_dofs.size:
             raise NotImplementedError("the CPU multifrontal baseline handles the penalty clamp of the benchmark workloads")
 
-    def solve(self, b):
+    def solve(self, b, by_level=True):
+        """Triangular sweeps with the factor.  ``by_level``: the fronts of a tree level in parallel (one per OpenMP thread,
+        single-threaded BLAS) -- the round-2 sweep visited the fronts one after the other and did not scale with the cores."""
         from threadpoolctl import threadpool_limits
         x = np.array(b, dtype=np.float64)
+        if by_level and self.nthreads > 1:
+            with threadpool_limits(limits=1):
+                self.s.lib.cpu_fronts_solve_levels(len(self.levels), _i(self.level_off), _i(self.order), _i(self.nf), _i(self.npiv),
+                                                   _l(self.front_off), _l(self.dof_off), _i(self.front_dofs), _d(self.F), _d(x),
+                                                   self.ptr["trsv"], self.ptr["gemv"], self.nthreads)
+            return x
         with threadpool_limits(limits=self.nthreads):
             self.s.lib.cpu_fronts_solve(self.order.size, _i(self.order), _i(self.nf), _i(self.npiv), _l(self.front_off), _l(self.dof_off),
                                         _i(self.front_dofs), _d(self.F), _d(x), self.ptr["trsv"], self.ptr["gemv"])

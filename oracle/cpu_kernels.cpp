@@ -7,6 +7,7 @@
 //   cpu_assemble_csr       K = sum_e K_e scattered into a given CSR pattern          (what dolfinx assemble_matrix +
 //                          FFCx tabulate_tensor do for derivative(residual, w), fea/utils_dolfinx.py:200-206)
 //   cpu_assemble_drdfield  the ndof x n_field matrices dR/dh, dR/dE, dR/dnu at a state w   (state_operation.py:283-286)
+//   cpu_apply_K, cpu_drdfield_T, cpu_dcompliance   matrix-free quadrature sweeps of the adjoint chain (best-effort CPU column)
 //   cpu_fronts_*           numeric phase of a multifrontal Cholesky on dense fronts with LAPACK/BLAS (the stand-in for
 //                          MUMPS behind PETSc, fea/utils_dolfinx.py:466,514-531), driven level by level from Python
 //
@@ -357,6 +358,156 @@ int cpu_load_vector(int nel, int nvc, int npc, int nq, const double* nodes, cons
     return 0;
 }
 
+
+// ---- matrix-free sweeps of the adjoint chain (no assembled matrix): what a best-effort CPU code would run
+// y += K_elastic x, element by element through the strains (s = B x_e, t = C s, y_e = B^T t)
+int cpu_apply_K(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2, int ndof_u,
+                const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* w, const double* wS,
+                const double* h, const double* E, const double* nu, int ewm, const double* hK, int quad, const double* x, double* y,
+                int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
+    const int ld = 3 * npc + 3 * nvc;
+    if (ld > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel for schedule(static, 64) num_threads(nthreads)
+    for (int e = 0; e < nel; ++e) {
+        ElemIn el;
+        load_elem(e, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
+        int dofs[MAXLD];
+        element_dofs(e, nvc, npc, cells, cell_p2, ndof_u, dofs);
+        double xe[MAXLD], ye[MAXLD] = {0}, B[9][MAXLD];
+        for (int i = 0; i < ld; ++i) xe[i] = x[dofs[i]];
+        for (int q = 0; q < nq; ++q) {
+            QP g;
+            qp_B(T, q, el.X, el.has_u ? el.U : nullptr, quad != 0, B, g);
+            double hq = 0, Eq = 0, nuq = 0;
+            for (int b = 0; b < nvc; ++b) { const double N = N1[(size_t)q * nvc + b]; hq += N * el.h[b]; Eq += N * el.E[b]; nuq += N * el.nu[b]; }
+            CQ C;
+            qp_C(hq, Eq, nuq, el.hK, w[q] * g.det, wS[q] * g.det, g.Ju, 0, C);
+            double s[9] = {0}, t[9];
+            for (int r = 0; r < 9; ++r)
+                for (int k = 0; k < ld; ++k) s[r] += B[r][k] * xe[k];
+            for (int i = 0; i < 3; ++i) {
+                t[i] = C.Cm[i][0] * s[0] + C.Cm[i][1] * s[1] + C.Cm[i][2] * s[2];
+                t[3 + i] = C.Cb[i][0] * s[3] + C.Cb[i][1] * s[4] + C.Cb[i][2] * s[5];
+            }
+            t[6] = C.cs * s[6]; t[7] = C.cs * s[7]; t[8] = C.cd * s[8];
+            for (int r = 0; r < 9; ++r)
+                for (int k = 0; k < ld; ++k) ye[k] += B[r][k] * t[r];
+        }
+        for (int i = 0; i < ld; ++i) {
+#pragma omp atomic
+            y[dofs[i]] += ye[i];
+        }
+    }
+    return 0;
+}
+
+// out (n_field) += scale * (dR/d field)^T lambda at the state: sum_q N1_b(q) (B lambda_e) . C'_q (B w_e)   (deriv 1 h, 2 E, 3 nu)
+int cpu_drdfield_T(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2, int ndof_u,
+                   const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* w, const double* wS,
+                   const double* h, const double* E, const double* nu, int ewm, const double* hK, int quad, int deriv,
+                   const double* state, const double* lam, double scale, double* out, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
+    const int ld = 3 * npc + 3 * nvc;
+    if (ld > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel for schedule(static, 64) num_threads(nthreads)
+    for (int e = 0; e < nel; ++e) {
+        ElemIn el;
+        load_elem(e, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
+        int dofs[MAXLD];
+        element_dofs(e, nvc, npc, cells, cell_p2, ndof_u, dofs);
+        double we[MAXLD], le[MAXLD], B[9][MAXLD], ge[4] = {0, 0, 0, 0};
+        for (int i = 0; i < ld; ++i) { we[i] = state[dofs[i]]; le[i] = lam[dofs[i]]; }
+        for (int q = 0; q < nq; ++q) {
+            QP g;
+            qp_B(T, q, el.X, el.has_u ? el.U : nullptr, quad != 0, B, g);
+            double hq = 0, Eq = 0, nuq = 0;
+            for (int b = 0; b < nvc; ++b) { const double N = N1[(size_t)q * nvc + b]; hq += N * el.h[b]; Eq += N * el.E[b]; nuq += N * el.nu[b]; }
+            CQ C;
+            qp_C(hq, Eq, nuq, el.hK, w[q] * g.det, wS[q] * g.det, g.Ju, deriv, C);
+            double s[9] = {0}, l[9] = {0}, t[9];
+            for (int r = 0; r < 9; ++r)
+                for (int k = 0; k < ld; ++k) { s[r] += B[r][k] * we[k]; l[r] += B[r][k] * le[k]; }
+            for (int i = 0; i < 3; ++i) {
+                t[i] = C.Cm[i][0] * s[0] + C.Cm[i][1] * s[1] + C.Cm[i][2] * s[2];
+                t[3 + i] = C.Cb[i][0] * s[3] + C.Cb[i][1] * s[4] + C.Cb[i][2] * s[5];
+            }
+            t[6] = C.cs * s[6]; t[7] = C.cs * s[7]; t[8] = C.cd * s[8];
+            double dens = 0;
+            for (int r = 0; r < 9; ++r) dens += l[r] * t[r];
+            if (ewm) ge[0] += dens;
+            else for (int b = 0; b < nvc; ++b) ge[b] += dens * N1[(size_t)q * nvc + b];
+        }
+        if (ewm) out[e] += scale * ge[0];
+        else for (int b = 0; b < nvc; ++b) {
+#pragma omp atomic
+            out[cells[(size_t)e * nvc + b]] += scale * ge[b];
+        }
+    }
+    return 0;
+}
+
+// out (ndof) += d/du int u.u J dx = 2 int N2_a u J det   (rm_shell_pde.py:85-89), and
+// gh (n_h) += alpha int grad h . grad M_b det            (the regularisation's thickness gradient, nodal thickness, :72-74)
+int cpu_dcompliance(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
+                    const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* N2, const double* w,
+                    const double* h, int ewm, double alpha, int quad, const double* state, double* out, double* gh, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, w};
+    if (3 * npc + 3 * nvc > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel for schedule(static, 64) num_threads(nthreads)
+    for (int e = 0; e < nel; ++e) {
+        double X[4][3], U[4][3], he[4], B[9][MAXLD], ue[9][3], Fe[9][3] = {{0}}, ge[4] = {0, 0, 0, 0};
+        bool has_u = false;
+        double area = 0;
+        for (int b = 0; b < nvc; ++b) {
+            const int v = cells[(size_t)e * nvc + b];
+            for (int i = 0; i < 3; ++i) {
+                X[b][i] = nodes[3 * (size_t)v + i];
+                U[b][i] = uhat ? uhat[3 * (size_t)v + i] : 0.0;
+                has_u = has_u || U[b][i] != 0.0;
+            }
+            he[b] = h[ewm ? e : v];
+        }
+        for (int a = 0; a < npc; ++a)
+            for (int i = 0; i < 3; ++i) ue[a][i] = state[3 * (size_t)cell_p2[(size_t)e * npc + a] + i];
+        for (int q = 0; q < nq; ++q) {
+            QP g;
+            qp_B(T, q, X, has_u ? U : nullptr, quad != 0, B, g);
+            double uq[3] = {0, 0, 0};
+            for (int a = 0; a < npc; ++a)
+                for (int i = 0; i < 3; ++i) uq[i] += N2[(size_t)q * npc + a] * ue[a][i];
+            const double wj = 2.0 * w[q] * g.det * g.Ju;
+            for (int a = 0; a < npc; ++a)
+                for (int i = 0; i < 3; ++i) Fe[a][i] += wj * N2[(size_t)q * npc + a] * uq[i];
+            if (ewm) { area += w[q] * g.det; continue; }
+            // surface gradient of the P1 functions (reference configuration): grad M_b = Kinv^T dN1_b
+            const double* d1 = dN1 + (size_t)q * nvc * 2;
+            double J0[3] = {0, 0, 0}, J1[3] = {0, 0, 0};
+            for (int b = 0; b < nvc; ++b)
+                for (int i = 0; i < 3; ++i) { J0[i] += X[b][i] * d1[2 * b]; J1[i] += X[b][i] * d1[2 * b + 1]; }
+            const double g00 = dot3(J0, J0), g01 = dot3(J0, J1), g11 = dot3(J1, J1), gd = g00 * g11 - g01 * g01;
+            double gM[4][3], grad_h[3] = {0, 0, 0};
+            for (int b = 0; b < nvc; ++b)
+                for (int i = 0; i < 3; ++i) {
+                    gM[b][i] = ((g11 * J0[i] - g01 * J1[i]) * d1[2 * b] + (-g01 * J0[i] + g00 * J1[i]) * d1[2 * b + 1]) / gd;
+                    grad_h[i] += gM[b][i] * he[b];
+                }
+            for (int b = 0; b < nvc; ++b) ge[b] += alpha * w[q] * g.det * dot3(gM[b], grad_h);
+        }
+        for (int a = 0; a < npc; ++a)
+            for (int i = 0; i < 3; ++i) {
+#pragma omp atomic
+                out[3 * (size_t)cell_p2[(size_t)e * npc + a] + i] += Fe[a][i];
+            }
+        if (ewm) gh[e] += alpha * he[0] * area;
+        else for (int b = 0; b < nvc; ++b) {
+#pragma omp atomic
+            gh[cells[(size_t)e * nvc + b]] += ge[b];
+        }
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ multifrontal numeric phase
 typedef void (*dpotrf_t)(const char*, const int*, double*, const int*, int*);
 typedef void (*dtrsm_t)(const char*, const char*, const char*, const char*, const int*, const int*, const double*, const double*,
@@ -479,6 +630,62 @@ int cpu_fronts_solve(int ntree, const int32_t* order, const int32_t* nf, const i
         if (nb > 0) gemv("T", &nb, &np, &mone, Ft + np, &n, buf.data() + np, &inc, &one, buf.data(), &inc);
         trsv("L", "T", "N", &np, Ft, &n, buf.data(), &inc);
         for (int i = 0; i < np; ++i) x[gd[i]] = buf[i];
+    }
+    return 0;
+}
+
+
+// the same sweeps level by level: the fronts of a tree level are independent (a forward sweep adds into the boundary
+// entries of x, which siblings may share: atomics), so the levels with many fronts run one front per thread; the few large
+// fronts at the top run one after the other (their BLAS calls may thread).  level_off: nlevels + 1 offsets into order.
+int cpu_fronts_solve_levels(int nlevels, const int32_t* level_off, const int32_t* order, const int32_t* nf, const int32_t* npiv,
+                            const int64_t* front_off, const int64_t* dof_off, const int32_t* front_dofs, const double* F, double* x,
+                            void* trsv_p, void* gemv_p, int nthreads) {
+    const dtrsv_t trsv = (dtrsv_t)trsv_p;
+    const dgemv_t gemv = (dgemv_t)gemv_p;
+    const int inc = 1;
+    const double one = 1.0, mone = -1.0;
+    for (int L = 0; L < nlevels; ++L) {                 // forward
+        const int b0 = level_off[L], cnt = level_off[L + 1] - b0;
+#pragma omp parallel num_threads(cnt >= 2 * nthreads ? nthreads : 1)
+        {
+            std::vector<double> buf;
+#pragma omp for schedule(dynamic, 4)
+            for (int k = 0; k < cnt; ++k) {
+                const int t = order[b0 + k], n = nf[t], np = npiv[t], nb = n - np;
+                if (np == 0) continue;
+                const int32_t* gd = front_dofs + dof_off[t];
+                const double* Ft = F + front_off[t];
+                buf.assign(n, 0.0);
+                for (int i = 0; i < np; ++i) buf[i] = x[gd[i]];
+                trsv("L", "N", "N", &np, Ft, &n, buf.data(), &inc);
+                if (nb > 0) gemv("N", &nb, &np, &mone, Ft + np, &n, buf.data(), &inc, &one, buf.data() + np, &inc);
+                for (int i = 0; i < np; ++i) x[gd[i]] = buf[i];
+                for (int i = np; i < n; ++i) {
+#pragma omp atomic
+                    x[gd[i]] += buf[i];
+                }
+            }
+        }
+    }
+    for (int L = nlevels - 1; L >= 0; --L) {            // backward
+        const int b0 = level_off[L], cnt = level_off[L + 1] - b0;
+#pragma omp parallel num_threads(cnt >= 2 * nthreads ? nthreads : 1)
+        {
+            std::vector<double> buf;
+#pragma omp for schedule(dynamic, 4)
+            for (int k = 0; k < cnt; ++k) {
+                const int t = order[b0 + k], n = nf[t], np = npiv[t], nb = n - np;
+                if (np == 0) continue;
+                const int32_t* gd = front_dofs + dof_off[t];
+                const double* Ft = F + front_off[t];
+                buf.resize(n);
+                for (int i = 0; i < n; ++i) buf[i] = x[gd[i]];
+                if (nb > 0) gemv("T", &nb, &np, &mone, Ft + np, &n, buf.data() + np, &inc, &one, buf.data(), &inc);
+                trsv("L", "T", "N", &np, Ft, &n, buf.data(), &inc);
+                for (int i = 0; i < np; ++i) x[gd[i]] = buf[i];
+            }
+        }
     }
     return 0;
 }

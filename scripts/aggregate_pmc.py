@@ -46,7 +46,12 @@ def main():
     rows.sort(key=lambda r: -r["total_ms"])
     json.dump(rows, open(out, "w"), indent=1)
     if workload:
-        d = {"source": os.path.basename(out), "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch"}
+        root_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root_)
+        from femo_alpha_amd import _build
+        # the digest of the library sources the counters were collected on: bench.py quotes these bytes only while it matches
+        d = {"source": os.path.basename(out), "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch",
+             "source_digest": _build.source_digest()}
         for r in rows:
             if r["kernel"].startswith("femo::k_apply4"):
                 d["apply_hbm_bytes_per_launch"] = r["hbm_bytes_corrected"]

@@ -29,12 +29,81 @@ class NumpyEngine:
         self.oracle = ShellOracle(sub, element_wise_material=element_wise_material)
         self.pf, self.beta = None, 1e15
         self.F, self.L = None, None
+        self.topbuf = self.scal = None
+
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
 
     def vec(self, name):
         return self.v[name]
 
     def new_tensor(self, n):
         return self.torch.zeros(n, dtype=self.torch.float64)
+
+    def dist_setup(self, top_local, nranks, n_local_levels, sel):
+        self.top = np.asarray(top_local, dtype=np.int64)
+        self.nl, self.nlev = int(n_local_levels), self.plan.nlevels
+        self.sel = np.asarray(sel, dtype=np.int64)
+        self.w = np.ones(self.nvec)
+        self.w[self.top] = 1.0 / nranks
+        self.topbuf = self.torch.zeros(self.top.size + 1, dtype=self.torch.float64)
+        self.scal = self.torch.zeros(8, dtype=self.torch.float64)
+
+    # ------------------------------------------------------------------ the phases of the partitioned PCG (femo_dist_*)
+    def pack(self, vec):
+        self.topbuf[:-1] = self.v[vec][self.top]
+
+    def unpack(self, vec):
+        self.v[vec][self.top] = self.topbuf[:-1]
+
+    def pcg_start(self, b, x):
+        self.v[x].zero_()
+        self.v["r"].copy_(self.v[b])
+        bn = self.v[b].numpy()
+        self.scal.zero_()
+        self.scal[3] = float(np.sum(self.w * bn * bn))
+
+    def precond_fwd(self):
+        self.v["z"].copy_(self.v["r"])
+        self._save = self.v["z"][self.top].clone()
+        self.sweep("z", 0, self.nl, False)
+        self.topbuf[:-1] = self.v["z"][self.top] - self._save
+        self.topbuf[-1] = self.scal[3]
+
+    def read(self):
+        return float(self.topbuf[-1]), float(self.scal[2])
+
+    def precond_rest(self):
+        self.v["z"][self.top] = self._save + self.topbuf[:-1]
+        self.sweep("z", self.nl, self.nlev, False)
+        self.sweep("z", self.nl, self.nlev, True)
+        self.sweep("z", 0, self.nl, True)
+        self.scal[1:4] = 0.0
+        self.scal[1] = float(np.sum(self.w * self.v["r"].numpy() * self.v["z"].numpy()))
+
+    def direction_apply(self, first):
+        if first:
+            self.v["p"].copy_(self.v["z"])
+        else:
+            self.v["p"].mul_(float(self.scal[1] / self.scal[0])).add_(self.v["z"])
+        self.apply("p", "Ap")
+        self.scal[2] = float(self.v["p"].numpy() @ self.v["Ap"].numpy())
+        self.topbuf[:-1] = self.v["Ap"][self.top]
+        self.topbuf[-1] = self.scal[2]
+
+    def update(self, x):
+        self.v["Ap"][self.top] = self.topbuf[:-1]
+        self.scal[2] = self.topbuf[-1]
+        alpha = float(self.scal[1] / self.scal[2])
+        self.v[x].add_(self.v["p"], alpha=alpha)
+        self.v["r"].add_(self.v["Ap"], alpha=-alpha)
+        rn = self.v["r"].numpy()
+        self.scal[3] = float(np.sum(self.w * rn * rn))
+        self.scal[0] = self.scal[1]
+
+    def gradient(self, functional, arg, lam, gglob):
+        gglob[self.sel] = self.torch.as_tensor(self.field_gradient_vec(functional, arg, lam))
 
     def set_field(self, name, values):
         key = {"thickness": "h", "E": "E", "nu": "nu", "density": "rho", "F_solid": "f"}[name]
@@ -90,16 +159,22 @@ class NumpyEngine:
                 self.F[t][n:, n:] -= L21 @ L21.T
                 self.L[t] = (L11, L21)
 
-    def schur_get(self, front, out):
+    def schur_pack(self, front, out):
+        """Lower triangle, column by column (the layout of femo_front_schur_pack)."""
         p = self.plan
         S = self.F[front][p.npiv[front]:, p.npiv[front]:]
-        out[: S.size] = self.torch.as_tensor(S.ravel())
+        n = S.shape[0]
+        r, c = np.tril_indices(n)
+        o = np.lexsort((r, c))                      # column-major order of the lower triangle
+        out[: r.size] = self.torch.as_tensor(S[r[o], c[o]])
 
-    def block_set(self, front, src):
-        # the driver hands over one triangle of the (symmetric) Schur complement; this engine works on full matrices
+    def block_unpack(self, front, src):
         n = self.plan.nf[front]
-        A = src.numpy()[: n * n].reshape(n, n)
-        self.F[front] = np.tril(A) + np.tril(A, -1).T if np.abs(np.triu(A, 1)).max() == 0 else np.triu(A) + np.triu(A, 1).T
+        r, c = np.tril_indices(n)
+        o = np.lexsort((r, c))
+        A = np.zeros((n, n))
+        A[r[o], c[o]] = src.numpy()[: r.size]
+        self.F[front] = A + np.tril(A, -1).T
 
     def sweep(self, vec, l0, l1, backward):
         p = self.plan
@@ -142,6 +217,10 @@ class NumpyEngine:
 
 def make_case(kind="wing"):
     from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
+    if kind == "wing1m":           # BASELINE config 3 / 4: the bench workload itself (1 015 470 DOF)
+        from bench import make_workload
+        m, fields, marker, _ = make_workload("wing1m")
+        return m, marker, {k: np.asarray(v, dtype=np.float64) for k, v in fields.items()}
     if kind == "wing":
         m = wing_skin_mesh(8, 24, shuffle=True)
         marker = lambda x: np.less(x[1], 1e-12)
@@ -172,15 +251,89 @@ def worker(rank, world, port, kind, engine, result_path):
         from femo_alpha_amd.parallel import Comm, DistributedShell
         m, marker, fields = make_case(kind)
         factory = (lambda sub, plan, info: NumpyEngine(sub, plan, info)) if engine == "numpy" else None
-        ds = DistributedShell(m, Comm(dist), bc_marker=marker, leaf_size=4, engine_factory=factory, device=0)
-        ds.rtol = 1e-12
-        ds.set_fields(**fields)
-        it, rel = ds.solve_state()
-        w = ds.gather_state()
-        J, M = ds.functional("compliance"), ds.functional("mass")
-        g, it2, rel2 = ds.total_gradient("compliance", "thickness")
+        ds = DistributedShell(m, Comm(dist), bc_marker=marker, leaf_size=12 if kind == "wing1m" else 4, engine_factory=factory, device=0)
+        res = run_driver(ds, fields)
         if rank == 0:
-            np.savez(result_path, w=w, J=J, M=M, g=g, it=it, rel=rel, it2=it2, rel2=rel2,
-                     nghost=ds.info["nghost"], ntop=ds.info["n_top"])
+            np.savez(result_path, **res)
     finally:
         dist.destroy_process_group()
+
+
+def run_driver(ds, fields, rtol=1e-12):
+    """Forward solve, outputs and adjoint gradient of one rank's driver; everything a test compares."""
+    ds.rtol = rtol
+    ds.set_fields(**fields)
+    it, rel = ds.solve_state()
+    w = ds.gather_state()
+    J, M = ds.functional("compliance"), ds.functional("mass")
+    g, it2, rel2 = ds.total_gradient("compliance", "thickness")
+    return dict(w=w, J=J, M=M, g=g, it=it, rel=rel, it2=it2, rel2=rel2, nghost=ds.info["nghost"], ntop=ds.info["n_top"])
+
+
+# ---- several ranks inside ONE process (threads): a GPU box admits at most 6 processes on its card, so the 8-partition case of
+# BASELINE config 4 runs its eight drivers as threads, each with its own context and HIP stream on the one GPU.  The
+# collectives are sums over the threads' host copies in rank order (the same order on every rank, so all ranks see
+# bit-identical results, as with a real all-reduce).
+class ThreadGroup:
+    def __init__(self, n):
+        import threading
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+
+
+class ThreadComm:
+    def __init__(self, group, rank):
+        self.g, self.rank, self.size = group, rank, group.n
+
+    def _exchange(self, h):
+        self.g.slots[self.rank] = h
+        self.g.barrier.wait()
+        parts = list(self.g.slots)
+        self.g.barrier.wait()               # nobody overwrites its slot before everyone has read all of them
+        return parts
+
+    def allreduce_(self, t, op="sum"):
+        import torch
+        parts = self._exchange(t.detach().cpu().clone())
+        tot = parts[0].clone()
+        for q in parts[1:]:
+            tot = torch.maximum(tot, q) if op == "max" else tot + q
+        t.copy_(tot)
+        return t
+
+    def allgather(self, t):
+        import torch
+        return torch.stack(self._exchange(t.detach().cpu().clone())).to(t.device)
+
+
+def run_threads(world, m, marker, fields, leaf_size=12, rtol=1e-12, device=0):
+    """``world`` drivers with the HIP engine as threads of this process; returns rank 0's results."""
+    import threading
+    from femo_alpha_amd.parallel import DistributedShell
+    from femo_alpha_amd.solver.symbolic import analyse
+    tree = analyse(m, leaf_size, min_depth=int(np.log2(world)))
+    group = ThreadGroup(world)
+    out, err = [None] * world, [None] * world
+
+    def body(rank):
+        try:
+            ds = DistributedShell(m, ThreadComm(group, rank), bc_marker=marker, leaf_size=leaf_size, device=device, tree=tree)
+            out[rank] = run_driver(ds, fields, rtol)
+            ds.eng.ctx.close()
+        except BaseException as e:          # noqa: BLE001 -- a dead rank must not leave the others waiting at the barrier
+            err[rank] = e
+            group.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return out[0]

@@ -62,3 +62,24 @@ def test_measure_protocol_on_a_small_plate():
     assert r["mf_relres"] < 1e-5 and r["superlu_vs_mf"] < 1e-7
     assert r["as_reference"]["forward_s"] > r["best_effort_superlu"]["forward_s"] > 0
     assert r["best_effort"]["dof_per_s"] > 0
+
+
+def test_matrix_free_sweeps_of_the_adjoint_chain(warped):
+    """The best-effort CPU adjoint of bench.py assembles no matrix: operator, d compliance / d u, the regularisation's
+    thickness gradient and (dR/dh)^T lambda as C++/OpenMP quadrature sweeps, against the numpy oracle."""
+    m, o, cs, rng = warped
+    x, lam = rng.uniform(-1, 1, m.ndof), rng.uniform(-1, 1, m.ndof)
+    assert rel(cs.apply_K(x, 2), o.apply_K(x)) < 1e-12
+    du, dh = cs.dcompliance(x, 2)
+    assert rel(du, o.dcompliance_du(x)) < 1e-12
+    assert rel(dh, o.dcompliance_dh(x)) < 1e-12
+    for name in ("h", "E", "nu"):
+        assert rel(cs.drdfield_T(name, x, lam, 2), o.dRdfield_T(name, x, lam)) < 1e-12
+
+
+def test_level_parallel_sweeps_equal_the_sequential_ones(warped):
+    m, o, cs, rng = warped
+    mf = cb.CpuMultifrontal(cs, build_plan(m, 4), 2)
+    mf.factorize()
+    b = rng.uniform(-1, 1, m.ndof)
+    assert rel(mf.solve(b, by_level=True), mf.solve(b, by_level=False)) < 1e-9

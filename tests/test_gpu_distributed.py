@@ -59,3 +59,59 @@ def test_partitions_agree_with_the_single_rank_run():
         assert int(r["it"]) == int(one["it"]) and int(r["it2"]) == int(one["it2"])
         assert ew < 1e-12 and eJ < 1e-12 and eg < 1e-12
         assert int(r["ntop"]) > 0
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 4 at full size
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_wing1m.npz")
+PARTITION_TOL = 1e-12
+
+
+def _check_against_config3_golden(r, tol=1e-7):
+    """The config-3 tolerance (tests/test_gpu_goldens.py: 1e-7, the conditioning floor of the 1.27 mm skin at 1 M DOF)."""
+    g = np.load(GOLDEN)
+    w = r["w"]
+    assert w.size == int(g["ndof"])
+    assert abs(np.abs(w).max() - float(g["w_maxabs"])) < tol * float(g["w_maxabs"])
+    assert np.abs(w[g["w_sample_index"]] - g["w_sample"]).max() < tol * float(g["w_maxabs"])
+    assert abs(float(r["J"]) - float(g["compliance"])) < tol * abs(float(g["compliance"]))
+    assert abs(float(r["M"]) - float(g["mass"])) < 1e-12 * float(g["mass"])
+    ref = g["dcompliance_dthickness"]
+    assert np.abs(r["g"] - ref).max() < tol * np.abs(ref).max()
+
+
+def test_config4_one_million_dof_skin_in_2_4_8_partitions():
+    """BASELINE config 4 as written, minus the hardware: the 1 015 470-DOF wing skin of the bench in 2, 4 and 8 element
+    partitions on the HIP engine, all partitions sharing the box's one GPU (threads: a box admits 6 GPU processes, config 4
+    needs 8 ranks).  Every partitioning against the committed config-3 golden at the config-3 tolerance, and against the
+    1-partition run of the same driver: PCG iteration counts within one, displacement / compliance / gradient to 1e-12
+    (measured at 2 partitions: 6e-14 / 1e-16 / 5e-14 -- PCG on the true residual to 1e-12 pins the
+    solution although one unit in the last place of the operator moves it by 7e-8, scripts/conditioning_floor.py)."""
+    m, marker, fields = H.make_case("wing1m")
+    res = {world: H.run_threads(world, m, marker, fields) for world in (1, 2, 4, 8)}
+    one = res[1]
+    assert int(one["it"]) <= 4 and int(one["it2"]) <= 4
+    for world in (1, 2, 4, 8):
+        _check_against_config3_golden(res[world])
+    for world in (2, 4, 8):
+        r = res[world]
+        ew = np.abs(r["w"] - one["w"]).max() / np.abs(one["w"]).max()
+        eJ = abs(float(r["J"]) - float(one["J"])) / abs(float(one["J"]))
+        eg = np.abs(r["g"] - one["g"]).max() / np.abs(one["g"]).max()
+        print(f"1M DOF, {world} partitions vs 1: iterations {int(r['it'])}/{int(r['it2'])} vs {int(one['it'])}/{int(one['it2'])}, "
+              f"displacement {ew:.2e}, compliance {eJ:.2e}, gradient {eg:.2e}, replicated DOFs {int(r['ntop'])}")
+        # "identical iteration counts +-1" (SURVEY.md section 8e): at rtol 1e-12 the last iteration of the adjoint solve sits on
+        # the threshold (measured: 2 partitions take 3 where one takes 2)
+        assert abs(int(r["it"]) - int(one["it"])) <= 1 and abs(int(r["it2"]) - int(one["it2"])) <= 1
+        assert ew < PARTITION_TOL and eJ < PARTITION_TOL and eg < PARTITION_TOL
+        assert int(r["ntop"]) > 0
+
+
+def test_config4_two_processes_over_gloo_at_full_size():
+    """The same 1 M-DOF skin in two partitions as two PROCESSES with torch.distributed (gloo, host-staged): the code path
+    bench.py --gpus 2 takes, but for the collective backend."""
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "res.npz")
+        mp.spawn(H.worker, args=(2, _free_port(), "wing1m", "hip", path), nprocs=2, join=True)
+        r = {k: v for k, v in np.load(path).items()}
+    assert int(r["it"]) <= 4 and int(r["it2"]) <= 4
+    _check_against_config3_golden(r)

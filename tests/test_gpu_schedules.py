@@ -44,7 +44,7 @@ def test_random_schedules_give_the_same_solution(case, seed):
     rng = np.random.default_rng(seed)
     for _ in range(8):
         post = dict(trailing=int(rng.integers(0, 3)), left_min=int(rng.choice([1, 8, 64, 4096])), left_max=int(rng.choice([16, 2048, 100000])),
-                    super_panel=int(rng.choice([0, 256, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
+                    super_panel=int(rng.choice([0, 200, 256, 384, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
                     super_panel_ahead=int(rng.integers(0, 2)), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
                     fused_schur=int(rng.integers(0, 2)), grid_chunk=int(rng.choice([3, 17, 65535])), xinv_small_cnt=int(rng.choice([0, 32, 100000])))
         pre = dict(wide_cnt=int(rng.choice([0, 8, 512, 100000])), wide_np=int(rng.choice([64, 512])), swork_slots=int(rng.choice([2, 100, 8192])))
@@ -54,3 +54,16 @@ def test_random_schedules_give_the_same_solution(case, seed):
         assert it <= it0 + 1, what
         assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max(), what
         assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max(), what
+
+
+@pytest.mark.parametrize("sp", [200, 384])
+def test_super_panel_between_multiples_of_the_outer_panel(sp):
+    """A super-panel width that is not a multiple of 128 is rounded DOWN by the schedule; the decision to let the first
+    rank-k update gather its columns from the children must use the rounded value too (200 -> 128: plain right-looking,
+    where a gathering update after every panel would discard the earlier panels' updates)."""
+    m, marker = plate_mesh(2.0, 5.0, 64, 64), (lambda x: np.less(x[0], 3e-16))
+    it0, w0, g0 = _solve(m, marker, False, 8, {}, dict(super_panel=0, fused_schur=0, lookahead=0))
+    it, w, g = _solve(m, marker, False, 8, {}, dict(trailing=2, super_panel=sp, super_panel_cnt=100000, fused_schur=1, lookahead=0))
+    assert it <= it0 + 1
+    assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
+    assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
