@@ -291,6 +291,7 @@ class ShellContext:
         self._chk(self.lib.femo_select_subdomain(self._h, int(sel)))
 
     def field_output(self, name="stress"):
+        """DG1 projection of the von Mises stress: 'stress' (top surface), 'stress_mid', 'stress_bot'."""
         out = np.empty(self.mesh.nvc * self.mesh.nel)
         self._chk(self.lib.femo_field_output(self._h, name.encode(), dptr(out), out.size))
         return out

@@ -99,6 +99,7 @@ struct femo_ctx {
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
         int allow_pivot_repair = 0;   // non-positive pivots: 0 = the factorisation fails, 1 = replace and count
         int profile_verbose = 0;
+        int diag_v1 = 0;              // diagonal-block kernel: 0 auto (see the launch), 1 round-2 kernel (sequential phases), 2 overlapped kernel
         int swork_slots = 8192;       // cap of the diagonal-block scratch (1 GB); larger levels are factorised in chunks (read at plan upload)
         int xinv_small_cnt = 32;      // inversion of L11: levels with at most this many fronts use 64 x 32 tiles
         // backward sweep, L21^T x: levels whose largest boundary has at least this many rows take the tiled (atomic) kernel.
@@ -674,9 +675,23 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                   int end = nb4 == NBO / NB ? cnt : first_above(C0 + NB * nb4);
                   int nblk = nb4;
                   if (cnt < 512) { end = cnt; nblk = std::min(NBO / NB, (fr.h_npiv[hn[cnt - 1]] - C0 + NB - 1) / NB); }
-                  if (end > start)
-                      hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), c->stream,
-                                         fd, lev, start, nblk, C0, sw, fr.info);
+                  if (end > start) {
+                      // The overlapped kernel (k_diag_block2) needs more LDS per workgroup (the blocks of the inverse and a scratch
+                      // block per wave).  On the levels of many small fronts what counts is workgroups per CU, not the latency of one:
+                      // classes of fewer than four sub-blocks keep the round-2 kernel there (measured at 1M DOF: levels 0-3 766 /
+                      // 261 / 242 / 178 us with the new kernel throughout against 517 / 164 / 192 / 156).  Option "diag_v1": 1 forces
+                      // the old kernel everywhere, 2 the new one.
+                      const bool v1 = c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= 512 && nblk < NBO / NB);
+                      if (v1)
+                          hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                                             fd, lev, start, nblk, C0, sw, fr.info);
+                      else if (c->opt.allow_pivot_repair)
+                          hipLaunchKernelGGL(k_diag_block2<true>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                                             fd, lev, start, nblk, C0, sw, fr.info);
+                      else
+                          hipLaunchKernelGGL(k_diag_block2<false>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                                             fd, lev, start, nblk, C0, sw, fr.info);
+                  }
                   start = end;
               } }
             int rows_below = 0;                          // rows under the diagonal block, the most over the chunk's fronts
@@ -1514,6 +1529,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "strict") o.strict = v != 0;
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
+    else if (k == "diag_v1") { if (v < 0 || v > 2) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel"); o.diag_v1 = v; }
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
@@ -1601,6 +1617,19 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
         double v[2];
         if (pnorm_dev(c, v)) return 1;
         *value = v[0] / stress_alpha_ref(c);
+        return 0;
+    }
+    if (s.rfind("sum_stress_", 0) == 0) {         // over the selected sub-domain (rm_shell_pde.py:130-150)
+        static const char* comps[6] = {"x", "y", "z", "xy", "xz", "yz"};
+        int k = -1;
+        for (int i = 0; i < 6; ++i) if (s.substr(11) == comps[i]) k = i;
+        if (k < 0) return fail(c, "unknown stress component in '" + s + "' (x, y, z, xy, xz, yz)");
+        HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
+        ELEM_LAUNCH(c, k_stress_sums, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, c->scal);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *value = c->scal_host[k];
         return 0;
     }
     return fail(c, "unknown functional '" + s + "'");
@@ -1940,6 +1969,10 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
     fr.ready = true;
     fr.factored = false;
     return 0;
@@ -2469,11 +2502,14 @@ int femo_select_subdomain(femo_ctx* c, int32_t sel) {
 
 int femo_field_output(femo_ctx* c, const char* name, double* out, int64_t n) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (std::string(name ? name : "") != "stress") return fail(c, "unknown field output");
+    const std::string fname(name ? name : "");
+    // von_Mises_stress(surface = 'Top' | 'Mid' | 'Bot') (rm_shell_pde.py:153-165): xi2 = h/2, 0, -h/2
+    const double zf = fname == "stress" ? 0.5 : fname == "stress_mid" ? 0.0 : fname == "stress_bot" ? -0.5 : 2.0;
+    if (zf > 1.0) return fail(c, "unknown field output '" + fname + "' (stress, stress_mid, stress_bot)");
     if (n != (int64_t)c->nvc * c->nel) return fail(c, "the DG1 stress field has nvc * nel entries");
     double* d = nullptr;
     HIPCHK(c, hipMalloc((void**)&d, (size_t)n * sizeof(double)));
-    ELEM_LAUNCH(c, k_stress_field, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, d);
+    ELEM_LAUNCH(c, k_stress_field, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->w, zf, d);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(d);

@@ -296,18 +296,21 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y;
 }
 
-__device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane) {
+// W = width of the block (32: lanes 0..31 rows, 32..63 identity columns; 16: lanes 0..15 rows, 16..31 identity columns, and
+// whatever rows lanes 32.. carry receive the same column operations, i.e. become rows of L21 = A21 L11^-T for free).
+template <int W>
+__device__ __forceinline__ int chol_inverse_w(double (&a)[W], int wb, int lane) {
     int bad = 0;
     // pivot of step 0
     double d = rl(a[0], 0);
     if (!(d > 0.0)) { if (0 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
     double y = rsqrt_newton(d);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < W; ++j) {
         // left half: column j of L for this lane's row (valid for lane >= j); right half: row j of L^-1
         const double l = (lane == j) ? d * y : a[j] * y;
         a[j] = l;
-        if (j + 1 < NB) {
+        if (j + 1 < W) {
             // the next pivot is final after the first update: start its reciprocal square root now, so that this
             // dependent chain (~150 cycles) runs beside the remaining updates of this step instead of after them
             a[j + 1] -= l * rl(l, j + 1);
@@ -321,18 +324,117 @@ __device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane)
             y = rsqrt_newton(d);
         }
 #pragma unroll
-        for (int c = j + 2; c < NB; c += 2) {
+        for (int c = j + 2; c < W; c += 2) {
             // two broadcasts ahead of two updates: no wait states between a v_readlane and the FMA that consumes it
             const double lc0 = rl(l, c);                      // L[c][j]
-            const double lc1 = (c + 1 < NB) ? rl(l, c + 1) : 0.0;
+            const double lc1 = (c + 1 < W) ? rl(l, c + 1) : 0.0;
             a[c] -= l * lc0;                                  // left half: only entries with c <= row are meaningful
-            if (c + 1 < NB) a[c + 1] -= l * lc1;
+            if (c + 1 < W) a[c + 1] -= l * lc1;
             // pin the updates to this step: a[c] is not consumed before step c, and left to itself the compiler
             // defers the FMAs until then, keeping every broadcast alive in SGPRs (1500 of them spilled)
             asm volatile("" : "+v"(a[c]));
-            if (c + 1 < NB) asm volatile("" : "+v"(a[c + 1]));
+            if (c + 1 < W) asm volatile("" : "+v"(a[c + 1]));
         }
     }
+    return bad;
+}
+
+__device__ __forceinline__ int chol32_inverse(double (&a)[NB], int wb, int lane) { return chol_inverse_w<NB>(a, wb, lane); }
+
+// The same factor + inverse without a square root on the critical path: A = L~ D L~^T (unit lower L~), one pivot per step.
+// The register elimination above spends ~500 cycles per step, most of them waiting: pivot -> rsq + two Newton steps -> scale
+// the column -> broadcast -> update the next diagonal entry -> broadcast it -> next pivot, a chain of ~20 dependent
+// instructions.  Here the next pivot is formed on the scalar side,  d' = A[j+1][j+1] - A[j+1][j]^2 / d,  from two broadcasts
+// that do not wait for this step (both entries were final one step earlier): the chain is  d -> rcp + two Newton steps -> one
+// FMA -> d',  and everything else -- the multipliers m = a[j] / d, their broadcasts, the updates a[c] -= a[j] m_c -- hangs off
+// it instead of sitting on it.  Left lanes (rows of A) and right lanes (columns of the identity, i.e. the forward
+// substitution z = L~^-1 e_k) run the same instruction stream, as above.
+// On return: lane 32 + k holds z (a[r] = (L~^-1)[r][k]); *rs = 1 / sqrt(d_lane) for lanes < 32, so that the inverse of the
+// Cholesky factor L = L~ D^1/2 is  X[r][k] = rs_r a[r].  REPAIR: non-positive pivots are replaced on the chain (option
+// "allow_pivot_repair"); otherwise they are only counted -- the factorisation fails anyway.
+__device__ __forceinline__ double rcp_newton(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
+// Width W as in chol_inverse_w: W = 16 leaves lanes 32.. free to carry rows below the block (they become L~21 D).
+template <int W, bool REPAIR>
+__device__ __forceinline__ int ldl_inverse_w(double (&a)[W], int wb, int lane, double* rs) {
+    int bad = 0;
+    double dvec = 1.0;                              // lane j keeps the pivot d_j
+    double d = rl(a[0], 0);
+    if (REPAIR && !(d > 0.0)) { if (0 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        dvec = (lane == j) ? d : dvec;
+        const double r = rcp_newton(d);
+        if (j + 1 < W) {
+            const double s = rl(a[j], j + 1), s2 = rl(a[j + 1], j + 1);
+            d = __builtin_fma(-(s * s), r, s2);
+            if (REPAIR && !(d > 0.0)) { if (j + 1 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+        }
+        const double m = a[j] * r;                  // left lanes: L~[row][j]
+#pragma unroll
+        for (int c = j + 1; c < W; c += 2) {
+            const double m0 = rl(m, c);
+            const double m1 = (c + 1 < W) ? rl(m, c + 1) : 0.0;
+            a[c] -= a[j] * m0;
+            if (c + 1 < W) a[c + 1] -= a[j] * m1;
+            asm volatile("" : "+v"(a[c]));
+            if (c + 1 < W) asm volatile("" : "+v"(a[c + 1]));
+        }
+    }
+    if (!REPAIR) bad = __popcll(__ballot(lane < wb && !(dvec > 0.0)));
+    *rs = rsqrt_newton(lane < W ? dvec : 1.0);
+    return bad;
+}
+
+template <bool REPAIR>
+__device__ __forceinline__ int ldl32_inverse(double (&a)[NB], int wb, int lane, double* rs) { return ldl_inverse_w<NB, REPAIR>(a, wb, lane, rs); }
+
+// ldl32_inverse with the multipliers of a step broadcast through LDS: a wave issues one instruction per ~4 cycles whatever its
+// kind, and the register broadcast costs two v_readlane_b32 per (step, column) on top of the FMA.  Here every lane stores its
+// multiplier once (ds_write_b64) and the updates read m_c back from wave-uniform addresses, two columns per ds_read -- 1.5
+// instead of 3 instructions per pair.  The round trip through LDS does not touch the pivot chain (see above), and the one
+// update that feeds the NEXT step's multipliers, column j + 1, keeps the register broadcast.  All reads of a step are issued
+// before its first FMA (one pin per step, not per column: a pin per column made every read wait for its own latency --
+// the round-2 LDS variant of the Cholesky elimination was 2.7 x slower than the register one for that reason).
+// `bc`: 64 doubles of LDS owned by the calling wave.
+template <bool REPAIR>
+__device__ __forceinline__ int ldl32_inverse_lds(double (&a)[NB], int wb, int lane, double* rs, double* bc) {
+    int bad = 0;
+    double dvec = 1.0;
+    double d = rl(a[0], 0);
+    if (REPAIR && !(d > 0.0)) { if (0 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        dvec = (lane == j) ? d : dvec;
+        const double r = rcp_newton(d);
+        if (j + 1 < NB) {
+            const double s = rl(a[j], j + 1), s2 = rl(a[j + 1], j + 1);
+            d = __builtin_fma(-(s * s), r, s2);
+            if (REPAIR && !(d > 0.0)) { if (j + 1 < wb) bad += 1; d = fabs(d) > 1e-300 ? fabs(d) : 1.0; }
+        }
+        const double m = a[j] * r;
+        if (j + 2 < NB) bc[lane] = m;
+        if (j + 1 < NB) a[j + 1] -= a[j] * rl(m, j + 1);
+        if (j + 2 < NB) {
+            double mc[NB];
+#pragma unroll
+            for (int c = j + 2; c < NB; ++c) mc[c] = bc[c];
+#pragma unroll
+            for (int c = j + 2; c < NB; ++c) a[c] -= a[j] * mc[c];
+        }
+        // pin the whole step: left to itself the compiler defers updates to the step that consumes them
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) asm volatile("" : "+v"(a[c]));
+    }
+    if (!REPAIR) bad = __popcll(__ballot(lane < wb && !(dvec > 0.0)));
+    *rs = rsqrt_newton(lane < NB ? dvec : 1.0);
     return bad;
 }
 
@@ -353,6 +455,115 @@ __device__ __forceinline__ void mfma_blk(mfma_d4& acc, const blk32& A, const blk
         const double b = TB ? B[16 * sj + l15][kk + l4] : B[kk + l4][16 * sj + l15];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
+}
+
+// One wave: acc += M1 (16 x 16) M2 (16 x 16), both row-major in LDS with leading dimension LDB = NB + 1 (quadrants of a blk32).
+// NEG1: the first operand enters negated.  TB: M2 is stored transposed (the product is M1 M2^T).
+template <bool NEG1, bool TB>
+__device__ __forceinline__ void mm16(mfma_d4& acc, const double* M1, const double* M2, int l15, int l4) {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+        const double a = M1[l15 * (NB + 1) + kk + l4];
+        const double b = TB ? M2[l15 * (NB + 1) + kk + l4] : M2[(kk + l4) * (NB + 1) + l15];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG1 ? -a : a, b, acc, 0, 0, 0);
+    }
+}
+
+// The inverse of the Cholesky factor of the 32 x 32 block B (lower triangle valid, in LDS), by ONE wave, in place: on return
+// B holds X = L^-1 (lower triangle, zeros above).  Two register factorisations of 16 columns instead of one of 32 -- a step of
+// the register elimination costs its pivot chain (~110 cycles) plus three instructions per remaining column, and half of the
+// columns halve that -- with the 16 x 16 glue on the matrix cores, staged through the free quadrants of B itself:
+//   A  lanes 0..15 rows of B11, 16..31 identity, 32..47 rows of B21:  L11, X11 = L11^-1, L21 = B21 L11^-T     (registers)
+//   B  B22 -= L21 L21^T                                                                                       (MFMA)
+//   C  lanes 0..15 rows of B22, 16..31 identity:  L22, X22                                                    (registers)
+//   D  X21 = -X22 (L21 X11)                                                                                   (MFMA)
+// LDS operations of one wave execute in order, so the phases need no barrier.  Returns the number of repaired pivots.
+template <bool LDL, bool REPAIR>
+__device__ __forceinline__ int chol32_inverse_v2(blk32& B, int wb, int lane) {
+    constexpr int H = NB / 2, LDB = NB + 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* b00 = &B[0][0];
+    double* b01 = b00 + H;                  // upper-right quadrant: scratch for L21 (zeroed at the end)
+    double* b10 = b00 + H * LDB;            // B21, then T = L21 X11, then X21
+    double* b11 = b10 + H;                  // B22, then X22
+    double a[H];
+    {
+        const int grp = lane >> 4;          // 0 rows of B11, 1 identity, 2 rows of B21, 3 unused
+        const double* src = grp == 2 ? b10 + l15 * LDB : b00 + l15 * LDB;
+#pragma unroll
+        for (int c = 0; c < H; ++c) {
+            const double v = src[c];
+            a[c] = (grp == 1) ? (c == l15 ? 1.0 : 0.0) : (grp == 3 ? 0.0 : v);
+        }
+    }
+    int bad;
+    if (LDL) {
+        // LDL^T elimination (no square root on the pivot chain), then L = L~ D^1/2: columns of the left rows (lanes 0..15 and
+        // 32..47: a[k] = L~[.][k] d_k) and rows of the inverse (lanes 16..31: a[r] = (L~^-1)[r][.]) take the same factor rs_i
+        double rs;
+        bad = ldl_inverse_w<H, REPAIR>(a, min(wb, H), lane, &rs);
+#pragma unroll
+        for (int i = 0; i < H; ++i) a[i] *= rl(rs, i);
+    } else {
+        bad = chol_inverse_w<H>(a, min(wb, H), lane);
+    }
+    // X11 into place (lane 16 + c holds its column c), L21 into the scratch quadrant (lane 32 + i holds its row i)
+    if (l4 == 1) {
+#pragma unroll
+        for (int r = 0; r < H; ++r) b00[r * LDB + l15] = (r >= l15 && r < wb && l15 < wb) ? a[r] : 0.0;
+    } else if (l4 == 2) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) b01[l15 * LDB + k] = a[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // B22 -= L21 L21^T (upper triangle: garbage in, garbage out -- never read)
+        mfma_d4 acc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[reg] = b11[(l4 + 4 * reg) * LDB + l15];
+        mm16<true, true>(acc, b01, b01, l15, l4);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) b11[(l4 + 4 * reg) * LDB + l15] = acc[reg];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const double* src = b11 + l15 * LDB;
+#pragma unroll
+        for (int c = 0; c < H; ++c) {
+            const double v = src[c];
+            a[c] = (l4 == 1) ? (c == l15 ? 1.0 : 0.0) : (l4 == 0 ? v : 0.0);
+        }
+    }
+    const int wb2 = max(wb - H, 0);
+    if (LDL) {
+        double rs;
+        bad += ldl_inverse_w<H, REPAIR>(a, wb2, lane, &rs);
+#pragma unroll
+        for (int i = 0; i < H; ++i) a[i] *= rl(rs, i);
+    } else {
+        bad += chol_inverse_w<H>(a, wb2, lane);
+    }
+    if (l4 == 1) {
+#pragma unroll
+        for (int r = 0; r < H; ++r) b11[r * LDB + l15] = (r >= l15 && r < wb2 && l15 < wb2) ? a[r] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // T = L21 X11 -> b10;  X21 = -X22 T -> b10
+        mfma_d4 t = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        mm16<false, false>(t, b01, b00, l15, l4);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) b10[(l4 + 4 * reg) * LDB + l15] = t[reg];
+        __builtin_amdgcn_wave_barrier();
+        mfma_d4 x = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        mm16<true, false>(x, b11, b10, l15, l4);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            b10[(l4 + 4 * reg) * LDB + l15] = x[reg];
+            b01[(l4 + 4 * reg) * LDB + l15] = 0.0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return bad;
 }
 
 // PA: the diagonal block [C0, C0+kw) x [C0, C0+kw), kw <= 128, of every front of the level -- one workgroup per front.
@@ -517,6 +728,256 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
         }
     }
     STAMP(21);
+}
+
+// ---- k_diag_block2: the same block, the same outputs, scheduled for latency.
+// k_diag_block runs its phases one after the other on ONE workgroup: four register factorisations on wave 0 (three waves
+// idle), then the MFMA phases with wave 0 idle in between, then the inverse S -- 45 us per block, and the chain of these
+// blocks IS the factorisation time at the top of the tree (0.018 of fp64 peak).  Here:
+//   * the 32 x 32 factor + inverse is the LDL^T elimination (ldl32_inverse: no square root on the pivot chain);
+//   * while wave 0 factorises D_jj, waves 1..3 work through whole 32 x 32 x 32 block products that do not depend on it:
+//     the rank-32 updates of the previous block column that the NEXT factorisation does not need, and the rows of the inverse
+//     S that are already determined;
+//   * between two factorisations only what the next one needs runs on all four waves (by 16 x 16 quadrant): the block column
+//     L_ij = D_ij Linv_j^T and the update of D_(j+1)(j+1);
+//   * after the last factorisation one product per remaining block of S.
+// LDS: D (lower block triangle), the off-diagonal blocks of S, one scratch block per wave 1..3.
+__device__ __host__ inline int diag_block2_lds_blocks(int nblk) { return nblk * (nblk + 1) / 2 + nblk * (nblk - 1) / 2 + (nblk > 1 ? 3 : 0); }
+
+// acc (2 x 2 quadrants, D layout) += A B for whole 32 x 32 blocks, one wave
+template <bool TA, bool TB>
+__device__ __forceinline__ void wave_mm(mfma_d4 (&acc)[2][2], const blk32& A, const blk32& B, int l15, int l4) {
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+        const double a0 = TA ? A[kk + l4][l15] : A[l15][kk + l4], a1 = TA ? A[kk + l4][16 + l15] : A[16 + l15][kk + l4];
+        const double b0 = TB ? B[l15][kk + l4] : B[kk + l4][l15], b1 = TB ? B[16 + l15][kk + l4] : B[kk + l4][16 + l15];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void wave_zero(mfma_d4 (&acc)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+}
+// block (LDS) = sign * acc, and optionally the same values to global memory (column-major, leading dimension ldg)
+template <bool NEG, bool SUB>
+__device__ __forceinline__ void wave_store(blk32& dst, const mfma_d4 (&acc)[2][2], int l15, int l4, double* g = nullptr, size_t ldg = 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 16 * a + l4 + 4 * reg, c = 16 * b + l15;
+                const double v = NEG ? -acc[a][b][reg] : acc[a][b][reg];
+                if (SUB) dst[r][c] -= v; else dst[r][c] = v;
+                if (g) g[r + ldg * c] = v;
+            }
+}
+
+template <bool REPAIR>
+__global__ void __launch_bounds__(256)
+k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
+              int* __restrict__ info) {
+    STAMP(31);
+    const int slot = first + blockIdx.x;
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t];
+    if (C0 >= np) return;
+    const int kw = min(NBO, np - C0);
+    const int nkb = (kw + NB - 1) / NB;
+    const int ldp = ldp_of(fd.nf[t]);
+    double* F = fd.P + fd.poff[t];
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
+    extern __shared__ double lds_raw[];
+    const int nD = nblk * (nblk + 1) / 2;
+    blk32* D = reinterpret_cast<blk32*>(lds_raw);              // D_ij, i >= j, at i (i + 1) / 2 + j; D_jj becomes Linv_j = S_jj
+    blk32* Sb = D + nD;                                         // S_ij, i > j, at i (i - 1) / 2 + j
+    blk32* Sc = Sb + nblk * (nblk - 1) / 2;                      // scratch block of wave w at Sc[w - 1]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
+#define DB(i, j) D[(i) * ((i) + 1) / 2 + (j)]
+#define SB(i, j) Sb[(i) * ((i) - 1) / 2 + (j)]
+#define SOUT(i, j) (Sout + NB * (i) + (size_t)lds_ * (NB * (j)))
+    // Load, identity padding beyond kw.  D_00 is needed by the first factorisation only: wave 0 reads its rows straight
+    // into registers and factorises them while the other blocks are still on their way to LDS (nobody else touches D[0]).
+    double a0[NB];
+    if (wv == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            a0[c] = (lane < NB) ? (lane == c ? 1.0 : 0.0) : (c == lane - NB ? 1.0 : 0.0);
+            if (lane < NB && c <= lane && lane < kw) a0[c] = F[(C0 + lane) + (size_t)ldp * (C0 + c)];
+        }
+    }
+    if (wv > 0) {
+        // the other nine blocks: waves 1..3, 192 threads, all loads of a thread in flight before the first store
+        constexpr int NL = (9 * NB * NB + 191) / 192;           // 48
+        const int t3 = tid - 64;
+        double v[NL];
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = t3 + 192 * q;
+            const int b = 1 + e / (NB * NB), idx = e % (NB * NB);
+            const int bi = b < 3 ? 1 : b < 6 ? 2 : 3;
+            const int bj = b - bi * (bi + 1) / 2;
+            const int r = idx % NB, c = idx / NB;
+            const int gr = NB * bi + r, gc = NB * bj + c;
+            v[q] = (gr == gc) ? 1.0 : 0.0;
+            if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
+        }
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = t3 + 192 * q;
+            const int b = 1 + e / (NB * NB), idx = e % (NB * NB);
+            if (b < nD) D[b][idx % NB][idx / NB] = v[q];
+        }
+    }
+    STAMP(0);
+    // block tasks of one wave.  L_ij (in place of D_ij) also goes to the front's factor columns.
+    auto factor_rows = [&](int i, int j) {                       // T(i, j): D_ij <- L_ij = D_ij Linv_j^T
+        mfma_d4 acc[2][2];
+        wave_zero(acc);
+        wave_mm<false, true>(acc, DB(i, j), DB(j, j), l15, l4);
+        blk32& Dij = DB(i, j);
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = 16 * qa + l4 + 4 * reg, c = 16 * qb + l15;
+                    Dij[r][c] = acc[qa][qb][reg];
+                    const int gr = NB * i + r, gc = NB * j + c;
+                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)ldp * (C0 + gc)] = acc[qa][qb][reg];
+                }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto update = [&](int i, int k, int j) {                    // U(i, k; j): D_ik -= L_ij L_kj^T
+        mfma_d4 acc[2][2];
+        wave_zero(acc);
+        wave_mm<false, true>(acc, DB(i, j), DB(k, j), l15, l4);
+        wave_store<false, true>(DB(i, k), acc, l15, l4);
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto s_block = [&](int i, int j, blk32& W) {                // S_ij = -Linv_i W  -> LDS and global
+        mfma_d4 acc[2][2];
+        wave_zero(acc);
+        wave_mm<false, false>(acc, DB(i, i), W, l15, l4);
+        wave_store<true, false>(SB(i, j), acc, l15, l4, SOUT(i, j), (size_t)lds_);
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto s_of = [&](int k, int j) -> const blk32& { return k == j ? DB(j, j) : SB(k, j); };
+    auto w_block = [&](int i, int j, blk32& W) {                // W = sum_{k=j}^{i-1} L_ik S_kj
+        mfma_d4 acc[2][2];
+        wave_zero(acc);
+        for (int k = j; k < i; ++k) wave_mm<false, false>(acc, DB(i, k), s_of(k, j), l15, l4);
+        wave_store<false, false>(W, acc, l15, l4);
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int last = nkb - 1;
+    for (int j = 0; j < nkb; ++j) {
+        STAMP(2 + 4 * j);
+        if (wv == 0) {
+            // ---- F(j): factor + inverse of D_jj in registers; Linv_j replaces D_jj and goes to Linv
+            blk32& Djj = DB(j, j);
+            const int wb = min(NB, kw - NB * j);
+            double a[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a[c] = j == 0 ? a0[c] : ((lane < NB) ? Djj[lane][c] : (c == lane - NB ? 1.0 : 0.0));
+            double rs;
+            const int bad = ldl32_inverse<REPAIR>(a, wb, lane, &rs);
+            // rows of the inverse take 1 / sqrt(d_row): the broadcast reads lanes < 32 and must stay outside the divergent store
+#pragma unroll
+            for (int r = 0; r < NB; ++r) a[r] *= rl(rs, r);
+            if (lane >= NB) {
+                const int cl = lane - NB;
+                double* Li = fd.Linv + fd.linvoff[t] + (size_t)(C0 / NB + j) * NB * NB;
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const double v = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
+                    Djj[r][cl] = v;
+                    Li[r + NB * cl] = v;
+                }
+                if (cl == 0 && bad) atomicAdd(info, bad);
+            }
+        } else if (j == 1) {
+            // ---- beside F(1): block column 0 below row 1 -- its factor rows and the updates they feed.  U(3, 2; 0) needs the
+            // rows of both waves and waits for the next stage (D_32 is first read between F(2) and F(3)).
+            if (wv == 1 && nkb > 2) { factor_rows(2, 0); update(2, 1, 0); update(2, 2, 0); }
+            if (wv == 3 && nkb > 3) { factor_rows(3, 0); update(3, 1, 0); update(3, 3, 0); }
+            if (nkb == 2 && wv == 2) w_block(1, 0, Sc[1]);      // last row: W_10 = L_10 S_00
+        } else if (j == 2) {
+            if (wv == 1 && nkb > 3) { factor_rows(3, 1); update(3, 2, 0); update(3, 2, 1); update(3, 3, 1); }
+            if (wv == 3) {                                      // row 1 of S; and the last row's W if this is the last stage
+                w_block(1, 0, Sc[2]);
+                s_block(1, 0, Sc[2]);
+                if (nkb == 3) w_block(2, 0, Sc[2]);             // W_20 = L_20 S_00 + L_21 S_10
+            }
+            if (nkb == 3 && wv == 2) w_block(2, 1, Sc[1]);      // W_21 = L_21 S_11
+        } else if (j == 3) {
+            if (wv == 1) { w_block(2, 0, Sc[0]); s_block(2, 0, Sc[0]); w_block(3, 0, Sc[0]); }
+            if (wv == 2) { w_block(2, 1, Sc[1]); s_block(2, 1, Sc[1]); w_block(3, 1, Sc[1]); }
+            if (wv == 3) { w_block(3, 2, Sc[2]); }
+        }
+        __syncthreads();
+        STAMP(3 + 4 * j);
+        {   // S_jj = Linv_j to its place (all threads; stores only)
+            const blk32& Sjj = DB(j, j);
+            for (int idx = tid; idx < NB * NB; idx += 256) {
+                const int r = idx % NB, c = idx / NB;
+                SOUT(j, j)[r + (size_t)lds_ * c] = Sjj[r][c];
+            }
+        }
+        if (j + 1 < nkb) {
+            // ---- between two factorisations, on all four waves by quadrant: only what F(j + 1) needs --
+            // L_(j+1)j = D_(j+1)j Linv_j^T, then D_(j+1)(j+1) -= L_(j+1)j L_(j+1)j^T
+            mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            mfma_blk<false, true>(acc, DB(j + 1, j), DB(j, j), si, sj, l15, l4);
+            __syncthreads();
+            {
+                blk32& Dij = DB(j + 1, j);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+                    Dij[r][c] = acc[reg];
+                    const int gr = NB * (j + 1) + r, gc = NB * j + c;
+                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)ldp * (C0 + gc)] = acc[reg];
+                }
+            }
+            __syncthreads();
+            mfma_d4 u = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            mfma_blk<false, true>(u, DB(j + 1, j), DB(j + 1, j), si, sj, l15, l4);
+            blk32& Dn = DB(j + 1, j + 1);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Dn[16 * si + l4 + 4 * reg][16 * sj + l15] -= u[reg];
+            __syncthreads();
+            STAMP(4 + 4 * j);
+        }
+    }
+    STAMP(20);
+    // ---- after the last factorisation: S_(last)(j) = -Linv_last W_(last)(j), by quadrant on all four waves
+    int wsrc[3] = {0, 0, 0};                                    // scratch block that holds W_(last)(j)
+    if (nkb == 2) wsrc[0] = 1;
+    if (nkb == 3) { wsrc[0] = 2; wsrc[1] = 1; }
+    if (nkb == 4) { wsrc[0] = 0; wsrc[1] = 1; wsrc[2] = 2; }
+    for (int j = 0; j < last; ++j) {
+        mfma_d4 x = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        mfma_blk<false, false>(x, DB(last, last), Sc[wsrc[j]], si, sj, l15, l4);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+            SOUT(last, j)[r + (size_t)lds_ * c] = -x[reg];
+        }
+    }
+    STAMP(21);
+#undef DB
+#undef SB
+#undef SOUT
 }
 
 // PB: rows below the diagonal block of the outer panel: L[r][C0 + c] = sum_{k <= c} A[r][C0 + k] S[c][k] -- one GEMM

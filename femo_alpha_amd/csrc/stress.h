@@ -19,9 +19,11 @@ struct TopStrain {
     double gh0, gh1;         // local gradx of the thickness
 };
 
+// zf: through-thickness coordinate as a fraction of the thickness, xi2 = zf h -- 1/2 top, 0 mid, -1/2 bottom surface
+// (RMShellPDE.von_Mises_stress(surface=...), rm_shell_pde.py:153-165)
 template <int NPC, int NVC>
 __device__ __forceinline__ TopStrain top_strain(const Tables& t, int q, const QPG& g, const double* hn, bool ewm,
-                                               const double* xe, double hq) {
+                                               const double* xe, double hq, double zf = 0.5) {
     const Gen s = strains_q<NPC, NVC>(t, q, g, xe);
     double th[3] = {0, 0, 0};
     double gh0 = 0.0, gh1 = 0.0;
@@ -39,10 +41,10 @@ __device__ __forceinline__ TopStrain top_strain(const Tables& t, int q, const QP
     r.b1 = dot3(th, g.E0);
     r.gh0 = gh0; r.gh1 = gh1;
     r.k00 = s.k00; r.k11 = s.k11; r.k01 = s.k01;
-    const double z = 0.5 * hq;
-    r.e0 = s.e00 - z * s.k00 - 0.5 * r.b0 * gh0;
-    r.e1 = s.e11 - z * s.k11 - 0.5 * r.b1 * gh1;
-    r.g = s.g01 - z * s.k01 - 0.5 * (r.b0 * gh1 + r.b1 * gh0);
+    const double z = zf * hq;
+    r.e0 = s.e00 - z * s.k00 - zf * r.b0 * gh0;
+    r.e1 = s.e11 - z * s.k11 - zf * r.b1 * gh1;
+    r.g = s.g01 - z * s.k01 - zf * (r.b0 * gh1 + r.b1 * gh0);
     return r;
 }
 
@@ -168,7 +170,7 @@ k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double
 // b_e = int vm phi_i dx  (phi = the cell's P1/Q1 basis); out[NVC * e + i]
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
-k_stress_field(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double* __restrict__ out) {
+k_stress_field(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double zf, double* __restrict__ out) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m.nel) return;
@@ -188,7 +190,7 @@ k_stress_field(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const dou
         qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
         const double wd = tab->w[q] * g.det;            // project() uses the plain dx (utils_dolfinx.py:582,589)
         const double hq = interp<NVC>(tab->N1[q], el.hn);
-        const TopStrain ts = top_strain<NPC, NVC>(*tab, q, g, el.hn, f.ewm != 0, xe, hq);
+        const TopStrain ts = top_strain<NPC, NVC>(*tab, q, g, el.hn, f.ewm != 0, xe, hq, zf);
         double sig[3];
         const double vm = von_mises(ts, interp<NVC>(tab->N1[q], el.En), interp<NVC>(tab->N1[q], el.nun), sig);
         for (int i = 0; i < NVC; ++i) {
@@ -211,6 +213,45 @@ k_stress_field(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const dou
         c[i] = s / A[i][i];
     }
     for (int i = 0; i < NVC; ++i) out[NVC * e + i] = c[i];
+}
+
+// RMShellPDE.sum_stress_subdomain (rm_shell_pde.py:130-150): the six integrals  int sigma_ij J dx  over the selected
+// sub-domain of the top-surface in-plane stress "in global coordinates" -- restated AS WRITTEN in
+// ShellStressRM.inplaneStress (linear_shell_model.py:446-458): sigma_ij = sum_kl E012[i][k] s3d[k][l] E012[j][l] with
+// E012[i][k] the k-th Cartesian component of the i-th local basis vector and s3d = [[s0, s2, 0], [s2, s1, 0], [0, 0, 0]],
+// i.e. only the x and y components of the basis vectors enter.  slots[0..5] += (xx, yy, zz, xy, xz, yz).
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_stress_sums(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ w, double* slots) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (e < m.nel && cell_selected(m, e)) {
+        Elem<NPC, NVC> el;
+        load_elem<NPC, NVC, UHAT>(m, f, e, el);
+        double xe[LD];
+        for (int a = 0; a < NPC; ++a)
+            for (int c = 0; c < 3; ++c) xe[3 * a + c] = w[3 * el.pid[a] + c];
+        for (int b = 0; b < NVC; ++b)
+            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
+        const int nq = tab->nq;
+        for (int q = 0; q < nq; ++q) {
+            QPG g;
+            qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+            const double wj = tab->w[q] * g.det * g.Ju;
+            const double hq = interp<NVC>(tab->N1[q], el.hn);
+            const TopStrain ts = top_strain<NPC, NVC>(*tab, q, g, el.hn, f.ewm != 0, xe, hq);
+            double sg[3];
+            von_mises(ts, interp<NVC>(tab->N1[q], el.En), interp<NVC>(tab->N1[q], el.nun), sg);
+            const double* Eb[3] = {g.E0, g.E1, g.E2};
+            auto comp = [&](int i, int j) {
+                return Eb[i][0] * (sg[0] * Eb[j][0] + sg[2] * Eb[j][1]) + Eb[i][1] * (sg[2] * Eb[j][0] + sg[1] * Eb[j][1]);
+            };
+            acc[0] += wj * comp(0, 0); acc[1] += wj * comp(1, 1); acc[2] += wj * comp(2, 2);
+            acc[3] += wj * comp(0, 1); acc[4] += wj * comp(0, 2); acc[5] += wj * comp(1, 2);
+        }
+    }
+    for (int k = 0; k < 6; ++k) block_accumulate(acc[k], slots + k);
 }
 
 }  // namespace femo

@@ -76,8 +76,11 @@ class RMShellPDE:
         return Form(self.ctx, "area", subdomain=int(dxx))
 
     def sum_stress_subdomain(self, w, uhat, h, E, nu, dxx):
-        raise NotImplementedError("the global-component stress sums are only referenced from commented-out code in the "
-                                  "reference (rm_shell_model.py:255-262); use pnorm_stress over the sub-domain")
+        """The six integrals of the top-surface in-plane stress components over the tagged sub-domain ``dxx``
+        (rm_shell_pde.py:130-150): (sum_x, sum_y, sum_z, sum_xy, sum_xz, sum_yz), restated as ShellStressRM.inplaneStress
+        writes them (linear_shell_model.py:446-458).  Values only: the reference registers these outputs in commented-out
+        code (rm_shell_model.py:255-262), their partials are not implemented."""
+        return tuple(Form(self.ctx, "sum_stress_" + c, subdomain=int(dxx)) for c in ("x", "y", "z", "xy", "xz", "yz"))
 
     def volume(self, uhat, h):
         """int h J dx (rm_shell_pde.py:98-99)."""
@@ -100,9 +103,13 @@ class RMShellPDE:
         return Form(self.ctx, "pnorm_stress", subdomain=-1 if dx is None else int(dx))
 
     def von_Mises_stress(self, w, uhat, h, E, nu, surface="Top"):
-        if surface != "Top":
-            raise NotImplementedError("only the top-surface stress is provided (the one rm_shell_model.py:207-208 registers)")
-        return FieldForm(self.ctx, "stress")
+        """von Mises stress at xi2 = h/2 ('Top'), 0 ('Mid') or -h/2 ('Bot') (rm_shell_pde.py:153-165), as a field the
+        backend projects onto DG1.  The reference falls through on any other value (it builds a TypeError without raising
+        it, :164) and then fails on the undefined name; here the bad argument is refused."""
+        names = {"Top": "stress", "Mid": "stress_mid", "Bot": "stress_bot"}
+        if surface not in names:
+            raise TypeError("Unsupported surface type for stress computation.")
+        return FieldForm(self.ctx, names[surface])
 
     # ------------------------------------------------------------------ maps
     def construct_force_to_pressure_map(self):

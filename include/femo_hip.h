@@ -187,13 +187,15 @@ int femo_set_stress_params(femo_ctx* ctx, double m, double rho);
  * cells of sub-domain sel, normalised by that sub-domain's reference area; sel = -1 selects the whole mesh again. */
 int femo_set_cell_tags(femo_ctx* ctx, const int32_t* tags, int64_t n, int32_t ntags);
 int femo_select_subdomain(femo_ctx* ctx, int32_t sel);
-/* Field output "stress": top-surface von Mises stress L2-projected onto DG1, nvc*nel values (cell-major, the
- * cell's vertices in connectivity order) -- replaces FEA.projectFieldOutput (fea/fea_dolfinx.py:205-206,
+/* Field outputs "stress" (top surface, xi2 = h/2), "stress_mid" (xi2 = 0), "stress_bot" (xi2 = -h/2): von Mises stress
+ * (RMShellPDE.von_Mises_stress(surface=...), rm_shell/rm_shell_pde.py:153-165) L2-projected onto DG1, nvc*nel values
+ * (cell-major, the cell's vertices in connectivity order) -- replaces FEA.projectFieldOutput (fea/fea_dolfinx.py:205-206,
  * csdl_alpha_opt/output_operation.py:116-123). */
 int femo_field_output(femo_ctx* ctx, const char* name, double* out, int64_t n);
 /* Scalar outputs for the stored state and fields: "compliance", "mass", "elastic_energy", "pnorm_stress", "volume",
  * "regularization" (the thickness term of the compliance, rm_shell_pde.py:64-83), and over the selected sub-domain
- * (femo_select_subdomain; the whole mesh if none) "tip_disp" = 0.5 int u.u J and "area" = int J (rm_shell_pde.py:95-105) --
+ * (femo_select_subdomain; the whole mesh if none) "tip_disp" = 0.5 int u.u J, "area" = int J (rm_shell_pde.py:95-105) and
+ * "sum_stress_x|y|z|xy|xz|yz" = int sigma_ij J dx of the top-surface in-plane stress (sum_stress_subdomain, :130-150) --
  * replaces assemble_scalar(form(c)) (csdl_alpha_opt/output_operation.py:51-56; forms at
  * rm_shell/rm_shell_pde.py:64-110). */
 int femo_functional(femo_ctx* ctx, const char* name, double* value);

@@ -544,10 +544,11 @@ class ShellOracle:
         return out
 
     # ------------------------------------------------------------------ stress outputs
-    def von_mises_top(self, w, sl=slice(None)):
-        """Top-surface von Mises stress at the quadrature points of this oracle's rule, (ne,nq), following
-        ShellStressRM (linear_shell_model.py:393-467) with xi2 = h/2 a *field* (rm_shell_pde.py:117-119):
-        eps = eps_m - h/2 kappa - 1/2 sym((E2 x theta)_loc (x) gradx(h)_loc)."""
+    def von_mises_top(self, w, sl=slice(None), zf=0.5, components=False):
+        """von Mises stress at xi2 = zf h (zf = 1/2 top, 0 mid, -1/2 bottom surface; rm_shell_pde.py:153-165) at the
+        quadrature points of this oracle's rule, (ne,nq), following ShellStressRM (linear_shell_model.py:393-467) with
+        xi2 a *field* (rm_shell_pde.py:117-119): eps = eps_m - zf h kappa - zf sym((E2 x theta)_loc (x) gradx(h)_loc).
+        ``components``: also return the local stresses (s0, s1, s2)."""
         B, g = self._B(sl)
         we = w[self.dofs[sl]]
         s = np.einsum("eqij,ej->eqi", B, we)
@@ -561,12 +562,13 @@ class ShellOracle:
             hn = self.h[self.mesh.cells[sl]]
             gh = np.einsum("eb,eqbj->eqj", hn, gxM)
             gh0 = np.einsum("eqj,eqj->eq", g["E0"], gh); gh1 = np.einsum("eqj,eqj->eq", g["E1"], gh)
-        e0 = s[..., 0] - 0.5 * h * s[..., 3] - 0.5 * b0 * gh0
-        e1 = s[..., 1] - 0.5 * h * s[..., 4] - 0.5 * b1 * gh1
-        gg = s[..., 2] - 0.5 * h * s[..., 5] - 0.5 * (b0 * gh1 + b1 * gh0)
+        e0 = s[..., 0] - zf * h * s[..., 3] - zf * b0 * gh0
+        e1 = s[..., 1] - zf * h * s[..., 4] - zf * b1 * gh1
+        gg = s[..., 2] - zf * h * s[..., 5] - zf * (b0 * gh1 + b1 * gh0)
         c = E / (1 - nu ** 2)
         s0, s1, s2 = c * (e0 + nu * e1), c * (nu * e0 + e1), c * 0.5 * (1 - nu) * gg
-        return np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2 + 3 * s2 ** 2), g
+        vm = np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2 + 3 * s2 ** 2)
+        return (vm, g, (s0, s1, s2)) if components else (vm, g)
 
     def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None, cells=None):
         """1/alpha int (m vm)^rho J dx (rm_shell_pde.py:112-128); use an oracle built with nquad=3 for the
@@ -583,11 +585,33 @@ class ShellOracle:
             area += np.sum(wd)
         return val / (area if alpha is None else alpha)
 
-    def stress_dg1(self, w):
-        """L2 projection of the top-surface von Mises stress onto DG1, (nel, nvc) (utils_dolfinx.py:568-602)."""
+    def sum_stress_subdomain(self, w, cells=None):
+        """(sum_x, sum_y, sum_z, sum_xy, sum_xz, sum_yz) = int sigma_ij J dx over ``cells`` of the top-surface in-plane
+        stress (rm_shell_pde.py:130-150), with sigma exactly as ShellStressRM.inplaneStress writes it
+        (linear_shell_model.py:446-458): sigma_ij = sum_kl E012[i,k] s3d[k,l] E012[j,l], E012[i,k] = component k of the
+        i-th local basis vector, s3d = [[s0, s2, 0], [s2, s1, 0], [0, 0, 0]] -- only the x and y components of the basis
+        vectors enter (restated as written, not "corrected")."""
+        out = np.zeros(6)
+        sel = None if cells is None else np.isin(np.arange(self.mesh.nel), np.asarray(cells))
+        for sl in self._chunks():
+            vm, g, (s0, s1, s2) = self.von_mises_top(w, sl, components=True)
+            wj = self.wts[None, :] * g["det"] * g["Ju"]
+            if sel is not None:
+                wj = wj * sel[sl][:, None]
+            Eb = [g["E0"], g["E1"], g["E2"]]
+            comp = lambda i, j: (Eb[i][..., 0] * (s0 * Eb[j][..., 0] + s2 * Eb[j][..., 1])
+                                 + Eb[i][..., 1] * (s2 * Eb[j][..., 0] + s1 * Eb[j][..., 1]))
+            for k, (i, j) in enumerate(((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))):
+                out[k] += np.sum(wj * comp(i, j))
+        return out
+
+    def stress_dg1(self, w, surface="Top"):
+        """L2 projection of the von Mises stress on the 'Top' | 'Mid' | 'Bot' surface onto DG1, (nel, nvc)
+        (rm_shell_pde.py:153-165, utils_dolfinx.py:568-602)."""
+        zf = {"Top": 0.5, "Mid": 0.0, "Bot": -0.5}[surface]
         out = np.zeros((self.mesh.nel, self.nvc))
         for sl in self._chunks():
-            vm, g = self.von_mises_top(w, sl)
+            vm, g = self.von_mises_top(w, sl, zf=zf)
             wd = self.wts[None, :] * g["det"]
             M = np.einsum("eq,qi,qj->eij", wd, self.N1, self.N1)
             b = np.einsum("eq,qi,eq->ei", wd, self.N1, vm)

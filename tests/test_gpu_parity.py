@@ -548,3 +548,31 @@ def test_switching_preconditioners_after_a_field_change():
     c.set_field("density", 3.0 * c.get_field("density"))            # operator changed: the factor must follow
     b2, it2, _ = c.solve_linear(x)
     assert it2 <= 6 and rel(b1, b2) > 1e-3
+
+
+@pytest.mark.parametrize("kind,ewm,uhat", [("plate", False, False), ("warped", False, True), ("warped", True, False)])
+def test_stress_on_the_mid_and_bottom_surfaces_and_global_component_sums(kind, ewm, uhat):
+    """von_Mises_stress(surface='Mid' | 'Bot') (rm_shell_pde.py:153-165) and sum_stress_subdomain (:130-150) against the
+    oracle's restatement of ShellStressRM (linear_shell_model.py:393-467); the sums over a tagged sub-domain and over the
+    whole mesh."""
+    m, o, c, rng = _pair(kind, ewm=ewm, uhat=uhat, beta=1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-4
+    c.set_state(w)
+    for surface, name in (("Top", "stress"), ("Mid", "stress_mid"), ("Bot", "stress_bot")):
+        assert rel(c.field_output(name).reshape(m.nel, -1), o.stress_dg1(w, surface)) < 1e-10, surface
+    top, bot = c.field_output("stress"), c.field_output("stress_bot")
+    assert rel(top, bot) > 1e-3                                   # bending present: the two surfaces differ
+    names = ["sum_stress_" + k for k in ("x", "y", "z", "xy", "xz", "yz")]
+    ref = o.sum_stress_subdomain(w)
+    got = np.array([c.functional(n) for n in names])
+    assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()
+    cells = rng.permutation(m.nel)[: m.nel // 3]
+    tags = -np.ones(m.nel, dtype=np.int32); tags[cells] = 0
+    c.set_cell_tags(tags, 1)
+    c.select_subdomain(0)
+    ref = o.sum_stress_subdomain(w, cells)
+    got = np.array([c.functional(n) for n in names])
+    assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()
+    c.select_subdomain(-1)
+    with pytest.raises(Exception, match="unknown field output"):
+        c.field_output("stress_side")

@@ -317,3 +317,35 @@ def test_oracle_reproduces_the_committed_config1_golden(golden_dir):
     assert abs(o.mass() - 20.0) < 1e-12 and abs(float(g["mass"]) - 20.0) < 1e-12           # rho h b L
     assert np.abs(w[g["w_sample_index"]] - g["w_sample"]).max() < 1e-7 * float(g["w_maxabs"])
     assert np.abs(dJ - g["dcompliance_dthickness"]).max() < 1e-7 * np.abs(g["dcompliance_dthickness"]).max()
+
+
+def test_stress_surfaces_and_component_sums_of_the_oracle():
+    """Pins for the oracle's ShellStressRM restatement beyond the top surface: pure membrane stretching gives the same
+    stress on all three surfaces; pure bending gives zero on the mid surface and equal von Mises stress top and bottom;
+    and the component sums follow the reference's formula as written (only the x, y components of the local basis enter:
+    on a plate in the x-y plane sum_x = int s0, sum_y = int s1, sum_xy = int s2, the z sums vanish)."""
+    from femo_alpha_amd.mesh import plate_mesh
+    from oracle.rm_shell_oracle import ShellOracle
+    m = plate_mesh(2.0, 3.0, 4, 6)
+    o = ShellOracle(m)
+    E, nu, h = 3e7, 0.3, 0.05
+    o.set_fields(h=h, E=E, nu=nu)
+    P2 = m.p2_coords
+    # membrane: u_x = a x
+    a = 1e-4
+    w = np.zeros(m.ndof)
+    w[0:3 * m.nP2:3] = a * P2[:, 0]
+    top, mid, bot = (o.stress_dg1(w, s) for s in ("Top", "Mid", "Bot"))
+    c = E / (1 - nu ** 2)
+    s0, s1 = c * a, c * nu * a
+    vm = np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2)
+    assert np.allclose(top, vm, rtol=1e-10) and np.allclose(mid, vm, rtol=1e-10) and np.allclose(bot, vm, rtol=1e-10)
+    sums = o.sum_stress_subdomain(w)
+    area = 6.0
+    assert np.allclose(sums, [s0 * area, s1 * area, 0.0, 0.0, 0.0, 0.0], rtol=1e-10, atol=1e-9 * s0 * area)
+    # bending: theta_y = b x  (rotation about y), no mid-surface displacement
+    w = np.zeros(m.ndof)
+    w[m.ndof_u + 1::3] = 1e-3 * m.nodes[:, 0]
+    top, mid, bot = (o.stress_dg1(w, s) for s in ("Top", "Mid", "Bot"))
+    assert np.abs(mid).max() < 1e-9 * np.abs(top).max()
+    assert np.allclose(top, bot, rtol=1e-10) and top.min() > 0
