@@ -94,6 +94,15 @@ SIGNATURES = {
     "femo_front_schur_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "femo_front_block_unpack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "femo_factorize_profile_get": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_newmark_setup": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "femo_newmark_set_forces": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
+    "femo_newmark_set_constant_load": (C.c_int, [C.c_void_p, _c_double_p]),
+    "femo_newmark_march": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _c_int32_p, _c_double_p]),
+    "femo_newmark_get_history": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
+    "femo_newmark_set_history": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
+    "femo_newmark_adjoint": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
+    "femo_newmark_residual_T": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
+    "femo_newmark_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "femo_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
 }
 

@@ -261,6 +261,49 @@ class ShellContext:
         self._chk(self.lib.femo_grad_get(self._h, dptr(out), out.size))
         return out
 
+    # ------------------------------------------------------------------ transient march in the library (femo_newmark_*)
+    def newmark_setup(self, time_levels, dt):
+        self._chk(self.lib.femo_newmark_setup(self._h, int(time_levels), float(dt)))
+        self._nm_levels = int(time_levels)
+
+    def newmark_set_forces(self, f_history):
+        f = np.ascontiguousarray(np.asarray(f_history, dtype=np.float64).reshape(-1, self.field_size("F_solid")))
+        self._chk(self.lib.femo_newmark_set_forces(self._h, dptr(f.ravel()), f.shape[0]))
+
+    def newmark_set_constant_load(self, F=None):
+        self._chk(self.lib.femo_newmark_set_constant_load(self._h, None if F is None else dptr(self._vec(F))))
+
+    def newmark_march(self, nsteps, reassemble_every_step=False):
+        it = np.zeros(nsteps, dtype=np.int32); rr = np.zeros(nsteps)
+        self._chk(self.lib.femo_newmark_march(self._h, int(nsteps), int(reassemble_every_step), iptr(it), dptr(rr)))
+        return list(zip(it.tolist(), rr.tolist()))
+
+    def newmark_history(self, which=0):
+        """(time_levels, ndof) host copy of the displacement (0) or adjoint (2) history."""
+        out = np.empty((self._nm_levels, self.ndof))
+        self._chk(self.lib.femo_newmark_get_history(self._h, int(which), dptr(out.ravel())))
+        return out
+
+    def newmark_set_history(self, H, which=0):
+        H = np.ascontiguousarray(np.asarray(H, dtype=np.float64).reshape(self._nm_levels, self.ndof))
+        self._chk(self.lib.femo_newmark_set_history(self._h, int(which), dptr(H.ravel())))
+
+    def newmark_adjoint(self, G):
+        G = np.ascontiguousarray(np.asarray(G, dtype=np.float64).reshape(-1, self.ndof))
+        self._chk(self.lib.femo_newmark_adjoint(self._h, dptr(G.ravel()), G.shape[0]))
+
+    def newmark_residual_T(self, levels):
+        g = np.empty(self.field_size("thickness")); dF = np.empty((levels, self.field_size("F_solid")))
+        self._chk(self.lib.femo_newmark_residual_T(self._h, int(levels), dptr(g), dptr(dF.ravel())))
+        return g, dF
+
+    def newmark_tensor(self, which=0):
+        """Zero-copy torch view of the resident displacement history (0: (levels, ndof)), velocity (1: (ndof,)) or adjoint history (2)."""
+        ptr = self.lib.femo_newmark_ptr(self._h, int(which))
+        n = self.ndof if which == 1 else self._nm_levels * self.ndof
+        t = self._dev_tensor(ptr, n)
+        return t if which == 1 else t.view(self._nm_levels, self.ndof)
+
     # ------------------------------------------------------------------ CSR export
     def enable_csr(self):
         """Pattern + destination-sorted contribution map (host, mesh only), uploaded once."""

@@ -65,6 +65,14 @@ struct femo_ctx {
         int *top_idx = nullptr, *sel = nullptr;
         double *wdot = nullptr, *topbuf = nullptr, *topsave = nullptr, *gloc = nullptr;
     } di;
+    // transient march (femo_newmark_*): history, force history and work vectors resident in HBM
+    struct Newmark {
+        bool ready = false;
+        int levels = 0, flevels = 0;
+        double dt = 0, a = 0, b = 0;
+        double *W = nullptr, *Fh = nullptr, *wdot = nullptr, *Fsw = nullptr, *mu0 = nullptr, *mu1 = nullptr, *Lam = nullptr, *Gh = nullptr;
+        bool has_sw = false;
+    } nm;
     // CSR assembly
     long long csr_ncontrib = 0; int csr_nnz = 0;
     int *csr_perm = nullptr, *csr_dest = nullptr;
@@ -367,10 +375,12 @@ static int refresh_diag(femo_ctx* c) {
     return 0;
 }
 
-static int load_vector_dev(femo_ctx* c, double* F) {
+static int load_vector_dev(femo_ctx* c, double* F, const double* f_override = nullptr) {
     const int64_t n = c->ndof;
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, 0.0, n);
-    ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, F, 1.0);
+    FieldsDev fdv = fields_dev(c);
+    if (f_override) fdv.f = const_cast<double*>(f_override);        // a level of the resident force history (femo_newmark_*)
+    ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
     if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, c->mask, n);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1269,6 +1279,9 @@ void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();                   // stream2 / stream3 may still hold work that reads the buffers freed below
+    void* nptrs[] = {c->nm.W, c->nm.Fh, c->nm.wdot, c->nm.Fsw, c->nm.mu0, c->nm.mu1, c->nm.Lam, c->nm.Gh};
+    for (void* p : nptrs)
+        if (p) hipFree(p);
     void* dptrs[] = {c->di.top_idx, c->di.sel, c->di.wdot, c->di.topbuf, c->di.topsave, c->di.gloc};
     for (void* p : dptrs)
         if (p) hipFree(p);
@@ -2429,6 +2442,189 @@ int femo_grad_get(femo_ctx* c, double* out, int64_t n) {
     return 0;
 }
 
+
+
+// ---- transient march in the library (BASELINE config 5): the reference's PlateSim.solve_dynamic_problem
+// (dynamic_rm_shell/plate_sim.py:281-361: per step update_f, solveNonlinear_mod, wdot update) and the backward sweep of its
+// adjoint (state_operation_dynamic.py:619-691), with history, force history and velocity resident in HBM.
+//   w_mid = (w_old + w)/2,  wdot = 2/dt (w - w_old) - wdot_old,  wddot = (wdot - wdot_old)/dt      (plate_sim.py:131-140)
+//   step:  (a M + K/2) w_i = F_i + M (a w_{i-1} + b wdot_{i-1}) - K/2 w_{i-1},   a = 2/dt^2, b = 2/dt
+int femo_newmark_setup(femo_ctx* c, int32_t time_levels, double dt) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (time_levels < 2 || !(dt > 0)) return fail(c, "femo_newmark_setup: need at least two time levels and dt > 0");
+    void* old[] = {nm.W, nm.Fh, nm.wdot, nm.Fsw, nm.mu0, nm.mu1, nm.Lam, nm.Gh};
+    for (void* p : old) if (p) hipFree(p);
+    nm = femo_ctx::Newmark();
+    const size_t n = (size_t)c->ndof;
+    HIPCHK(c, hipMalloc((void**)&nm.W, (size_t)time_levels * n * sizeof(double)));
+    HIPCHK(c, hipMemset(nm.W, 0, (size_t)time_levels * n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&nm.wdot, n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&nm.mu0, n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&nm.mu1, n * sizeof(double)));
+    nm.levels = time_levels; nm.dt = dt; nm.a = 2.0 / (dt * dt); nm.b = 2.0 / dt;
+    if (0.5 != c->op_aK || nm.a != c->op_aM) { c->op_aK = 0.5; c->op_aM = nm.a; operator_changed(c); }
+    nm.ready = true;
+    return 0;
+}
+
+// pressure history, (levels_given x field length of F_solid) row-major; levels beyond the last one repeat it
+int femo_newmark_set_forces(femo_ctx* c, const double* f_history, int32_t levels_given) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    if (levels_given < 1 || !f_history) return fail(c, "empty force history");
+    if (nm.Fh) { hipFree(nm.Fh); nm.Fh = nullptr; }
+    const size_t bytes = (size_t)levels_given * 3 * c->nF * sizeof(double);
+    HIPCHK(c, hipMalloc((void**)&nm.Fh, bytes));
+    HIPCHK(c, hipMemcpy(nm.Fh, f_history, bytes, hipMemcpyHostToDevice));
+    nm.flevels = levels_given;
+    return 0;
+}
+
+// a load vector added to every step's right-hand side (the self weight of element-wise thickness as consistent nodal loads); null: none
+int femo_newmark_set_constant_load(femo_ctx* c, const double* F) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    nm.has_sw = F != nullptr;
+    if (!F) return 0;
+    if (!nm.Fsw) HIPCHK(c, hipMalloc((void**)&nm.Fsw, (size_t)c->ndof * sizeof(double)));
+    HIPCHK(c, hipMemcpy(nm.Fsw, F, (size_t)c->ndof * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void* femo_newmark_ptr(femo_ctx* c, int32_t which) { return which == 0 ? (void*)c->nm.W : which == 1 ? (void*)c->nm.wdot : which == 2 ? (void*)c->nm.Lam : nullptr; }
+
+// March levels 1 .. nsteps from zero initial conditions.  reassemble != 0: the step operator is re-assembled and re-factorised
+// before every solve, as the reference does (nonlinear_utils.py:210-233).  iters / relres: nsteps entries (may be null).
+int femo_newmark_march(femo_ctx* c, int32_t nsteps, int reassemble, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready || !nm.Fh) return fail(c, "femo_newmark_march: set-up or force history missing");
+    if (nsteps < 1 || nsteps >= nm.levels) return fail(c, "nsteps must be in 1 .. time_levels - 1");
+    if (c->op_aK != 0.5 || c->op_aM != nm.a) return fail(c, "the operator was changed after femo_newmark_setup");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    HIPCHK(c, hipMemsetAsync(nm.W, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(nm.wdot, 0, (size_t)n * sizeof(double), c->stream));
+    for (int i = 1; i <= nsteps; ++i) {
+        const double* w_old = nm.W + (size_t)(i - 1) * n;
+        double* w_new = nm.W + (size_t)i * n;
+        if (load_vector_dev(c, c->b, nm.Fh + (size_t)std::min(i, nm.flevels - 1) * 3 * c->nF)) return 1;
+        if (op_apply(c, w_old, c->Ap, nullptr, nullptr, nullptr, false, -0.5, nm.a)) return 1;        // (a M - K/2) w_old
+        if (op_apply(c, nm.wdot, c->z, nullptr, nullptr, nullptr, false, 0.0, nm.b)) return 1;        // b M wdot_old
+        hipLaunchKernelGGL(k_newmark_rhs, dim3(vg), dim3(256), 0, c->stream, c->b, (const double*)(nm.has_sw ? nm.Fsw : nullptr),
+                           (const double*)c->Ap, (const double*)c->z, mask, n);
+        if (reassemble) operator_changed(c);
+        int32_t it = 0; double rr = 0;
+        if (int rc = solve_dispatch(c, c->b, w_new, true, &it, &rr)) return rc;
+        if (iters) iters[i - 1] = it;
+        if (relres) relres[i - 1] = rr;
+        hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, nm.wdot, (const double*)w_new, w_old, nm.b, n);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->w, nm.W + (size_t)nsteps * n, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // the reference's self.w
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// history to the host, (time_levels x ndof) row-major (level-major); which: 0 displacement history, 2 adjoint history
+int femo_newmark_get_history(femo_ctx* c, int32_t which, double* out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    const double* src = which == 0 ? nm.W : which == 2 ? nm.Lam : nullptr;
+    if (!nm.ready || !src) return fail(c, "no such history");
+    HIPCHK(c, hipMemcpy(out, src, (size_t)nm.levels * c->ndof * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int femo_newmark_set_history(femo_ctx* c, int32_t which, const double* H) {      // a history from outside (the caller's adjoint seed, restarts): level-major
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    if (which != 0 && which != 2) return fail(c, "which: 0 displacement history, 2 adjoint history");
+    const size_t hb = (size_t)nm.levels * c->ndof * sizeof(double);
+    if (which == 2 && !nm.Lam) HIPCHK(c, hipMalloc((void**)&nm.Lam, hb));
+    HIPCHK(c, hipMemcpy(which == 0 ? nm.W : nm.Lam, H, hb, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Lambda solving (dR/dy)^T Lambda = G for the whole-history residual, by the backward two-vector recursion
+//   mu_i = b M lam_{i+1} - mu_{i+1},   A lam_i = G_i + b mu_i + (a M - K/2) lam_{i+1} - b mu_{i+1},   lam_0 = G_0 + (a M - K/2) lam_1 - b mu_1
+// (the O(T) form of state_operation_dynamic.py:619-691).  G: (levels x ndof) level-major, host; the result stays on the device
+// (femo_newmark_get_history(ctx, 2, ..)) for femo_newmark_residual_T.
+int femo_newmark_adjoint(femo_ctx* c, const double* G, int32_t levels) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    if (levels < 1 || levels > nm.levels) return fail(c, "bad number of levels");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    const size_t hb = (size_t)nm.levels * n * sizeof(double);
+    if (!nm.Lam) HIPCHK(c, hipMalloc((void**)&nm.Lam, hb));
+    if (!nm.Gh) HIPCHK(c, hipMalloc((void**)&nm.Gh, hb));
+    HIPCHK(c, hipMemsetAsync(nm.Lam, 0, hb, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nm.Gh, G, (size_t)levels * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(nm.mu0, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->lam, 0, (size_t)n * sizeof(double), c->stream));
+    double *mu_next = nm.mu0, *mu_i = nm.mu1;
+    const double* lam_next = c->lam;                               // zero above the last level
+    for (int i = levels - 1; i >= 0; --i) {
+        if (op_apply(c, lam_next, c->Ap, nullptr, nullptr, nullptr, false, 0.0, 1.0)) return 1;        // M lam_{i+1}
+        if (op_apply(c, lam_next, c->z, nullptr, nullptr, nullptr, false, -0.5, nm.a)) return 1;       // (a M - K/2) lam_{i+1}
+        double* Li = nm.Lam + (size_t)i * n;
+        hipLaunchKernelGGL(k_newmark_adj, dim3(vg), dim3(256), 0, c->stream, c->b, mu_i, i == 0 ? Li : (double*)nullptr,
+                           (const double*)(nm.Gh + (size_t)i * n), (const double*)c->Ap, (const double*)c->z, (const double*)mu_next, mask, nm.b, n);
+        if (i == 0) break;
+        if (int rc = solve_dispatch(c, c->b, Li, true, nullptr, nullptr)) return rc;
+        lam_next = Li;
+        std::swap(mu_next, mu_i);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// g_t (thickness length) = sum_i lam_i^T [ K'/2 (w_i + w_{i-1}) + M' (a (w_i - w_{i-1}) - b wdot_{i-1}) ],
+// dF (levels x field length of F_solid, level-major; level 0 zero) = (dR_i/df)^T lam_i, for the resident displacement and
+// adjoint histories (state_operation_dynamic.py:406-427: the thickness gradient re-assembled per level)
+int femo_newmark_residual_T(femo_ctx* c, int32_t levels, double* g_t, double* dF) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready || !nm.Lam) return fail(c, "femo_newmark_residual_T: no adjoint history (femo_newmark_adjoint)");
+    if (levels < 1 || levels > nm.levels) return fail(c, "bad number of levels");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int g = nblk(c->nel, EB);
+    if (!c->gradbuf) HIPCHK(c, hipMalloc((void**)&c->gradbuf, (size_t)std::max<int64_t>(c->nT, 1) * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->gradbuf, 0, (size_t)c->nT * sizeof(double), c->stream));
+    double* dFd = nullptr;
+    const size_t fl = (size_t)3 * c->nF;
+    HIPCHK(c, hipMalloc((void**)&dFd, (size_t)levels * fl * sizeof(double)));
+    hipMemsetAsync(dFd, 0, (size_t)levels * fl * sizeof(double), c->stream);
+    HIPCHK(c, hipMemsetAsync(nm.wdot, 0, (size_t)n * sizeof(double), c->stream));
+    for (int i = 1; i < levels; ++i) {
+        const double *wi = nm.W + (size_t)i * n, *wo = nm.W + (size_t)(i - 1) * n, *li = nm.Lam + (size_t)i * n;
+        hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, wi, 1.0, wo, 0.0, (const double*)nullptr, n);         // w_i + w_{i-1}
+        hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->z, nm.a, wi, -nm.a, wo, -nm.b, (const double*)nm.wdot, n);     // a (w_i - w_{i-1}) - b wdot_{i-1}
+        ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->p, li, 0.5, c->gradbuf);
+        ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, c->z, li, 1.0, c->gradbuf);
+        ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, li, -1.0, dFd + (size_t)i * fl);
+        hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, nm.wdot, wi, wo, nm.b, n);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && g_t) e = hipMemcpy(g_t, c->gradbuf, (size_t)c->nT * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dF) e = hipMemcpy(dF, dFd, (size_t)levels * fl * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dFd);
+    HIPCHK(c, e);
+    return 0;
+}
 
 // ---- CSR assembly of the elastic stiffness (what assembleMatrix(dR_du) returns in the reference,
 // csdl_alpha_opt/state_operation.py:289; fea/utils_dolfinx.py:200-206) -----------------------------------------

@@ -1456,6 +1456,43 @@ __global__ void k_tril_unpack(double* __restrict__ full, const double* __restric
         full[r + (size_t)n * c] = packed[base + (r - c)];
 }
 
+// ---- transient march (femo_newmark_*): the vector algebra of one step / one adjoint step, fused
+// rhs = F (+ Fsw) + y1 + y2, masked rows zero
+__global__ void k_newmark_rhs(double* __restrict__ b, const double* __restrict__ Fsw, const double* __restrict__ y1, const double* __restrict__ y2,
+                              const unsigned char* __restrict__ mask, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = b[i] + y1[i] + y2[i];
+        if (Fsw) v += Fsw[i];
+        b[i] = (mask && mask[i]) ? 0.0 : v;
+    }
+}
+// wdot <- bb (w_new - w_old) - wdot     (plate_sim.py:243-244, 333)
+__global__ void k_newmark_wdot(double* __restrict__ wdot, const double* __restrict__ wn, const double* __restrict__ wo, double bb, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        wdot[i] = bb * (wn[i] - wo[i]) - wdot[i];
+}
+// adjoint step: mu_i = bb keep (M lam) - mu_next ; rhs = G_i + keep ((a M - K/2) lam) - bb mu_next ; b = rhs + bb mu_i (masked rows of b zero);
+// out_rhs (level 0 only) = rhs
+__global__ void k_newmark_adj(double* __restrict__ b, double* __restrict__ mu_i, double* __restrict__ rhs_out, const double* __restrict__ G,
+                              const double* __restrict__ Mlam, const double* __restrict__ AKlam, const double* __restrict__ mu_next,
+                              const unsigned char* __restrict__ mask, double bb, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool mk = mask && mask[i];
+        const double keep = mk ? 0.0 : 1.0;
+        const double mi = bb * Mlam[i] * keep - mu_next[i];
+        const double rhs = G[i] + AKlam[i] * keep - bb * mu_next[i];
+        mu_i[i] = mi;
+        if (rhs_out) rhs_out[i] = rhs;
+        b[i] = mk ? 0.0 : rhs + bb * mi;
+    }
+}
+// out = a x + c y + d z
+__global__ void k_lincomb3(double* __restrict__ out, double a, const double* __restrict__ x, double c, const double* __restrict__ y, double d,
+                           const double* __restrict__ z, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + c * y[i] + (z ? d * z[i] : 0.0);
+}
+
 // r = b - Ap (or r = b when Ap == null); masked rows zero; z = dinv r; p = z; Ap = 0; rz[0] += r.z; rr[0] += r.r
 __global__ void k_pcg_init(const double* __restrict__ b, double* __restrict__ Ap, const double* __restrict__ dinv,
                            const unsigned char* __restrict__ mask, double* __restrict__ r, double* __restrict__ z,

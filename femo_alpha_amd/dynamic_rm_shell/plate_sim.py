@@ -17,7 +17,9 @@ nearest text: elastic energy of linear_shell_model.py:275-306 at uhat = 0, inert
 The operator is linear and constant over the march, so it is factorised once per thickness (the reference
 re-assembles and re-factorises it every step, nonlinear_utils.py:210-233) and each step is one preconditioned
 solve; the adjoint is the O(T) two-vector recursion instead of the reference's O(T^2) history sums
-(state_operation_dynamic.py:606-702).  History layout at the boundary: (fe_dofs, time_levels), flattened
+(state_operation_dynamic.py:606-702).  The march, the backward sweep and the per-level gradient products run inside
+libfemo_hip (``femo_newmark_*``, include/femo_hip.h) with the histories resident in HBM: one call per march, the pressure
+history uploaded once.  History layout at the boundary: (fe_dofs, time_levels), flattened
 column-major by the operators (dynamic_rm_shell/utils.py:9-16).
 """
 from __future__ import annotations
@@ -71,26 +73,38 @@ class PlateSim:
 
     def update_nsteps(self, Nsteps):
         self.Nsteps, self.time_levels = Nsteps, Nsteps + 1
+        self._nm_ready = False
 
     def _gravity(self):
         return (-1.0 if self.g_factor is None else self.g_factor) * 9.81
 
-    def _force_at(self, i):
-        f = self.f_history[min(i, self.f_history.shape[0] - 1)].reshape(-1, 3).copy()
+    def _force_history(self):
+        """(time_levels, 3 nn) pressure history as the library marches it; self weight f_d = (0, 0, rho t g) rides on it when the
+        thickness is nodal (plate_sim.py:204-211)."""
+        k = np.minimum(np.arange(self.time_levels), self.f_history.shape[0] - 1)
+        F = self.f_history[k].reshape(self.time_levels, -1, 3).copy()
         if self.add_self_weight and self._sw_weights is None:
-            f[:, 2] += self.rho * self.t * self._gravity()               # f_d = (0, 0, rho t g), plate_sim.py:204-211
-        return f
+            F[:, :, 2] += (self.rho * self.t * self._gravity())[None, :]
+        return F.reshape(self.time_levels, -1)
+
+    def _force_at(self, i):
+        return self._force_history()[i].reshape(-1, 3)
 
     def _self_weight_load(self):
-        """Device vector of the self-weight load for element-wise thickness: F[3 p + 2] += rho t_e g int N2_a dS."""
+        """Self-weight load vector for element-wise thickness: F[3 p + 2] += rho t_e g int N2_a dS."""
         F = np.zeros(self.fe_dofs)
         np.add.at(F, 3 * self.mesh.cell_p2.ravel() + 2, (self._sw_weights * (self.rho * self._gravity() * self.t)[:, None]).ravel())
         F[self.bc_dofs] = 0.0
-        return self.torch.as_tensor(F, device=self._v["state"].device)
+        return F
 
     # ------------------------------------------------------------------ forward march
     def _sync(self):
         self.torch.cuda.synchronize()
+
+    def _newmark(self):
+        if not getattr(self, "_nm_ready", False):
+            self.ctx.newmark_setup(self.time_levels, self.dt)
+            self._nm_ready = True
 
     def solve_dynamic_problem(self, residual=None, saving_outputs=False, PATH=None, timing=False, reassemble_every_step=False):
         """March from zero initial conditions; returns the (fe_dofs, time_levels) history.
@@ -99,32 +113,13 @@ class PlateSim:
         (``solveNonlinear_mod`` assembles the Jacobian and runs a fresh LU per step, nonlinear_utils.py:210-233 from
         plate_sim.py:319).  The operator does not change along the march, so the default factorises once per thickness;
         the flag exists so that BASELINE config 5 can be timed as written ("re-assembly per step")."""
-        ctx, v, torch = self.ctx, self._v, self.torch
-        W = self.W = torch.zeros((self.time_levels, self.fe_dofs), dtype=torch.float64, device=v["state"].device)
-        wdot = torch.zeros_like(v["state"])
-        self.solve_info = []
-        F_sw = self._self_weight_load() if self._sw_weights is not None else None
-        for i in range(1, self.time_levels):
-            w_old = W[i - 1]
-            ctx.set_field("F_solid", self._force_at(i))
-            ctx.load_vec("b")                                            # F_i with BC rows zeroed
-            if F_sw is not None:
-                v["b"].add_(F_sw)
-            v["p"].copy_(w_old).mul_(self.a).add_(wdot, alpha=self.b)    # 2/dt^2 w_old + 2/dt wdot_old
-            v["adjoint"].copy_(w_old)
-            self._sync()
-            ctx.op_apply_vec2("p", "Ap", 0.0, 1.0, False)               # M (...)
-            ctx.op_apply_vec2("adjoint", "z", 1.0, 0.0, False)          # K w_old
-            v["b"].add_(v["Ap"]).add_(v["z"], alpha=-0.5)
-            self._sync()
-            ctx.vec_mask_zero("b")
-            if reassemble_every_step:
-                ctx.set_field("thickness", self.t)                       # marks the factorisation stale: next solve re-assembles
-            self.solve_info.append(ctx.solve_vec("b", "state", zero_guess=True))
-            W[i].copy_(v["state"])
-            wdot = self.b * (W[i] - w_old) - wdot                        # plate_sim.py:243-244, 333
-        self._sync()
-        return W.T.cpu().numpy().copy(order="F")
+        ctx = self.ctx
+        self._newmark()
+        ctx.newmark_set_forces(self._force_history())
+        ctx.newmark_set_constant_load(self._self_weight_load() if self._sw_weights is not None else None)
+        self.solve_info = ctx.newmark_march(self.Nsteps, reassemble_every_step)
+        self.W = ctx.newmark_tensor(0)                 # device history, (time_levels, fe_dofs), zero-copy
+        return ctx.newmark_history(0).T.copy(order="F")
 
     def energy_audit(self):
         """Discrete energy balance of the last march.  The midpoint rule with the force at the new level satisfies
@@ -136,13 +131,14 @@ class PlateSim:
         W = self.W
         U, T, work = np.zeros(self.time_levels), np.zeros(self.time_levels), np.zeros(self.time_levels)
         wdot = torch.zeros_like(v["state"])
+        FH = self._force_history()
         for i in range(1, self.time_levels):
             wdot = self.b * (W[i] - W[i - 1]) - wdot
             v["p"].copy_(W[i]); v["adjoint"].copy_(wdot)
             self._sync()
             ctx.op_apply_vec2("p", "z", 1.0, 0.0, False)                # K w_i
             ctx.op_apply_vec2("adjoint", "Ap", 0.0, 1.0, False)         # M wdot_i
-            ctx.set_field("F_solid", self._force_at(i))
+            ctx.set_field("F_solid", FH[i])
             ctx.load_vec("b")
             U[i] = 0.5 * float(torch.dot(W[i], v["z"]))
             T[i] = 0.5 * float(torch.dot(wdot, v["Ap"]))
@@ -199,59 +195,25 @@ class PlateSim:
         """Lambda solving (dR/dy)^T Lambda = G for the whole-history residual R(y) (y = all levels), by the
         backward two-vector recursion
             mu_i = b M lam_{i+1} - mu_{i+1},   A lam_i = G_i + b mu_i + (a M - K/2) lam_{i+1} - b mu_{i+1},
-        lam_0 = G_0 + (a M - K/2) lam_1 - b mu_1.  G, Lambda: (fe_dofs, time_levels)."""
-        ctx, v, torch = self.ctx, self._v, self.torch
-        dev = v["state"].device
-        Gd = torch.as_tensor(np.ascontiguousarray(np.asarray(G, dtype=np.float64).T), device=dev)
-        Lam = torch.zeros_like(Gd)
-        lam_next = torch.zeros_like(v["state"])
-        mu_next = torch.zeros_like(v["state"])
-        keep = torch.ones_like(v["state"]); keep[torch.as_tensor(self.bc_dofs.astype(np.int64), device=dev)] = 0.0
-        for i in range(self.time_levels - 1, -1, -1):
-            v["p"].copy_(lam_next)
-            self._sync()
-            ctx.op_apply_vec2("p", "Ap", 0.0, 1.0, False)               # M lam_{i+1}
-            ctx.op_apply_vec2("p", "z", 1.0, 0.0, False)                # K lam_{i+1}
-            mu_i = self.b * v["Ap"] * keep - mu_next
-            rhs = Gd[i] + (self.a * v["Ap"] - 0.5 * v["z"]) * keep - self.b * mu_next
-            if i == 0:
-                Lam[0] = rhs
-                break
-            v["b"].copy_(rhs + self.b * mu_i)
-            self._sync()
-            ctx.vec_mask_zero("b")
-            ctx.solve_vec("b", "adjoint", zero_guess=True)
-            Lam[i].copy_(v["adjoint"])
-            lam_next, mu_next = Lam[i].clone(), mu_i
-        self._sync()
-        self.Lam = Lam
-        return Lam.T.cpu().numpy().copy(order="F")
+        lam_0 = G_0 + (a M - K/2) lam_1 - b mu_1 (femo_newmark_adjoint).  G, Lambda: (fe_dofs, time_levels)."""
+        self._newmark()
+        self.ctx.newmark_adjoint(np.ascontiguousarray(np.asarray(G, dtype=np.float64).T))
+        self.Lam = self.ctx.newmark_tensor(2)
+        return self.ctx.newmark_history(2).T.copy(order="F")
 
-    def residual_T_products(self, Lam_host):
-        """(sum_i (dR_i/dt)^T lam_i,  [(dR_i/df)^T lam_i]_i) for the history self.W of the last march."""
-        ctx, v, torch = self.ctx, self._v, self.torch
-        dev = v["state"].device
-        Lam = torch.as_tensor(np.ascontiguousarray(np.asarray(Lam_host, dtype=np.float64).T), device=dev)
-        W = self.W
-        wdot = torch.zeros_like(v["state"])
-        ctx.grad_reset()
-        dF = np.zeros((self.time_levels, 3 * self.nn))
+    def residual_T_products(self, Lam_host=None):
+        """(sum_i (dR_i/dt)^T lam_i,  [(dR_i/df)^T lam_i]_i) for the displacement history of the last march and the adjoint
+        history ``Lam_host`` ((fe_dofs, time_levels); None: the one the last ``adjoint_history`` left on the device)."""
+        if Lam_host is not None:
+            self.ctx.newmark_set_history(np.ascontiguousarray(np.asarray(Lam_host, dtype=np.float64).T), which=2)
+        g, dF = self.ctx.newmark_residual_T(self.time_levels)
         g_sw = np.zeros(self.num_var)
-        for i in range(1, self.time_levels):
-            v["adjoint"].copy_(Lam[i])
-            v["p"].copy_(W[i] + W[i - 1])
-            v["z"].copy_(W[i] - W[i - 1]).mul_(self.a).add_(wdot, alpha=-self.b)
-            self._sync()
-            ctx.grad_add("K", "p", "adjoint", 0.5)                       # 1/2 lam^T K' (w_i + w_{i-1})
-            ctx.grad_add("M", "z", "adjoint", 1.0)                       # lam^T M' (a (w_i - w_{i-1}) - b wdot_{i-1})
-            lam_i = Lam[i].cpu().numpy()
-            dfi = ctx.dRdarg_T("F_solid", lam_i)
-            dF[i] = dfi
-            if self.add_self_weight and self._sw_weights is None:
-                g_sw += dfi.reshape(-1, 3)[:, 2] * self.rho * self._gravity()
-            elif self.add_self_weight:
-                # R_i = ... - F_sw(t):  (dR_i/dt_e)^T lam = -rho g sum_a lam_z(p_a) int N2_a dS   (BC rows carry no load)
-                lz = lam_i.copy(); lz[self.bc_dofs] = 0.0
-                g_sw -= self.rho * self._gravity() * (self._sw_weights * lz[3 * self.mesh.cell_p2 + 2]).sum(axis=1)
-            wdot = self.b * (W[i] - W[i - 1]) - wdot
-        return ctx.grad_get() + g_sw, dF
+        if self.add_self_weight and self._sw_weights is None:
+            g_sw = dF.reshape(self.time_levels, -1, 3)[:, :, 2].sum(axis=0) * self.rho * self._gravity()
+        elif self.add_self_weight:
+            # R_i = ... - F_sw(t):  (dR_i/dt_e)^T lam = -rho g sum_a lam_z(p_a) int N2_a dS   (BC rows carry no load)
+            Lam = self.ctx.newmark_history(2)
+            Lam[:, self.bc_dofs] = 0.0
+            lz = Lam[1:, :][:, 3 * self.mesh.cell_p2 + 2].sum(axis=0)                 # (nel, npc), summed over the levels 1..
+            g_sw = -self.rho * self._gravity() * (self._sw_weights * lz).sum(axis=1)
+        return g + g_sw, dF

@@ -64,7 +64,7 @@ def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: 
 class RMShellModel:
     def __init__(self, mesh: ShellMesh, shell_bc_func: callable = None, element_wise_material=False, rho=100,
                  PENALTY_BC=True, additional_outputs=None, mesh_tags=None, record=True, elementwise_pressure=False,
-                 device=0, renumber=False):
+                 device=0, renumber=False, nquad=4):
         # caller order <-> solver order.  dolfinx reorders every mesh it is given and the reference carries the maps
         # (rm_shell_model.py:116, 396-438, 505-527); with renumber=True this build does the same with a Morton order of
         # the cells (ShellMesh.renumbered): inputs are gathered into solver order, nodal displacements come back in
@@ -95,6 +95,10 @@ class RMShellModel:
         self.nel, self.nn = mesh.nel, mesh.nn
         self.elementwise_pressure = elementwise_pressure
         self.device = device
+        # n x n Gauss points per quadrilateral for the static forms (2..5).  The reference leaves the degree to UFL's
+        # estimate, which on quadrilaterals comes out near 47 (scripts/ufl_degree_estimate.py): exact integration.  n = 4 is
+        # exact on flat cells with uniform E, nu; on warped cells the answer converges in n.
+        self.nquad = int(nquad)
         self.association_table = None
         if shell_bc_func is None:
             raise ValueError("Please provide the shell bc location function.\n"
@@ -126,7 +130,8 @@ class RMShellModel:
     def set_up_fea(self):
         mesh = self.mesh
         shell_pde = self.shell_pde = RMShellPDE(mesh, element_wise_material=self.element_wise_material,
-                                                elementwise_pressure=self.elementwise_pressure, device=self.device)
+                                                elementwise_pressure=self.elementwise_pressure, device=self.device,
+                                                nquad=self.nquad)
         fea = FEA(mesh)
         fea.PDE_SOLVER = "Newton"
         fea.REPORT = False

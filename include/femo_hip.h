@@ -276,6 +276,22 @@ int femo_front_block_unpack(femo_ctx* ctx, int32_t front, const void* src_dev);
  * "profile" is on (same layout as femo_factorize_profile): the partitioned driver factorises in two ranges */
 int femo_factorize_profile_get(femo_ctx* ctx, double* out32);
 
+/* ---- Transient march (BASELINE config 5) -- replaces PlateSim.solve_dynamic_problem (dynamic_rm_shell/plate_sim.py:281-361:
+ * per step update_f + solveNonlinear_mod + the velocity update of :243-244,333) and the backward sweep of the dynamic
+ * StateOperation (state_operation_dynamic.py:406-427, 619-691).  Displacement history, pressure history, velocity and the
+ * adjoint history stay resident in HBM; one call marches all steps.  Time discretisation of plate_sim.py:131-140:
+ *   (a M + K/2) w_i = F_i + M (a w_{i-1} + b wdot_{i-1}) - K/2 w_{i-1},   a = 2/dt^2, b = 2/dt,   force at the new level.
+ * Histories cross the boundary level-major: (time_levels x femo_ndof) row-major. */
+int femo_newmark_setup(femo_ctx* ctx, int32_t time_levels, double dt);          /* allocates; selects the operator K/2 + a M */
+int femo_newmark_set_forces(femo_ctx* ctx, const double* f_history, int32_t levels_given);   /* (levels x F_solid length) */
+int femo_newmark_set_constant_load(femo_ctx* ctx, const double* F);             /* ndof load vector added to every step, or NULL */
+int femo_newmark_march(femo_ctx* ctx, int32_t nsteps, int reassemble_every_step, int32_t* iters, double* relres);
+int femo_newmark_get_history(femo_ctx* ctx, int32_t which, double* out);        /* which: 0 displacements, 2 adjoint */
+int femo_newmark_set_history(femo_ctx* ctx, int32_t which, const double* H);   /* which: 0 displacements, 2 adjoint */
+int femo_newmark_adjoint(femo_ctx* ctx, const double* G, int32_t levels);       /* (dR/dy)^T Lambda = G, O(T) recursion */
+int femo_newmark_residual_T(femo_ctx* ctx, int32_t levels, double* g_thickness, double* dF);
+void* femo_newmark_ptr(femo_ctx* ctx, int32_t which);                           /* device: 0 history, 1 velocity, 2 adjoint history */
+
 /* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")
  * for zero-copy wrapping by the caller (e.g. torch.from_dlpack-free ctypes views). */
 void* femo_device_ptr(femo_ctx* ctx, const char* name);

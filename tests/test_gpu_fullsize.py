@@ -168,3 +168,36 @@ def test_config5_full_size_properties():
     eps = 1e-4 * 0.1
     fd = (total_strain_energy(t0 + eps * d) - total_strain_energy(t0 - eps * d)) / (2 * eps)
     assert abs(g @ d - fd) < 2e-6 * abs(fd), (g @ d, fd)
+
+
+def test_quadrature_rule_sensitivity_at_config3():
+    """What the quadrature rule is worth on the warped cells of BASELINE config 3.  The reference lets UFL estimate the degree
+    of its static forms; on quadrilaterals the published rules give ~47 (scripts/ufl_degree_estimate.py), i.e. exact
+    integration, while this repository integrates with n x n Gauss, n = 4 by default (exact on flat cells).  The wing skin's
+    cells are warped and its integrand rational: the solution converges in n, and the step 4 -> 5 bounds what parity with
+    FEniCSx on this mesh can be claimed at n = 4.  Measured numbers are printed and quoted in DESIGN.md section 2."""
+    from bench import make_workload
+    from femo_alpha_amd.backend import ShellContext
+    m, fields, marker, _ = make_workload("wing1m")
+    res = {}
+    for n in (3, 4, 5):
+        c = ShellContext(m, nquad=n)
+        for k, v in fields.items():
+            c.set_field(k, v)
+        c.set_penalty_facets(m.penalty_facets(marker))
+        c.use_direct_solver()
+        it, rr = c.solve_state(zero_guess=True)
+        assert it <= 4
+        g, _, _ = c.total_gradient("compliance", "thickness")
+        res[n] = (c.get_state(), c.functional("compliance"), g)
+        c.close()
+    d = {}
+    for a, b in ((3, 4), (4, 5)):
+        wa, Ja, ga = res[a]; wb, Jb, gb = res[b]
+        d[(a, b)] = (np.abs(wa - wb).max() / np.abs(wb).max(), abs(Ja - Jb) / abs(Jb), np.abs(ga - gb).max() / np.abs(gb).max())
+        print(f"n = {a} -> {b}: displacement {d[(a, b)][0]:.3e}, compliance {d[(a, b)][1]:.3e}, d compliance / d thickness {d[(a, b)][2]:.3e}")
+    # convergence in n: every step smaller than the one before
+    assert all(d[(4, 5)][k] < d[(3, 4)][k] for k in range(3))
+    # n = 4 against n = 5 stays below the level at which the two rules would be different discretisations (1e-3); whether
+    # it reaches the 1e-8 of the north star is what the printed numbers say -- it does not, see DESIGN.md
+    assert all(d[(4, 5)][k] < 1e-3 for k in range(3))
