@@ -42,13 +42,13 @@ def apply_flops(nel, nq=16):
     return nel * (nq * APPLY_FLOPS_PER_QP + APPLY_FLOPS_PER_CELL_EXTRA)
 
 
-def spmv_roofline(apply_ms, ndof, nel, traffic, where=""):
+def spmv_roofline(apply_ms, ndof, nel, traffic, where="", nq=16):
     """The north star's SpMV (k_apply4 + k_gather_sum) against BOTH roofs: HBM on the algorithmic bytes of SURVEY.md section 8d
     (B_spmv,ebe = 16 B/DOF + 340 B/cell) and the fp64 vector ALU on the counted flops.  Counter traffic equals the algorithmic
     bytes, so the HBM fraction is not what binds; the VALU fraction is the achieved share of the binding roof."""
     alg_bytes = 16.0 * ndof + 340.0 * nel
     gbs = alg_bytes / (apply_ms * 1e-3) / 1e9
-    fl = apply_flops(nel)
+    fl = apply_flops(nel, nq)
     tf = fl / (apply_ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": "k_apply4 (matrix-free CG2xCG1 shell operator)" + where,
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
     ap.add_argument("--leaf", type=int, default=12)
+    ap.add_argument("--nquad", type=int, default=4, help="n x n Gauss points per quadrilateral (2..5): the reference integrates (nearly) exactly, "
+                    "scripts/ufl_degree_estimate.py; n = 4 is exact on flat cells, on the warped wing skin n = 5 is within 1e-9 of the limit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-numbering", action="store_true", help="run on the generator's (shuffled) numbering")
     ap.add_argument("--no-keep-numbering-leg", action="store_true", help="skip the extra forward solve on the shuffled numbering")
@@ -353,7 +355,7 @@ def main():
     setup = {}
     m, fields, marker, desc = make_workload(args.workload, renumber=not args.keep_numbering, timings=setup)
     t0 = time.perf_counter()
-    ctx = ShellContext(m, device=local_rank)
+    ctx = ShellContext(m, device=local_rank, nquad=args.nquad)
     for k, v in fields.items():
         ctx.set_field(k, v)
     ctx.set_penalty_facets(m.penalty_facets(marker))
@@ -407,7 +409,7 @@ def main():
     # the matrix-free element operator (the SpMV of the north star), HIP events around back-to-back launches
     apply_ms = ctx.bench_kernel("apply", 100)
     traffic, traffic_trailing = pmc_traffic(args.workload)
-    roof_spmv = spmv_roofline(apply_ms, m.ndof, m.nel, traffic)
+    roof_spmv = spmv_roofline(apply_ms, m.ndof, m.nel, traffic, nq=args.nquad ** 2)
     roof = roof_spmv
     prof = None
     if args.solver == "frontal":
@@ -467,7 +469,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
+            "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel, "gauss_points_per_direction": args.nquad,
                        "true_relres_forward": true_relres,
                        "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
                                   f"(nested dissection, leaves of <= {args.leaf} cells)" if args.solver == "frontal"

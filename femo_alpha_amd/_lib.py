@@ -55,6 +55,8 @@ SIGNATURES = {
     "femo_grad_reset": (C.c_int, [C.c_void_p]),
     "femo_grad_add": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_double]),
     "femo_grad_get": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
+    "femo_build_csr_map": (C.c_int, [C.c_void_p, _c_int32_p]),
+    "femo_get_csr_pattern": (C.c_int, [C.c_void_p, _c_int32_p, _c_int32_p]),
     "femo_set_csr_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, _c_int32_p, _c_int32_p]),
     "femo_assemble_csr": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     "femo_set_stress_params": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
@@ -102,6 +104,8 @@ SIGNATURES = {
     "femo_newmark_set_history": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
     "femo_newmark_adjoint": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
     "femo_newmark_residual_T": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
+    "femo_newmark_jvp": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p, _c_double_p]),
+    "femo_newmark_tangent": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32]),
     "femo_newmark_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "femo_device_ptr": (C.c_void_p, [C.c_void_p, C.c_char_p]),
 }

@@ -297,6 +297,21 @@ class ShellContext:
         self._chk(self.lib.femo_newmark_residual_T(self._h, int(levels), dptr(g), dptr(dF.ravel())))
         return g, dF
 
+    def newmark_jvp(self, levels, dY=None, dthickness=None, dF=None):
+        """[J dY + (dR/dt) dthickness + (dR/df) dF] as a (levels, ndof) array (forward mode of the whole-history residual)."""
+        a = None if dY is None else np.ascontiguousarray(np.asarray(dY, dtype=np.float64).reshape(levels, self.ndof))
+        b = None if dthickness is None else self._vec(dthickness)
+        cf = None if dF is None else np.ascontiguousarray(np.asarray(dF, dtype=np.float64).reshape(levels, self.field_size("F_solid")))
+        self._chk(self.lib.femo_newmark_jvp(self._h, int(levels), None if a is None else dptr(a.ravel()), None if b is None else dptr(b),
+                                            None if cf is None else dptr(cf.ravel())))
+        return self.newmark_history(2)[:levels]
+
+    def newmark_tangent(self, dR):
+        """dY = J^-1 dR (the tangent linear march), (levels, ndof)."""
+        dR = np.ascontiguousarray(np.asarray(dR, dtype=np.float64).reshape(-1, self.ndof))
+        self._chk(self.lib.femo_newmark_tangent(self._h, dptr(dR.ravel()), dR.shape[0]))
+        return self.newmark_history(2)[: dR.shape[0]]
+
     def newmark_tensor(self, which=0):
         """Zero-copy torch view of the resident displacement history (0: (levels, ndof)), velocity (1: (ndof,)) or adjoint history (2)."""
         ptr = self.lib.femo_newmark_ptr(self._h, int(which))
@@ -305,12 +320,20 @@ class ShellContext:
         return t if which == 1 else t.view(self._nm_levels, self.ndof)
 
     # ------------------------------------------------------------------ CSR export
-    def enable_csr(self):
-        """Pattern + destination-sorted contribution map (host, mesh only), uploaded once."""
-        from .csr import build_csr_map
-        self.csr = build_csr_map(self.mesh)
-        self._chk(self.lib.femo_set_csr_map(self._h, self.csr["nnz"], self.csr["perm"].size, iptr(self.csr["perm"]),
-                                            iptr(self.csr["dest"])))
+    def enable_csr(self, host_map=False):
+        """Pattern + destination-sorted contribution map, once per mesh: built on the device (radix sort of the nel * ld^2
+        (row, column) keys); ``host_map=True`` builds it with numpy instead (femo_alpha_amd/csr.py, the cross-check)."""
+        if host_map:
+            from .csr import build_csr_map
+            self.csr = build_csr_map(self.mesh)
+            self._chk(self.lib.femo_set_csr_map(self._h, self.csr["nnz"], self.csr["perm"].size, iptr(self.csr["perm"]),
+                                                iptr(self.csr["dest"])))
+            return self.csr
+        nnz = C.c_int32()
+        self._chk(self.lib.femo_build_csr_map(self._h, C.byref(nnz)))
+        rowptr, colidx = np.empty(self.mesh.ndof + 1, dtype=np.int32), np.empty(nnz.value, dtype=np.int32)
+        self._chk(self.lib.femo_get_csr_pattern(self._h, iptr(rowptr), iptr(colidx)))
+        self.csr = dict(nnz=int(nnz.value), rowptr=rowptr, colidx=colidx)
         return self.csr
 
     def assemble_csr(self):

@@ -5,6 +5,7 @@
 #include "frontal.h"
 #include "shape_sens.h"
 #include "stress.h"
+#include "csr_map.h"
 
 #include <hip/hip_runtime.h>
 
@@ -75,7 +76,7 @@ struct femo_ctx {
     } nm;
     // CSR assembly
     long long csr_ncontrib = 0; int csr_nnz = 0;
-    int *csr_perm = nullptr, *csr_dest = nullptr;
+    int *csr_perm = nullptr, *csr_dest = nullptr, *csr_rowptr = nullptr, *csr_colidx = nullptr;
     double *csr_vals = nullptr, *csr_ke = nullptr;
     double op_aK = 1.0, op_aM = 0.0;      // the operator every solve / factorisation uses: aK * K + aM * M
     int nquad = 4, nred = 0;
@@ -1285,7 +1286,7 @@ void femo_destroy(femo_ctx* c) {
     void* dptrs[] = {c->di.top_idx, c->di.sel, c->di.wdot, c->di.topbuf, c->di.topsave, c->di.gloc};
     for (void* p : dptrs)
         if (p) hipFree(p);
-    void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -2626,6 +2627,123 @@ int femo_newmark_residual_T(femo_ctx* c, int32_t levels, double* g_t, double* dF
     return 0;
 }
 
+// ---- forward mode of the transient operator (the "tangent linear model", state_operation_dynamic.py:228-329, 534-605).
+// The whole-history Jacobian J = dR/dy couples a level to ALL earlier ones through the velocity recursion (the reference
+// carries alternating-sign history sums with factors 2/dt, 4/dt); here the perturbed velocity is marched beside the perturbed
+// displacement, O(T).  Dirichlet rows follow the reference's zeroRows: identity in dR/dw_i, zero elsewhere.
+// out_i = [J dY]_i + (dR_i/dt) dthickness + (dR_i/df) dF_i.  Any of dY (levels x ndof), dthickness, dF (levels x F length) may be
+// null.  The result lands in the adjoint-history buffer (femo_newmark_get_history(ctx, 2, ..)).
+int femo_newmark_jvp(femo_ctx* c, int32_t levels, const double* dY, const double* dthickness, const double* dF) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    if (levels < 1 || levels > nm.levels) return fail(c, "bad number of levels");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    const size_t hb = (size_t)nm.levels * n * sizeof(double);
+    if (!nm.Lam) HIPCHK(c, hipMalloc((void**)&nm.Lam, hb));
+    if (!nm.Gh) HIPCHK(c, hipMalloc((void**)&nm.Gh, hb));
+    HIPCHK(c, hipMemsetAsync(nm.Lam, 0, hb, c->stream));
+    if (dY) HIPCHK(c, hipMemcpyAsync(nm.Gh, dY, (size_t)levels * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double *dh = nullptr, *dFd = nullptr;
+    const size_t fl = (size_t)3 * c->nF;
+    if (dthickness) {
+        HIPCHK(c, hipMalloc((void**)&dh, (size_t)std::max<int64_t>(c->nT, 1) * sizeof(double)));
+        HIPCHK(c, hipMemcpyAsync(dh, dthickness, (size_t)c->nT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (dF) {
+        HIPCHK(c, hipMalloc((void**)&dFd, (size_t)levels * fl * sizeof(double)));
+        HIPCHK(c, hipMemcpyAsync(dFd, dF, (size_t)levels * fl * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    const MeshDev m = mesh_dev(c);
+    const FieldsDev f = fields_dev(c);
+    const int g = nblk(c->nel, EB);
+    double* dwd = nm.mu0;                      // perturbed velocity
+    double* wd = nm.wdot;                      // velocity of the stored history, re-marched
+    HIPCHK(c, hipMemsetAsync(dwd, 0, (size_t)n * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(wd, 0, (size_t)n * sizeof(double), c->stream));
+    if (dY) HIPCHK(c, hipMemcpyAsync(nm.Lam, nm.Gh, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));     // level 0: identity
+    int rc = 0;
+    for (int i = 1; i < levels && !rc; ++i) {
+        double* out = nm.Lam + (size_t)i * n;
+        const double *wi = nm.W + (size_t)i * n, *wo = nm.W + (size_t)(i - 1) * n;
+        if (dY) {
+            const double *dwi = nm.Gh + (size_t)i * n, *dwo = nm.Gh + (size_t)(i - 1) * n;
+            rc = op_apply(c, dwi, c->r, nullptr, nullptr, nullptr, false, 0.5, nm.a);                    // (a M + K/2) dw_i
+            if (!rc) rc = op_apply(c, dwo, c->Ap, nullptr, nullptr, nullptr, false, -0.5, nm.a);         // (a M - K/2) dw_{i-1}
+            if (!rc) rc = op_apply(c, dwd, c->z, nullptr, nullptr, nullptr, false, 0.0, nm.b);           // b M dwdot_{i-1}
+            if (rc) break;
+            hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, out, 1.0, (const double*)c->r, -1.0, (const double*)c->Ap, -1.0, (const double*)c->z, n);
+            hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, dwd, dwi, dwo, nm.b, n);
+        }
+        if (dh) {
+            // (dR_i/dt) dh = M'[dh] (a (w_i - w_{i-1}) - b wdot_{i-1}) + K'[dh] (w_i + w_{i-1}) / 2
+            hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, wi, 1.0, wo, 0.0, (const double*)nullptr, n);
+            hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->z, nm.a, wi, -nm.a, wo, -nm.b, (const double*)wd, n);
+            ELEM_LAUNCH(c, k_apply_dh, NOEXTRA, g, EB, m, f, c->tab, (const double*)dh, 0.5, 0.0, (const double*)c->p, out);
+            ELEM_LAUNCH(c, k_apply_dh, NOEXTRA, g, EB, m, f, c->tab, (const double*)dh, 0.0, 1.0, (const double*)c->z, out);
+        }
+        if (dFd) {
+            FieldsDev fdv = f;
+            fdv.f = dFd + (size_t)i * fl;
+            ELEM_LAUNCH(c, k_load, NOEXTRA, g, EB, m, fdv, c->tab, out, -1.0);                               // (dR_i/df) df_i = - load(df_i)
+        }
+        if (mask) {
+            if (dY) hipLaunchKernelGGL(k_mask_identity, dim3(vg), dim3(256), 0, c->stream, out, (const double*)(nm.Gh + (size_t)i * n), mask, n);
+            else hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, out, mask, n);
+        }
+        hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, wd, wi, wo, nm.b, n);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dh) hipFree(dh);
+    if (dFd) hipFree(dFd);
+    if (rc) return rc;
+    HIPCHK(c, e);
+    return 0;
+}
+
+// dY = J^-1 dR, level by level (the direct method):  dw_0 = dr_0;  A dw_i = dr_i + (a M - K/2) dw_{i-1} + b M dwdot_{i-1} on the free
+// rows, dw_i = dr_i on the Dirichlet rows (their coupling into the free rows moved to the right-hand side).  The result lands in the
+// adjoint-history buffer.
+int femo_newmark_tangent(femo_ctx* c, const double* dR, int32_t levels) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& nm = c->nm;
+    if (!nm.ready) return fail(c, "call femo_newmark_setup first");
+    if (levels < 1 || levels > nm.levels || !dR) return fail(c, "bad arguments");
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    const size_t hb = (size_t)nm.levels * n * sizeof(double);
+    if (!nm.Lam) HIPCHK(c, hipMalloc((void**)&nm.Lam, hb));
+    if (!nm.Gh) HIPCHK(c, hipMalloc((void**)&nm.Gh, hb));
+    HIPCHK(c, hipMemsetAsync(nm.Lam, 0, hb, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nm.Gh, dR, (size_t)levels * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nm.Lam, nm.Gh, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    double* dwd = nm.mu0;
+    HIPCHK(c, hipMemsetAsync(dwd, 0, (size_t)n * sizeof(double), c->stream));
+    for (int i = 1; i < levels; ++i) {
+        const double *dri = nm.Gh + (size_t)i * n, *dwo = nm.Lam + (size_t)(i - 1) * n;
+        double* dwi = nm.Lam + (size_t)i * n;
+        if (op_apply(c, dwo, c->Ap, nullptr, nullptr, nullptr, false, -0.5, nm.a)) return 1;
+        if (op_apply(c, dwd, c->z, nullptr, nullptr, nullptr, false, 0.0, nm.b)) return 1;
+        hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->b, 1.0, dri, 1.0, (const double*)c->Ap, 1.0, (const double*)c->z, n);
+        if (mask) {
+            hipLaunchKernelGGL(k_mask_select, dim3(vg), dim3(256), 0, c->stream, c->p, dri, mask, n);
+            if (op_apply(c, c->p, c->r, nullptr, nullptr, nullptr, false, 0.5, nm.a)) return 1;          // coupling of the Dirichlet values
+            hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->b, -1.0, (const double*)c->r, 1.0, n);
+            hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->b, mask, n);
+        }
+        if (int rc = solve_dispatch(c, c->b, dwi, true, nullptr, nullptr)) return rc;
+        if (mask) hipLaunchKernelGGL(k_mask_identity, dim3(vg), dim3(256), 0, c->stream, dwi, dri, mask, n);
+        hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, dwd, (const double*)dwi, dwo, nm.b, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // ---- CSR assembly of the elastic stiffness (what assembleMatrix(dR_du) returns in the reference,
 // csdl_alpha_opt/state_operation.py:289; fea/utils_dolfinx.py:200-206) -----------------------------------------
 // perm[k]: index into the element-matrix buffer (element * ld*ld + i*ld + j) of the k-th contribution in
@@ -2647,6 +2765,64 @@ int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* 
     HIPCHK(c, hipMemcpy(c->csr_perm, perm, (size_t)ncontrib * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->csr_dest, dest, (size_t)ncontrib * sizeof(int), hipMemcpyHostToDevice));
     c->csr_ncontrib = ncontrib; c->csr_nnz = nnz;
+    return 0;
+}
+
+// pattern + destination-sorted contribution map on the device (csr_map.h); *nnz_out = number of stored entries
+int femo_build_csr_map(femo_ctx* c, int32_t* nnz_out) {
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long nc = (long long)c->nel * c->ld * c->ld;
+    if (nc >= (1ll << 31)) return fail(c, "CSR export: more than 2^31 element contributions (the matrix-free solvers have no such limit)");
+    void* old[] = {c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke};
+    for (void* p : old) if (p) hipFree(p);
+    c->csr_perm = c->csr_dest = c->csr_rowptr = c->csr_colidx = nullptr; c->csr_vals = c->csr_ke = nullptr;
+    long long *k0 = nullptr, *k1 = nullptr;
+    int *v0 = nullptr, *flags = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0, t2 = 0;
+    HIPCHK(c, hipMalloc((void**)&k0, nc * sizeof(long long)));
+    HIPCHK(c, hipMalloc((void**)&k1, nc * sizeof(long long)));
+    HIPCHK(c, hipMalloc((void**)&v0, nc * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_perm, nc * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_dest, nc * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&flags, nc * sizeof(int)));
+    const unsigned gb = (unsigned)((nc + 255) / 256);
+    hipLaunchKernelGGL(k_csr_keys, dim3(gb), dim3(256), 0, c->stream, nc, c->nel, c->ld, c->npc, c->ndof_u, (long long)c->ndof, (const int*)c->cellp2,
+                       (const int*)c->cells, k0, v0);
+    int bits = 1;
+    while (bits < 63 && (1ull << bits) <= (unsigned long long)c->ndof * (unsigned long long)c->ndof) ++bits;
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, c->csr_perm, (int)nc, 0, bits, c->stream));
+    HIPCHK(c, hipcub::DeviceScan::InclusiveSum(nullptr, t2, flags, c->csr_dest, (int)nc, c->stream));
+    tmp_bytes = std::max(tmp_bytes, t2);
+    HIPCHK(c, hipMalloc(&tmp, tmp_bytes));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, c->csr_perm, (int)nc, 0, bits, c->stream));
+    hipLaunchKernelGGL(k_csr_heads, dim3(gb), dim3(256), 0, c->stream, nc, (const long long*)k1, flags);
+    HIPCHK(c, hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, flags, c->csr_dest, (int)nc, c->stream));
+    int nnz = 0;
+    HIPCHK(c, hipMemcpyAsync(&nnz, c->csr_dest + (nc - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMalloc((void**)&c->csr_colidx, (size_t)nnz * sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_rowptr, ((size_t)c->ndof + 1) * sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->csr_rowptr, 0, ((size_t)c->ndof + 1) * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_csr_pattern, dim3(gb), dim3(256), 0, c->stream, nc, (const long long*)k1, (const int*)flags, c->csr_dest, (long long)c->ndof,
+                       c->csr_colidx, c->csr_rowptr);
+    HIPCHK(c, hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, c->csr_rowptr, c->csr_rowptr, c->ndof + 1, c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(k0); hipFree(k1); hipFree(v0); hipFree(flags); hipFree(tmp);
+    HIPCHK(c, hipMalloc((void**)&c->csr_vals, (size_t)nnz * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->csr_ke, (size_t)nc * sizeof(double)));
+    c->csr_ncontrib = nc; c->csr_nnz = nnz;
+    if (nnz_out) *nnz_out = nnz;
+    return 0;
+}
+
+// the pattern to the host: rowptr (ndof + 1), colidx (nnz), int32 (sorted columns per row)
+int femo_get_csr_pattern(femo_ctx* c, int32_t* rowptr, int32_t* colidx) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->csr_rowptr) return fail(c, "call femo_build_csr_map first");
+    HIPCHK(c, hipMemcpy(rowptr, c->csr_rowptr, ((size_t)c->ndof + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(colidx, c->csr_colidx, (size_t)c->csr_nnz * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

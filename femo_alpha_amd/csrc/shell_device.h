@@ -1009,6 +1009,53 @@ k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doubl
     }
 }
 
+// y += (aK dK/dh[dh] + aM dM/dh[dh]) x : the directional derivative of the step operator along a thickness perturbation dh
+// (forward mode of the transient operator, state_operation_dynamic.py:295-316: dRdt assembled per level and multiplied by
+// d_inputs['thickness']) -- matrix-free, one thread per cell.  Not a hot kernel: T launches per forward-mode product.
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__global__ void __launch_bounds__(128)
+k_apply_dh(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* __restrict__ dh, double aK, double aM,
+           const double* __restrict__ x, double* __restrict__ y) {
+    constexpr int LD = 3 * NPC + 3 * NVC;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    Elem<NPC, NVC> el;
+    load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    double xe[LD], ye[LD], dhn[NVC];
+    for (int a = 0; a < NPC; ++a)
+        for (int c = 0; c < 3; ++c) xe[3 * a + c] = x[3 * el.pid[a] + c];
+    for (int b = 0; b < NVC; ++b) {
+        for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = x[m.ndof_u + 3 * el.vid[b] + c];
+        dhn[b] = dh[f.ewm ? e : el.vid[b]];
+    }
+    for (int i = 0; i < LD; ++i) ye[i] = 0.0;
+    const int nq = tab->nq;
+    for (int q = 0; q < nq; ++q) {
+        QPG g;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
+        const double hq = interp<NVC>(tab->N1[q], el.hn), dq = interp<NVC>(tab->N1[q], dhn);
+        if (aK != 0.0) {
+            Mat mat, ex;
+            material<DERIV_H>(hq, interp<NVC>(tab->N1[q], el.En), interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det,
+                              tab->w[q] * g.det, g.Ju, mat, ex);
+            const double sc = aK * dq;
+            mat.cm *= sc; mat.cb *= sc; mat.cs *= sc; mat.cd *= sc;
+            const Gen s = strains_q<NPC, NVC>(*tab, q, g, xe);
+            const Gen t = stress_of(s, mat);
+            strains_T_q<NPC, NVC>(*tab, q, g, t, ye);
+        }
+        if (aM != 0.0 && tab->w[q] != 0.0) {
+            double rq = 0.0;
+            for (int b = 0; b < NVC; ++b) rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
+            mass_qp<NPC, NVC>(*tab, q, aM * rq * dq * tab->w[q] * g.det * g.Ju, el.hK, xe, ye);
+        }
+    }
+    for (int a = 0; a < NPC; ++a)
+        for (int c = 0; c < 3; ++c) atomicAdd(&y[3 * el.pid[a] + c], ye[3 * a + c]);
+    for (int b = 0; b < NVC; ++b)
+        for (int c = 0; c < 3; ++c) atomicAdd(&y[m.ndof_u + 3 * el.vid[b] + c], ye[3 * NPC + 3 * b + c]);
+}
+
 // out += scale * y^T (dM/dh) x  per thickness DOF:  int rho M_b (x_u.y_u + h_K^2 x_theta.y_theta) J dx
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
@@ -1111,12 +1158,14 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
     if (j >= LD) return;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, UHAT>(m, f, e, el);
-    double xe[LD], ye[LD];
+    double ye[LD];
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
-        xe[i] = (i == j) ? 1.0 : 0.0;
-        ye[i] = 0.0;
-    }
+    for (int i = 0; i < LD; ++i) ye[i] = 0.0;
+    // the lane's unit vector e_j: displacement component cj of P2 node aj, or rotation component cj of vertex aj -- its strains
+    // without the 39-entry reduction (as k_front_assemble does: 2.03 -> see profiles/r3_csr_wing1m.txt)
+    const bool is_u = j < 3 * NPC;
+    const int aj = is_u ? j / 3 : (j - 3 * NPC) / 3;
+    const int cj = j - 3 * (is_u ? aj : NPC + aj);
     const int nq = tab->nq;
     for (int q = 0; q < nq; ++q) {
         QPG g;
@@ -1126,7 +1175,20 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
         Mat mat, ex;
         material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
                              interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
-        const Gen s = strains<NPC, NVC>(g, d, mm, tab->N1[q], xe);
+        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
+        const double dk0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], dk1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double Mj = is_u ? 0.0 : tab->N1[q][aj];
+        double G0[3], G1[3], th[3], T0[3], T1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double ec = (c == cj) ? 1.0 : 0.0;
+            G0[c] = is_u ? dk0 * ec : 0.0;
+            G1[c] = is_u ? dk1 * ec : 0.0;
+            th[c] = Mj * ec;
+            T0[c] = is_u ? 0.0 : dk0 * ec;
+            T1[c] = is_u ? 0.0 : dk1 * ec;
+        }
+        const Gen s = strains_reduced(g, G0, G1, th, T0, T1);
         const Gen t = stress_of(s, mat);
         strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
     }
@@ -1485,6 +1547,11 @@ __global__ void k_newmark_adj(double* __restrict__ b, double* __restrict__ mu_i,
         if (rhs_out) rhs_out[i] = rhs;
         b[i] = mk ? 0.0 : rhs + bb * mi;
     }
+}
+// out = mask ? src : 0   (the Dirichlet rows of a tangent right-hand side)
+__global__ void k_mask_select(double* __restrict__ out, const double* __restrict__ src, const unsigned char* __restrict__ mask, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (mask && mask[i]) ? src[i] : 0.0;
 }
 // out = a x + c y + d z
 __global__ void k_lincomb3(double* __restrict__ out, double a, const double* __restrict__ x, double c, const double* __restrict__ y, double d,

@@ -65,7 +65,9 @@ class StateOperation(csdl.experimental.CustomImplicitOperation):
             G = reshape_vector_into_array(np.asarray(d_outputs[self.state_name]), ps.time_levels)
             d_residuals[self.state_name] = stack_array_into_vector(ps.adjoint_history(G))
         elif mode == "fwd":
-            raise NotImplementedError("forward-mode linearised march is not provided; totals use mode='rev'")
+            # the direct method / tangent linear model (state_operation_dynamic.py:534-605)
+            dR = reshape_vector_into_array(np.asarray(d_residuals[self.state_name]), ps.time_levels)
+            d_outputs[self.state_name] = stack_array_into_vector(ps.tangent_history(dR))
         else:
             raise ValueError("mode must be either 'fwd' or 'rev'.")
 
@@ -80,7 +82,12 @@ class StateOperation(csdl.experimental.CustomImplicitOperation):
                 if "force_history" in d_inputs:
                     d_inputs["force_history"] += g_f.reshape(np.shape(d_inputs["force_history"]))
         elif mode == "fwd":
-            raise NotImplementedError("forward-mode products are not provided; totals use mode='rev'")
+            # d_inputs, d_outputs --> d_residuals (state_operation_dynamic.py:228-329)
+            if self.state_name in d_residuals:
+                dY = reshape_vector_into_array(np.asarray(d_outputs[self.state_name]), ps.time_levels) if self.state_name in d_outputs else None
+                dth = np.asarray(d_inputs["thickness"]) if "thickness" in d_inputs else None
+                dF = np.asarray(d_inputs["force_history"]).reshape(ps.time_levels, -1) if "force_history" in d_inputs else None
+                d_residuals[self.state_name] = d_residuals[self.state_name] + stack_array_into_vector(ps.jacobian_products_fwd(dY, dth, dF))
         else:
             raise ValueError("mode must be either 'fwd' or 'rev'.")
 

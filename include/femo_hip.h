@@ -173,8 +173,12 @@ int femo_grad_get(femo_ctx* ctx, double* out, int64_t n);
 
 /* ---- CSR assembly of the elastic stiffness matrix (what assembleMatrix(dR_du) hands back in the reference,
  * csdl_alpha_opt/state_operation.py:289, fea/utils_dolfinx.py:200-206).  The solver never needs it (the operator is
- * matrix-free); it exists for callers that want the matrix.  The map comes from femo_alpha_amd/csr.py: the
- * nel*ldof^2 element contributions sorted by CSR destination.  ms2 = { element matrices ms, scatter ms }. */
+ * matrix-free); it exists for callers that want the matrix.  The map -- the nel*ldof^2 element contributions sorted by CSR
+ * destination -- and the pattern are built on the device by femo_build_csr_map (once per mesh; what dolfinx create_matrix does
+ * per form); femo_set_csr_map accepts a map built elsewhere (femo_alpha_amd/csr.py, the host cross-check).
+ * ms2 = { element matrices ms, scatter ms }. */
+int femo_build_csr_map(femo_ctx* ctx, int32_t* nnz);
+int femo_get_csr_pattern(femo_ctx* ctx, int32_t* rowptr, int32_t* colidx);
 int femo_set_csr_map(femo_ctx* ctx, int32_t nnz, int64_t ncontrib, const int32_t* perm, const int32_t* dest);
 int femo_assemble_csr(femo_ctx* ctx, double* vals, double* ms2);
 
@@ -290,6 +294,10 @@ int femo_newmark_get_history(femo_ctx* ctx, int32_t which, double* out);        
 int femo_newmark_set_history(femo_ctx* ctx, int32_t which, const double* H);   /* which: 0 displacements, 2 adjoint */
 int femo_newmark_adjoint(femo_ctx* ctx, const double* G, int32_t levels);       /* (dR/dy)^T Lambda = G, O(T) recursion */
 int femo_newmark_residual_T(femo_ctx* ctx, int32_t levels, double* g_thickness, double* dF);
+/* Forward mode (state_operation_dynamic.py:228-329: compute_jacvec_product fwd; :534-605: apply_inverse_jacobian fwd, the
+ * "tangent linear model").  Results land in the adjoint-history buffer (femo_newmark_get_history(ctx, 2, ..)). */
+int femo_newmark_jvp(femo_ctx* ctx, int32_t levels, const double* dY, const double* dthickness, const double* dF);
+int femo_newmark_tangent(femo_ctx* ctx, const double* dR, int32_t levels);
 void* femo_newmark_ptr(femo_ctx* ctx, int32_t which);                           /* device: 0 history, 1 velocity, 2 adjoint history */
 
 /* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")

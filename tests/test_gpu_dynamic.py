@@ -132,3 +132,61 @@ def test_self_weight_with_elementwise_thickness_and_postprocessing():
     D = ps.construct_nodal_disp_map()
     w_last = ps.W[N].cpu().numpy()
     assert np.array_equal(D @ w_last, np.concatenate([w_last[c:3 * mesh.nn:3] for c in range(3)]))
+
+
+@pytest.mark.parametrize("ewt,self_weight", [(False, False), (True, True), (False, True)])
+def test_forward_mode_of_the_transient_operator(ewt, self_weight):
+    """Forward mode (state_operation_dynamic.py:228-329, 534-605): the Jacobian-vector product of the whole-history residual
+    against finite differences of the march's own residual identity, the tangent solve as its inverse, and forward against
+    reverse mode through the dot-product test  <Lambda, J dY> = <J^T Lambda, dY>,  <Lambda, (dR/dt) dt> = <(dR/dt)^T Lambda, dt>."""
+    from femo_alpha_amd.dynamic_rm_shell.operations import StateOperation
+    from femo_alpha_amd.dynamic_rm_shell.plate_sim import PlateSim
+    mesh = plate_mesh(2.0, 10.0, 4, 12)
+    E, nu, rho, dt, N = 1e8, 0.3, 10.0, 0.01, 8
+    ps = PlateSim(mesh, E, nu, rho, dt, N, element_wise_thickness=ewt, add_self_weight=self_weight, quad_deg=3, leaf_size=8, rtol=1e-12)
+    n_t = mesh.nel if ewt else mesh.nn
+    rng = np.random.default_rng(3)
+    t0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, n_t))
+    F = _gust(N + 1, mesh.nn, dt)
+    ps.update_f_history(F)
+
+    def march(t, Fh=F):
+        ps.update_f_history(Fh); ps.update_t(t)
+        return ps.solve_dynamic_problem()
+    # tangent of the march: dW/dt . d  =  - J^-1 (dR/dt) d   against central differences of the march itself
+    d = rng.uniform(-1, 1, n_t) * t0
+    eps = 1e-5
+    fd = (march(t0 + eps * d) - march(t0 - eps * d)) / (2 * eps)
+    W0 = march(t0)
+    dRdt_d = ps.jacobian_products_fwd(dthickness=d)
+    assert np.abs(dRdt_d[ps.bc_dofs]).max() == 0.0 and np.abs(dRdt_d[:, 0]).max() == 0.0
+    dW = -ps.tangent_history(dRdt_d)
+    assert np.abs(dW - fd).max() < 2e-6 * np.abs(fd).max()
+    # the same for a perturbation of the load history
+    dFh = rng.uniform(-1, 1, F.shape)
+    fdF = (march(t0, F + 1e-3 * dFh) - march(t0, F - 1e-3 * dFh)) / 2e-3
+    march(t0)
+    dWF = -ps.tangent_history(ps.jacobian_products_fwd(dF=dFh))
+    assert np.abs(dWF - fdF).max() < 1e-7 * np.abs(fdF).max()
+    # J J^-1 = identity
+    R = rng.uniform(-1, 1, W0.shape)
+    back = ps.jacobian_products_fwd(dY=ps.tangent_history(R))
+    assert np.abs(back - R).max() < 1e-6 * np.abs(R).max()          # J scales like 2/dt^2 M: the solve tolerance, amplified
+    # forward against reverse mode
+    # (on the free rows: the adjoint keeps the Dirichlet entries of Lambda at zero -- they multiply rows of dR/dt and dR/df that are
+    #  zero -- so the transpose relation is the one of the free-free blocks)
+    Y, L = rng.uniform(-1, 1, W0.shape), rng.uniform(-1, 1, W0.shape)
+    Y[ps.bc_dofs] = 0.0; L[ps.bc_dofs] = 0.0
+    JY = ps.jacobian_products_fwd(dY=Y)
+    Lam = ps.adjoint_history(L)                       # (J^T)^-1 L
+    lhs = np.sum(Lam * JY)                            # <J^-T L, J Y> = <L, Y>
+    assert abs(lhs - np.sum(L * Y)) < 1e-8 * abs(np.sum(L * Y)) + 1e-10 * np.abs(L).sum()
+    g_t, g_f = ps.residual_T_products(Lam)
+    assert abs(np.sum(Lam * dRdt_d) - g_t @ d) < 1e-8 * abs(g_t @ d)
+    assert abs(np.sum(Lam * ps.jacobian_products_fwd(dF=dFh)) - np.sum(g_f * dFh)) < 1e-8 * abs(np.sum(g_f * dFh))
+    # operator surface: mode='fwd' no longer raises
+    op = StateOperation(ps)
+    out = {op.state_name: None}
+    op.apply_inverse_jacobian({}, {}, out, {op.state_name: R.ravel(order="F")}, "fwd")
+    ref = ps.tangent_history(R)          # (the sweeps of the factor add with atomics: repeatable to rounding, not bit for bit)
+    assert np.abs(out[op.state_name].reshape(W0.shape, order="F") - ref).max() < 1e-9 * np.abs(ref).max()

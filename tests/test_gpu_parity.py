@@ -486,6 +486,11 @@ def test_csr_assembly(kind):
     assert abs(K - Kref).max() < 1e-11 * abs(Kref).max()
     K2 = c.assemble_csr()                                    # repeatable
     assert abs(K2 - K).max() <= 1e-13 * abs(Kref).max()
+    # the device-built map against the numpy one: same pattern, same values
+    rowptr, colidx = info["rowptr"].copy(), info["colidx"].copy()
+    host = c.enable_csr(host_map=True)
+    assert np.array_equal(rowptr, host["rowptr"]) and np.array_equal(colidx, host["colidx"])
+    assert abs(c.assemble_csr() - K).max() <= 1e-13 * abs(Kref).max()
 
 
 def test_non_convergence_and_indefinite_operators_raise():
@@ -576,3 +581,26 @@ def test_stress_on_the_mid_and_bottom_surfaces_and_global_component_sums(kind, e
     c.select_subdomain(-1)
     with pytest.raises(Exception, match="unknown field output"):
         c.field_output("stress_side")
+
+
+def test_csr_assembly_at_config2():
+    """The CSR export at BASELINE config 2 (58 x 290 plate, 255 438 DOF, 18 685 548 stored entries) against the oracle's scipy
+    assembly of the same matrix -- the matrix the full-size goldens were solved with."""
+    from femo_alpha_amd.backend import ShellContext
+    from femo_alpha_amd.mesh import plate_mesh
+    from oracle.rm_shell_oracle import ShellOracle
+    m = plate_mesh(2.0, 10.0, 58, 290)
+    rng = np.random.default_rng(0)
+    h = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn))
+    c = ShellContext(m)
+    for k, v in dict(thickness=h, E=[1e8], nu=[0.3]).items():
+        c.set_field(k, v)
+    info = c.enable_csr()
+    assert info["nnz"] == 18685548
+    K = c.assemble_csr()
+    o = ShellOracle(m)
+    o.set_fields(h=h, E=1e8, nu=0.3)
+    Kref = o.assemble_K(with_penalty=False, with_strong=False)
+    assert Kref.nnz == info["nnz"]
+    assert abs(K - Kref).max() < 1e-11 * abs(Kref).max()
+    c.close()
