@@ -148,6 +148,8 @@ struct femo_ctx {
         double prof_flops[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // algorithmic flops of what the launches of a class execute (lower triangles only)
         double prof_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // compulsory HBM bytes of those launches (every operand entry once, results read + written)
         std::vector<hipEvent_t> pev;
+        std::vector<double> pmeta;            // per profiled launch group: algorithmic flops, compulsory bytes (rank-k updates only)
+        double last_fl = 0, last_by = 0;
         int cur_level = 0;
     } fr;
 };
@@ -485,6 +487,8 @@ struct ProfScope {
         if (!c->fr.profile) return;
         hipEventRecord(b, s);
         c->fr.pev.push_back(a); c->fr.pev.push_back(b); c->fr.pev.push_back((hipEvent_t)(intptr_t)(cls + 16 * c->fr.cur_level));
+        c->fr.pmeta.push_back(cls == 2 ? c->fr.last_fl : 0.0); c->fr.pmeta.push_back(cls == 2 ? c->fr.last_by : 0.0);
+        c->fr.last_fl = c->fr.last_by = 0;
     }
 };
 
@@ -615,6 +619,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 by += 16.0 * entries + 8.0 * kw * (nf - col_lo);     // C read + written once, the factor rows [col_lo, nf) x kw read once
             }
             fr.prof_flops[2] += fl; fr.prof_bytes[2] += by;
+            fr.last_fl += fl; fr.last_by += by;
         };
         // 64-row tiles a k_trailing_mfma launch needs from its even column anchor down: the largest extent over the chunk's
         // fronts (a grid sized by the largest front alone launches mostly idle workgroups on levels of small fronts)
@@ -848,10 +853,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const int tag = (int)(intptr_t)fr.pev[i + 2];
         const int cls = tag % 16;
         fr.prof_ms[cls] += ms; fr.prof_calls[cls] += 1;
-        if (c->opt.profile_verbose) fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
+        if (c->opt.profile_verbose) {
+            if (cls == 2) fprintf(stderr, "prof level %d class %d %.1f us flops %.6e bytes %.6e\n", tag / 16, cls, ms * 1e3, fr.pmeta[i / 3 * 2], fr.pmeta[i / 3 * 2 + 1]);
+            else fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
+        }
         hipEventDestroy(fr.pev[i]); hipEventDestroy(fr.pev[i + 1]);
     }
     fr.pev.clear();
+    fr.pmeta.clear();
     return pivot_rc;
 }
 
