@@ -60,6 +60,7 @@ SIGNATURES = {
     "femo_set_csr_map": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, _c_int32_p, _c_int32_p]),
     "femo_assemble_csr": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p]),
     "femo_set_stress_params": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "femo_set_stress_alpha": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "femo_set_cell_tags": (C.c_int, [C.c_void_p, _c_int32_p, C.c_int64, C.c_int32]),
     "femo_select_subdomain": (C.c_int, [C.c_void_p, C.c_int32]),
     "femo_field_output": (C.c_int, [C.c_void_p, C.c_char_p, _c_double_p, C.c_int64]),

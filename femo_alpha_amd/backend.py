@@ -348,6 +348,10 @@ class ShellContext:
     def set_stress_params(self, m=1e-6, rho=100.0):
         self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
 
+    def set_stress_alpha(self, alpha=None, sel=-1):
+        """The aggregate's normalisation given by the caller (None: the reference area, evaluated at first use)."""
+        self._chk(self.lib.femo_set_stress_alpha(self._h, int(sel), -1.0 if alpha is None else float(alpha)))
+
     def set_cell_tags(self, tags, ntags):
         """Sub-domain index of every cell (-1: none) for the per-tag stress aggregates."""
         t = np.ascontiguousarray(tags, dtype=np.int32)

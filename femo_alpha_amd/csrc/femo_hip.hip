@@ -108,6 +108,11 @@ struct femo_ctx {
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
         int allow_pivot_repair = 0;   // non-positive pivots: 0 = the factorisation fails, 1 = replace and count
         int profile_verbose = 0;
+        // 128 x 128 tiles for the triangular-grid rank-k updates when a launch has at least big_min_wg of them.  Built, validated (schedule
+        // fuzz) and measured SLOWER than the 64 x 64 kernel on every level at 1M DOF (rank-k updates 11.6 against 9.2 ms; levels 6-11:
+        // 26-38 against 33-43 TFLOP/s): two waves per SIMD instead of four hide the stage barriers worse, and diagonal / edge tiles waste
+        // twice as much.  Off by default.
+        int big_tiles = 0, big_min_wg = 512;
         int diag_v1 = 0;              // diagonal-block kernel: 0 auto (see the launch), 1 round-2 kernel (sequential phases), 2 overlapped kernel
         int swork_slots = 8192;       // cap of the diagonal-block scratch (1 GB); larger levels are factorised in chunks (read at plan upload)
         int xinv_small_cnt = 32;      // inversion of L11: levels with at most this many fronts use 64 x 32 tiles
@@ -632,6 +637,20 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             return (need + TS - 1) / TS;
         };
+        // Triangular-grid updates (schur 1, 2, 5): 128 x 128 tiles where that still fills the chip (at least "big_min_wg" workgroups
+        // over the launch), 64 x 64 tiles otherwise.  `ntr`: 64-row tiles the launch needs (trail_tiles).
+        auto launch_tri = [&](bool gather, int ntr, int off, int n, int C0_, int mode, int K0_, int KW_, hipStream_t st) {
+            const int ntb = (ntr + 1) / 2;
+            const long long big_wgs = (long long)ntb * (ntb + 1) / 2 * n;
+            if (c->opt.big_tiles && big_wgs >= c->opt.big_min_wg) {
+                const size_t shm = 4 * sizeof(double) * 16 * LSTRB;
+                if (gather) hipLaunchKernelGGL(k_trailing_big<true>, dim3(ntb * (ntb + 1) / 2, 1, n), dim3(256), shm, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
+                else hipLaunchKernelGGL(k_trailing_big<false>, dim3(ntb * (ntb + 1) / 2, 1, n), dim3(256), shm, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
+            } else {
+                if (gather) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
+                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
+            }
+        };
         // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
         auto count_panel = [&](int C0) {
             if (!fr.profile) return;
@@ -734,10 +753,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                         }
                         { ProfScope ps(c, 2, bs);
                           count_trailing(S0, mode, 0, SP);
-                          FOR_FRONT_CHUNKS(cnt, off, n) {
-                              if (fused_schur && S0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP, mask);
-                              else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, bs, fd, lev, off, S0, mode, 0, SP, mask);
-                          } }
+                          FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur && S0 == 0, ntr, off, n, S0, mode, 0, SP, bs); }
                         if (sp_ahead) {
                             HIPCHK(c, hipEventRecord(c->ev_sp[sp_bulks & 1], c->stream2));
                             ++sp_bulks;
@@ -749,11 +765,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 if (!lookahead) {
                     ProfScope ps(c, 2);
                     count_trailing(C0, 2);
-                    FOR_FRONT_CHUNKS(cnt, off, n) {
-                        // only the FIRST update behind the pivot columns may gather: a later one would overwrite the earlier panels' updates
-                        if (fused_schur && !left_level && C0 == 0) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
-                        else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 2, 0, NBO, mask);
-                    }
+                    // only the FIRST update behind the pivot columns may gather: a later one would overwrite the earlier panels' updates
+                    FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur && !left_level && C0 == 0, ntr, off, n, C0, 2, 0, NBO, c->stream);
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
                     // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
@@ -784,10 +797,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             count_trailing(0, 1);
             const int ntr = trail_tiles(0, 1);
             if (ntr > 0)
-            FOR_FRONT_CHUNKS(cnt, off, n) {
-                if (fused_schur) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO, mask);
-                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, c->stream, fd, lev, off, 0, 1, 0, NBO, mask);
-            }
+            FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur, ntr, off, n, 0, 1, 0, NBO, c->stream);
         }
         }   // chunks of the level
         if (wide && max_np_level > NBO) {
@@ -1552,6 +1562,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "strict") o.strict = v != 0;
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
+    else if (k == "big_tiles") o.big_tiles = v != 0;
+    else if (k == "big_min_wg") o.big_min_wg = v;
     else if (k == "diag_v1") { if (v < 0 || v > 2) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel"); o.diag_v1 = v; }
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
@@ -1992,6 +2004,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2859,6 +2873,14 @@ int femo_assemble_csr(femo_ctx* c, double* vals, double* ms2) {
 int femo_set_stress_params(femo_ctx* c, double m, double rho) {
     if (!(m > 0) || !(rho > 0)) return fail(c, "stress aggregation parameters must be positive");
     c->stress_m = m; c->stress_rho = rho;
+    return 0;
+}
+
+// alpha of pnorm_stress = 1/alpha int (m vm)^rho J dx given by the caller (RMShellPDE.pnorm_stress(alpha=...), rm_shell_pde.py:112-128)
+// for the whole mesh (sel = -1) or one sub-domain; alpha <= 0 returns to "the reference area, evaluated at first use"
+int femo_set_stress_alpha(femo_ctx* c, int32_t sel, double alpha) {
+    if (sel < -1 || sel >= c->ntags) return fail(c, "unknown sub-domain");
+    (sel < 0 ? c->stress_alpha : c->alpha_tag[sel]) = alpha > 0 ? alpha : -1.0;
     return 0;
 }
 

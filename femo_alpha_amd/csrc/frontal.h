@@ -1316,6 +1316,214 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             }
 }
 
+// ---- the same rank-k update on 128 x 128 tiles (schur 1, 2, 5: the updates of whole Schur complements / trailing matrices).
+// The per-level counter table (profiles/r3_pmc_trailing_levels.md) shows where the 64 x 64 kernel loses: on the MFMA-bound
+// levels (6 and up) it moves 2.2-3 x its compulsory bytes at ~4 TB/s -- every tile re-reads 2 x 64 rows of the K panel, and
+// the tiles of a front are spread over eight L2s -- and it issues one LDS read per MFMA.  A workgroup of the same four waves on a
+// 128 x 128 tile (a wave: 64 x 64 = 4 x 4 MFMA blocks, 128 accumulator registers) reads half the panel bytes per updated entry and
+// one LDS operand per TWO MFMAs.  Used where the fronts are large enough to fill the chip with such tiles (host: option "big_nb").
+constexpr int TSB = 128;
+constexpr int LSTRB = TSB + 16;
+
+template <bool GATHER>
+__global__ void __launch_bounds__(256, 2)
+k_trailing_big(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW,
+               const unsigned char* __restrict__ mask) {
+    const int t = level_nodes[first + blockIdx.z];
+    const int np = fd.npiv[t];
+    const int nf = fd.nf[t];
+    const TrailRange tr = trail_range(schur, C0, K0, KW, np, nf);
+    const int kc0 = tr.kc0, kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
+    if (kw <= 0) return;
+    const int lin = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
+    while (ti * (ti + 1) / 2 > lin) --ti;
+    const int by = lin - ti * (ti + 1) / 2, bx = ti - by;          // column tile by, row tile by + bx
+    const int cj = (col_lo & ~1) + by * TSB;
+    if (cj >= col_hi) return;
+    const int ri = cj + bx * TSB;
+    if (ri >= nf) return;
+    const FrontView fv = front_view(fd, t);
+    constexpr int KC = 16;
+    extern __shared__ __attribute__((aligned(16))) double lds_big[];
+    typedef double stage_t[KC][LSTRB];
+    stage_t* si = reinterpret_cast<stage_t*>(lds_big);             // si[buf][k][r] = L[ri + r][kc0 + k0 + k]
+    stage_t* sj = si + 2;                                          // sj[buf][k][c] = L[cj + c][kc0 + k0 + k]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 64, wc = (wv >> 1) * 64;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // staging: thread (row pair rp of 64, group cg of 4) loads factor columns cg, cg + 4, cg + 8, cg + 12 of both operand blocks
+    const int rp = tid & 63, cg = tid >> 6;
+    const int ldp = ldp_of(nf);
+    const int rowi = min(ri + 2 * rp, ldp - 2), rowj = min(cj + 2 * rp, ldp - 2);
+    const char* base = reinterpret_cast<const char*>(fv.P + (size_t)ldp * kc0);
+    const size_t stage_bytes = (size_t)ldp * KC * 8;
+    unsigned obi[4], obj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        obi[q] = 8u * (unsigned)(rowi + ldp * (cg + 4 * q));
+        obj[q] = 8u * (unsigned)(rowj + ldp * (cg + 4 * q));
+    }
+    d2 pi[4], pj[4];
+    auto fetch = [&](const char* b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pi[q] = *reinterpret_cast<const d2*>(b + obi[q]);
+            pj[q] = *reinterpret_cast<const d2*>(b + obj[q]);
+        }
+    };
+    auto fetch_tail = [&](const char* b, int left) {
+        const d2 z = {0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned a = 8u * (unsigned)(ldp * min(cg + 4 * q, left - 1));
+            const d2 vi = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowi + a), vj = *reinterpret_cast<const d2*>(b + 8u * (unsigned)rowj + a);
+            pi[q] = cg + 4 * q < left ? vi : z;
+            pj[q] = cg + 4 * q < left ? vj : z;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<d2*>(&si[buf][cg + 4 * q][2 * rp]) = pi[q];
+            *reinterpret_cast<d2*>(&sj[buf][cg + 4 * q][2 * rp]) = pj[q];
+        }
+    };
+    if (kw >= KC) fetch(base); else fetch_tail(base, kw);
+    base += stage_bytes;
+    mfma_d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kw; k0 += KC) {
+        const int left = kw - k0 - KC;
+        if (left > 0) {
+            if (left >= KC) fetch(base); else fetch_tail(base, left);
+            base += stage_bytes;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = sj[cur][kk + l4][wc + 16 * a + l15];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = si[cur][kk + l4][wr + 16 * b + l15];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (left > 0) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue, one 16-column block of the wave's quarter at a time (a): C -= D, or C = (children's entries) - D
+    const long long dp = fd.doff[t];
+    int rr[2][4];
+    const double* Sc[2] = {nullptr, nullptr};
+    int npc[2] = {0, 0}, nbc[2] = {0, 0}, chv[2] = {-1, -1};
+    if (GATHER) {
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int ch = fd.child[sd][t];
+            const int chs = ch >= 0 ? ch : t;
+            chv[sd] = ch;
+            npc[sd] = fd.npiv[chs]; nbc[sd] = fd.nf[chs] - npc[sd];
+            Sc[sd] = fd.S + fd.soff[chs];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r = ri + wr + 16 * b + l15;
+                rr[sd][b] = fd.cinv[sd][dp + min(r, nf - 1)];
+                if (ch < 0 || r >= nf) rr[sd][b] = -1;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        bool cok[4];
+        double* cp[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+            cok[reg] = cc >= col_lo && cc < col_hi;
+            cp[reg] = cok[reg] ? fv.col(cc) : fv.P - (nf - 1);
+        }
+        double cv[4][4];
+        if (!GATHER) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const bool ok = cok[reg] && r < nf && r >= cc;
+                    cv[b][reg] = cp[reg][ok ? r : nf - 1];
+                }
+        } else {
+            int cr[2][4];
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    cr[sd][reg] = fd.cinv[sd][dp + min(cc, nf - 1)];
+                    if (chv[sd] < 0 || !cok[reg]) cr[sd][reg] = -1;
+                }
+            double g0[4][4], g1[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    const bool tri = r >= cc;
+                    {
+                        const int x = rr[0][b], y = cr[0][reg];
+                        const bool ok = tri && x >= 0 && y >= 0;
+                        const int lo = min(x, y) - npc[0], hi = max(x, y) - npc[0];
+                        g0[b][reg] = Sc[0][ok ? hi + (size_t)nbc[0] * lo : 0];
+                        if (!ok) g0[b][reg] = 0.0;
+                    }
+                    {
+                        const int x = rr[1][b], y = cr[1][reg];
+                        const bool ok = tri && x >= 0 && y >= 0;
+                        const int lo = min(x, y) - npc[1], hi = max(x, y) - npc[1];
+                        g1[b][reg] = Sc[1][ok ? hi + (size_t)nbc[1] * lo : 0];
+                        if (!ok) g1[b][reg] = 0.0;
+                    }
+                }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) cv[b][reg] = g0[b][reg] + g1[b][reg];
+            if (mask && bx == 0) {
+                const int* gd = fd.dofs + dp;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                        const int r = ri + wr + 16 * b + l15;
+                        if (r == cc && cok[reg] && cc < np && mask[gd[r]]) cv[b][reg] = 1.0;
+                    }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                const int r = ri + wr + 16 * b + l15;
+                if (cok[reg] && r < nf && r >= cc) cp[reg][r] = cv[b][reg] - acc[a][b][reg];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ solves
 // M^-1 = L^-T L^-1 applied level by level.  Each sweep is split per level into a sequential part on
 // the triangular pivot block L11 (one workgroup per front, panels chained through the stored diagonal

@@ -96,11 +96,14 @@ class RMShellPDE:
     def pnorm_stress(self, w, uhat, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False):
         """1/alpha int (m vm_top)^rho J dx with the degree-4 measure (rm_shell_pde.py:112-128); alpha is the
         reference area, evaluated by the backend on first use."""
-        if regularization or alpha is not None:
-            raise NotImplementedError("only the reference's call pattern (alpha=None, regularization=False) is supported")
+        if regularization:
+            raise NotImplementedError("pnorm_stress(regularization=True) adds 0.5e3 int h^rho J dx (rm_shell_pde.py:120-122); no caller "
+                                      "of the reference sets it and it is not provided")
         self.ctx.set_stress_params(m, rho)
         # dx: None for the whole mesh, or the index i of a tagged sub-domain (the reference passes dxx(i))
-        return Form(self.ctx, "pnorm_stress", subdomain=-1 if dx is None else int(dx))
+        sel = -1 if dx is None else int(dx)
+        self.ctx.set_stress_alpha(alpha, sel)          # None: the reference area, evaluated by the backend at first use (:123-127)
+        return Form(self.ctx, "pnorm_stress", subdomain=sel)
 
     def von_Mises_stress(self, w, uhat, h, E, nu, surface="Top"):
         """von Mises stress at xi2 = h/2 ('Top'), 0 ('Mid') or -h/2 ('Bot') (rm_shell_pde.py:153-165), as a field the

@@ -185,6 +185,9 @@ int femo_assemble_csr(femo_ctx* ctx, double* vals, double* ms2);
 /* Stress aggregation parameters (m, rho) of pnorm_stress = 1/alpha int (m vm_top)^rho J dx
  * (rm_shell/rm_shell_pde.py:112-128; defaults 1e-6, 100 as rm_shell_model.py:63). */
 int femo_set_stress_params(femo_ctx* ctx, double m, double rho);
+/* alpha of the aggregate given by the caller (pnorm_stress(alpha=...), rm_shell_pde.py:123-127) for the whole mesh (sel = -1) or a
+ * sub-domain; alpha <= 0: back to the reference area evaluated at first use. */
+int femo_set_stress_alpha(femo_ctx* ctx, int32_t sel, double alpha);
 /* Sub-domains for the stress aggregate -- the reference's mesh tags / dxx(i) measure
  * (rm_shell/rm_shell_model.py:101-133, 242-253).  tags[nel] holds the sub-domain index of every cell
  * (0 .. ntags-1, or -1 for none).  femo_select_subdomain(sel) restricts "pnorm_stress" and its derivatives to the

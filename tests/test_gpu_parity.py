@@ -604,3 +604,23 @@ def test_csr_assembly_at_config2():
     assert Kref.nnz == info["nnz"]
     assert abs(K - Kref).max() < 1e-11 * abs(Kref).max()
     c.close()
+
+
+def test_pnorm_stress_with_a_given_alpha():
+    """pnorm_stress(alpha=...) (rm_shell_pde.py:112-128): the caller's normalisation replaces the reference area."""
+    from oracle.rm_shell_oracle import ShellOracle
+    m, o, c, rng = _pair("warped", beta=1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-4
+    c.set_state(w)
+    o3 = ShellOracle(m, nquad=3)
+    o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
+    c.set_stress_params(1e-6, 6.0)
+    c.set_stress_alpha(2.5)
+    ref = o3.pnorm_stress(w, 1e-6, 6.0, alpha=2.5)
+    assert abs(c.functional("pnorm_stress") - ref) < 1e-10 * ref
+    g = c.dfunctional("pnorm_stress", "disp_solid")
+    c.set_stress_alpha(None)
+    ref0 = o3.pnorm_stress(w, 1e-6, 6.0)
+    assert abs(c.functional("pnorm_stress") - ref0) < 1e-10 * ref0
+    g0 = c.dfunctional("pnorm_stress", "disp_solid")
+    assert rel(g * 2.5, g0 * (ref0 / ref * 2.5)) < 1e-12 or rel(g * ref0, g0 * ref) < 1e-10
