@@ -24,8 +24,16 @@ from femo_alpha_amd.solver.symbolic import analyse, rank_plan     # noqa: E402
 COLLECTIVE_US = 30.0        # assumed latency of one small RCCL all-reduce over xGMI at 8 ranks (not measurable here)
 LINK_GBS = 100.0            # assumed achieved rate of one xGMI link (peak ~153 GB/s per direction)
 which = sys.argv[1] if len(sys.argv) > 1 else "wing1m"
+weak = len(sys.argv) > 2 and sys.argv[2] == "weak"          # weak scaling: P times the span, one 1 M-DOF partition per rank
 m, fields, marker, _ = make_workload(which)
 leaf = 12
+
+
+def weak_workload(P):
+    from femo_alpha_amd.mesh import wing_skin_mesh
+    mm = wing_skin_mesh(116, 580 * P, span=6.0 * P).renumbered()[0]
+    ff = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0], F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (mm.nn, 1)))
+    return mm, ff
 
 
 def engine(P, tree, rank):
@@ -52,6 +60,8 @@ def timed(fn, reps=5):
 
 rows = []
 for P in (1, 2, 4, 8):
+    if weak:
+        m, fields = weak_workload(P)
     tree = analyse(m, leaf, min_depth=int(np.log2(P)))
     packed, local_ms, cap = {}, [], 0
     eng0 = None
@@ -98,7 +108,7 @@ for P in (1, 2, 4, 8):
     pcg = iters * (precond + apply_ms + 0.15 + ncoll * COLLECTIVE_US * 1e-3) + (sw["local"] / 2 + COLLECTIVE_US * 1e-3 if P > 1 else sw["local"] / 2)
     fwd = max(local_ms) + gather_ms + top_ms + pcg
     serial = top_ms + gather_ms + iters * (sw["top"] + ncoll * COLLECTIVE_US * 1e-3)
-    rows.append(dict(P=P, cells_per_rank=int(sub0.nel), replicated_dofs=int(info0["n_top"]), local_levels=int(nl), top_levels=int(nlev - nl),
+    rows.append(dict(P=P, ndof=int(m.ndof), cells_per_rank=int(sub0.nel), replicated_dofs=int(info0["n_top"]), local_levels=int(nl), top_levels=int(nlev - nl),
                      local_assemble_factor_ms_max=max(local_ms), local_assemble_factor_ms_all=local_ms,
                      top_factor_ms=top_ms, top_fronts=len(top_fronts), top_gflop=top_gflop,
                      schur_allgather_bytes_received=int(gather_bytes), schur_packed_doubles=int(cap), schur_allgather_ms_assumed=gather_ms,
@@ -107,8 +117,8 @@ for P in (1, 2, 4, 8):
     eng0.ctx.close()
 base = rows[0]["forward_ms_composed"]
 for r in rows:
-    r["speedup_vs_1"] = base / r["forward_ms_composed"]
-out = dict(workload=which, ndof=int(m.ndof), assumptions=dict(collective_us=COLLECTIVE_US, xgmi_link_GBs=LINK_GBS, pcg_iterations=2,
+    r["speedup_vs_1"] = base / r["forward_ms_composed"] * (r["P"] if weak else 1)      # weak: throughput relative to one GPU
+out = dict(workload=which + (" x P (weak scaling)" if weak else ""), ndof=int(m.ndof), assumptions=dict(collective_us=COLLECTIVE_US, xgmi_link_GBs=LINK_GBS, pcg_iterations=2,
            note="local work of every rank run ALONE on one MI355X; collectives are not executed, their cost is the assumption above"), rows=rows)
 print(json.dumps(out, indent=1))
 hdr = "| P | cells / rank | replicated DOFs | local assembly + factorisation (max over ranks) | replicated top: factorisation | Schur all-gather received | sweeps local / top | operator | forward composed | speed-up | does not shrink with P |"
