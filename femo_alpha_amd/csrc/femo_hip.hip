@@ -54,7 +54,7 @@ struct femo_ctx {
     double* hK = nullptr;
     Tables* tab = nullptr;
     Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
-    double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0;
+    double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0, stress_reg = 0.0;
     int* ctag = nullptr;                     // sub-domain index per cell
     int csel = -1, ntags = 0;
     std::vector<double> alpha_tag;           // reference area of every sub-domain (frozen at first use, like stress_alpha)
@@ -88,6 +88,8 @@ struct femo_ctx {
     double *fM2 = nullptr, *fM1 = nullptr;
     double beta = 1e15;
     bool penalty_dirty = true;
+    double* gdir = nullptr;       // prescribed values g of the penalty term beta/h_E |..| (w - g).v (linear_shell_model.py:323-333); null = zero
+    bool has_g = false;
     unsigned char* mask = nullptr;
     bool has_mask = false;
     // vectors
@@ -389,6 +391,12 @@ static int load_vector_dev(femo_ctx* c, double* F, const double* f_override = nu
     FieldsDev fdv = fields_dev(c);
     if (f_override) fdv.f = const_cast<double*>(f_override);        // a level of the resident force history (femo_newmark_*)
     ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
+    if (c->has_g && c->nf > 0) {
+        // penalty with prescribed values: R = ... + P (w - g)  ->  the right-hand side gains P g
+        if (refresh_penalty(c)) return 1;
+        hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 0, (const double*)c->gdir, F,
+                           (double*)nullptr);
+    }
     if (c->has_mask) hipLaunchKernelGGL(k_mask_zero, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, c->mask, n);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1299,6 +1307,7 @@ void femo_destroy(femo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();                   // stream2 / stream3 may still hold work that reads the buffers freed below
+    if (c->gdir) hipFree(c->gdir);
     void* nptrs[] = {c->nm.W, c->nm.Fh, c->nm.wdot, c->nm.Fsw, c->nm.mu0, c->nm.mu1, c->nm.Lam, c->nm.Gh};
     for (void* p : nptrs)
         if (p) hipFree(p);
@@ -1340,6 +1349,7 @@ static double* field_ptr(const femo_ctx* c, const char* name, int64_t* n) {
     if (s == "density") { *n = c->nT; return c->rho; }
     if (s == "F_solid") { *n = 3 * c->nF; return c->f; }
     if (s == "uhat") { *n = 3 * (int64_t)c->nn; return c->uhat; }
+    if (s == "dirichlet" && c->gdir) { *n = c->ndof; return c->gdir; }
     *n = -1;
     return nullptr;
 }
@@ -1407,6 +1417,10 @@ int femo_set_strong_dofs(femo_ctx* c, int32_t n, const int32_t* dofs) {
 
 int femo_set_field(femo_ctx* c, const char* name, const double* v, int64_t n) {
     HIPCHK(c, hipSetDevice(c->device));
+    if (name && std::string(name) == "dirichlet" && !c->gdir) {
+        HIPCHK(c, hipMalloc((void**)&c->gdir, (size_t)c->ndof * sizeof(double)));
+        HIPCHK(c, hipMemset(c->gdir, 0, (size_t)c->ndof * sizeof(double)));
+    }
     int64_t len;
     double* d = field_ptr(c, name, &len);
     if (!d) return fail(c, std::string("unknown field '") + (name ? name : "") + "'");
@@ -1427,6 +1441,13 @@ int femo_set_field(femo_ctx* c, const char* name, const double* v, int64_t n) {
             if (v[i] != 0.0) { any = true; break; }
         c->has_uhat = any;
         c->penalty_dirty = true;
+    }
+    if (d == c->gdir) {
+        bool any = false;
+        for (int64_t i = 0; i < n; ++i)
+            if (v[i] != 0.0) { any = true; break; }
+        c->has_g = any;
+        return 0;                                   // the prescribed values enter the right-hand side only
     }
     // the load never enters the operator; the density only through the inertia term aM M
     if (d != c->f && (d != c->rho || c->op_aM != 0.0)) operator_changed(c);
@@ -1561,6 +1582,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     }
     else if (k == "strict") o.strict = v != 0;
     else if (k == "allow_pivot_repair") o.allow_pivot_repair = v != 0;
+    else if (k == "stress_regularization") { if (value < 0) return fail(c, "stress_regularization: a coefficient >= 0 (the reference's is 0.5e3)"); c->stress_reg = value; }
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
     else if (k == "big_tiles") o.big_tiles = v != 0;
     else if (k == "big_min_wg") o.big_min_wg = v;
@@ -1613,7 +1635,7 @@ static double& stress_alpha_ref(femo_ctx* c) { return c->csel < 0 ? c->stress_al
 // int (m vm)^rho J dx over the cells and (first call) the reference area alpha
 static int pnorm_dev(femo_ctx* c, double out2[2]) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
-    ELEM_LAUNCH(c, k_pnorm, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab_s, 0, c->stress_m, c->stress_rho, 1.0,
+    ELEM_LAUNCH(c, k_pnorm, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab_s, 0, c->stress_m, c->stress_rho, 1.0, c->stress_reg,
                 c->w, (double*)nullptr, c->scal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1678,11 +1700,16 @@ static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const doub
     const Tables* tb = mode == 4 ? c->tab_s : c->tab;
     if (c->quad)
         hipLaunchKernelGGL((k_shape_gradient<9, 4, true>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w, lam,
-                           scale, c->stress_m, c->stress_rho, out);
+                           scale, c->stress_m, c->stress_rho, c->stress_reg, out);
     else
         hipLaunchKernelGGL((k_shape_gradient<6, 3, false>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w,
-                           lam, scale, c->stress_m, c->stress_rho, out);
+                           lam, scale, c->stress_m, c->stress_rho, c->stress_reg, out);
     if (mode == 0 && c->nf > 0) {
+        if (c->has_g) {           // the penalty term is P(uhat) (w - g)
+            hipLaunchKernelGGL(k_lincomb3, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->tmp, 1.0, w, -1.0, (const double*)c->gdir, 0.0,
+                               (const double*)nullptr, (int64_t)c->ndof);
+            w = c->tmp;
+        }
         const int nt = c->nf * 3 * c->nvc;
         if (c->quad)
             hipLaunchKernelGGL((k_shape_gradient_penalty<4, true>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta,
@@ -1737,7 +1764,7 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         if (stress_alpha_ref(c) < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
         const int mode = wrt == "disp_solid" ? 1 : wrt == "thickness" ? 2 : wrt == "E" ? 3 : wrt == "nu" ? 4 : 0;
         if (mode)
-            ELEM_LAUNCH(c, k_pnorm, NOEXTRA, g, EB, m, f, c->tab_s, mode, c->stress_m, c->stress_rho, 1.0 / stress_alpha_ref(c), c->w, out,
+            ELEM_LAUNCH(c, k_pnorm, NOEXTRA, g, EB, m, f, c->tab_s, mode, c->stress_m, c->stress_rho, 1.0 / stress_alpha_ref(c), c->stress_reg, c->w, out,
                         (double*)nullptr);
     } else {
         return fail(c, "unknown functional '" + fn + "'");

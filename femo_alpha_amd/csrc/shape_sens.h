@@ -176,7 +176,7 @@ __device__ __forceinline__ D1 energy_density_dual(const GenD& a, const GenD& b, 
 template <int NPC, int NVC, bool QUAD>
 __global__ void __launch_bounds__(128)
 k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, const double* __restrict__ w,
-                 const double* __restrict__ lam, double scale, double ms, double rho, double* __restrict__ out) {
+                 const double* __restrict__ lam, double scale, double ms, double rho, double regc, double* __restrict__ out) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gid / (3 * NVC), dir = gid - e * (3 * NVC);
@@ -254,6 +254,7 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
                 const D1 pw = mk(p, rho * p / vm.v * vm.d);
                 phi = phi + wdet * (pw * s.Ju);
             }
+            if (regc != 0.0) phi = phi + (wdet * regc * pow(hq, rho)) * s.Ju;
         } else if (mode == 1) {
             double uq[3] = {0, 0, 0};
             for (int a = 0; a < NPC; ++a)

@@ -70,7 +70,7 @@ __device__ __forceinline__ void dvm_deps(const double* sig, double vm, double E,
 // mode 2: out_f  += d/dh, mode 3: d/dE, mode 4: d/dnu   (field-space gradients)
 template <int NPC, int NVC, bool QUAD, bool UHAT>
 __global__ void __launch_bounds__(128)
-k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double ms, double rho, double scale,
+k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double ms, double rho, double scale, double regc,
         const double* __restrict__ w, double* __restrict__ out, double* slots) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,10 +96,19 @@ k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double
             double sig[3];
             const double vm = von_mises(ts, Eq, nuq, sig);
             const double p = pow(ms * vm, rho);
+            // regc: coefficient of pnorm_stress(regularization=True), + regc int h^rho J dx with regc = 0.5e3 (rm_shell_pde.py:120-122)
             if (mode == 0) {
                 acc += wj * p;
+                if (regc != 0.0) acc += wj * regc * pow(hq, rho);
                 area += tab->w[q] * g.det;          // alpha: area of the reference configuration (rm_shell_pde.py:124-127)
                 continue;
+            }
+            if (mode == 2 && regc != 0.0) {
+                const double dr = wj * regc * rho * pow(hq, rho - 1.0);
+                for (int b = 0; b < NVC; ++b) {
+                    ge[b] += dr * (f.ewm ? 1.0 : tab->N1[q][b]);
+                    if (f.ewm) break;
+                }
             }
             if (!(vm > 0.0)) continue;
             const double dp = wj * rho * p / vm;              // d/dvm of wj (m vm)^rho

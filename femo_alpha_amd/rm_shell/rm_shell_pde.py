@@ -41,11 +41,16 @@ class RMShellPDE:
     # ------------------------------------------------------------------ residual
     def pdeRes(self, h, w, uhat, f, E, nu, penalty=False, dss=None, dSS=None, g=None):
         """Residual of the elastic energy + penalty - load (rm_shell_pde.py:50-58,
-        linear_shell_model.py:308-333).  ``g`` (the prescribed value) must be zero."""
+        linear_shell_model.py:308-333).  ``g``: the prescribed state of the penalty term (a Function on W; the reference's
+        model passes zeros, rm_shell_model.py:183-185); values on strongly imposed DOFs are not used (those are homogeneous,
+        as in the reference, rm_shell_model.py:168-180)."""
         h.bind("thickness"); w.bind("state"); uhat.bind("uhat"); f.bind("F_solid"); E.bind("E"); nu.bind("nu")
-        if g is not None and np.any(g.get()):
-            raise NotImplementedError("non-zero Dirichlet data g is not supported (the reference always passes 0, "
-                                      "rm_shell_model.py:183-185)")
+        if g is not None:
+            if not penalty and np.any(g.get()):
+                raise NotImplementedError("prescribed values need the penalty treatment (PENALTY_BC=True)")
+            g0 = g.get()
+            g.bind("dirichlet")
+            g.set(g0)
         if penalty:
             pairs = [s.pairs for s in (dss, dSS) if s is not None]
             self.ctx.set_penalty_facets(np.vstack(pairs) if pairs else np.zeros((0, 2), np.int32), PENALTY_BETA)
@@ -96,9 +101,8 @@ class RMShellPDE:
     def pnorm_stress(self, w, uhat, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False):
         """1/alpha int (m vm_top)^rho J dx with the degree-4 measure (rm_shell_pde.py:112-128); alpha is the
         reference area, evaluated by the backend on first use."""
-        if regularization:
-            raise NotImplementedError("pnorm_stress(regularization=True) adds 0.5e3 int h^rho J dx (rm_shell_pde.py:120-122); no caller "
-                                      "of the reference sets it and it is not provided")
+        # regularization=True adds 0.5 * 1e3 int h^rho J dx inside the 1/alpha (rm_shell_pde.py:120-122)
+        self.ctx.set_option("stress_regularization", 0.5e3 if regularization else 0.0)
         self.ctx.set_stress_params(m, rho)
         # dx: None for the whole mesh, or the index i of a tagged sub-domain (the reference passes dxx(i))
         sel = -1 if dx is None else int(dx)

@@ -65,7 +65,9 @@ int femo_set_penalty_facets(femo_ctx* ctx, int32_t nfacets, const int32_t* cell_
 int femo_set_strong_dofs(femo_ctx* ctx, int32_t n, const int32_t* dofs);
 
 /* Copy an input field into the context (a length-1 array broadcasts) --
- * replaces update(Function, ndarray) (fea/utils_dolfinx.py:319-330). */
+ * replaces update(Function, ndarray) (fea/utils_dolfinx.py:319-330).  Besides the six inputs of the model, "dirichlet"
+ * (femo_ndof values) sets the prescribed state g of the penalty term beta/h_E |J F^-T N| (w - g).v
+ * (linear_shell_model.py:323-333; the reference's RMShellModel always passes zeros, rm_shell_model.py:183-185). */
 int femo_set_field(femo_ctx* ctx, const char* name, const double* values, int64_t n);
 int femo_get_field(femo_ctx* ctx, const char* name, double* values, int64_t n);
 

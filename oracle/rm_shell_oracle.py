@@ -414,9 +414,16 @@ class ShellOracle:
         D = sp.diags(keep)
         return (D @ K @ D + sp.diags(1.0 - keep)).tocsr()
 
+    def set_dirichlet_values(self, g=None):
+        """Prescribed state g of the penalty term beta/h_E |..| (w - g).v (linear_shell_model.py:323-333); None = zero."""
+        self.g_dirichlet = None if g is None else np.asarray(g, dtype=np.float64).copy()
+
     def load_vector(self):
-        """F_a = int f . N_a J dx (linear_shell_model.py:320)."""
+        """F_a = int f . N_a J dx (linear_shell_model.py:320), plus P g when the penalty term carries prescribed values."""
         Fv = np.zeros(self.mesh.ndof)
+        if getattr(self, "g_dirichlet", None) is not None:
+            for d, blk in self._penalty_blocks():
+                Fv[d] += blk @ self.g_dirichlet[d]
         for sl in self._chunks():
             g = self._geometry(sl, self.N1, self.dN1)
             wj = self.wts[None, :] * g["det"] * g["Ju"]
@@ -570,10 +577,11 @@ class ShellOracle:
         vm = np.sqrt(s0 ** 2 - s0 * s1 + s1 ** 2 + 3 * s2 ** 2)
         return (vm, g, (s0, s1, s2)) if components else (vm, g)
 
-    def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None, cells=None):
+    def pnorm_stress(self, w, m=1e-6, rho=100, alpha=None, cells=None, regularization=False):
         """1/alpha int (m vm)^rho J dx (rm_shell_pde.py:112-128); use an oracle built with nquad=3 for the
         reference's degree-4 measure (rm_shell_model.py:200-205).  alpha defaults to the reference area.
-        ``cells``: restrict the measure to a sub-domain (the reference's dxx(i), rm_shell_model.py:242-253)."""
+        ``cells``: restrict the measure to a sub-domain (the reference's dxx(i), rm_shell_model.py:242-253).
+        ``regularization``: + 0.5 * 1e3 int h^rho J dx inside the 1/alpha (:120-122)."""
         val, area = 0.0, 0.0
         sel = None if cells is None else np.isin(np.arange(self.mesh.nel), np.asarray(cells))
         for sl in self._chunks():
@@ -582,6 +590,8 @@ class ShellOracle:
             if sel is not None:
                 wd = wd * sel[sl][:, None]
             val += np.sum(wd * g["Ju"] * (m * vm) ** rho)
+            if regularization:
+                val += np.sum(wd * g["Ju"] * 0.5e3 * self._at_qp(self.h, sl) ** rho)
             area += np.sum(wd)
         return val / (area if alpha is None else alpha)
 

@@ -624,3 +624,82 @@ def test_pnorm_stress_with_a_given_alpha():
     assert abs(c.functional("pnorm_stress") - ref0) < 1e-10 * ref0
     g0 = c.dfunctional("pnorm_stress", "disp_solid")
     assert rel(g * 2.5, g0 * (ref0 / ref * 2.5)) < 1e-12 or rel(g * ref0, g0 * ref) < 1e-10
+
+
+def test_penalty_with_prescribed_values():
+    """Non-zero Dirichlet data g in the penalty term beta/h_E |J F^-T N| (w - g).v (linear_shell_model.py:323-333): load vector,
+    state, residual and the shape sensitivity of the penalty term against the oracle; the state follows g on the clamped edge."""
+    m, o, c, rng = _pair("warped", uhat=True)
+    g = np.zeros(m.ndof)
+    pf = m.penalty_facets(lambda x: np.less(x[1], 1e-12))
+    cd = m.cell_dofs()
+    edge_cells = np.unique(pf[:, 0])
+    touched = np.unique(cd[edge_cells])
+    g[touched] = 1e-3 * rng.uniform(-1, 1, touched.size)
+    c.set_field("dirichlet", g); o.set_dirichlet_values(g)
+    assert rel(c.load_vector(), o.load_vector()) < 1e-11
+    c.use_direct_solver(leaf_size=8)
+    it, rr = c.solve_state(zero_guess=True)
+    w, w0 = c.get_state(), o.solve()
+    assert it <= 6 and rel(w, w0) < 1e-8
+    # the clamped DOFs (those of the facets' own nodes) follow the prescribed values
+    fd = np.unique(np.concatenate([d for d, _ in o._penalty_blocks()]))
+    assert np.abs(w[fd] - g[fd]).max() < 1e-6 * np.abs(g[fd]).max()
+    assert np.abs(c.residual()).max() < 1e-6 * np.abs(o.apply_K(w0)).max()
+    # shape sensitivity of lam . R with the penalty term P(uhat) (w - g): finite difference of the oracle along one direction
+    lam = rng.uniform(-1, 1, m.ndof)
+    gu = c.dRdarg_T("uhat", lam).reshape(-1, 3)
+    u0 = o.uhat.copy()
+    d = rng.uniform(-1, 1, u0.shape)
+    eps = 1e-6
+    def lamR(u):
+        # lam . [K_el w + P(u) (w - g) - F]: the penalty term evaluated on the difference (P w and P g are 1e12 each)
+        o.set_fields(uhat=u)
+        o.set_dirichlet_values(None)
+        r = o.apply_K(w, with_penalty=False) - o.load_vector()
+        for dofs, blk in o._penalty_blocks():
+            r[dofs] += blk @ (w - g)[dofs]
+        o.set_dirichlet_values(g)
+        return lam @ r
+    fdv = (lamR(u0 + eps * d) - lamR(u0 - eps * d)) / (2 * eps)
+    o.set_fields(uhat=u0)
+    assert abs(np.sum(gu * d) - fdv) < 1e-5 * abs(fdv)
+    c.set_field("dirichlet", np.zeros(m.ndof)); o.set_dirichlet_values(None)
+    assert rel(c.load_vector(), o.load_vector()) < 1e-11
+
+
+@pytest.mark.parametrize("ewm,uhat", [(False, True), (True, False)])
+def test_pnorm_stress_with_the_thickness_regularisation(ewm, uhat):
+    """pnorm_stress(regularization=True) (rm_shell_pde.py:120-122): value and the thickness / shape gradients of the added
+    0.5e3 int h^rho J dx term against the oracle (finite differences for the gradients)."""
+    from oracle.rm_shell_oracle import ShellOracle
+    m, o, c, rng = _pair("warped", ewm=ewm, uhat=uhat, beta=1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-4
+    c.set_state(w)
+    o3 = ShellOracle(m, element_wise_material=ewm, nquad=3)
+    hh = 1.0 + 0.3 * rng.uniform(-1, 1, o.h.size)                       # thickness ~ 1 so that h^rho is neither 0 nor inf
+    o3.set_fields(h=hh, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
+    c.set_field("thickness", hh)
+    mval, rho = 1e-6, 6.0
+    c.set_stress_params(mval, rho)
+    c.set_option("stress_regularization", 0.5e3)
+    alpha = ShellOracle(m, element_wise_material=ewm, nquad=3).pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
+    P = lambda: o3.pnorm_stress(w, mval, rho, alpha=alpha, regularization=True)
+    ref = P()
+    assert abs(c.functional("pnorm_stress") - ref) < 1e-10 * ref
+    assert ref > 10 * o3.pnorm_stress(w, mval, rho, alpha=alpha)          # the added term is what is being tested
+    g = c.dfunctional("pnorm_stress", "thickness")
+    for i in rng.choice(g.size, 3, replace=False):
+        v = hh.copy(); st = 1e-6 * v[i]
+        v[i] += st; o3.set_fields(h=v); fp = P()
+        v[i] -= 2 * st; o3.set_fields(h=v); fm = P()
+        o3.set_fields(h=hh)
+        assert abs(g[i] - (fp - fm) / (2 * st)) <= 1e-6 * np.abs(g).max()
+    if uhat:
+        gu = c.dfunctional("pnorm_stress", "uhat").reshape(-1, 3)
+        u0 = o3.uhat.copy(); d = rng.uniform(-1, 1, u0.shape); eps = 1e-6
+        o3.set_fields(uhat=u0 + eps * d); fp = P()
+        o3.set_fields(uhat=u0 - eps * d); fm = P()
+        o3.set_fields(uhat=u0)
+        assert abs(np.sum(gu * d) - (fp - fm) / (2 * eps)) < 1e-5 * abs((fp - fm) / (2 * eps))
+    c.set_option("stress_regularization", 0.0)
