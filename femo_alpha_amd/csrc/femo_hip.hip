@@ -38,6 +38,8 @@ struct femo_ctx {
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
+    hipStream_t stream_m = nullptr;          // diagonal look-ahead: a stream that may not use the CUs reserved for the diagonal blocks
+    hipEvent_t ev_da[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;           // L11^-1 of a finished level is formed beside the factorisation of the next ones
     hipEvent_t ev_x[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
@@ -104,6 +106,10 @@ struct femo_ctx {
         int left_min = 64, left_max = 2048;   // auto: levels with this many fronts are left-looking
         int lookahead = 1, lookahead_cnt = 16;
         int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
+        int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
+        int narrow_split = 1, narrow_split_wg = 1024;
+        int super_tiles = 0, super_tiles_min = 8;   // rank-k updates of few large fronts: 4 x 4 super-tiles per XCD from this many 64-row tiles
+        int diag_ahead = 0;                   // super-panel levels: the next diagonal block runs beside the rest of this panel's rows and updates
         int fused_schur = 1;          // left-looking levels: the Schur update gathers its block from the children
         int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
         int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
@@ -655,9 +661,28 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 if (gather) hipLaunchKernelGGL(k_trailing_big<true>, dim3(ntb * (ntb + 1) / 2, 1, n), dim3(256), shm, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
                 else hipLaunchKernelGGL(k_trailing_big<false>, dim3(ntb * (ntb + 1) / 2, 1, n), dim3(256), shm, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
             } else {
-                if (gather) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
-                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (ntr + 1) / 2, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask);
+                // levels of few large fronts: 4 x 4 super-tiles per XCD (k_trailing_mfma, tile_map 1); the grid covers whole rounds of
+                // eight super-tiles, the tiles beyond the front leave at once
+                const bool sup = c->opt.super_tiles && n < 256 && ntr >= c->opt.super_tiles_min;
+                const int nst = (ntr + 3) / 4, nsup = nst * (nst + 1) / 2;
+                const int gx = sup ? (nsup + 7) / 8 * 128 : ntr * (ntr + 1) / 2;
+                if (gather) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask, 0, sup ? 1 : 0);
+                else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, 1, n), dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask, 0, sup ? 1 : 0);
             }
+        };
+        // narrow (schur 0) updates of few workgroups: their K range is cut into slices that run side by side and add their
+        // products with atomics (options "narrow_split": most slices, "narrow_split_wg": most tiles of a launch that is cut)
+        auto narrow_slices = [&](int gx, int n, int K) {
+            if (c->opt.narrow_split <= 1 || (long long)gx * n > c->opt.narrow_split_wg) return 1;
+            return std::max(1, std::min(c->opt.narrow_split, K / 32));
+        };
+        // rows below a diagonal block: launches of few workgroups (what one workgroup takes is what the launch takes) use the
+        // kernel that brings all of S into LDS at once (option "rows_preload_wg": up to that many workgroups per launch)
+        auto launch_rows = [&](int ntiles, int off, int n, int C0_, const double* sw_, int tile_first, hipStream_t st) {
+            if ((long long)ntiles * n <= c->opt.rows_preload_wg)
+                hipLaunchKernelGGL(k_panel_rows_preload, dim3(ntiles, n), dim3(256), PANEL_ROWS_PRELOAD_LDS, st, fd, lev, off, C0_, sw_, tile_first);
+            else
+                hipLaunchKernelGGL(k_panel_rows, dim3(ntiles, n), dim3(256), 0, st, fd, lev, off, C0_, sw_, tile_first);
         };
         // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
         auto count_panel = [&](int C0) {
@@ -683,6 +708,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const int SP = use_sp ? SP_opt : NBO;
         const bool sp_ahead = use_sp && c->opt.super_panel_ahead != 0;
         int sp_bulks = 0;                                // bulk updates of this chunk issued on stream2 so far
+        // Diagonal look-ahead inside a super-panel (option "diag_ahead"): the chain diagonal block -> rows -> narrow update of
+        // the next panel -> next diagonal block is what the top of the tree waits for, but the next diagonal block needs only
+        // the rows of the NEXT panel (two 64-row tiles) and the three tiles of the narrow update that cover it.  Those stay on
+        // the main stream; the other row tiles and the other tiles of the narrow update go to stream_m and run beside the
+        // next diagonal block, whose rows wait for them (ev_da[1]).
+        const bool diag_ahead = use_sp && !sp_ahead && c->opt.diag_ahead && c->stream_m;
+        constexpr int DIAG_TILES = 3, NEXT_ROW_TILES = NBO / TS;
+        bool rest_pending = false;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             const int S0 = C0 / SP * SP;                 // start of this panel's super-panel (== C0 when SP == NBO)
@@ -698,10 +731,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 // fused levels: these pivot columns are touched here for the first time (left-looking: every panel behind
                 // the first; super-panel schedule: the panels of the first super-panel) -- gathered from the children
                 const bool gather_panel = fused_schur && K0 == 0;
+                // diagonal look-ahead: only the tiles of the diagonal block here, the others were issued on stream_m behind the previous rows
+                const int gx = diag_ahead ? std::min(DIAG_TILES, ntr * (NBO / TS)) : ntr * (NBO / TS);
                 if (ntr > 0)
                 FOR_FRONT_CHUNKS(cnt, off, n) {
-                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask);
-                    else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask);
+                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
+                    else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, narrow_slices(gx, n, C0 - K0), n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
                 }
             }
             count_panel(C0);
@@ -743,10 +778,36 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 if (np > C0) rows_below = std::max(rows_below, fr.h_nf[t] - C0 - std::min(NBO, np - C0));
             }
             const int tiles = (rows_below + TS - 1) / TS;
-            if (tiles > 0) {
+            // the rest of this panel's narrow update ran on stream_m: these rows read what it wrote
+            if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_da[1], 0)); rest_pending = false; }
+            // the next panel of the same super-panel takes a narrow update from this one
+            const bool ahead = diag_ahead && C0 + NBO < S0 + SP && C0 + NBO < max_np;
+            const int tiles_main = ahead ? std::min(tiles, NEXT_ROW_TILES) : tiles;
+            if (tiles_main > 0) {
                 ProfScope ps(c, 0);
                 FOR_FRONT_CHUNKS(cnt, off, n)
-                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, n), dim3(256), 0, c->stream, fd, lev, off, C0, sw);
+                    launch_rows(tiles_main, off, n, C0, sw, 0, c->stream);
+            }
+            if (ahead) {
+                HIPCHK(c, hipEventRecord(c->ev_da[0], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream_m, c->ev_da[0], 0));
+                if (tiles > tiles_main) {
+                    ProfScope ps(c, 0, c->stream_m);
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        launch_rows(tiles - tiles_main, off, n, C0, sw, tiles_main, c->stream_m);
+                }
+                const int C1 = C0 + NBO;
+                const int gx = trail_tiles(C1, 0, K0) * (NBO / TS) - DIAG_TILES;
+                if (gx > 0) {
+                    ProfScope ps(c, 2, c->stream_m);
+                    const bool gather_panel = fused_schur && K0 == 0;
+                    FOR_FRONT_CHUNKS(cnt, off, n) {
+                        if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, c->stream_m, fd, lev, off, C1, 0, K0, NBO, mask, DIAG_TILES, 0);
+                        else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, narrow_slices(gx, n, C1 - K0), n), dim3(256), 0, c->stream_m, fd, lev, off, C1, 0, K0, NBO, mask, DIAG_TILES, 0);
+                    }
+                }
+                HIPCHK(c, hipEventRecord(c->ev_da[1], c->stream_m));
+                rest_pending = true;
             }
             if (right_looking && SP > NBO) {
                 if (C0 + NBO >= S0 + SP || C0 + NBO >= max_np) {
@@ -783,14 +844,14 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
                     { ProfScope ps(c, 2);
                       count_trailing(C0, 3);
-                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO, mask); }
+                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO, mask, 0, 0); }
                     const int ntb = trail_tiles(C0, 4);
                     if (ntb > 0) {
                         HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
                           count_trailing(C0, 4);
-                          hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4, 0, NBO, mask); }
+                          hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntb * (ntb + 1) / 2, 1, cnt), dim3(256), 0, c->stream2, fd, lev, 0, C0, 4, 0, NBO, mask, 0, 0); }
                         HIPCHK(c, hipEventRecord(c->ev_la[1], c->stream2));
                         bulk_pending = true;
                     }
@@ -798,6 +859,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
         }
         if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
+        if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_da[1], 0)); rest_pending = false; }
         if (sp_bulks > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sp[(sp_bulks - 1) & 1], 0));     // stream2 runs its launches in order
         if (max_nb > 0 && !right_looking) {
             // Schur complement: one update with all npiv factor columns
@@ -1160,6 +1222,17 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sp[i], hipEventDisableTiming));
     HIPCHK(c, hipStreamCreate(&c->stream3));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
+    {
+        // The diagonal look-ahead (factorize_fronts) runs the bulk of a panel's work on stream_m beside the next diagonal
+        // block, whose one workgroup per front needs a whole CU's LDS: stream_m leaves 32 of the 256 CUs alone (bits whose
+        // index / 8 is a multiple of 8 -- four CUs per XCD if the mask interleaves the XCDs, eight in every other XCD if
+        // it runs through them one after the other), so those workgroups start at once.  Without the mask the schedule
+        // is still correct; the option falls back to the plain super-panel order when the stream cannot be made.
+        uint32_t cumask[8];
+        for (int w = 0; w < 8; ++w) cumask[w] = (w & 1) ? 0xffffffffu : 0xffffff00u;
+        if (hipExtStreamCreateWithCUMask(&c->stream_m, 8, cumask) != hipSuccess) { (void)hipGetLastError(); c->stream_m = nullptr; }
+        for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_da[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < 4; ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     const int nel = c->nel, nvc = c->nvc, npc = c->npc;
     // SoA connectivity
@@ -1333,6 +1406,9 @@ void femo_destroy(femo_ctx* c) {
     }
     for (int i = 0; i < 2; ++i)
         if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_da[i]) hipEventDestroy(c->ev_da[i]);
+    if (c->stream_m) hipStreamDestroy(c->stream_m);
     if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1573,6 +1649,12 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "super_panel") { if (v < 0) return fail(c, "super_panel: a column count (rounded down to whole 128-column panels; < 256 switches it off)"); o.super_panel = v; }
     else if (k == "super_panel_cnt") o.super_panel_cnt = v;
     else if (k == "super_panel_ahead") o.super_panel_ahead = v != 0;
+    else if (k == "diag_ahead") o.diag_ahead = v != 0;
+    else if (k == "rows_preload_wg") o.rows_preload_wg = v;
+    else if (k == "narrow_split") { if (v < 1 || v > 32) return fail(c, "narrow_split: 1..32 slices of the K range"); o.narrow_split = v; }
+    else if (k == "narrow_split_wg") o.narrow_split_wg = v;
+    else if (k == "super_tiles") o.super_tiles = v != 0;
+    else if (k == "super_tiles_min") o.super_tiles_min = v;
     else if (k == "fused_schur") o.fused_schur = v != 0;
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {
@@ -2031,6 +2113,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_panel_rows_preload, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_ROWS_PRELOAD_LDS));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -986,7 +986,7 @@ k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int n
 // S streams from L2 as the A operand, and the product is formed transposed so that the stores run along the
 // columns of the column-major front.
 __global__ void __launch_bounds__(256, 4)      // four waves per SIMD (measured: -15 % against three, 20 B of scratch)
-k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork) {
+k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
     const int slot = first + blockIdx.y;                       // position of the front in its level
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];
@@ -995,7 +995,7 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     const int nf = fd.nf[t];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int tile0 = C0 + kw + blockIdx.x * TS;
+    const int tile0 = C0 + kw + (blockIdx.x + tile_first) * TS;     // tile_first: a launch may take the row tiles from there on only
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.P + fd.poff[t];                             // pivot columns only
@@ -1046,6 +1046,65 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     }
 }
 
+// The same product for levels of few fronts, where a launch lasts as long as ONE workgroup does: k_panel_rows exposes the
+// latency of a load of S from L2 eight times (once per 16 output columns; the products between two loads are too short to
+// cover it).  Here all 36 lower-triangular 16 x 16 blocks of S travel to LDS in one burst (72 KB, two workgroups per CU),
+// and the 144 MFMAs of a wave follow without a barrier or a global load between them.
+constexpr int PANEL_ROWS_PRELOAD_LDS = (NBO / 16) * (NBO / 16 + 1) / 2 * 256 * (int)sizeof(double);
+__global__ void __launch_bounds__(256, 2)
+k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
+    extern __shared__ double sall[];                           // block (cb, kb <= cb) at cb (cb + 1) / 2 + kb: [k][c], 16 x 16
+    const int slot = first + blockIdx.y;
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t];
+    if (C0 >= np) return;
+    const int kw = min(NBO, np - C0);
+    const int nf = fd.nf[t];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int tile0 = C0 + kw + (blockIdx.x + tile_first) * TS;
+    if (tile0 >= nf) return;
+    const int row0 = tile0 + 16 * wv;
+    double* F = fd.P + fd.poff[t];
+    const int ldp = ldp_of(nf);
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
+    const int sc = tid & 15, sk = tid >> 4;                    // this thread's entry of every block: column sc, row sk
+    constexpr int NCB = NBO / 16, NBLK = NCB * (NCB + 1) / 2;
+    const int ncb = (kw + 15) / 16;                            // block rows this panel has (the same S entries k_panel_rows reads)
+    double pre[NBLK];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int kb = 0; kb <= cb; ++kb)
+            pre[cb * (cb + 1) / 2 + kb] = cb < ncb ? S[(16 * cb + sc) + (size_t)lds_ * (16 * kb + sk)] : 0.0;
+    const int row = row0 + l15;
+    const bool rok = row < nf;
+    double a[NBO / 4];
+#pragma unroll
+    for (int kk = 0; kk < NBO / 4; ++kk) {
+        const int k = 4 * kk + l4;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) sall[b * 256 + sk * 16 + sc] = pre[b];
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb >= ncb) break;
+        mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        const double* blk = sall + cb * (cb + 1) / 2 * 256;
+#pragma unroll
+        for (int kk = 0; kk < 4 * cb + 4; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[(kk >> 2) * 256 + (4 * (kk & 3) + l4) * 16 + l15], a[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int c = 16 * cb + l4 + 4 * reg;
+            if (rok && c < kw) F[row + (size_t)ldp * (C0 + c)] = acc[reg];
+        }
+    }
+}
+
 // P2: rank-k update  C[r][c] -= sum_m L[r][m] L[c][m]  of lower-triangle 64x64 tiles with v_mfma_f64_16x16x4_f64.
 // Workgroup = 4 waves = one 64x64 tile of the front; wave w owns the 32x32 quarter (w&1 rows, w>>1 columns) as
 // 2x2 MFMA blocks.  To make the stores run along rows of the column-major front (coalesced), the product is
@@ -1085,7 +1144,7 @@ __device__ __host__ inline TrailRange trail_range(int schur, int C0, int K0, int
 template <bool GATHER>
 __global__ void __launch_bounds__(256, 4)      // 128 registers: four waves per SIMD (measured: -6 % against three)
 k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW,
-                const unsigned char* __restrict__ mask) {
+                const unsigned char* __restrict__ mask, int bx_first, int tile_map) {
     // Which (front, tile) this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in
     // launch order, x fastest; the two or three tiles of a small front read the same rows of its factor panel.  On levels
     // of many fronts (a multiple of 8, at least 256) XCD x therefore takes the fronts x, x + 8, ... whole, tile after tile:
@@ -1100,18 +1159,45 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             zv = (q / G) * 8 + x; bxv = q % G;
         }
     }
+    bxv += bx_first;               // a launch may take the tiles from linear index bx_first on only (diagonal look-ahead)
     const int t = level_nodes[first + zv];
     const int np = fd.npiv[t];
     const int nf = fd.nf[t];
     const TrailRange tr = trail_range(schur, C0, K0, KW, np, nf);
-    const int kc0 = tr.kc0, kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
+    int kc0 = tr.kc0, kw = tr.kw;
+    const int col_lo = tr.col_lo, col_hi = tr.col_hi;
     if (kw <= 0) return;
+    // gridDim.y > 1 (never with GATHER): the K range is cut into that many slices of whole 16-column stages, one workgroup per
+    // slice, and the products are ADDED to C with atomics -- for launches of few tiles at the top of the tree, where the time
+    // of the launch is the time one workgroup needs to walk through its K range
+    const bool ksplit = !GATHER && gridDim.y > 1;
+    if (ksplit) {
+        const int per = (kw + 16 * (int)gridDim.y - 1) / (16 * (int)gridDim.y) * 16;
+        const int lo = (int)blockIdx.y * per;
+        if (lo >= kw) return;
+        kc0 += lo; kw = min(per, kw - lo);
+    }
     // tile from the linear block index: consecutive workgroups go to different XCDs, so a (row tile, column tile)
     // grid whose x extent is a multiple of 8 would pin every row-tile offset to one XCD -- and the lower triangle has
     // 8x more tiles at offset 0 than at offset 7.  The linear order spreads them evenly (measured: up to 2.2x).
     int bx, by;
     if (schur == 0 || schur == 3) {
         by = bxv & 1; bx = bxv >> 1;                               // two column tiles per panel
+    } else if (tile_map == 1) {
+        // Few, large fronts (MFMA-bound levels): what the linear order costs there is L2 misses -- the tiles one XCD gets share
+        // a row block at best, and every tile pulls its 2 x 64 rows of the K panel through that XCD's L2 (measured 2.2-3 x the
+        // compulsory bytes).  Here an XCD takes 4 x 4 super-tiles whole: its workgroups 16 q .. 16 q + 15 (the grid's x extent
+        // is a multiple of 128, so workgroup b of any front lands on XCD b % 8) are the tiles of super-tile 8 q + xcd, which
+        // walk through K side by side and read 8 row blocks of the panel between them instead of 32.
+        const int x = bxv & 7, slot = bxv >> 3;
+        const int st = (slot >> 4) * 8 + x, within = slot & 15;
+        int I = (int)((sqrt(8.0 * st + 1.0) - 1.0) * 0.5);
+        while ((I + 1) * (I + 2) / 2 <= st) ++I;
+        while (I * (I + 1) / 2 > st) --I;
+        const int J = st - I * (I + 1) / 2;
+        const int rt = 4 * I + (within & 3), ct = 4 * J + (within >> 2);
+        if (rt < ct) return;
+        by = ct; bx = rt - ct;
     } else {
         const int lin = bxv;
         int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
@@ -1214,6 +1300,19 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         return cok[a][reg] ? fv.col(cc) : fv.P - (nf - 1);
     };
     double cv[2][2][4];
+    if (ksplit) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = cj + wc + 16 * a + l4 + 4 * reg;
+                    const int r = ri + wr + 16 * b + l15;
+                    if (cok[a][reg] && r < nf && r >= cc) atomicAdd(col_ptr(a, reg) + r, -acc[a][b][reg]);
+                }
+        return;
+    }
     if (!GATHER) {
         double* cp[2][4];
 #pragma unroll
@@ -1836,12 +1935,14 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
     }
     __syncthreads();
     const double x0 = xs[lane], x1 = xs[lane + 64];
+    // the wave's 32 column sums in one butterfly (wave_sum_cols), out in ONE atomic instruction of 32 lanes
+    double p[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        const double sum = wave_sum(a0[k] * x0 + a1[k] * x1);
-        const int c = c0 + 32 * wv + k;
-        if (lane == 0 && c < np) atomicAdd(&out[gd[c]], TRI ? sum : -sum);
-    }
+    for (int k = 0; k < 32; ++k) p[k] = a0[k] * x0 + a1[k] * x1;
+    int col;
+    const double sum = wave_sum_cols<32>(p, lane, col);
+    const int c = c0 + 32 * wv + col;
+    if (!(lane & 1) && c < np) atomicAdd(&out[gd[c]], TRI ? sum : -sum);
 }
 
 // s_p = y_p - L21^T x_B with one workgroup per 16 pivot columns and ALL boundary rows of the front (no atomics, fixed

@@ -85,6 +85,33 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 
+// Column sums of N per-lane values (N = 2 .. 32, a power of two) over the 64 lanes in one butterfly: at every step a lane keeps half of
+// its values and hands the other half to its partner (lane ^ 32, ^ 16, ...), so N - 1 exchanges leave ONE column per group of
+// 64 / N neighbouring lanes, which then add up among themselves.  Returns the sum of column `col` (the same in all lanes of the
+// group; p is clobbered).  N separate wave_sum calls cost 6 N cross-lane steps -- in the transposed products of the
+// triangular sweeps they, not the loads, set the pace (k_sweep_gemv_t with X^T: 25-36 -> 13-18 us per level at 1M DOF).
+template <int N>
+__device__ __forceinline__ double wave_sum_cols(double (&p)[N], int lane, int& col) {
+    static_assert(N >= 2 && N <= 32 && (N & (N - 1)) == 0, "N: a power of two in 2..32");
+    col = 0;
+    int bit = 32;
+#pragma unroll
+    for (int w = N / 2; w >= 1; w >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int i = 0; i < w; ++i) {
+            const double keep = up ? p[i + w] : p[i], send = up ? p[i] : p[i + w];
+            p[i] = keep + __shfl_xor(send, bit);
+        }
+        col += up ? w : 0;
+        bit >>= 1;
+    }
+    double v = p[0];
+#pragma unroll
+    for (int m = 32 / N; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
 // one atomic per block into *slot (slot may be null)
 __device__ __forceinline__ void block_accumulate(double v, double* slot) {
     __shared__ double s_part[16];

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
                 float ms2 = 0;
                 if (tiles > 0) {
                     CK(hipEventRecord(e0));
-                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, Sw);
+                    hipLaunchKernelGGL(k_panel_rows, dim3(tiles, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, Sw, 0);
                     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                     CK(hipEventElapsedTime(&ms2, e0, e1)); tp += ms2;
                 }
@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
             const int nt = (nf - C0 - kw + 1 + TS - 1) / TS;
             if (nt > 0) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, 2, 0, NBO, (const unsigned char*)nullptr);
+                hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(nt * (nt + 1) / 2, 1, nfr), dim3(256), 0, 0, fd, dlev, 0, C0, 2, 0, NBO, (const unsigned char*)nullptr, 0, 0);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt += ms;
                 if (rep == 1) printf("  trailing C0=%4d nt=%3d: %7.1f us\n", C0, nt, ms * 1e3);

@@ -1,5 +1,5 @@
 """Per-level times of one preconditioner application (forward and backward sweep, both launches of the wide levels) with the
-factor bytes each level reads: where the application is below the HBM roof.   python scripts/r3_sweeps.py [wing1m]"""
+factor bytes each level reads: where the application is below the HBM roof.   python scripts/r3_sweeps.py [wing1m] [key=value ...]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,12 +8,16 @@ from bench import make_workload
 from femo_alpha_amd.backend import ShellContext
 
 which = sys.argv[1] if len(sys.argv) > 1 else "wing1m"
+opts = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[2:]}
 m, fields, marker, desc = make_workload(which)
 c = ShellContext(m)
 for k, v in fields.items():
     c.set_field(k, v)
 c.set_penalty_facets(m.penalty_facets(marker))
 plan = c.enable_frontal(12)
+for k, v in opts.items():
+    c.set_option(k, v)
+print("options", opts)
 c.set_solver(preconditioner=2, rtol=1e-10, maxit=30, check_every=1)
 c.factorize()
 t = np.min([c.sweep_profile(detail=True) for _ in range(5)], axis=0)

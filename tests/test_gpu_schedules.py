@@ -45,7 +45,7 @@ def test_random_schedules_give_the_same_solution(case, seed):
     for _ in range(8):
         post = dict(trailing=int(rng.integers(0, 3)), left_min=int(rng.choice([1, 8, 64, 4096])), left_max=int(rng.choice([16, 2048, 100000])),
                     super_panel=int(rng.choice([0, 200, 256, 384, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
-                    super_panel_ahead=int(rng.integers(0, 2)), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
+                    super_panel_ahead=int(rng.integers(0, 2)), diag_ahead=int(rng.integers(0, 2)), rows_preload_wg=int(rng.choice([0, 64, 100000])), narrow_split=int(rng.choice([1, 3, 4, 8])), narrow_split_wg=int(rng.choice([8, 1024, 100000])), super_tiles=int(rng.integers(0, 2)), super_tiles_min=int(rng.choice([1, 3, 8])), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
                     fused_schur=int(rng.integers(0, 2)), diag_v1=int(rng.integers(0, 3)), big_tiles=int(rng.integers(0, 2)), big_min_wg=int(rng.choice([1, 64, 512])), grid_chunk=int(rng.choice([3, 17, 65535])), xinv_small_cnt=int(rng.choice([0, 32, 100000])))
         pre = dict(wide_cnt=int(rng.choice([0, 8, 512, 100000])), wide_np=int(rng.choice([64, 512])), swork_slots=int(rng.choice([2, 100, 8192])))
         leaf = int(rng.choice([4, 8, 12, 20]))
@@ -67,3 +67,24 @@ def test_super_panel_between_multiples_of_the_outer_panel(sp):
     assert it <= it0 + 1
     assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
     assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
+
+
+@pytest.mark.parametrize("sp,fused,case", [(256, 0, "plate"), (512, 1, "plate"), (384, 1, "wing_strong"), (512, 0, "wing_strong")])
+def test_diagonal_look_ahead_inside_super_panels(sp, fused, case):
+    """Option "diag_ahead": inside a super-panel only the two row tiles and three update tiles the next diagonal block needs stay
+    on the main stream, the rest runs on a second stream beside that block.  Every level is forced onto the super-panel
+    schedule here (all fronts of more than one panel go through the split), and with the look-ahead on the rows take the
+    kernel that preloads S and the narrow updates are cut into four K slices; same factor as the plain schedule."""
+    if case == "plate":
+        m, marker, strong = plate_mesh(2.0, 5.0, 64, 64), (lambda x: np.less(x[0], 3e-16)), False
+    else:
+        m, marker, strong = wing_skin_mesh(32, 96, shuffle=True).renumbered()[0], (lambda x: np.less(x[1], 1e-9)), True
+    it0, w0, g0 = _solve(m, marker, strong, 8, {}, dict(super_panel=0, fused_schur=0, lookahead=0))
+    res = {}
+    for da in (0, 1):
+        res[da] = _solve(m, marker, strong, 8, {}, dict(trailing=2, super_panel=sp, super_panel_cnt=100000, fused_schur=fused, lookahead=0, diag_ahead=da, rows_preload_wg=100000 * da, narrow_split=1 + 3 * da, narrow_split_wg=100000))
+        it, w, g = res[da]
+        assert it <= it0 + 1
+        assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
+        assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-10 * np.abs(w0).max()
