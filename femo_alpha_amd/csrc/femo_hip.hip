@@ -127,6 +127,7 @@ struct femo_ctx {
         // backward sweep, L21^T x: levels whose largest boundary has at least this many rows take the tiled (atomic) kernel.
         // Measured at 1M DOF: one workgroup per 32 columns wins on every level (43-57 us against 49-115), so the default is never
         int bnd_tiled_nb = 1 << 30;
+        int sweep_butterfly = 3;              // backward sweep column sums in one butterfly: bit 0 k_front_bwd_small, bit 1 k_sweep_bnd_cols
     } opt;
     // solver
     int precond = 0;
@@ -1005,8 +1006,12 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
                         hipLaunchKernelGGL(k_sweep_gemv_t<false>, dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
                 } else {
                     FOR_FRONT_CHUNKS(cnt, off, n)
-                        hipLaunchKernelGGL(k_sweep_bnd_cols, dim3((maxnp + BB_COLS - 1) / BB_COLS, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream,
-                                           fd, lev, off, y, (const double*)v);
+                        if (c->opt.sweep_butterfly & 2)
+                            hipLaunchKernelGGL(k_sweep_bnd_cols<true>, dim3((maxnp + BB_COLS - 1) / BB_COLS, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream,
+                                               fd, lev, off, y, (const double*)v);
+                        else
+                            hipLaunchKernelGGL(k_sweep_bnd_cols<false>, dim3((maxnp + BB_COLS - 1) / BB_COLS, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream,
+                                               fd, lev, off, y, (const double*)v);
                 }
             }
             mark();
@@ -1014,7 +1019,8 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
                 hipLaunchKernelGGL(k_sweep_gemv_t<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)y, v);
         } else {
             const size_t shm = (size_t)(maxnp + maxnb + SMALL_PART) * sizeof(double);
-            hipLaunchKernelGGL(k_front_bwd_small, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
+            if (c->opt.sweep_butterfly & 1) hipLaunchKernelGGL(k_front_bwd_small<true>, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
+            else hipLaunchKernelGGL(k_front_bwd_small<false>, dim3(cnt), dim3(256), shm, c->stream, fd, lev, y, v);
             mark();
         }
         mark();
@@ -1671,6 +1677,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "diag_v1") { if (v < 0 || v > 2) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel"); o.diag_v1 = v; }
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
+    else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
     else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;
     else return fail(c, "unknown option '" + k + "'");
@@ -2108,8 +2115,10 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     if ((size_t)max_sweep * sizeof(double) > 48 * 1024) {
         const int bytes = (int)(max_sweep * sizeof(double));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_fwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));

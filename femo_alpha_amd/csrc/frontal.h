@@ -1706,12 +1706,14 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
             const int r = rb + rs;
             const double* row = F + np + min(r, nb - 1);
             double s = 0.0;
-            for (int cb = cbeg; cb < cend; cb += 16) {
-                double a[16];
+            // 32 loads in flight per thread: on the levels that fit the chip in one round of workgroups the sweep lasts as long as one
+            // workgroup's chain of dependent load rounds does
+            for (int cb = cbeg; cb < cend; cb += 32) {
+                double a[32];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) a[q] = cb + q < cend ? row[(size_t)ldp * (cb + q)] : 0.0;
+                for (int q = 0; q < 32; ++q) a[q] = cb + q < cend ? row[(size_t)ldp * (cb + q)] : 0.0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) s += a[q] * y[min(cb + q, np - 1)];
+                for (int q = 0; q < 32; ++q) s += a[q] * y[min(cb + q, np - 1)];
             }
             if (G > 1) {
                 if (g) part[slots * (g - 1) + rs] = s;
@@ -1726,6 +1728,7 @@ k_front_fwd_small(FrontDev fd, const int* __restrict__ level_nodes, double* __re
 }
 
 // backward: x_p = L11^-T (y_p - L21^T x_B)
+template <bool BFLY>
 __global__ void __launch_bounds__(256, 4)
 k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.x];
@@ -1762,10 +1765,16 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
                     for (int q = 0; q < 8; ++q) s[q] += a[q][u] * xr;
                 }
             }
+            if (BFLY) {
+                int q;
+                const double tot = wave_sum_cols<8>(s, lane, q);
+                if (!(lane & 7) && cb + q < np) x[cb + q] -= tot;            // a column belongs to one wave
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double tot = wave_sum(s[q]);
-                if (lane == 0 && cb + q < np) x[cb + q] -= tot;              // a column belongs to one wave
+                for (int q = 0; q < 8; ++q) {
+                    const double tot = wave_sum(s[q]);
+                    if (lane == 0 && cb + q < np) x[cb + q] -= tot;
+                }
             }
         }
         __syncthreads();
@@ -1795,10 +1804,16 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
                     for (int q = 0; q < 8; ++q) s[q] += a[q][u] * xr;
                 }
             }
+            if (BFLY) {
+                int q;
+                const double tot = wave_sum_cols<8>(s, lane, q);
+                if (!(lane & 7) && cb + q < wb) x[c0 + cb + q] -= tot;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double tot = wave_sum(s[q]);
-                if (lane == 0 && cb + q < wb) x[c0 + cb + q] -= tot;
+                for (int q = 0; q < 8; ++q) {
+                    const double tot = wave_sum(s[q]);
+                    if (lane == 0 && cb + q < wb) x[c0 + cb + q] -= tot;
+                }
             }
             __syncthreads();
         }
@@ -1861,16 +1876,19 @@ k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
     const int ld = TRI ? ldx_of(np) : ldp_of(nf);
     const double* M = TRI ? fd.X + fd.xoff[t] : fd.P + fd.poff[t] + np;       // L21 starts at row np of the pivot columns
     const int nrows = TRI ? np : nf - np;
-    const int r0 = 128 * ti, c0 = 128 * tj;
+    // L21: the pivot columns are dealt evenly over the front's column tiles (np = 210: 106 + 104 columns, not 128 + 82 -- a
+    // workgroup lasts as long as its longest thread); X keeps square tiles, its triangle is enumerated that way
+    const int cw = TRI ? 128 : ((np + nct - 1) / nct + 1) & ~1, hw = cw / 2;
+    const int r0 = 128 * ti, c0 = cw * tj;
     __shared__ double xs[128];
     __shared__ double part[128];
     const int tid = threadIdx.x, lr = tid & 127, ch = tid >> 7;
-    if (tid < 128) xs[tid] = (c0 + tid < np) ? in[gd[c0 + tid]] : 0.0;
+    if (tid < 128) xs[tid] = (tid < cw && c0 + tid < np) ? in[gd[c0 + tid]] : 0.0;
     const int r = r0 + lr;
-    const double* row = M + r + (size_t)ld * (c0 + 64 * ch);
+    const double* row = M + r + (size_t)ld * (c0 + hw * ch);
     // triangular tiles on the diagonal: only columns <= row
-    const int cmax = min(np - c0 - 64 * ch, 64);             // columns of this half inside the pivot block
-    const int clim = (TRI && ti == tj) ? min(cmax, lr - 64 * ch + 1) : cmax;
+    const int cmax = min(np - c0 - hw * ch, hw);             // columns of this half inside the pivot block
+    const int clim = (TRI && ti == tj) ? min(cmax, lr - hw * ch + 1) : cmax;
     double a[32];
     double s = 0.0;
     __syncthreads();
@@ -1879,7 +1897,7 @@ k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
 #pragma unroll
         for (int k = 0; k < 32; ++k) a[k] = (r < nrows && 32 * h + k < clim) ? row[(size_t)ld * (32 * h + k)] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += a[k] * xs[64 * ch + 32 * h + k];
+        for (int k = 0; k < 32; ++k) s += a[k] * xs[hw * ch + 32 * h + k];              // hw <= 64: inside xs
     }
     if (ch) part[lr] = s;
     __syncthreads();
@@ -1949,6 +1967,7 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
 // summation order): the better shape for the many medium fronts of the middle levels, where a front's L21 is a few
 // hundred rows; the tiled kernel above takes over where one workgroup per 32 columns could not pull the block out of HBM.
 constexpr int BB_COLS = 16;
+template <bool BFLY>
 __global__ void __launch_bounds__(256)
 k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, double* __restrict__ sv, const double* __restrict__ xv) {
     const int t = level_nodes[first + blockIdx.y];
@@ -1983,10 +2002,16 @@ k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, do
             for (int k = 0; k < 4; ++k) s[k] += a[k][u] * xr;
         }
     }
+    if (BFLY) {
+        int k;
+        const double tot = wave_sum_cols<4>(s, lane, k);
+        if (!(lane & 15) && cb + k < np) sv[gd[cb + k]] -= tot;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double tot = wave_sum(s[k]);
-        if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
+        for (int k = 0; k < 4; ++k) {
+            const double tot = wave_sum(s[k]);
+            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
+        }
     }
 }
 

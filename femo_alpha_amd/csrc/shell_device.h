@@ -85,30 +85,57 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 
-// Column sums of N per-lane values (N = 2 .. 32, a power of two) over the 64 lanes in one butterfly: at every step a lane keeps half of
-// its values and hands the other half to its partner (lane ^ 32, ^ 16, ...), so N - 1 exchanges leave ONE column per group of
-// 64 / N neighbouring lanes, which then add up among themselves.  Returns the sum of column `col` (the same in all lanes of the
-// group; p is clobbered).  N separate wave_sum calls cost 6 N cross-lane steps -- in the transposed products of the
+// Column sums of N per-lane values (N = 4, 8, 16 or 32) over the 64 lanes in one butterfly: at every step a lane keeps half of its
+// values and hands the other half to a partner in the other half of the wave / row pair / row / ..., so N - 1 exchanges
+// leave ONE column per group of 64 / N neighbouring lanes, which then add up among themselves.  All on the vector ALU: the two
+// widest steps are gfx950's v_permlane32_swap / v_permlane16_swap (the swap puts both halves of a column's sum into the
+// same lane: no select), the steps inside a row of 16 lanes are DPP moves.  Returns the sum of column `col` (the same in all
+// lanes of the group; p is clobbered).  N separate wave_sum calls cost 25 N instructions -- in the transposed products of the
 // triangular sweeps they, not the loads, set the pace (k_sweep_gemv_t with X^T: 25-36 -> 13-18 us per level at 1M DOF).
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// a: lanes 32-63 <-> b: lanes 0-31.  Afterwards a = [a.lower | b.lower], b = [a.upper | b.upper]
+__device__ __forceinline__ void permlane32_swap(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// odd rows (of 16 lanes) of a <-> even rows of b.  Afterwards a = [a.r0, b.r0, a.r2, b.r2], b = [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ void permlane16_swap(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// one butterfly step inside a row: the partner (DPP pattern CTRL, an involution that flips the lane bit `up` tests) gets the W
+// values this lane does not keep
+template <int CTRL, int W, int N>
+__device__ __forceinline__ void dpp_halve(double (&p)[N], bool up) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        const double keep = up ? p[i + W] : p[i], send = up ? p[i] : p[i + W];
+        p[i] = keep + dpp_get<CTRL>(send);
+    }
+}
 template <int N>
 __device__ __forceinline__ double wave_sum_cols(double (&p)[N], int lane, int& col) {
-    static_assert(N >= 2 && N <= 32 && (N & (N - 1)) == 0, "N: a power of two in 2..32");
-    col = 0;
-    int bit = 32;
+    static_assert(N == 4 || N == 8 || N == 16 || N == 32, "N: 4, 8, 16 or 32");
 #pragma unroll
-    for (int w = N / 2; w >= 1; w >>= 1) {
-        const bool up = (lane & bit) != 0;
+    for (int i = 0; i < N / 2; ++i) { permlane32_swap(p[i], p[i + N / 2]); p[i] += p[i + N / 2]; }
+    col = (lane & 32) ? N / 2 : 0;
 #pragma unroll
-        for (int i = 0; i < w; ++i) {
-            const double keep = up ? p[i + w] : p[i], send = up ? p[i] : p[i + w];
-            p[i] = keep + __shfl_xor(send, bit);
-        }
-        col += up ? w : 0;
-        bit >>= 1;
-    }
-    double v = p[0];
-#pragma unroll
-    for (int m = 32 / N; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    for (int i = 0; i < N / 4; ++i) { permlane16_swap(p[i], p[i + N / 4]); p[i] += p[i + N / 4]; }
+    col += (lane & 16) ? N / 4 : 0;
+    if constexpr (N >= 8)  { dpp_halve<0x140, N / 8>(p, (lane & 8) != 0);  col += (lane & 8) ? N / 8 : 0; }     // row_mirror
+    if constexpr (N >= 16) { dpp_halve<0x141, N / 16>(p, (lane & 4) != 0); col += (lane & 4) ? N / 16 : 0; }    // row_half_mirror
+    if constexpr (N >= 32) { dpp_halve<0x4E, 1>(p, (lane & 2) != 0);       col += (lane & 2) ? 1 : 0; }         // quad_perm [2,3,0,1]
+    double v = dpp_add<0xB1>(p[0]);
+    if constexpr (N <= 16) v = dpp_add<0x4E>(v);
+    if constexpr (N <= 8) v = dpp_add<0x141>(v);
+    if constexpr (N <= 4) v = dpp_add<0x140>(v);
     return v;
 }
 

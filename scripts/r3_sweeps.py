@@ -14,9 +14,11 @@ c = ShellContext(m)
 for k, v in fields.items():
     c.set_field(k, v)
 c.set_penalty_facets(m.penalty_facets(marker))
-plan = c.enable_frontal(12)
+pre = {k: v for k, v in opts.items() if k in ("wide_np", "wide_cnt", "swork_slots")}
+plan = c.enable_frontal(12, **pre)
 for k, v in opts.items():
-    c.set_option(k, v)
+    if k not in pre:
+        c.set_option(k, v)
 print("options", opts)
 c.set_solver(preconditioner=2, rtol=1e-10, maxit=30, check_every=1)
 c.factorize()
@@ -30,4 +32,6 @@ for L in range(plan.nlevels):
     tot_b += by
     f, b = t[L, 0] + t[L, 1], t[L, 2] + t[L, 3]
     print(f"{L:5d} {len(ts):5d} {int(npv.max()):7d} {int((nf - npv).max()):7d} {by / 1e6:10.1f} | {t[L,0]*1e3:6.1f} {t[L,1]*1e3:6.1f} | {t[L,2]*1e3:6.1f} {t[L,3]*1e3:6.1f}      | {by / f / 1e6:8.0f} {by / b / 1e6:8.0f}")
+ts = [c.factorize()["factor_ms"] for _ in range(4)]
+print("factor_ms:", " ".join(f"{x:.2f}" for x in ts))
 print(f"total: forward {t[:, :2].sum():.3f} ms, backward {t[:, 2:].sum():.3f} ms, factor {tot_b / 1e9:.2f} GB per sweep -> {2 * tot_b / t.sum() / 1e6:.0f} GB/s")
