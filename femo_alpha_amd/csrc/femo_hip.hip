@@ -35,6 +35,7 @@ struct femo_ctx {
     hipStream_t stream = nullptr;
     int krylov = 0;                          // 0: conjugate gradients, 1: BiCGStab (femo_set_krylov)
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
+    int tab_nq = 0;                          // quadrature points of the operator's tables (c->tab)
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
@@ -332,6 +333,18 @@ static FacetDev facet_dev(const femo_ctx* c) {
             else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
         }                                                                                                     \
     } while (0)
+// the same with dynamic LDS (kernels that stage their quadrature points: stage_qpoints)
+#define ELEM_LAUNCH_S(c, KERNEL, EXTRA, grid, block, shm, ...)                                                \
+    do {                                                                                                      \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+    } while (0)
+#define QPOINT_LDS(c) ((size_t)(c)->tab_nq * ((c)->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>)))
 #define NOEXTRA
 #define COMMA_H , DERIV_H
 #define COMMA_E , DERIV_E
@@ -551,11 +564,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         if (refresh_penalty(c)) return 1;
         { ProfScope ps(c, 4);
         if (c->op_aM != 0.0)
-            ELEM_LAUNCH(c, k_front_assemble, COMMA_TRUE, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
-                        fr.elem_map, mask);
+            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_TRUE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+                          fr.elem_map, mask);
         else
-            ELEM_LAUNCH(c, k_front_assemble, COMMA_FALSE, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
-                        fr.elem_map, mask); }
+            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_FALSE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+                          fr.elem_map, mask); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
                                fr.elem_map, c->ld, c->npc, c->nvc, mask);
@@ -1317,6 +1330,7 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     build_tables(c->quad, nquad, T);
     HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    c->tab_nq = T.nq;
     Tables TS_;
     build_tables(c->quad, 3, TS_);               // quadrature_degree 4 (rm_shell_model.py:200-201)
     HIPCHK(c, hipMalloc((void**)&c->tab_s, sizeof(Tables)));
@@ -1627,7 +1641,7 @@ int femo_element_matrices(femo_ctx* c, int32_t first, int32_t count, double* Ke)
     double* d = nullptr;
     const size_t bytes = (size_t)count * c->ld * c->ld * sizeof(double);
     HIPCHK(c, hipMalloc((void**)&d, bytes));
-    ELEM_LAUNCH(c, k_element_matrices, NOEXTRA, count, 64, mesh_dev(c), fields_dev(c), c->tab, first, count, d);
+    ELEM_LAUNCH_S(c, k_element_matrices, NOEXTRA, count, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, first, count, d);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(Ke, d, bytes, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -2522,6 +2536,7 @@ int femo_set_strain_quadrature(femo_ctx* c, int32_t nred) {
     Tables T;
     build_tables(true, c->nquad, T, nred);
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    c->tab_nq = T.nq;
     c->nred = nred; operator_changed(c);
     return 0;
 }
@@ -2973,7 +2988,7 @@ int femo_assemble_csr(femo_ctx* c, double* vals, double* ms2) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->csr_perm) return fail(c, "call femo_set_csr_map first");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    ELEM_LAUNCH(c, k_element_matrices, NOEXTRA, c->nel, 64, mesh_dev(c), fields_dev(c), c->tab, 0, c->nel, c->csr_ke);
+    ELEM_LAUNCH_S(c, k_element_matrices, NOEXTRA, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, 0, c->nel, c->csr_ke);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemsetAsync(c->csr_vals, 0, (size_t)c->csr_nnz * sizeof(double), c->stream));
     hipLaunchKernelGGL(k_csr_segmented, dim3((unsigned)((c->csr_ncontrib + 255) / 256)), dim3(256), 0, c->stream, c->csr_ncontrib,

@@ -80,15 +80,20 @@ __device__ __host__ inline int ldx_of(int np) { return (np + SPD - 1) / SPD * SP
 // one wave per element; lane j evaluates column j of K_e (operator applied to e_j) and adds its
 // lower-triangle entries into the element's leaf front.  Masked (strong-BC) rows/columns are skipped.
 template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64)          // 239 registers, two waves per SIMD; capped at 167 (three waves, 52 B of scratch): 1.33 against 1.07 ms
 k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double aK, double aM, FrontDev fd,
                  const int* __restrict__ elem_front, const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x;
     const int j = threadIdx.x;
-    if (e >= m.nel || j >= LD) return;
+    if (e >= m.nel) return;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    // the quadrature-point data all lanes share: computed once, by lane q for point q, and parked in LDS (stage_qpoints)
+    extern __shared__ double sq_raw[];
+    QPoint<NPC, NVC>* sq = reinterpret_cast<QPoint<NPC, NVC>*>(sq_raw);
+    stage_qpoints<NPC, NVC, QUAD, UHAT>(tab, el, aK, j, 64, sq);
+    if (j >= LD) return;
     double ye[LD];
 #pragma unroll
     for (int i = 0; i < LD; ++i) ye[i] = 0.0;
@@ -98,19 +103,11 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
     const int cj = j - 3 * (is_u ? aj : NPC + aj);
     const int nq = tab->nq;
     for (int q = 0; q < nq; ++q) {
-        QPG g;
-        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
-        double d[NPC][2], mm[NVC][2];
-        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
-        Mat mat, ex;
-        const double hq = interp<NVC>(tab->N1[q], el.hn);
-        material<DERIV_NONE>(hq, interp<NVC>(tab->N1[q], el.En),
-                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
-        mat.cm *= aK; mat.cb *= aK; mat.cs *= aK; mat.cd *= aK;
+        const QPoint<NPC, NVC>& p = sq[q];
         // strains of e_j without the 39-entry reduction: the reduced vectors are scalar multiples of one unit vector;
         // the lane reads its own node's table row (a per-lane index into d[][] would send the array to scratch)
         const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
-        const double dk0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], dk1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double dk0 = r0 * p.g.Q[0][0] + r1 * p.g.Q[1][0], dk1 = r0 * p.g.Q[0][1] + r1 * p.g.Q[1][1];
         const double Mj = is_u ? 0.0 : tab->N1[q][aj];
         double G0[3], G1[3], th[3], T0[3], T1[3];
 #pragma unroll
@@ -122,16 +119,16 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
             T0[c] = is_u ? 0.0 : dk0 * ec;
             T1[c] = is_u ? 0.0 : dk1 * ec;
         }
-        const Gen s = strains_reduced(g, G0, G1, th, T0, T1);
-        const Gen t = stress_of(s, mat);
-        strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+        const Gen s = strains_reduced(p.g, G0, G1, th, T0, T1);
+        const Gen t = stress_of(s, p.mat);
+        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->N1[q], t, ye);
         if (MASS) {            // compiled out of the static operator: keeps its register budget
             double rq = 0.0;
             for (int b = 0; b < NVC; ++b) rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
             double xe[LD];
 #pragma unroll
             for (int i = 0; i < LD; ++i) xe[i] = (i == j) ? 1.0 : 0.0;
-            mass_qp<NPC, NVC>(*tab, q, aM * rq * hq * tab->w[q] * g.det * g.Ju, el.hK, xe, ye);
+            mass_qp<NPC, NVC>(*tab, q, aM * rq * p.hq * tab->w[q] * p.g.det * p.g.Ju, el.hK, xe, ye);
         }
     }
     const int t = elem_front[e];

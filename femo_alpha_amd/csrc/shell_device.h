@@ -488,6 +488,36 @@ __device__ __forceinline__ double interp(const double* M, const double* v) {
     return r;
 }
 
+// What every lane of a wave that forms ONE element's matrix needs at a quadrature point -- local frame, derivative map,
+// the local derivatives of all shape functions, the constitutive coefficients -- is the same for the 39 lanes: there is no
+// scalar fp64 unit to compute it once, so the lanes used to compute it 39 times over (two square roots and seven divisions
+// among it: about half of the kernel's instructions).  Here lane q computes point q ONCE, all points side by side, and parks
+// it in LDS; the column loop reads it back as broadcast operands.
+template <int NPC, int NVC>
+struct QPoint {
+    QPG g;
+    Mat mat;
+    double d[NPC][2], mm[NVC][2];
+    double hq;
+};
+template <int NPC, int NVC, bool QUAD, bool UHAT>
+__device__ __forceinline__ void stage_qpoints(const Tables* __restrict__ tab, const Elem<NPC, NVC>& el, double aK, int lane, int nlanes,
+                                              QPoint<NPC, NVC>* sq) {
+    const int nq = tab->nq;
+    for (int q = lane; q < nq; q += nlanes) {
+        QPoint<NPC, NVC> p;
+        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], p.g);
+        local_derivs<NPC, NVC>(*tab, q, p.g.Q, p.d, p.mm);
+        Mat ex;
+        p.hq = interp<NVC>(tab->N1[q], el.hn);
+        material<DERIV_NONE>(p.hq, interp<NVC>(tab->N1[q], el.En), interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * p.g.det,
+                             tab->w[q] * p.g.det, p.g.Ju, p.mat, ex);
+        p.mat.cm *= aK; p.mat.cb *= aK; p.mat.cs *= aK; p.mat.cd *= aK;
+        sq[q] = p;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------ kernels
 // register-lean variants for the production operator: local derivatives are recomputed from the
 // (scalar-cached) tables where they are used instead of being kept in 26 register pairs
@@ -1202,35 +1232,32 @@ k_dRdf_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* _
 // dense element matrices, one wave per element: K_e[i][j] = sum_q B_i^T C B_j
 // Column j of K_e is the operator applied to the unit vector e_j, so lanes own columns.
 template <int NPC, int NVC, bool QUAD, bool UHAT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64)          // 238 registers, two waves per SIMD (three: 1.05 against 0.95 ms; four: 3.4 ms, 212 B of scratch)
 k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int first, int count, double* __restrict__ Ke) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int le = blockIdx.x;
     if (le >= count) return;
     const int e = first + le;
     const int j = threadIdx.x;
-    if (j >= LD) return;
     Elem<NPC, NVC> el;
     load_elem<NPC, NVC, UHAT>(m, f, e, el);
+    extern __shared__ double sq_raw[];
+    QPoint<NPC, NVC>* sq = reinterpret_cast<QPoint<NPC, NVC>*>(sq_raw);     // nq points (stage_qpoints)
+    stage_qpoints<NPC, NVC, QUAD, UHAT>(tab, el, 1.0, j, 64, sq);
+    if (j >= LD) return;
     double ye[LD];
 #pragma unroll
     for (int i = 0; i < LD; ++i) ye[i] = 0.0;
     // the lane's unit vector e_j: displacement component cj of P2 node aj, or rotation component cj of vertex aj -- its strains
-    // without the 39-entry reduction (as k_front_assemble does: 2.03 -> see profiles/r3_csr_wing1m.txt)
+    // without the 39-entry reduction (as k_front_assemble does)
     const bool is_u = j < 3 * NPC;
     const int aj = is_u ? j / 3 : (j - 3 * NPC) / 3;
     const int cj = j - 3 * (is_u ? aj : NPC + aj);
     const int nq = tab->nq;
     for (int q = 0; q < nq; ++q) {
-        QPG g;
-        qp_geometry<NVC, QUAD, UHAT>(el.X, el.Uh, tab->N1[q], tab->dN1[q], g);
-        double d[NPC][2], mm[NVC][2];
-        local_derivs<NPC, NVC>(*tab, q, g.Q, d, mm);
-        Mat mat, ex;
-        material<DERIV_NONE>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
-                             interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
+        const QPoint<NPC, NVC>& p = sq[q];
         const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
-        const double dk0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], dk1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
+        const double dk0 = r0 * p.g.Q[0][0] + r1 * p.g.Q[1][0], dk1 = r0 * p.g.Q[0][1] + r1 * p.g.Q[1][1];
         const double Mj = is_u ? 0.0 : tab->N1[q][aj];
         double G0[3], G1[3], th[3], T0[3], T1[3];
 #pragma unroll
@@ -1242,9 +1269,9 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
             T0[c] = is_u ? 0.0 : dk0 * ec;
             T1[c] = is_u ? 0.0 : dk1 * ec;
         }
-        const Gen s = strains_reduced(g, G0, G1, th, T0, T1);
-        const Gen t = stress_of(s, mat);
-        strains_T<NPC, NVC>(g, d, mm, tab->N1[q], t, ye);
+        const Gen s = strains_reduced(p.g, G0, G1, th, T0, T1);
+        const Gen t = stress_of(s, p.mat);
+        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->N1[q], t, ye);
     }
     double* out = Ke + (size_t)le * LD * LD;
 #pragma unroll

@@ -4,7 +4,10 @@ from femo_alpha_amd.mesh import plate_mesh, wing_skin_mesh
 from femo_alpha_amd.backend import ShellContext
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 m = plate_mesh(2, 10, 58, 290) if which == "c2" else wing_skin_mesh(116, 580)
-c = ShellContext(m); c.set_field("thickness", [0.05]); c.set_field("E", [1e9]); c.set_field("nu", [0.3])
+c = ShellContext(m)
+for a in sys.argv[2:]:                       # schedule options, key=value
+    c.set_option(a.split("=")[0], float(a.split("=")[1]))
+c.set_field("thickness", [0.05]); c.set_field("E", [1e9]); c.set_field("nu", [0.3])
 t = time.time(); info = c.enable_csr(); print(f"device map (radix sort of the contributions, once per mesh): {time.time()-t:.2f}s nnz={info['nnz']} contributions={m.nel * m.ldof ** 2}", flush=True)
 for r in range(3):
     t = time.time(); K = c.assemble_csr(); dt = time.time() - t
