@@ -2991,7 +2991,7 @@ int femo_assemble_csr(femo_ctx* c, double* vals, double* ms2) {
     ELEM_LAUNCH_S(c, k_element_matrices, NOEXTRA, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, 0, c->nel, c->csr_ke);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemsetAsync(c->csr_vals, 0, (size_t)c->csr_nnz * sizeof(double), c->stream));
-    hipLaunchKernelGGL(k_csr_segmented, dim3((unsigned)((c->csr_ncontrib + 255) / 256)), dim3(256), 0, c->stream, c->csr_ncontrib,
+    hipLaunchKernelGGL(k_csr_segmented, dim3((unsigned)((c->csr_ncontrib + 256 * CSR_R - 1) / (256 * CSR_R))), dim3(256), 0, c->stream, c->csr_ncontrib,
                        c->csr_perm, c->csr_dest, c->csr_ke, c->csr_vals);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
