@@ -39,6 +39,8 @@ struct femo_ctx {
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
+    hipStream_t stream_g = nullptr;          // second stream of the levels whose fronts are dealt to two streams (option "split_cnt")
+    hipEvent_t ev_g[2] = {nullptr, nullptr};
     hipStream_t stream_m = nullptr;          // diagonal look-ahead: a stream that may not use the CUs reserved for the diagonal blocks
     hipEvent_t ev_da[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;           // L11^-1 of a finished level is formed beside the factorisation of the next ones
@@ -109,6 +111,7 @@ struct femo_ctx {
         int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
         int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
         int narrow_split = 1, narrow_split_wg = 1024;
+        int split_cnt = 0, split_groups = 2;        // levels of 2..split_cnt fronts: dealt to two streams in split_groups groups (off: no gain measured)
         int super_tiles = 0, super_tiles_min = 8;   // rank-k updates of few large fronts: 4 x 4 super-tiles per XCD from this many 64-row tiles
         int diag_ahead = 0;                   // super-panel levels: the next diagonal block runs beside the rest of this panel's rows and updates
         int fused_schur = 1;          // left-looking levels: the Schur update gathers its block from the children
@@ -614,8 +617,24 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const int* lev_level = lev;
         // the other levels park the inverse of a diagonal block in Swork between k_diag_block and k_panel_rows, one 128 x 128
         // slot per front: levels with more fronts than Swork has slots are factorised in chunks of that many fronts
-        const int chunk_cap = wide ? cnt_level : std::min(cnt_level, fr.swork_slots);
+        // Levels of a handful of large fronts (option "split_cnt": at most that many, at least two): the fronts are dealt to TWO streams in
+        // "split_groups" contiguous groups (fronts are sorted by size: groups alternate between the streams).  Each stream runs the whole
+        // chain of its groups -- while one is inside a diagonal block (one workgroup per front: the chip is empty), the other's rows
+        // and rank-k updates fill it.  Only wide levels (their diagonal-block inverses go to X, not to the shared Swork slots), and
+        // not with the schedules that use the second stream themselves.
+        const bool level_right = c->opt.trailing == 2 ? true : c->opt.trailing == 1 ? false : (cnt_level < c->opt.left_min || cnt_level > c->opt.left_max);
+        const bool level_sp = level_right && SP_opt > NBO && cnt_level <= c->opt.super_panel_cnt && max_np_level > NBO;
+        const bool level_la = level_right && !level_sp && cnt_level < c->opt.lookahead_cnt && c->opt.lookahead != 0;
+        const bool split = wide && c->stream_g && cnt_level >= 2 && cnt_level <= c->opt.split_cnt && !level_la &&
+                           !(level_sp && (c->opt.super_panel_ahead || c->opt.diag_ahead));
+        const int ngroups = split ? std::max(2, std::min(cnt_level, c->opt.split_groups)) : 1;
+        const int chunk_cap = split ? (cnt_level + ngroups - 1) / ngroups : wide ? cnt_level : std::min(cnt_level, fr.swork_slots);
+        if (split) {
+            HIPCHK(c, hipEventRecord(c->ev_g[0], c->stream));                  // the extend-add of the level
+            HIPCHK(c, hipStreamWaitEvent(c->stream_g, c->ev_g[0], 0));
+        }
         for (int chunk_b = b; chunk_b < fr.h_level_off[L + 1]; chunk_b += chunk_cap) {
+        hipStream_t st = (split && ((chunk_b - fr.h_level_off[L]) / chunk_cap) % 2 == 1) ? c->stream_g : c->stream;
         const int b = chunk_b, e = std::min(chunk_b + chunk_cap, fr.h_level_off[L + 1]);
         const int cnt = e - b;
         const int* lev = fr.level_nodes + b;
@@ -727,7 +746,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // the rows of the NEXT panel (two 64-row tiles) and the three tiles of the narrow update that cover it.  Those stay on
         // the main stream; the other row tiles and the other tiles of the narrow update go to stream_m and run beside the
         // next diagonal block, whose rows wait for them (ev_da[1]).
-        const bool diag_ahead = use_sp && !sp_ahead && c->opt.diag_ahead && c->stream_m;
+        // (wide levels only: elsewhere the inverse of a diagonal block sits in the front's ONE Swork slot, which the next diagonal block
+        // would overwrite while the rest of this panel's rows still read it)
+        const bool diag_ahead = use_sp && !sp_ahead && c->opt.diag_ahead && c->stream_m && wide;
         constexpr int DIAG_TILES = 3, NEXT_ROW_TILES = NBO / TS;
         bool rest_pending = false;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
@@ -736,10 +757,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             const int K0 = !right_looking ? 0 : sp_ahead ? std::max(0, S0 - SP) : S0;
             if (sp_ahead && C0 == S0 && sp_bulks >= 2)
                 // the bulk update two super-panels back wrote this super-panel's columns
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sp[sp_bulks & 1], 0));
+                HIPCHK(c, hipStreamWaitEvent(st, c->ev_sp[sp_bulks & 1], 0));
             if (C0 > K0) {
                 // left-looking update of this panel's columns with the factor columns [K0, C0) to their left
-                ProfScope ps(c, 2);
+                ProfScope ps(c, 2, st);
                 count_trailing(C0, 0, K0);
                 const int ntr = trail_tiles(C0, 0, K0);
                 // fused levels: these pivot columns are touched here for the first time (left-looking: every panel behind
@@ -749,12 +770,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const int gx = diag_ahead ? std::min(DIAG_TILES, ntr * (NBO / TS)) : ntr * (NBO / TS);
                 if (ntr > 0)
                 FOR_FRONT_CHUNKS(cnt, off, n) {
-                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
-                    else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, narrow_slices(gx, n, C0 - K0), n), dim3(256), 0, c->stream, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
+                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, st, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
+                    else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, narrow_slices(gx, n, C0 - K0), n), dim3(256), 0, st, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
                 }
             }
             count_panel(C0);
-            { ProfScope ps(c, 1);
+            { ProfScope ps(c, 1, st);
               // classes of equal sub-block count (fronts are sorted by pivot count); small levels go in one launch
               const int* hn = fr.h_level_nodes.data() + b;
               auto first_above = [&](int thr) {          // first position whose front has more than thr pivots
@@ -775,13 +796,13 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                       // the old kernel everywhere, 2 the new one.
                       const bool v1 = c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= 512 && nblk < NBO / NB);
                       if (v1)
-                          hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                          hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
                                              fd, lev, start, nblk, C0, sw, fr.info);
                       else if (c->opt.allow_pivot_repair)
-                          hipLaunchKernelGGL(k_diag_block2<true>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                          hipLaunchKernelGGL(k_diag_block2<true>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st,
                                              fd, lev, start, nblk, C0, sw, fr.info);
                       else
-                          hipLaunchKernelGGL(k_diag_block2<false>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), c->stream,
+                          hipLaunchKernelGGL(k_diag_block2<false>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st,
                                              fd, lev, start, nblk, C0, sw, fr.info);
                   }
                   start = end;
@@ -793,17 +814,17 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             const int tiles = (rows_below + TS - 1) / TS;
             // the rest of this panel's narrow update ran on stream_m: these rows read what it wrote
-            if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_da[1], 0)); rest_pending = false; }
+            if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_da[1], 0)); rest_pending = false; }
             // the next panel of the same super-panel takes a narrow update from this one
             const bool ahead = diag_ahead && C0 + NBO < S0 + SP && C0 + NBO < max_np;
             const int tiles_main = ahead ? std::min(tiles, NEXT_ROW_TILES) : tiles;
             if (tiles_main > 0) {
-                ProfScope ps(c, 0);
+                ProfScope ps(c, 0, st);
                 FOR_FRONT_CHUNKS(cnt, off, n)
-                    launch_rows(tiles_main, off, n, C0, sw, 0, c->stream);
+                    launch_rows(tiles_main, off, n, C0, sw, 0, st);
             }
             if (ahead) {
-                HIPCHK(c, hipEventRecord(c->ev_da[0], c->stream));
+                HIPCHK(c, hipEventRecord(c->ev_da[0], st));
                 HIPCHK(c, hipStreamWaitEvent(c->stream_m, c->ev_da[0], 0));
                 if (tiles > tiles_main) {
                     ProfScope ps(c, 0, c->stream_m);
@@ -829,9 +850,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                     const int mode = sp_ahead ? 5 : 2;
                     const int ntr = trail_tiles(S0, mode, 0, SP);
                     if (ntr > 0) {
-                        hipStream_t bs = sp_ahead ? c->stream2 : c->stream;
+                        hipStream_t bs = sp_ahead ? c->stream2 : st;
                         if (sp_ahead) {
-                            HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
+                            HIPCHK(c, hipEventRecord(c->ev_la[0], st));
                             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         }
                         { ProfScope ps(c, 2, bs);
@@ -846,22 +867,22 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             } else if (right_looking && trail_tiles(C0, 2) > 0) {
                 const int ntr = trail_tiles(C0, 2);              // tiles are anchored at an even column, at most one before the first updated one
                 if (!lookahead) {
-                    ProfScope ps(c, 2);
+                    ProfScope ps(c, 2, st);
                     count_trailing(C0, 2);
                     // only the FIRST update behind the pivot columns may gather: a later one would overwrite the earlier panels' updates
-                    FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur && !left_level && C0 == 0, ntr, off, n, C0, 2, 0, NBO, c->stream);
+                    FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur && !left_level && C0 == 0, ntr, off, n, C0, 2, 0, NBO, st);
                 } else {
                     // look-ahead: the next panel's 128 columns are updated first, on the main stream; everything behind
                     // them goes to the second stream and runs beside the next diagonal block and its rows, which are a
                     // chain of latency-bound launches at the top of the tree.  The next narrow update touches columns
                     // the bulk update also writes, so it waits for it (ev_la[1]).
-                    if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
-                    { ProfScope ps(c, 2);
+                    if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_la[1], 0)); bulk_pending = false; }
+                    { ProfScope ps(c, 2, st);
                       count_trailing(C0, 3);
-                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, c->stream, fd, lev, 0, C0, 3, 0, NBO, mask, 0, 0); }
+                      hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(ntr * (NBO / TS), 1, cnt), dim3(256), 0, st, fd, lev, 0, C0, 3, 0, NBO, mask, 0, 0); }
                     const int ntb = trail_tiles(C0, 4);
                     if (ntb > 0) {
-                        HIPCHK(c, hipEventRecord(c->ev_la[0], c->stream));
+                        HIPCHK(c, hipEventRecord(c->ev_la[0], st));
                         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_la[0], 0));
                         { ProfScope ps(c, 2, c->stream2);
                           count_trailing(C0, 4);
@@ -872,18 +893,22 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 }
             }
         }
-        if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_la[1], 0)); bulk_pending = false; }
-        if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_da[1], 0)); rest_pending = false; }
-        if (sp_bulks > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sp[(sp_bulks - 1) & 1], 0));     // stream2 runs its launches in order
+        if (bulk_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_la[1], 0)); bulk_pending = false; }
+        if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_da[1], 0)); rest_pending = false; }
+        if (sp_bulks > 0) HIPCHK(c, hipStreamWaitEvent(st, c->ev_sp[(sp_bulks - 1) & 1], 0));     // stream2 runs its launches in order
         if (max_nb > 0 && !right_looking) {
             // Schur complement: one update with all npiv factor columns
-            ProfScope ps(c, 2);
+            ProfScope ps(c, 2, st);
             count_trailing(0, 1);
             const int ntr = trail_tiles(0, 1);
             if (ntr > 0)
-            FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur, ntr, off, n, 0, 1, 0, NBO, c->stream);
+            FOR_FRONT_CHUNKS(cnt, off, n) launch_tri(fused_schur, ntr, off, n, 0, 1, 0, NBO, st);
         }
         }   // chunks of the level
+        if (split) {
+            HIPCHK(c, hipEventRecord(c->ev_g[1], c->stream_g));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_g[1], 0));
+        }
         if (wide && max_np_level > NBO) {
             const int max_np = max_np_level, cnt = cnt_level;
             const int* lev = lev_level;
@@ -1241,6 +1266,8 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_sp[i], hipEventDisableTiming));
     HIPCHK(c, hipStreamCreate(&c->stream3));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreate(&c->stream_g));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming));
     {
         // The diagonal look-ahead (factorize_fronts) runs the bulk of a panel's work on stream_m beside the next diagonal
         // block, whose one workgroup per front needs a whole CU's LDS: stream_m leaves 32 of the 256 CUs alone (bits whose
@@ -1426,6 +1453,9 @@ void femo_destroy(femo_ctx* c) {
     }
     for (int i = 0; i < 2; ++i)
         if (c->ev_x[i]) hipEventDestroy(c->ev_x[i]);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_g[i]) hipEventDestroy(c->ev_g[i]);
+    if (c->stream_g) hipStreamDestroy(c->stream_g);
     for (int i = 0; i < 2; ++i)
         if (c->ev_da[i]) hipEventDestroy(c->ev_da[i]);
     if (c->stream_m) hipStreamDestroy(c->stream_m);
@@ -1673,6 +1703,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "rows_preload_wg") o.rows_preload_wg = v;
     else if (k == "narrow_split") { if (v < 1 || v > 32) return fail(c, "narrow_split: 1..32 slices of the K range"); o.narrow_split = v; }
     else if (k == "narrow_split_wg") o.narrow_split_wg = v;
+    else if (k == "split_cnt") o.split_cnt = v;
+    else if (k == "split_groups") { if (v < 2) return fail(c, "split_groups: at least 2"); o.split_groups = v; }
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;
     else if (k == "fused_schur") o.fused_schur = v != 0;
