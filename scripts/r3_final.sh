@@ -3,6 +3,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -x -q -m gpu --durations=5 > gpurun_out/r3_final_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3_final_tests.log
+python -c 'import __graft_entry__ as g; g.smoke()' > gpurun_out/r3_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/r3_smoke.log
 ./scripts/micro/wsum_micro > gpurun_out/r3_micro.txt 2>&1; ./scripts/micro/stage_qpoints_micro >> gpurun_out/r3_micro.txt 2>&1
 # the counter passes first: they write profiles/pmc_wing1m.json with the digest of these sources, which the bench lines below read
 bash scripts/r3_rocprof.sh > gpurun_out/r3_rocprof.log 2>&1

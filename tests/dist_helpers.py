@@ -241,12 +241,18 @@ def reference_solution(m, marker, fields):
     return w, J, dJ, o.mass()
 
 
-def worker(rank, world, port, kind, engine, result_path):
-    """Entry point of one spawned rank: run the distributed driver, rank 0 stores the results."""
+def worker(rank, world, port, kind, engine, result_path, backend="gloo"):
+    """Entry point of one spawned rank: run the distributed driver, rank 0 stores the results.  ``backend`` "nccl" (= RCCL) wants one
+    device per rank: on a one-GPU box only world 1 -- which still sends every collective of the driver through RCCL on device
+    tensors, in stream order with the library's launches (the gloo path copies through the host and would hide an ordering bug)."""
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from femo_alpha_amd.parallel import Comm, DistributedShell
         m, marker, fields = make_case(kind)

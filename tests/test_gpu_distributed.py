@@ -37,6 +37,26 @@ def test_hip_partitioned_solve_matches_oracle(world):
     assert np.abs(r["g"] - dJ0).max() < 1e-7 * np.abs(dJ0).max()
 
 
+def test_single_rank_over_rccl_matches_the_gloo_run():
+    """Backend nccl (= RCCL), world 1 (RCCL wants a device per rank; the box has one): every collective of the driver goes through
+    RCCL on the DEVICE tensors -- the code path of bench.py --gpus N on a multi-GPU node, which the gloo tests (host-staged copies)
+    do not take -- and must be ordered with the library's own stream.  Same result as the gloo run to rounding."""
+    m, marker, fields = H.make_case("wing")
+    w0, J0, dJ0, M0 = H.reference_solution(m, marker, fields)
+    res = {}
+    for backend in ("gloo", "nccl"):
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "res.npz")
+            mp.spawn(H.worker, args=(1, _free_port(), "wing", "hip", path, backend), nprocs=1, join=True)
+            res[backend] = {k: v for k, v in np.load(path).items()}
+    r, g = res["nccl"], res["gloo"]
+    assert int(r["it"]) == int(g["it"]) and int(r["it2"]) == int(g["it2"])
+    assert np.abs(r["w"] - g["w"]).max() < 1e-12 * np.abs(g["w"]).max()
+    assert np.abs(r["g"] - g["g"]).max() < 1e-12 * np.abs(g["g"]).max()
+    assert np.abs(r["w"] - w0).max() < 1e-8 * np.abs(w0).max()
+    assert np.abs(r["g"] - dJ0).max() < 1e-7 * np.abs(dJ0).max()
+
+
 def test_partitions_agree_with_the_single_rank_run():
     """SURVEY.md section 8e "correctness check": the P-rank result against the 1-rank result of the SAME driver --
     displacement <= 1e-12 relative, identical PCG iteration counts (measured: 4e-15 on displacement, 4e-16 on the
