@@ -111,6 +111,8 @@ struct femo_ctx {
         int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
         int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
         int narrow_split = 1, narrow_split_wg = 1024;
+        int fuse_rows = 1, fuse_rows_cnt = 4096;    // single-panel fronts of non-wide levels with at least that many fronts: rows in k_diag_block
+        int diag_v1_cnt = 512;                      // levels of at least this many fronts: k_diag_block (80 KB of LDS, two workgroups per CU)
         int split_cnt = 0, split_groups = 2;        // levels of 2..split_cnt fronts: dealt to two streams in split_groups groups (off: no gain measured)
         int super_tiles = 0, super_tiles_min = 8;   // rank-k updates of few large fronts: 4 x 4 super-tiles per XCD from this many 64-row tiles
         int diag_ahead = 0;                   // super-panel levels: the next diagonal block runs beside the rest of this panel's rows and updates
@@ -751,6 +753,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const bool diag_ahead = use_sp && !sp_ahead && c->opt.diag_ahead && c->stream_m && wide;
         constexpr int DIAG_TILES = 3, NEXT_ROW_TILES = NBO / TS;
         bool rest_pending = false;
+        // single-panel fronts on a level that keeps no S: rows inside the diagonal-block kernel (option "fuse_rows")
+        const bool fuse_rows = !wide && max_np_level <= NBO && c->opt.fuse_rows != 0 && cnt_level >= c->opt.fuse_rows_cnt;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             const int S0 = C0 / SP * SP;                 // start of this panel's super-panel (== C0 when SP == NBO)
@@ -794,10 +798,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                       // classes of fewer than four sub-blocks keep the round-2 kernel there (measured at 1M DOF: levels 0-3 766 /
                       // 261 / 242 / 178 us with the new kernel throughout against 517 / 164 / 192 / 156).  Option "diag_v1": 1 forces
                       // the old kernel everywhere, 2 the new one.
-                      const bool v1 = c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= 512 && nblk < NBO / NB);
+                      const bool v1 = fuse_rows || c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= c->opt.diag_v1_cnt) || (c->opt.diag_v1 == 3 && cnt >= 512 && nblk < NBO / NB);
                       if (v1)
                           hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
-                                             fd, lev, start, nblk, C0, sw, fr.info);
+                                             fd, lev, start, nblk, C0, sw, fr.info, fuse_rows ? 1 : 0);
                       else if (c->opt.allow_pivot_repair)
                           hipLaunchKernelGGL(k_diag_block2<true>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st,
                                              fd, lev, start, nblk, C0, sw, fr.info);
@@ -812,7 +816,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const int t = fr.h_level_nodes[i], np = fr.h_npiv[t];
                 if (np > C0) rows_below = std::max(rows_below, fr.h_nf[t] - C0 - std::min(NBO, np - C0));
             }
-            const int tiles = (rows_below + TS - 1) / TS;
+            const int tiles = fuse_rows ? 0 : (rows_below + TS - 1) / TS;        // fused: the diagonal-block kernel did the rows
             // the rest of this panel's narrow update ran on stream_m: these rows read what it wrote
             if (rest_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_da[1], 0)); rest_pending = false; }
             // the next panel of the same super-panel takes a narrow update from this one
@@ -1704,6 +1708,9 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "narrow_split") { if (v < 1 || v > 32) return fail(c, "narrow_split: 1..32 slices of the K range"); o.narrow_split = v; }
     else if (k == "narrow_split_wg") o.narrow_split_wg = v;
     else if (k == "split_cnt") o.split_cnt = v;
+    else if (k == "diag_v1_cnt") o.diag_v1_cnt = v;
+    else if (k == "fuse_rows") o.fuse_rows = v != 0;
+    else if (k == "fuse_rows_cnt") o.fuse_rows_cnt = v;
     else if (k == "split_groups") { if (v < 2) return fail(c, "split_groups: at least 2"); o.split_groups = v; }
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;
@@ -1720,7 +1727,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
     else if (k == "big_tiles") o.big_tiles = v != 0;
     else if (k == "big_min_wg") o.big_min_wg = v;
-    else if (k == "diag_v1") { if (v < 0 || v > 2) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel"); o.diag_v1 = v; }
+    else if (k == "diag_v1") { if (v < 0 || v > 3) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel, 3 the rule before the LDS diet"); o.diag_v1 = v; }
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;

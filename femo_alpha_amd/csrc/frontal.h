@@ -582,11 +582,17 @@ __device__ long long g_stamps[32];
 // LDS is sized by the launch: `nblk` = the largest number of 32-column sub-blocks any front of the launch has in this
 // panel (the host sorts the fronts of a level by pivot count and launches them in classes), so that the many small
 // fronts at the bottom of the tree run two or three workgroups per CU instead of one.
-__device__ __host__ inline int diag_block_lds_blocks(int nblk) { return nblk * (nblk + 1) / 2 + (nblk - 1) + 1; }
+// r3: the inverse needs no LDS of its own -- column j of S and the scratch block of a product live in the sub-blocks of L's
+// column j, each of which is dead once its row's sum has been formed (112 -> 80 KB for four sub-blocks: two workgroups per CU).
+__device__ __host__ inline int diag_block_lds_blocks(int nblk) { return nblk * (nblk + 1) / 2; }
 
+// fuse_rows (fronts of ONE panel on levels that do not keep S): the rows below the block are turned into factor rows here, with
+// S read from LDS where the inverse phase leaves it -- S never goes to memory and k_panel_rows is not launched.  On the leaves
+// this kernel is HBM-bound (block in, factor sub-blocks, the 32 x 32 inverses and the 128 x 128 S out: 2.4 GB at 1 M DOF), and S is
+// the largest item; k_panel_rows then read it back.
 __global__ void __launch_bounds__(256)
 k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
-             int* __restrict__ info) {
+             int* __restrict__ info, int fuse_rows) {
     STAMP(31);
     const int slot = first + blockIdx.x;                       // position of the front in its level
     const int t = level_nodes[slot];
@@ -602,8 +608,6 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
     extern __shared__ double lds_raw[];
     blk32* D = reinterpret_cast<blk32*>(lds_raw);              // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
-    blk32* Sx = D + nblk * (nblk + 1) / 2;                      // column j of S below its diagonal sub-block
-    blk32& Wt = Sx[nblk - 1];
     const int nD = nblk * (nblk + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
@@ -699,32 +703,65 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     STAMP(20);
     for (int j = 0; j < nkb; ++j) {
         const blk32& Sjj = D[j * (j + 1) / 2 + j];
+        if (!fuse_rows)
         for (int idx = tid; idx < NB * NB; idx += 256) {
             const int r = idx % NB, c = idx / NB;
             Sout[(NB * j + r) + (size_t)lds_ * (NB * j + c)] = Sjj[r][c];
         }
         for (int i = j + 1; i < nkb; ++i) {
-            // W = sum_{k=j}^{i-1} L_ik S_kj
+            // W = sum_{k=j}^{i-1} L_ik S_kj: S_kj (j < k < i) already sits where L_kj was; L_ij is read here for the last time
+            blk32& Dij = D[i * (i + 1) / 2 + j];
             mfma_d4 w = (mfma_d4){0.0, 0.0, 0.0, 0.0};
             for (int k = j; k < i; ++k)
-                mfma_blk<false, false>(w, D[i * (i + 1) / 2 + k], k == j ? Sjj : Sx[k - j - 1], si, sj, l15, l4);
-            __syncthreads();                                   // previous readers of Wt are done
+                mfma_blk<false, false>(w, D[i * (i + 1) / 2 + k], D[k * (k + 1) / 2 + j], si, sj, l15, l4);
+            __syncthreads();                                   // every wave has read L_ij: its sub-block takes W
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) Wt[16 * si + l4 + 4 * reg][16 * sj + l15] = w[reg];
+            for (int reg = 0; reg < 4; ++reg) Dij[16 * si + l4 + 4 * reg][16 * sj + l15] = w[reg];
             __syncthreads();
             // S_ij = -Linv_i W
             mfma_d4 x = (mfma_d4){0.0, 0.0, 0.0, 0.0};
-            mfma_blk<false, false>(x, D[i * (i + 1) / 2 + i], Wt, si, sj, l15, l4);
+            mfma_blk<false, false>(x, D[i * (i + 1) / 2 + i], Dij, si, sj, l15, l4);
+            __syncthreads();                                   // every wave has read W: the sub-block takes S_ij
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
-                Sx[i - j - 1][r][c] = -x[reg];
-                Sout[(NB * i + r) + (size_t)lds_ * (NB * j + c)] = -x[reg];
+                Dij[r][c] = -x[reg];
+                if (!fuse_rows) Sout[(NB * i + r) + (size_t)lds_ * (NB * j + c)] = -x[reg];
             }
             __syncthreads();
         }
     }
     STAMP(21);
+    if (fuse_rows) {
+        // L[r][C0 + c] = sum_{k <= c} A[r][C0 + k] S[c][k] for the rows below the block (k_panel_rows' product): a wave takes 16 rows
+        // at a time, their kw entries in registers as the MFMA B operand, S[c][k] from the sub-blocks in LDS as the A operand
+        __syncthreads();
+        const int nf = fd.nf[t];
+        for (int row0 = C0 + kw + 16 * wv; row0 < nf; row0 += 64) {
+            const int row = row0 + l15;
+            const bool rok = row < nf;
+            double a[NBO / 4];
+#pragma unroll
+            for (int kk = 0; kk < NBO / 4; ++kk) {
+                const int k = 4 * kk + l4;
+                a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NBO / 16; ++cb) {
+                if (16 * cb >= kw) break;
+                const int bi = cb >> 1;
+                mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4 * cb + 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[bi * (bi + 1) / 2 + (kk >> 3)][16 * (cb & 1) + l15][4 * (kk & 7) + l4], a[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = 16 * cb + l4 + 4 * reg;
+                    if (rok && c < kw) F[row + (size_t)ldp * (C0 + c)] = acc[reg];
+                }
+            }
+        }
+    }
 }
 
 // ---- k_diag_block2: the same block, the same outputs, scheduled for latency.

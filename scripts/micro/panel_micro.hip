@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
             const int kw = std::min(NBO, np - C0);
             {
                 CK(hipEventRecord(e0));
-                if (variant == 0) hipLaunchKernelGGL(k_diag_block, dim3(nfr), dim3(256), diag_block_lds_blocks(4) * sizeof(blk32), 0, fd, dlev, 0, 4, C0, Sw, info);
-                else hipLaunchKernelGGL(k_diag_block2<false>, dim3(nfr), dim3(256), diag_block2_lds_blocks(4) * sizeof(blk32), 0, fd, dlev, 0, 4, C0, Sw, info);
+                if (variant == 0) hipLaunchKernelGGL(k_diag_block, dim3(nfr), dim3(256), diag_block_lds_blocks(4) * sizeof(blk32), 0, fd, dlev, 0, 4, C0, Sw, info, 0);
+                else hipLaunchKernelGGL(k_diag_block2<false>, dim3(nfr), dim3(256), diag_block2_lds_blocks(4) * sizeof(blk32), 0, fd, dlev, 0, 4, C0, Sw, info, 0);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tp += ms;
                 const int tiles = (nf - C0 - kw + TS - 1) / TS;
