@@ -338,7 +338,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    # FEMO_BENCH_FORCE_DIST=1: take the N > 1 code path with ONE rank (RCCL wants a device per rank, a one-GPU box has one): the whole
+    # distributed bench -- process group over nccl, the driver's collectives on device tensors, the max-over-ranks timing -- runs
+    # through RCCL; a rehearsal of what the 8-GPU node executes, not a measurement
+    force_dist = world == 1 and os.environ.get("FEMO_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank if torch.cuda.device_count() > local_rank else 0)
         backend = os.environ.get("FEMO_BENCH_BACKEND", "nccl")     # "gloo" only to rehearse ranks that share one GPU
@@ -350,7 +359,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from femo_alpha_amd.backend import ShellContext
-    if world > 1:
+    if world > 1 or force_dist:
         return main_distributed(args, rank, local_rank, world, torch, dist)
     setup = {}
     m, fields, marker, desc = make_workload(args.workload, renumber=not args.keep_numbering, timings=setup)
