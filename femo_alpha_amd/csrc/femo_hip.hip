@@ -36,6 +36,7 @@ struct femo_ctx {
     int krylov = 0;                          // 0: conjugate gradients, 1: BiCGStab (femo_set_krylov)
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     int tab_nq = 0;                          // quadrature points of the operator's tables (c->tab)
+    long long opt_version = 0;               // bumped by every femo_set_option
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
@@ -112,6 +113,7 @@ struct femo_ctx {
         int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
         int narrow_split = 1, narrow_split_wg = 1024;
         int fuse_rows = 1, fuse_rows_cnt = 4096;    // single-panel fronts of non-wide levels with at least that many fronts: rows in k_diag_block
+        int sweep_graph = 0;                        // the preconditioner application of the PCG loop replayed as a HIP graph
         int diag_v1_cnt = 512;                      // levels of at least this many fronts: k_diag_block (80 KB of LDS, two workgroups per CU)
         int split_cnt = 0, split_groups = 2;        // levels of 2..split_cnt fronts: dealt to two streams in split_groups groups (off: no gain measured)
         int super_tiles = 0, super_tiles_min = 8;   // rank-k updates of few large fronts: 4 x 4 super-tiles per XCD from this many 64-row tiles
@@ -154,6 +156,8 @@ struct femo_ctx {
             *cinv0 = nullptr, *cinv1 = nullptr;
         long long *poff = nullptr, *soff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
         double *P = nullptr, *S = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
+        hipGraphExec_t sweep_graph = nullptr; // one preconditioner application on c->z, captured (option "sweep_graph")
+        long long sweep_graph_key = -1;       // options version the graph was captured under
         std::vector<long long> h_soff;        // host copy of the Schur offsets (femo_front_schur_get / block_set)
         long long p_doubles = 0, s_doubles = 0, linv_doubles = 0, x_doubles = 0;
         int swork_slots = 1;                  // 128 x 128 scratch blocks for the diagonal-block inverses of the non-wide levels
@@ -1076,6 +1080,28 @@ static int frontal_solve(femo_ctx* c, double* v) {
     return frontal_bwd(c, v, 0, c->fr.nlevels);
 }
 
+// The preconditioner application of the PCG loop (always on c->z: ~56 dependent launches whose arguments depend on the plan and the
+// options only) captured once as a HIP graph and replayed (option "sweep_graph").
+static int frontal_solve_z(femo_ctx* c) {
+    auto& fr = c->fr;
+    if (!c->opt.sweep_graph) return frontal_solve(c, c->z);
+    if (join_xinv(c)) return 1;                            // the cross-stream join stays outside the capture
+    if (!fr.sweep_graph || fr.sweep_graph_key != c->opt_version) {
+        if (fr.sweep_graph) { hipGraphExecDestroy(fr.sweep_graph); fr.sweep_graph = nullptr; }
+        hipGraph_t g = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = frontal_solve(c, c->z);
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        HIPCHK(c, e);
+        HIPCHK(c, hipGraphInstantiate(&fr.sweep_graph, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+        fr.sweep_graph_key = c->opt_version;
+    }
+    HIPCHK(c, hipGraphLaunch(fr.sweep_graph, c->stream));
+    return 0;
+}
+
 // PCG preconditioned by the multifrontal factorisation (a handful of iterations)
 static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
     const int64_t n = c->ndof;
@@ -1116,7 +1142,7 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     while (bb > 0 && rr > target && k < c->maxit) {
         HIPCHK(c, hipMemsetAsync(c->scal + 1, 0, 3 * sizeof(double), c->stream));
         HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        if (frontal_solve(c, c->z)) return 1;
+        if (frontal_solve_z(c)) return 1;
         hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, c->r, c->z, n, c->scal + 1);
         hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->scal, k == 0 ? 1 : 0, n);
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
@@ -1448,6 +1474,7 @@ void femo_destroy(femo_ctx* c) {
                      c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1};
     for (void* p : fptrs)
         if (p) hipFree(p);
+    if (c->fr.sweep_graph) hipGraphExecDestroy(c->fr.sweep_graph);
     if (c->scal_host) hipHostFree(c->scal_host);
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -1695,6 +1722,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     const std::string k(key ? key : "");
     const int v = (int)value;
     auto& o = c->opt;
+    ++c->opt_version;                        // captured launch sequences are stale
     if (k == "trailing") { if (v < 0 || v > 2) return fail(c, "trailing: 0 auto, 1 left-looking, 2 right-looking"); o.trailing = v; }
     else if (k == "left_min") o.left_min = v;
     else if (k == "left_max") o.left_max = v;
@@ -1709,6 +1737,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "narrow_split_wg") o.narrow_split_wg = v;
     else if (k == "split_cnt") o.split_cnt = v;
     else if (k == "diag_v1_cnt") o.diag_v1_cnt = v;
+    else if (k == "sweep_graph") o.sweep_graph = v != 0;
     else if (k == "fuse_rows") o.fuse_rows = v != 0;
     else if (k == "fuse_rows_cnt") o.fuse_rows_cnt = v;
     else if (k == "split_groups") { if (v < 2) return fail(c, "split_groups: at least 2"); o.split_groups = v; }
@@ -2183,6 +2212,7 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
     fr.ready = true;
+    if (fr.sweep_graph) { hipGraphExecDestroy(fr.sweep_graph); fr.sweep_graph = nullptr; }     // captured for another plan
     fr.factored = false;
     return 0;
 }
