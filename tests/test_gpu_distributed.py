@@ -135,3 +135,22 @@ def test_config4_two_processes_over_gloo_at_full_size():
         r = {k: v for k, v in np.load(path).items()}
     assert int(r["it"]) <= 4 and int(r["it2"]) <= 4
     _check_against_config3_golden(r)
+
+
+def test_bench_distributed_path_over_rccl_with_one_rank():
+    """bench.py's N > 1 code path (process group over nccl = RCCL, the partitioned driver, max-over-ranks timing, the JSON line with both
+    roofline objects) with ONE rank -- FEMO_BENCH_FORCE_DIST=1 -- on a shortened wing skin: what a one-GPU box can rehearse of the
+    multi-GPU bench."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEMO_BENCH_FORCE_DIST="1", FEMO_BENCH_NS="60", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "DOF/s"
+    assert line["config"]["pcg_iterations_forward"] <= 4 and line["config"]["relres_forward"] < 1e-9
+    assert line["roofline"]["bound"] == "mfma" and line["roofline_spmv"]["bound"] == "hbm"
