@@ -47,6 +47,7 @@ SIGNATURES = {
     "femo_set_krylov": (C.c_int, [C.c_void_p, C.c_int]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_force_to_pressure": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_double, C.c_int32, _c_int32_p, _c_double_p]),
     "femo_set_operator": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "femo_set_strain_quadrature": (C.c_int, [C.c_void_p, C.c_int32]),
     "femo_op_apply_vec2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int]),

@@ -26,9 +26,13 @@ class ShellContext:
     VEC_IDS = {"state": 0, "adjoint": 1, "r": 2, "z": 3, "p": 4, "Ap": 5, "b": 6}
 
     def __init__(self, mesh: ShellMesh, element_wise_material=False, elementwise_pressure=False,
-                 nquad=4, device=0, nghost=0):
+                 nquad=None, device=0, nghost=0):
         self.lib = _lib.load()
         self.mesh = mesh
+        # Gauss points per direction: by default what the mesh asks for (4 on affine cells, where that is exact; 5 on warped
+        # quadrilaterals, where the reference's near-exact integration is only met to 1e-9 by 5 -- ShellMesh.recommended_nquad)
+        nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
+        self.nquad = nquad
         self.element_wise_material = bool(element_wise_material)
         self.elementwise_pressure = bool(elementwise_pressure)
         h = C.c_void_p()
@@ -226,6 +230,17 @@ class ShellContext:
         self._chk(self.lib.femo_solve_linear(self._h, dptr(rhs), dptr(x), C.byref(it), C.byref(rr)))
         return x, it.value, rr.value
 
+    def force_to_pressure(self, force, rtol=1e-13, maxit=500):
+        """pressure = A^-1 force, A the consistent mass matrix of [CG1]^3 (rm_shell_model.py:414-421): Jacobi-PCG on the device."""
+        f = self._vec(force)
+        if f.size != 3 * self.mesh.nn:
+            raise ValueError("force vector has the wrong length")
+        out = np.empty_like(f)
+        it = C.c_int32(); rr = C.c_double()
+        self._chk(self.lib.femo_force_to_pressure(self._h, dptr(f), dptr(out), float(rtol), int(maxit), C.byref(it), C.byref(rr)))
+        self.last_force_to_pressure = (it.value, rr.value)
+        return out
+
     # ------------------------------------------------------------------ outputs
     def functional(self, name):
         v = C.c_double()
@@ -346,6 +361,7 @@ class ShellContext:
         return sp.csr_matrix((vals, self.csr["colidx"], self.csr["rowptr"]), shape=(n, n))
 
     def set_stress_params(self, m=1e-6, rho=100.0):
+        self._stress_params = None             # whatever a Form cached as "the parameters the context holds" is void now
         self._chk(self.lib.femo_set_stress_params(self._h, float(m), float(rho)))
 
     def set_stress_alpha(self, alpha=None, sel=-1):

@@ -1571,6 +1571,72 @@ __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b
     block_accumulate((s0 + s1) + (s2 + s3), slot);
 }
 
+// ---- consistent mass matrix of the pressure space [CG1]^3, matrix-free: y += A x (diag != null: diag += diag(A) instead), one thread
+// per cell, node-major xyz vectors of length 3 nn.  A = int Pv . w dx on the undeformed surface (rm_shell_pde.py:194-209): 3 x 3
+// Gauss points on quadrilaterals, the 3-point rule on triangles (exact for the bilinear / linear basis on affine cells).
+template <int NVC>
+__global__ void __launch_bounds__(128)
+k_vmass_apply(MeshDev m, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ diag) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m.nel) return;
+    int vid[NVC];
+    double X[NVC][3], xe[NVC][3], ye[NVC][3], de[NVC];
+#pragma unroll
+    for (int b = 0; b < NVC; ++b) {
+        vid[b] = m.cells[(size_t)b * m.nel + e];
+        de[b] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { X[b][c] = m.xyz[3 * (size_t)vid[b] + c]; xe[b][c] = x ? x[3 * (size_t)vid[b] + c] : 0.0; ye[b][c] = 0.0; }
+    }
+    constexpr int NQ = NVC == 4 ? 9 : 3;
+    for (int q = 0; q < NQ; ++q) {
+        double N[NVC], dN[NVC][2], wq;
+        if (NVC == 4) {
+            const double g[3] = {-0.7745966692414834, 0.0, 0.7745966692414834}, gw[3] = {5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0};
+            const double xi = g[q / 3], eta = g[q % 3];
+            const double sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+            wq = gw[q / 3] * gw[q % 3];
+#pragma unroll
+            for (int b = 0; b < NVC; ++b) {
+                N[b] = 0.25 * (1 + sx[b] * xi) * (1 + sy[b] * eta);
+                dN[b][0] = 0.25 * sx[b] * (1 + sy[b] * eta);
+                dN[b][1] = 0.25 * sy[b] * (1 + sx[b] * xi);
+            }
+        } else {
+            const double P[3][2] = {{1.0 / 6, 1.0 / 6}, {2.0 / 3, 1.0 / 6}, {1.0 / 6, 2.0 / 3}};
+            wq = 1.0 / 6;
+            N[0] = 1 - P[q][0] - P[q][1]; N[1] = P[q][0]; N[2] = P[q][1];
+            dN[0][0] = -1; dN[0][1] = -1; dN[1][0] = 1; dN[1][1] = 0; dN[2][0] = 0; dN[2][1] = 1;
+        }
+        double J0[3] = {0, 0, 0}, J1[3] = {0, 0, 0}, nrm[3];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { J0[c] += X[b][c] * dN[b][0]; J1[c] += X[b][c] * dN[b][1]; }
+        cross3(J0, J1, nrm);
+        const double wd = wq * sqrt(dot3(nrm, nrm));
+        double xq[3] = {0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < NVC; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) xq[c] += N[b] * xe[b][c];
+#pragma unroll
+        for (int b = 0; b < NVC; ++b) {
+            de[b] += wd * N[b] * N[b];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ye[b][c] += wd * N[b] * xq[c];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NVC; ++b)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(diag ? &diag[3 * (size_t)vid[b] + c] : &y[3 * (size_t)vid[b] + c], diag ? de[b] : ye[b][c]);
+}
+
+__global__ void k_div(double* __restrict__ z, const double* __restrict__ r, const double* __restrict__ d, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) z[i] = r[i] / d[i];
+}
+
 // ---- element-partitioned (multi-GPU) driver: the replicated separator entries of a vector are packed into one
 // contiguous buffer for the all-reduce and written back; global dot products weigh every entry by 1 / (ranks holding it)
 __global__ void k_gather_idx(double* __restrict__ out, const double* __restrict__ v, const int* __restrict__ idx, int n) {

@@ -3,19 +3,21 @@
 // The reference hands its assembled Jacobian to MUMPS through PETSc (reference femo_alpha/fea/utils_dolfinx.py:466,
 // 495-531); the analysis phase of that solver (ordering + elimination tree + front structure) is what this file
 // replaces, driven by the mesh instead of a sparse matrix:
-//   1. nested dissection of the ELEMENTS by recursive coordinate bisection (stable sort along the longest extent of the
-//      centroids, split in the middle) down to leaves of <= leaf_size cells;
+//   1. nested dissection of the ELEMENTS by recursive coordinate bisection (stable sort of the centroids along one axis; cut in
+//      the middle, or at the largest gap near the middle: femo_plan_build_ex) down to leaves of <= leaf_size cells;
 //   2. every P2 node is eliminated at the deepest tree node whose element interval holds all its elements;
 //   3. front of a tree node = the DOFs of its own nodes (pivots) + the DOFs of the ancestor-owned nodes its subtree
 //      touches (boundary), children's boundaries merged upwards;
 //   4. index maps: boundary row of a child -> row of its parent, element DOF -> row of its leaf front; levels by height.
 // The host-side Python module femo_alpha_amd/solver/symbolic.py states the same algorithm in numpy and is kept as the
-// cross-check (tests/test_symbolic_native.py compares every array).  The tree shape depends on the element count only, so
-// it is laid out first; the sorts of one depth are independent and run in parallel (OpenMP).
+// cross-check (tests/test_symbolic_native.py compares every array).  The tree grows depth by depth; the sorts of one depth are
+// independent and run in parallel (OpenMP).
 #include <omp.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -47,64 +49,98 @@ const char* femo_plan_last_error(void) { return g_error.c_str(); }
 
 void femo_plan_free(femo_plan* p) { delete p; }
 
-int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
-                    const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth) {
-    if (!out || nel < 1 || nP2 < 1 || nV < 1 || npc < 1 || ndpc < 1 || !cell_p2 || !cent || !cell_dofs || leaf_size < 1 || min_depth < 0) {
+int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                       const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
+                       int32_t axis_rule, double gap_coeff) {
+    if (!out || nel < 1 || nP2 < 1 || nV < 1 || npc < 1 || ndpc < 1 || !cell_p2 || !cent || !cell_dofs || leaf_size < 1 || min_depth < 0 ||
+        axis_rule < 0 || axis_rule > 1 || (axis_rule == 1 && !cext) || !(gap_coeff >= 0.0)) {
         g_error = "femo_plan_build: bad arguments";
         return 1;
     }
     // at most 16 threads: several ranks of a multi-GPU job run this at the same time on one host
     const int nthreads = std::max(1, std::min(omp_get_max_threads(), 16));
     const int64_t ndof_u = 3 * (int64_t)nP2;
-    // ---- 1a. shape of the bisection tree (same creation order as a stack-driven recursion: children of the node
-    //          popped last come first)
+    // ---- 1. the bisection tree, depth by depth (the sorts of one depth are independent and run in parallel; ids in creation
+    //         order: the nodes of a depth in the order of their parents, left before right -- children > parent)
+    //   where to cut (gap_coeff > 0): not at the middle element but at the LARGEST GAP between consecutive sorted centroid
+    //   coordinates within  mid +- min(1/8, gap_coeff / sqrt(n)) n  (about one row of cells either way).  On meshes with any
+    //   row structure the middle element sits inside a row, and the cut through that row is a zigzag that drags both
+    //   neighbouring mesh lines into the separator (BASELINE config 3: separators of 1401-1455 DOFs where a mesh line has
+    //   1050); a cut at a gap follows a mesh line.  Truly unstructured meshes have no such gaps and get a cut near the middle.
+    //   The tree then has a FIXED DEPTH (the smallest one whose average leaf holds <= leaf_size cells): unequal halves must
+    //   not put siblings on different levels of the schedule.
+    //   along which axis (axis_rule 1): the one along which the piece is longest IN CELLS (centroid extent / mean cell extent),
+    //   not in metres -- a tapered wing's cells are squeezed chordwise, and the shortest separator crosses the fewest cells.
+    int32_t fixed_depth = 0;
+    while (((int64_t)leaf_size << fixed_depth) < (int64_t)nel) ++fixed_depth;
+    fixed_depth = std::max(fixed_depth, min_depth);
+    const bool gap_mode = gap_coeff > 0.0;
+    constexpr int32_t GAP_NMIN = 64;           // smaller pieces are halved exactly (a row is a large share of them)
     std::vector<int32_t> lo{0}, hi{nel}, left{-1}, right{-1}, parent{-1}, depth{0};
+    std::vector<int32_t> eorder(nel);
+    std::iota(eorder.begin(), eorder.end(), 0);
     {
-        std::vector<int32_t> stack{0};
-        while (!stack.empty()) {
-            const int32_t t = stack.back(); stack.pop_back();
-            const int32_t a = lo[t], b = hi[t];
-            if (b - a <= leaf_size && depth[t] >= min_depth) continue;
-            if (b - a < 2) { g_error = "mesh too small for the requested number of partitions"; return 2; }
-            const int32_t mid = a + (b - a) / 2;
-            for (int side = 0; side < 2; ++side) {
-                const int32_t id = (int32_t)lo.size();
-                lo.push_back(side ? mid : a); hi.push_back(side ? b : mid); left.push_back(-1); right.push_back(-1);
-                parent.push_back(t); depth.push_back(depth[t] + 1);
-                (side ? right : left)[t] = id;
-                stack.push_back(id);
+        std::vector<int32_t> frontier{0};
+        while (!frontier.empty()) {
+            std::vector<int32_t> split(frontier.size(), -1);        // position of the cut inside [lo, hi), or -1: a leaf
+            int bad = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1) reduction(| : bad)
+            for (int64_t k = 0; k < (int64_t)frontier.size(); ++k) {
+                const int32_t t = frontier[k], a = lo[t], b = hi[t], n = b - a;
+                const bool want = gap_mode ? depth[t] < fixed_depth : (n > leaf_size || depth[t] < min_depth);
+                if (!want) continue;
+                if (n < 2) { if (depth[t] < min_depth) bad |= 1; continue; }
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, cs[3] = {0.0, 0.0, 0.0};
+                for (int32_t i = a; i < b; ++i)
+                    for (int c = 0; c < 3; ++c) {
+                        const double v = cent[3 * (int64_t)eorder[i] + c];
+                        mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v);
+                        if (axis_rule == 1) cs[c] += cext[3 * (int64_t)eorder[i] + c];        // sequential sum (the numpy twin: cumsum)
+                    }
+                double score[3];
+                for (int c = 0; c < 3; ++c) {
+                    score[c] = mx[c] - mn[c];
+                    if (axis_rule == 1) { const double mean = cs[c] / n; score[c] = mean > 0.0 ? score[c] / mean : 0.0; }
+                }
+                int ax = 0;
+                for (int c = 1; c < 3; ++c)
+                    if (score[c] > score[ax]) ax = c;                     // first of equal scores, as numpy's argmax
+                std::stable_sort(eorder.begin() + a, eorder.begin() + b,
+                                 [&](int32_t x, int32_t y) { return cent[3 * (int64_t)x + ax] < cent[3 * (int64_t)y + ax]; });
+                int32_t mid = n / 2;
+                if (gap_mode && n >= GAP_NMIN) {
+                    const int32_t w = std::max<int32_t>(1, (int32_t)(std::min(0.125, gap_coeff / std::sqrt((double)n)) * n));
+                    const int32_t ka = std::max<int32_t>(1, mid - w), kb = std::min<int32_t>(n - 1, mid + w);
+                    int32_t best = mid;
+                    double gbest = -1.0;
+                    for (int32_t kk = ka; kk <= kb; ++kk) {
+                        const double g = cent[3 * (int64_t)eorder[a + kk] + ax] - cent[3 * (int64_t)eorder[a + kk - 1] + ax];
+                        // the largest gap; of equal gaps the one nearest the middle, then the lower one
+                        if (g > gbest || (g == gbest && std::abs(kk - mid) < std::abs(best - mid))) { gbest = g; best = kk; }
+                    }
+                    mid = best;
+                }
+                split[k] = mid;
             }
+            if (bad) { g_error = "mesh too small for the requested number of partitions"; return 2; }
+            std::vector<int32_t> next;
+            for (size_t k = 0; k < frontier.size(); ++k) {
+                if (split[k] < 0) continue;
+                const int32_t t = frontier[k], a = lo[t], b = hi[t], mid = a + split[k];
+                for (int side = 0; side < 2; ++side) {
+                    const int32_t id = (int32_t)lo.size();
+                    lo.push_back(side ? mid : a); hi.push_back(side ? b : mid); left.push_back(-1); right.push_back(-1);
+                    parent.push_back(t); depth.push_back(depth[t] + 1);
+                    (side ? right : left)[t] = id;
+                    next.push_back(id);
+                }
+            }
+            frontier.swap(next);
         }
     }
     const int32_t ntree = (int32_t)lo.size();
     int32_t maxdepth = 0;
     for (int32_t t = 0; t < ntree; ++t) maxdepth = std::max(maxdepth, depth[t]);
-    // ---- 1b. the sorts, depth by depth
-    std::vector<int32_t> eorder(nel);
-    std::iota(eorder.begin(), eorder.end(), 0);
-    {
-        std::vector<std::vector<int32_t>> by_depth(maxdepth + 1);
-        for (int32_t t = 0; t < ntree; ++t)
-            if (left[t] >= 0) by_depth[depth[t]].push_back(t);
-        for (int32_t d = 0; d <= maxdepth; ++d) {
-            const auto& nodes = by_depth[d];
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-            for (int64_t k = 0; k < (int64_t)nodes.size(); ++k) {
-                const int32_t t = nodes[k], a = lo[t], b = hi[t];
-                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int32_t i = a; i < b; ++i)
-                    for (int c = 0; c < 3; ++c) {
-                        const double v = cent[3 * (int64_t)eorder[i] + c];
-                        mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v);
-                    }
-                int ax = 0;
-                for (int c = 1; c < 3; ++c)
-                    if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;          // first of equal extents, as numpy's argmax
-                std::stable_sort(eorder.begin() + a, eorder.begin() + b,
-                                 [&](int32_t x, int32_t y) { return cent[3 * (int64_t)x + ax] < cent[3 * (int64_t)y + ax]; });
-            }
-        }
-    }
     std::vector<int32_t> epos(nel);
     for (int32_t i = 0; i < nel; ++i) epos[eorder[i]] = i;
     // ---- 2. owners
@@ -256,6 +292,11 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
     p->i32["level_nodes"] = std::move(level_nodes); p->i64["level_off"] = std::move(level_off);
     *out = p;
     return 0;
+}
+
+int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                    const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth) {
+    return femo_plan_build_ex(out, nel, nP2, nV, npc, ndpc, cell_p2, cent, nullptr, cell_dofs, leaf_size, min_depth, 0, 0.0);
 }
 
 int64_t femo_plan_size(const femo_plan* p, const char* name) {

@@ -56,6 +56,7 @@ class PlateSim:
         # application is that direct solve (relative residual 6e-9 at 508 k DOF, the history within 7e-10 of the fully converged
         # one, scripts/r3_dyn_probe.py), a second one drives the residual to 1e-18.  rtol = 1e-8 stops after the first, as the
         # reference does; rtol = 1e-11 buys the refinement step for 40 % more time per step.
+        self.rtol = float(rtol)
         ctx.set_solver(preconditioner=2, rtol=rtol, maxit=50, check_every=1)
         self.a, self.b = 2.0 / dt ** 2, 2.0 / dt
         ctx.set_operator(0.5, self.a)
@@ -79,6 +80,9 @@ class PlateSim:
     def update_nsteps(self, Nsteps):
         self.Nsteps, self.time_levels = Nsteps, Nsteps + 1
         self._nm_ready = False
+        # the next set-up re-allocates the resident histories: the zero-copy views of the old ones must not outlive them
+        self.W = None
+        self.Lam = None
 
     def _gravity(self):
         return (-1.0 if self.g_factor is None else self.g_factor) * 9.81

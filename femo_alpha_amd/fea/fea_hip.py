@@ -110,13 +110,21 @@ class Form:
     """Scalar output known to the backend: 'compliance', 'mass', 'elastic_energy', 'pnorm_stress', 'volume'.
     ``subdomain`` restricts the stress aggregate to one tagged set of cells (the reference's ``dxx(i)`` measure)."""
 
-    def __init__(self, ctx, name, subdomain=-1):
+    def __init__(self, ctx, name, subdomain=-1, stress_params=None):
         self.ctx, self.name, self.subdomain = ctx, name, subdomain
+        # (m, rho, regularisation coefficient) of a p-norm stress form: every form keeps its own, as every UFL expression of the
+        # reference does (rm_shell_pde.py:112-128), and hands them to the context right before it is evaluated
+        self.stress_params = stress_params
 
     def _select(self):
         if self.subdomain >= 0 or getattr(self.ctx, "_subdomain", -1) >= 0:
             self.ctx.select_subdomain(self.subdomain)
             self.ctx._subdomain = self.subdomain
+        if self.stress_params is not None and getattr(self.ctx, "_stress_params", None) != self.stress_params:
+            m, rho, regc = self.stress_params
+            self.ctx.set_option("stress_regularization", regc)
+            self.ctx.set_stress_params(m, rho)
+            self.ctx._stress_params = self.stress_params
 
 
 class FieldForm:

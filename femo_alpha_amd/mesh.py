@@ -161,6 +161,20 @@ class ShellMesh:
                 d = np.maximum(d, np.linalg.norm(x[:, i] - x[:, j], axis=1))
         return d
 
+    def recommended_nquad(self):
+        """Gauss points per direction that reproduce the reference's integration of the static forms.  The reference leaves
+        the degree to UFL (plain ``dx``, linear_shell_model.py:88-103), whose estimate is 43-53 on quadrilaterals
+        (scripts/ufl_degree_estimate.py): (nearly) exact integration.  On affine cells (parallelograms) the integrand is a
+        polynomial of degree <= 7 per direction and 4 points are exact; on any other quadrilateral the frame, the
+        derivative map and the differentiated normal are rational in the reference coordinates and 4 points are 7.5e-8 away
+        from the limit in d compliance / d thickness at BASELINE config 3, 5 points 1e-9
+        (tests/test_gpu_fullsize.py::test_quadrature_rule_sensitivity_at_config3).  Triangles are affine: one rule."""
+        if not self.is_quad:
+            return 4
+        x = self.nodes[self.cells]
+        defect = np.linalg.norm(x[:, 0] - x[:, 1] + x[:, 2] - x[:, 3], axis=1)       # zero for a parallelogram
+        return 4 if np.all(defect <= 1e-10 * self.cell_diameters()) else 5
+
     # ------------------------------------------------------------------ Dirichlet sets
     @staticmethod
     def _eval_marker(func, pts):

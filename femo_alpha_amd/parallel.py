@@ -78,11 +78,13 @@ class Comm:
 class HipEngine:
     """The local pieces on one MI355X (a ``ShellContext`` on the rank's sub-mesh)."""
 
-    def __init__(self, sub, plan, info, device=0, element_wise_material=False, elementwise_pressure=False):
+    def __init__(self, sub, plan, info, device=0, element_wise_material=False, elementwise_pressure=False, nquad=None):
         import torch
         from .backend import ShellContext
         self.torch = torch
-        self.ctx = ShellContext(sub, element_wise_material, elementwise_pressure, device=device, nghost=info["nghost"])
+        # nquad: the rule of the WHOLE mesh (DistributedShell passes it) -- a partition made of affine cells only must not
+        # integrate with another rule than its neighbours
+        self.ctx = ShellContext(sub, element_wise_material, elementwise_pressure, device=device, nghost=info["nghost"], nquad=nquad)
         self.ctx.enable_frontal(plan=plan)
         self.ctx.set_solver(preconditioner=2, rtol=1e-10, maxit=50, check_every=1)
         self.device = torch.device("cuda", device)
@@ -165,16 +167,18 @@ class DistributedShell:
     """Forward solve, scalar outputs and the adjoint gradient on an element partition."""
 
     def __init__(self, mesh, comm: Comm, bc_marker=None, beta=1.0e15, leaf_size=12, engine_factory=None,
-                 element_wise_material=False, device=0, tree=None):
+                 element_wise_material=False, device=0, tree=None, nquad=None, strict=True):
         import torch
         self.torch = torch
+        self.strict = bool(strict)       # a PCG that stops at maxit short of rtol raises (option "strict" of the single-GPU path)
         self.mesh, self.comm = mesh, comm
         self.ewm = bool(element_wise_material)
         d = int(np.log2(comm.size))
         self.tree = analyse(mesh, leaf_size, min_depth=d) if tree is None else tree
         self.sub, self.plan, self.info = rank_plan(mesh, self.tree, comm.rank, comm.size)
+        self.nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
         factory = engine_factory or (lambda sub, plan, info: HipEngine(sub, plan, info, device=device,
-                                                                       element_wise_material=element_wise_material))
+                                                                       element_wise_material=element_wise_material, nquad=self.nquad))
         self.eng = factory(self.sub, self.plan, self.info)
         if bc_marker is not None:
             self.eng.set_penalty_facets(self.sub.penalty_facets(bc_marker), beta)
@@ -214,6 +218,12 @@ class DistributedShell:
 
     # ------------------------------------------------------------------ preconditioner set-up
     def factorize(self):
+        # everything below -- the scratch tensor, the Schur all-gather and its host staging under gloo -- must run on the
+        # context's stream, where the pack / unpack kernels run; the scope is re-entrant, callers need not wrap the call
+        with self.eng.on_stream():
+            self._factorize()
+
+    def _factorize(self):
         eng, info = self.eng, self.info
         eng.factor(0, self.nl, True)
         if self.comm.size > 1:
@@ -253,7 +263,16 @@ class DistributedShell:
                     raise RuntimeError("PCG broke down (NaN residual)")
                 if k > 0 and not pAp > 0:
                     raise RuntimeError("PCG broke down: p.Ap <= 0 (preconditioner or operator not positive definite)")
-                if bb == 0 or rr <= self.rtol ** 2 * bb or k >= self.maxit:
+                if bb == 0 or rr <= self.rtol ** 2 * bb:
+                    break
+                if k >= self.maxit:
+                    # as the single-GPU path does under option "strict" (status 4): an unconverged state must not flow on into
+                    # the bench line or the adjoint gradient
+                    self.last["converged"] = False
+                    if self.strict:
+                        from .backend import FemoConvergenceError
+                        raise FemoConvergenceError(f"partitioned PCG stopped at maxit = {self.maxit} with relative residual "
+                                                   f"{(rr / bb) ** 0.5:.3e} > rtol = {self.rtol:.1e}")
                     break
                 eng.precond_rest()                        # top of the tree, backward sweeps, share of r.z
                 if comm.size > 1:

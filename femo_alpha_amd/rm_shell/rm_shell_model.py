@@ -17,13 +17,13 @@ from ..mesh import ShellMesh
 from .rm_shell_pde import FacetSet, RMShellPDE
 
 
-def solve_linear(A, b):
+def solve_linear(A, b, ctx=None):
     """pressure = A^-1 force as a differentiable node: ``csdl.solve_linear`` when csdl_alpha is installed (what the
-    reference calls, rm_shell_model.py:420), otherwise a small explicit operation of the stand-in."""
+    reference calls, rm_shell_model.py:420); otherwise an explicit operation whose solve runs on the device
+    (``femo_force_to_pressure``: Jacobi-PCG with the consistent [CG1]^3 mass matrix applied cell by cell -- the matrix ``A`` of
+    ``construct_force_to_pressure_map`` is the same operator and is not touched)."""
     if csdl.HAVE_CSDL_ALPHA:
         return csdl.solve_linear(A.toarray(), b)
-    import scipy.sparse.linalg as spla
-    lu = spla.splu(A.tocsc())
 
     class _Solve(csdl.CustomExplicitOperation):
         def evaluate(self, rhs):
@@ -34,10 +34,10 @@ def solve_linear(A, b):
             return x
 
         def compute(self, input_vals, output_vals):
-            output_vals["x"] = lu.solve(np.asarray(input_vals["b"], dtype=np.float64))
+            output_vals["x"] = ctx.force_to_pressure(np.asarray(input_vals["b"], dtype=np.float64))
 
         def vjp(self, bar):                      # A is symmetric: bar_b = A^-T bar_x
-            return lu.solve(bar)
+            return ctx.force_to_pressure(bar)
 
     return _Solve().evaluate(b)
 
@@ -64,7 +64,7 @@ def createCustomMeasure(mesh: ShellMesh, dim, SubdomainFunc, measure: str, tag: 
 class RMShellModel:
     def __init__(self, mesh: ShellMesh, shell_bc_func: callable = None, element_wise_material=False, rho=100,
                  PENALTY_BC=True, additional_outputs=None, mesh_tags=None, record=True, elementwise_pressure=False,
-                 device=0, renumber=False, nquad=4):
+                 device=0, renumber=False, nquad=None):
         # caller order <-> solver order.  dolfinx reorders every mesh it is given and the reference carries the maps
         # (rm_shell_model.py:116, 396-438, 505-527); with renumber=True this build does the same with a Morton order of
         # the cells (ShellMesh.renumbered): inputs are gathered into solver order, nodal displacements come back in
@@ -96,9 +96,10 @@ class RMShellModel:
         self.elementwise_pressure = elementwise_pressure
         self.device = device
         # n x n Gauss points per quadrilateral for the static forms (2..5).  The reference leaves the degree to UFL's
-        # estimate, which on quadrilaterals comes out near 47 (scripts/ufl_degree_estimate.py): exact integration.  n = 4 is
-        # exact on flat cells with uniform E, nu; on warped cells the answer converges in n.
-        self.nquad = int(nquad)
+        # estimate, which on quadrilaterals comes out near 47 (scripts/ufl_degree_estimate.py): exact integration.  Default:
+        # what the mesh asks for -- 4 on affine cells (exact there), 5 as soon as one cell is warped (within 1e-9 of the
+        # limit at BASELINE config 3; ShellMesh.recommended_nquad).
+        self.nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
         self.association_table = None
         if shell_bc_func is None:
             raise ValueError("Please provide the shell bc location function.\n"
@@ -193,8 +194,9 @@ class RMShellModel:
             shell_inputs.F_solid = reshaped_force
         else:
             # nodal forces -> nodal pressures through the consistent mass matrix (rm_shell_model.py:414-421)
-            A = self.shell_pde.construct_force_to_pressure_map()
-            shell_inputs.F_solid = solve_linear(A, reshaped_force)
+            # the matrix itself is only needed by csdl_alpha's solve_linear; the stand-in solves on the device
+            A = self.shell_pde.construct_force_to_pressure_map() if csdl.HAVE_CSDL_ALPHA else None
+            shell_inputs.F_solid = solve_linear(A, reshaped_force, ctx=self.shell_pde.ctx)
         shell_inputs.F_solid.add_name("F_solid")
         if node_disp is None:
             node_disp = csdl.Variable(value=0.0, shape=(mesh.nn, 3), name="node_disp")

@@ -22,7 +22,7 @@ class FacetSet:
 
 
 class RMShellPDE:
-    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=4, device=0, solver="direct"):
+    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=None, device=0, solver="direct"):
         self.mesh = mesh
         self.element_wise_material = element_wise_material
         self.elementwise_pressure = elementwise_pressure
@@ -101,13 +101,12 @@ class RMShellPDE:
     def pnorm_stress(self, w, uhat, h, E, nu, dx=None, m=1e-6, rho=100, alpha=None, regularization=False):
         """1/alpha int (m vm_top)^rho J dx with the degree-4 measure (rm_shell_pde.py:112-128); alpha is the
         reference area, evaluated by the backend on first use."""
-        # regularization=True adds 0.5 * 1e3 int h^rho J dx inside the 1/alpha (rm_shell_pde.py:120-122)
-        self.ctx.set_option("stress_regularization", 0.5e3 if regularization else 0.0)
-        self.ctx.set_stress_params(m, rho)
+        # regularization=True adds 0.5 * 1e3 int h^rho J dx inside the 1/alpha (rm_shell_pde.py:120-122); (m, rho, that coefficient)
+        # travel with the form and reach the context when the form is evaluated: two forms with different parameters coexist
         # dx: None for the whole mesh, or the index i of a tagged sub-domain (the reference passes dxx(i))
         sel = -1 if dx is None else int(dx)
         self.ctx.set_stress_alpha(alpha, sel)          # None: the reference area, evaluated by the backend at first use (:123-127)
-        return Form(self.ctx, "pnorm_stress", subdomain=sel)
+        return Form(self.ctx, "pnorm_stress", subdomain=sel, stress_params=(float(m), float(rho), 0.5e3 if regularization else 0.0))
 
     def von_Mises_stress(self, w, uhat, h, E, nu, surface="Top"):
         """von Mises stress at xi2 = h/2 ('Top'), 0 ('Mid') or -h/2 ('Bot') (rm_shell_pde.py:153-165), as a field the

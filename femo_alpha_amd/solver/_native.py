@@ -13,6 +13,8 @@ _i32p = C.POINTER(C.c_int32)
 SIGNATURES = {
     "femo_plan_build": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p,
                                   C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32]),
+    "femo_plan_build_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "femo_plan_size": (C.c_int64, [C.c_void_p, C.c_char_p]),
     "femo_plan_itemsize": (C.c_int, [C.c_void_p, C.c_char_p]),
     "femo_plan_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
@@ -37,16 +39,19 @@ def load():
     return _lib
 
 
-def plan_arrays(mesh, leaf_size, min_depth=0):
+def plan_arrays(mesh, leaf_size, min_depth=0, axis_rule=0, gap=0.0):
     """All arrays of include/femo_symbolic.h for ``mesh`` as a dict of numpy arrays."""
     lib = load()
     cell_p2 = np.ascontiguousarray(mesh.cell_p2, dtype=np.int32)
-    cent = np.ascontiguousarray(mesh.nodes[mesh.cells].mean(axis=1), dtype=np.float64)
+    xc = mesh.nodes[mesh.cells]
+    cent = np.ascontiguousarray(xc.mean(axis=1), dtype=np.float64)
+    cext = np.ascontiguousarray(xc.max(axis=1) - xc.min(axis=1), dtype=np.float64)
     cell_dofs = np.ascontiguousarray(mesh.cell_dofs(), dtype=np.int32)
     h = C.c_void_p()
-    rc = lib.femo_plan_build(C.byref(h), mesh.nel, mesh.nP2, mesh.nV, cell_p2.shape[1], cell_dofs.shape[1],
-                             cell_p2.ctypes.data_as(_i32p), cent.ctypes.data_as(C.POINTER(C.c_double)),
-                             cell_dofs.ctypes.data_as(_i32p), int(leaf_size), int(min_depth))
+    dp = C.POINTER(C.c_double)
+    rc = lib.femo_plan_build_ex(C.byref(h), mesh.nel, mesh.nP2, mesh.nV, cell_p2.shape[1], cell_dofs.shape[1],
+                                cell_p2.ctypes.data_as(_i32p), cent.ctypes.data_as(dp), cext.ctypes.data_as(dp),
+                                cell_dofs.ctypes.data_as(_i32p), int(leaf_size), int(min_depth), int(axis_rule), float(gap))
     if rc:
         msg = lib.femo_plan_last_error().decode()
         raise ValueError(msg) if rc == 2 else RuntimeError(msg)

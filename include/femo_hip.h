@@ -160,6 +160,13 @@ int femo_solve_state(femo_ctx* ctx, int zero_guess, int32_t* iters, double* relr
  * the same call serves both modes (reference quirk Q3). */
 int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iters, double* relres);
 
+/* pressure = A^-1 force with A the consistent mass matrix of the pressure space [CG1]^3 (node-major xyz, 3 nn entries) -- replaces
+ * csdl.solve_linear(A, force) on the matrix of RMShellPDE.construct_force_to_pressure_map (rm_shell/rm_shell_model.py:414-421,
+ * rm_shell_pde.py:194-209; dynamic_rm_shell/plate_sim.py:452-468).  Jacobi-preconditioned conjugate gradients with the matrix
+ * applied cell by cell on the device; A is symmetric, so the same call serves the reverse mode.  Status 4: maxit reached short of
+ * rtol (option "strict"). */
+int femo_force_to_pressure(femo_ctx* ctx, const double* force, double* pressure, double rtol, int32_t maxit, int32_t* iters, double* relres);
+
 /* ---- Dynamic shell (reference femo_alpha/dynamic_rm_shell/plate_sim.py:131-140,190-215): building blocks on
  * device vectors.  The time loop and its adjoint live in femo_alpha_amd/dynamic_rm_shell (Python, like the
  * reference's PlateSim); these calls supply the operator A = aK K + aM M of one midpoint/Newmark step, its
@@ -303,7 +310,10 @@ int femo_newmark_residual_T(femo_ctx* ctx, int32_t levels, double* g_thickness, 
  * "tangent linear model").  Results land in the adjoint-history buffer (femo_newmark_get_history(ctx, 2, ..)). */
 int femo_newmark_jvp(femo_ctx* ctx, int32_t levels, const double* dY, const double* dthickness, const double* dF);
 int femo_newmark_tangent(femo_ctx* ctx, const double* dR, int32_t levels);
-void* femo_newmark_ptr(femo_ctx* ctx, int32_t which);                           /* device: 0 history, 1 velocity, 2 adjoint history */
+/* Device addresses of the resident buffers: 0 displacement history, 1 velocity of the last level the march reached, 2 adjoint /
+ * tangent history.  Lifetime: until the next femo_newmark_setup on this context (which re-allocates them) or femo_destroy; a
+ * caller that wraps them (the zero-copy torch views of PlateSim) must drop its views before either. */
+void* femo_newmark_ptr(femo_ctx* ctx, int32_t which);
 
 /* Raw device pointer of a named buffer ("state","thickness","E","nu","density","F_solid","uhat")
  * for zero-copy wrapping by the caller (e.g. torch.from_dlpack-free ctypes views). */

@@ -7,7 +7,7 @@
  *
  * Arrays are read back by name with femo_plan_size / femo_plan_itemsize / femo_plan_get:
  *   tree (one entry per tree node, ids in creation order, children > parent):
- *     "lo", "hi"        element interval [lo, hi) of the node in "eorder"        int32
+ *     "lo", "hi"        element interval [lo, hi) of the node in "eorder"        int32     (ids: depth by depth, left before right)
  *     "left", "right", "parent", "depth", "height"                               int32
  *   elements:  "eorder" (bisection order -> cell), "epos" (cell -> position)     int32
  *              "elem_front" (cell -> leaf front), "elem_map" (nel x ndpc: row of every element DOF in its leaf front)
@@ -34,6 +34,16 @@ typedef struct femo_plan femo_plan;
  * femo_plan_last_error() set. */
 int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
                     const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth);
+/* The same with the two rules of the bisection exposed (femo_plan_build = axis_rule 0, gap_coeff 0: the plain median cut along the
+ * longest centroid extent).
+ *   gap_coeff > 0: a piece of n >= 64 cells is cut at the largest gap between consecutive sorted centroid coordinates within
+ *     n/2 +- min(1/8, gap_coeff / sqrt(n)) n (about one row of cells either way), so that the cut follows a mesh line where the mesh
+ *     has any row structure; the tree then has the fixed depth max(min_depth, ceil(log2(nel / leaf_size))).
+ *   axis_rule 1: cut across the axis along which the piece is longest in CELLS (centroid extent / mean cell extent; cext: nel x 3
+ *     extents of the cells' bounding boxes), not in length units. */
+int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                       const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
+                       int32_t axis_rule, double gap_coeff);
 /* number of entries of a named array (-1: no such array); 4 or 8 bytes per entry (0: no such array) */
 int64_t femo_plan_size(const femo_plan* p, const char* name);
 int femo_plan_itemsize(const femo_plan* p, const char* name);

@@ -104,6 +104,7 @@ class CpuShell:
         self.w, self.wS = c(o.wts, dtype=np.float64), c(o.wts_strain, dtype=np.float64)
         self.hK = c(o.hK, dtype=np.float64)
         self.uhat = c(o.uhat) if np.any(o.uhat) else None
+        self.N2 = c(o.N2)
         self.ld = o.ldof
         self._pattern = None
 
@@ -190,6 +191,18 @@ class CpuShell:
             y += self._P @ x
         return y
 
+    def apply_op(self, x, aK, aM, nthreads=1, out=None):
+        """out += (aK K_elastic + aM M) x, matrix-free (the step operator of the transient path and its right-hand side
+        products; M = rho h (u.v + h_K^2 theta.eta) J dx, oracle assemble_M)."""
+        m, o = self.mesh, self.o
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(m.ndof) if out is None else out
+        rho = np.ascontiguousarray(o.rho, dtype=np.float64)
+        rc = self.lib.cpu_apply_op(*self._common(), _i(self.cell_p2), m.ndof_u, self._u(), *self._tables(), *self._fields(),
+                                   _d(self.N2), _d(rho), C.c_double(aK), C.c_double(aM), _d(x), _d(y), int(nthreads))
+        assert rc == 0
+        return y
+
     def drdfield_T(self, name, state, lam, nthreads=1, scale=1.0, out=None):
         """out += scale * (dR/d field)^T lam at ``state`` by quadrature -- no matrix is assembled."""
         m, o = self.mesh, self.o
@@ -256,15 +269,23 @@ class CpuMultifrontal:
         self.level_off = c(np.concatenate([[0], np.cumsum([l.size for l in self.levels])]), dtype=np.int32)
         self.F = np.empty(int(p.front_off[-1]))
         self.leaves = c(np.nonzero(p.left < 0)[0], dtype=np.int32)
+        self.operator = (1.0, 0.0)          # (aK, aM): the matrix factorised is aK K + aM M (+ Dirichlet treatment)
 
     def factorize(self):
         """Returns (assembly seconds, factorisation seconds)."""
         from threadpoolctl import threadpool_limits
         s, lib = self.s, self.s.lib
         t0 = time.perf_counter()
-        rc = lib.cpu_fronts_assemble(self.leaves.size, _i(self.leaves), _i(self.nf), _l(self.front_off), _i(self.elem_start),
-                                     _i(self.elem_order), _i(self.elem_map), s.o.nvc, s.o.npc, s.o.nq, _d(s.nodes), _i(s.cells),
-                                     s._u(), *s._tables(), *s._fields(), _d(self.F), self.nthreads)
+        if self.operator == (1.0, 0.0):
+            rc = lib.cpu_fronts_assemble(self.leaves.size, _i(self.leaves), _i(self.nf), _l(self.front_off), _i(self.elem_start),
+                                         _i(self.elem_order), _i(self.elem_map), s.o.nvc, s.o.npc, s.o.nq, _d(s.nodes), _i(s.cells),
+                                         s._u(), *s._tables(), *s._fields(), _d(self.F), self.nthreads)
+        else:
+            rho = np.ascontiguousarray(s.o.rho, dtype=np.float64)
+            rc = lib.cpu_fronts_assemble_op(self.leaves.size, _i(self.leaves), _i(self.nf), _l(self.front_off), _i(self.elem_start),
+                                            _i(self.elem_order), _i(self.elem_map), s.o.nvc, s.o.npc, s.o.nq, _d(s.nodes), _i(s.cells),
+                                            s._u(), *s._tables(), *s._fields(), _d(s.N2), _d(rho), C.c_double(self.operator[0]),
+                                            C.c_double(self.operator[1]), _d(self.F), self.nthreads)
         assert rc == 0
         self._dirichlet()
         t1 = time.perf_counter()
@@ -294,7 +315,24 @@ class CpuMultifrontal:
                 lower = ii >= jj
                 np.add.at(Ft, (ii[lower], jj[lower]), blk[lower])
         if o.strong_dofs.size:
-            raise NotImplementedError("the CPU multifrontal baseline handles the penalty clamp of the benchmark workloads")
+            # strong rows / columns out of the leaf fronts, unit diagonal in their place (dolfinx assemble_matrix(bcs) semantics,
+            # oracle _apply_strong).  A constrained DOF shared by k leaves ends up with the pivot k: its row of the system reads
+            # k x = 0 either way, the right-hand side is zeroed there.
+            if getattr(self, "_strong_leaves", None) is None:
+                is_strong = np.zeros(o.mesh.ndof, dtype=bool)
+                is_strong[o.strong_dofs] = True
+                self._strong_leaves = []
+                for t in self.leaves:
+                    fd = p.front_dofs[p.dof_off[t]:p.dof_off[t + 1]]
+                    pos = np.nonzero(is_strong[fd])[0]
+                    if pos.size:
+                        self._strong_leaves.append((int(t), pos))
+            for t, pos in self._strong_leaves:
+                n = int(p.nf[t])
+                Ft = self.F[p.front_off[t]:p.front_off[t + 1]].reshape(n, n, order="F")
+                Ft[pos, :] = 0.0
+                Ft[:, pos] = 0.0
+                Ft[pos, pos] = 1.0
 
     def solve(self, b, by_level=True):
         """Triangular sweeps with the factor.  ``by_level``: the fronts of a tree level in parallel (one per OpenMP thread,
@@ -311,6 +349,43 @@ class CpuMultifrontal:
             self.s.lib.cpu_fronts_solve(self.order.size, _i(self.order), _i(self.nf), _i(self.npiv), _l(self.front_off), _l(self.dof_off),
                                         _i(self.front_dofs), _d(self.F), _d(x), self.ptr["trsv"], self.ptr["gemv"])
         return x
+
+
+def dynamic_march(cs, mf, f_history, dt, nsteps, cores, reassemble_every_step=False):
+    """Midpoint / Newmark march of the reference's PlateSim on the host cores (oracle dynamic_history with the C++/OpenMP kernels
+    and the multifrontal Cholesky in place of numpy + SuperLU): per step
+        (2/dt^2 M + K/2) w_i = F_i + M (2/dt^2 w_{i-1} + 2/dt wdot_{i-1}) - K/2 w_{i-1},   wdot_i = 2/dt (w_i - w_{i-1}) - wdot_{i-1},
+    strong Dirichlet rows, zero initial state, ONE direct solve per step (solveNonlinear_mod runs a single Newton iteration,
+    nonlinear_utils.py:220-229).  ``reassemble_every_step``: the step operator is assembled and factorised before every solve, as
+    the reference does (plate_sim.py:319 -> nonlinear_utils.py:210-233) and BASELINE config 5 words it; otherwise once.
+    Returns (last state, seconds per phase: assemble, factor, rhs, solve)."""
+    o = cs.o
+    a, b = 2.0 / dt ** 2, 2.0 / dt
+    mf.operator = (0.5, a)
+    mf.nthreads = cores
+    keep = np.ones(o.mesh.ndof); keep[o.strong_dofs] = 0.0
+    w = np.zeros(o.mesh.ndof); wd = np.zeros(o.mesh.ndof)
+    f0 = o.f.copy()
+    t = dict(assemble=0.0, factor=0.0, rhs=0.0, solve=0.0)
+    for i in range(1, nsteps + 1):
+        if reassemble_every_step or i == 1:
+            ta, tf = mf.factorize()
+            t["assemble"] += ta; t["factor"] += tf
+        t0 = time.perf_counter()
+        o.f = np.asarray(f_history[min(i, len(f_history) - 1)], dtype=np.float64).reshape(-1, 3)
+        rhs = cs.load_vector(cores)
+        y = cs.apply_op(w, -0.5, a, cores)                 # (a M - K/2) w_{i-1}
+        cs.apply_op(wd, 0.0, b, cores, out=y)              # + b M wdot_{i-1}
+        rhs += keep * y
+        rhs[o.strong_dofs] = 0.0
+        t1 = time.perf_counter()
+        wn = mf.solve(rhs)
+        t2 = time.perf_counter()
+        wd = b * (wn - w) - wd
+        w = wn
+        t["rhs"] += t1 - t0; t["solve"] += t2 - t1
+    o.f = f0
+    return w, t
 
 
 def cpu_model_name():

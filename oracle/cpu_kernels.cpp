@@ -553,6 +553,139 @@ int cpu_fronts_assemble(int nlist, const int32_t* fronts, const int32_t* nf, con
     return 0;
 }
 
+// ---- the step operator of the transient path, A = aK K + aM M (dynamic_rm_shell/plate_sim.py:131-140,190-215: midpoint rule,
+// aK = 1/2, aM = 2/dt^2), for the CPU column of BASELINE config 5.  M is the inertia of oracle assemble_M:
+// rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348).
+namespace {
+// Ke += aM * M_e
+void element_mass_add(const Tables& T, const double* N2, const ElemIn& el, const double* rho_e, bool quad, double aM, double* Ke) {
+    const int ld = 3 * T.npc + 3 * T.nvc;
+    double B[9][MAXLD];
+    for (int q = 0; q < T.nq; ++q) {
+        if (T.w[q] == 0.0) continue;
+        QP g;
+        qp_B(T, q, el.X, el.has_u ? el.U : nullptr, quad, B, g);
+        double hq = 0, rq = 0;
+        for (int b = 0; b < T.nvc; ++b) { const double N = T.N1[(size_t)q * T.nvc + b]; hq += N * el.h[b]; rq += N * rho_e[b]; }
+        const double cm = aM * T.w[q] * g.det * g.Ju * rq * hq, ct = cm * el.hK * el.hK;
+        const double* n2 = N2 + (size_t)q * T.npc;
+        const double* n1 = T.N1 + (size_t)q * T.nvc;
+        for (int a = 0; a < T.npc; ++a)
+            for (int b = 0; b < T.npc; ++b) {
+                const double v = cm * n2[a] * n2[b];
+                for (int c = 0; c < 3; ++c) Ke[(size_t)(3 * a + c) * ld + 3 * b + c] += v;
+            }
+        for (int a = 0; a < T.nvc; ++a)
+            for (int b = 0; b < T.nvc; ++b) {
+                const double v = ct * n1[a] * n1[b];
+                for (int c = 0; c < 3; ++c) Ke[(size_t)(3 * T.npc + 3 * a + c) * ld + 3 * T.npc + 3 * b + c] += v;
+            }
+    }
+}
+inline void load_rho(int e, int nvc, const int32_t* cells, const double* rho, int ewm, double* rho_e) {
+    for (int b = 0; b < nvc; ++b) rho_e[b] = rho[ewm ? e : cells[(size_t)e * nvc + b]];
+}
+}  // namespace
+
+// leaf fronts of A = aK K + aM M (cpu_fronts_assemble with the inertia added)
+int cpu_fronts_assemble_op(int nlist, const int32_t* fronts, const int32_t* nf, const int64_t* front_off, const int32_t* elem_start,
+                           const int32_t* elem_order, const int32_t* elem_map, int nvc, int npc, int nq, const double* nodes,
+                           const int32_t* cells, const double* uhat, const double* N1, const double* dN1, const double* dN2,
+                           const double* w, const double* wS, const double* h, const double* E, const double* nu, int ewm, const double* hK,
+                           int quad, const double* N2, const double* rho, double aK, double aM, double* F, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
+    const int ld = 3 * npc + 3 * nvc;
+    if (ld > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        std::vector<double> Ke((size_t)ld * ld);
+#pragma omp for schedule(dynamic, 8)
+        for (int i = 0; i < nlist; ++i) {
+            const int t = fronts[i], n = nf[t];
+            double* Ft = F + front_off[t];
+            std::memset(Ft, 0, sizeof(double) * (size_t)n * n);
+            for (int k = elem_start[t]; k < elem_start[t + 1]; ++k) {
+                const int e = elem_order[k];
+                ElemIn el;
+                double rho_e[4];
+                load_elem(e, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
+                load_rho(e, nvc, cells, rho, ewm, rho_e);
+                element_matrix(T, el, quad != 0, 0, Ke.data());
+                if (aK != 1.0) for (double& v : Ke) v *= aK;
+                if (aM != 0.0) element_mass_add(T, N2, el, rho_e, quad != 0, aM, Ke.data());
+                const int32_t* map = elem_map + (size_t)e * ld;
+                for (int a = 0; a < ld; ++a)
+                    for (int b = 0; b < ld; ++b)
+                        if (map[a] >= map[b]) Ft[map[a] + (size_t)n * map[b]] += Ke[(size_t)a * ld + b];     // lower triangle
+            }
+        }
+    }
+    return 0;
+}
+
+// y += (aK K + aM M) x, element by element (cpu_apply_K with the inertia added)
+int cpu_apply_op(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2, int ndof_u,
+                 const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* w, const double* wS,
+                 const double* h, const double* E, const double* nu, int ewm, const double* hK, int quad, const double* N2,
+                 const double* rho, double aK, double aM, const double* x, double* y, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
+    const int ld = 3 * npc + 3 * nvc;
+    if (ld > MAXLD || nq > MAXQ) return 1;
+#pragma omp parallel for schedule(static, 64) num_threads(nthreads)
+    for (int e = 0; e < nel; ++e) {
+        ElemIn el;
+        double rho_e[4];
+        load_elem(e, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
+        load_rho(e, nvc, cells, rho, ewm, rho_e);
+        int dofs[MAXLD];
+        element_dofs(e, nvc, npc, cells, cell_p2, ndof_u, dofs);
+        double xe[MAXLD], ye[MAXLD] = {0}, B[9][MAXLD];
+        for (int i = 0; i < ld; ++i) xe[i] = x[dofs[i]];
+        for (int q = 0; q < nq; ++q) {
+            QP g;
+            qp_B(T, q, el.X, el.has_u ? el.U : nullptr, quad != 0, B, g);
+            double hq = 0, Eq = 0, nuq = 0, rq = 0;
+            for (int b = 0; b < nvc; ++b) {
+                const double N = N1[(size_t)q * nvc + b];
+                hq += N * el.h[b]; Eq += N * el.E[b]; nuq += N * el.nu[b]; rq += N * rho_e[b];
+            }
+            if (aK != 0.0) {
+                CQ C;
+                qp_C(hq, Eq, nuq, el.hK, w[q] * g.det, wS[q] * g.det, g.Ju, 0, C);
+                double s[9] = {0}, t[9];
+                for (int r = 0; r < 9; ++r)
+                    for (int k = 0; k < ld; ++k) s[r] += B[r][k] * xe[k];
+                for (int i = 0; i < 3; ++i) {
+                    t[i] = C.Cm[i][0] * s[0] + C.Cm[i][1] * s[1] + C.Cm[i][2] * s[2];
+                    t[3 + i] = C.Cb[i][0] * s[3] + C.Cb[i][1] * s[4] + C.Cb[i][2] * s[5];
+                }
+                t[6] = C.cs * s[6]; t[7] = C.cs * s[7]; t[8] = C.cd * s[8];
+                for (int r = 0; r < 9; ++r)
+                    for (int k = 0; k < ld; ++k) ye[k] += aK * B[r][k] * t[r];
+            }
+            if (aM != 0.0 && w[q] != 0.0) {
+                const double cm = aM * w[q] * g.det * g.Ju * rq * hq, ct = cm * el.hK * el.hK;
+                const double* n2 = N2 + (size_t)q * npc;
+                const double* n1 = N1 + (size_t)q * nvc;
+                double uq[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
+                for (int a = 0; a < npc; ++a)
+                    for (int c = 0; c < 3; ++c) uq[c] += n2[a] * xe[3 * a + c];
+                for (int b = 0; b < nvc; ++b)
+                    for (int c = 0; c < 3; ++c) tq[c] += n1[b] * xe[3 * npc + 3 * b + c];
+                for (int a = 0; a < npc; ++a)
+                    for (int c = 0; c < 3; ++c) ye[3 * a + c] += cm * n2[a] * uq[c];
+                for (int b = 0; b < nvc; ++b)
+                    for (int c = 0; c < 3; ++c) ye[3 * npc + 3 * b + c] += ct * n1[b] * tq[c];
+            }
+        }
+        for (int i = 0; i < ld; ++i) {
+#pragma omp atomic
+            y[dofs[i]] += ye[i];
+        }
+    }
+    return 0;
+}
+
 // one tree level: [extend-add of the children] + partial Cholesky (potrf on the pivot block, trsm, syrk) per front
 int cpu_fronts_factor_level(int nlist, const int32_t* fronts, const int32_t* nf, const int32_t* npiv, const int64_t* front_off,
                             const int64_t* dof_off, const int32_t* left, const int32_t* right, const int32_t* up_map, double* F,

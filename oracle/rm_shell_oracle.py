@@ -41,7 +41,27 @@ REG_ALPHA1 = 1.0e-2          # rm_shell_pde.py:67
 
 
 # ----------------------------------------------------------------------------- tables
+# Gauss-Legendre rules up to 5 points from decimal literals of the exact nodes and weights (computed with mpmath at 50 digits):
+# the correctly rounded doubles.  numpy's leggauss is up to 4e-16 away from them, and at BASELINE config 3 (1 M DOF) a change of
+# that size in the 5-point weights moves displacement / compliance / gradient by 3.5e-7 / 2.8e-7 / 3.5e-7
+# (tests/golden/make_config3_golden.py with either table): the tables are part of the definition of the discrete problem at that
+# size, so the checker and the HIP library each carry the exact ones.
+_GL = {
+    1: ([0.0], [2.0]),
+    2: ([-0.5773502691896257645091488, 0.5773502691896257645091488], [1.0, 1.0]),
+    3: ([-0.7745966692414833770358531, 0.0, 0.7745966692414833770358531],
+        [0.5555555555555555555555556, 0.8888888888888888888888889, 0.5555555555555555555555556]),
+    4: ([-0.8611363115940525752239465, -0.3399810435848562648026658, 0.3399810435848562648026658, 0.8611363115940525752239465],
+        [0.3478548451374538573730639, 0.6521451548625461426269361, 0.6521451548625461426269361, 0.3478548451374538573730639]),
+    5: ([-0.9061798459386639927976269, -0.5384693101056830910363144, 0.0, 0.5384693101056830910363144, 0.9061798459386639927976269],
+        [0.236926885056189087514264, 0.4786286704993664680412915, 0.5688888888888888888888889, 0.4786286704993664680412915,
+         0.236926885056189087514264]),
+}
+
+
 def gauss_legendre(n):
+    if n in _GL:
+        return np.array(_GL[n][0]), np.array(_GL[n][1])
     x, w = np.polynomial.legendre.leggauss(n)
     return x, w
 
@@ -128,8 +148,13 @@ class ShellOracle:
     (attributes nodes, cells, cell_p2, nV, nP2, ndof, ndof_u, is_quad)."""
 
     def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False,
-                 nquad=4, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None, nred=0):
+                 nquad=None, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None, nred=0):
         self.mesh = mesh
+        if nquad is None:
+            # the rule the mesh asks for: 4 x 4 Gauss on affine cells (exact there), 5 x 5 on warped quadrilaterals -- the
+            # reference integrates its static forms (nearly) exactly (plain dx, linear_shell_model.py:88-103)
+            nquad = mesh.recommended_nquad() if hasattr(mesh, "recommended_nquad") else 4
+        self.nquad = int(nquad)
         self.ewm = bool(element_wise_material)
         self.ewp = bool(elementwise_pressure)
         self.beta = float(beta)

@@ -16,7 +16,7 @@ if ROOT not in sys.path:
 
 
 class NumpyEngine:
-    def __init__(self, sub, plan, info, element_wise_material=False):
+    def __init__(self, sub, plan, info, element_wise_material=False, nquad=None):
         import torch
         from oracle.rm_shell_oracle import ShellOracle
         self.torch = torch
@@ -26,7 +26,8 @@ class NumpyEngine:
         self.nvec = sub.ndof + info["nghost"]
         self.v = {n: torch.zeros(self.nvec, dtype=torch.float64) for n in ("state", "adjoint", "r", "z", "p", "Ap", "b")}
         self.tmp = np.zeros(self.nvec)
-        self.oracle = ShellOracle(sub, element_wise_material=element_wise_material)
+        self.nquad = nquad                 # the rule of the whole mesh, the same on every rank
+        self.oracle = ShellOracle(sub, element_wise_material=element_wise_material, nquad=nquad)
         self.pf, self.beta = None, 1e15
         self.F, self.L = None, None
         self.topbuf = self.scal = None
@@ -112,7 +113,7 @@ class NumpyEngine:
     def set_penalty_facets(self, pairs, beta):
         from oracle.rm_shell_oracle import ShellOracle
         o = self.oracle
-        self.oracle = ShellOracle(self.sub, element_wise_material=self.ewm, penalty_facets=pairs, beta=beta)
+        self.oracle = ShellOracle(self.sub, element_wise_material=self.ewm, penalty_facets=pairs, beta=beta, nquad=self.nquad)
         self.oracle.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f)
 
     # ------------------------------------------------------------------ operator
@@ -256,7 +257,7 @@ def worker(rank, world, port, kind, engine, result_path, backend="gloo"):
     try:
         from femo_alpha_amd.parallel import Comm, DistributedShell
         m, marker, fields = make_case(kind)
-        factory = (lambda sub, plan, info: NumpyEngine(sub, plan, info)) if engine == "numpy" else None
+        factory = (lambda sub, plan, info: NumpyEngine(sub, plan, info, nquad=m.recommended_nquad())) if engine == "numpy" else None
         ds = DistributedShell(m, Comm(dist), bc_marker=marker, leaf_size=12 if kind == "wing1m" else 4, engine_factory=factory, device=0)
         res = run_driver(ds, fields)
         if rank == 0:

@@ -51,9 +51,15 @@ def test_parity_triple_against_fullsize_golden(name):
     c.close()
 
 
-def test_parity_triple_against_the_one_million_dof_golden():
+@pytest.mark.parametrize("nquad", [None, 4])
+def test_parity_triple_against_the_one_million_dof_golden(nquad):
     """BASELINE config 3 -- the bench workload itself, 1 015 470 DOF (tests/golden/make_config3_golden.py: CPU multifrontal
     Cholesky of the oracle's matrix, polished in extended precision to 1e-10).
+
+    nquad None: the rule the mesh asks for and the bench runs -- 5 x 5 Gauss points on these warped cells, within 1e-9 of the
+    reference's (nearly) exact integration (linear_shell_model.py:88-103; golden config3_wing1m.npz, made with n = 5).
+    nquad 4: the rule of rounds 1-3 against ITS golden (config3_wing1m_n4.npz); the two goldens differ by 7.5e-8 in the
+    gradient, which is why n = 4 is no longer the default on warped meshes.
 
     Tolerance 1e-7, not 1e-8: at this size and slenderness (1.27 mm skin, 6 m span) the discrete solution itself is only
     defined to ~7e-8 in double precision -- changing the oracle's stiffness entries by ONE unit in the last place moves the
@@ -64,11 +70,12 @@ def test_parity_triple_against_the_one_million_dof_golden():
     from bench import make_workload
     from femo_alpha_amd.backend import ShellContext
     tol = 1e-7
-    g = np.load(os.path.join(GOLDEN, "config3_wing1m.npz"))
-    assert max(float(g["w_correction"]), float(g["lam_correction"])) < 1e-2 * TOL
+    g = np.load(os.path.join(GOLDEN, "config3_wing1m.npz" if nquad is None else f"config3_wing1m_n{nquad}.npz"))
+    assert max(float(g["w_correction"]), float(g["lam_correction"])) < 1e-2 * tol          # the golden is sharper than the bar
     m, fields, marker, _ = make_workload("wing1m")
     assert m.ndof == int(g["ndof"])
-    c = ShellContext(m)
+    c = ShellContext(m, nquad=nquad)
+    assert c.nquad == (5 if nquad is None else nquad) and int(g["nquad"] if "nquad" in g.files else 4) == c.nquad
     for k, v in fields.items():
         c.set_field(k, v)
     c.set_penalty_facets(m.penalty_facets(marker))

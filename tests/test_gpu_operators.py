@@ -151,6 +151,34 @@ def test_forces_instead_of_pressures():
     assert g.shape == (nn, 3) and np.abs(g[:, 2]).max() > 0
 
 
+@pytest.mark.parametrize("kind", ["warped_quads", "triangles"])
+def test_force_to_pressure_solve_on_the_device(kind):
+    """femo_force_to_pressure (Jacobi-PCG, the [CG1]^3 mass matrix applied cell by cell on the device) against a host sparse solve
+    with the matrix of construct_force_to_pressure_map (rm_shell_pde.py:194-209) on warped quadrilaterals and on triangles; the
+    operator is symmetric, so the same call is its own transpose (the reverse mode of rm_shell_model.py:420)."""
+    import scipy.sparse.linalg as spla                     # test-side checker only
+    from femo_alpha_amd.backend import ShellContext
+    from femo_alpha_amd.mesh import quads_to_triangles, wing_skin_mesh
+    from femo_alpha_amd.rm_shell.rm_shell_pde import force_to_pressure_map
+    mesh = wing_skin_mesh(8, 24, shuffle=True)
+    if kind == "triangles":
+        mesh = quads_to_triangles(mesh)
+    A = force_to_pressure_map(mesh)
+    rng = np.random.default_rng(3)
+    f = rng.uniform(-1, 1, 3 * mesh.nn)
+    c = ShellContext(mesh)
+    p = c.force_to_pressure(f)
+    it, rr = c.last_force_to_pressure
+    ref = spla.spsolve(A.tocsc(), f)
+    assert it < 200 and rr <= 1e-13
+    assert np.abs(p - ref).max() < 1e-11 * np.abs(ref).max()
+    g = rng.uniform(-1, 1, 3 * mesh.nn)
+    assert abs(g @ p - c.force_to_pressure(g) @ f) < 1e-11 * abs(g @ p)        # symmetry: g . A^-1 f = (A^-1 g) . f
+    with pytest.raises(ValueError):
+        c.force_to_pressure(f[:-1])
+    c.close()
+
+
 def test_mesh_tags_give_per_tag_stress_aggregates():
     """RMShellModel(mesh_tags=...) registers pnorm_stress_<tag> per sub-domain (rm_shell_model.py:101-133, 242-253)."""
     from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
