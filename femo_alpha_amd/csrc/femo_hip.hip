@@ -65,6 +65,7 @@ struct femo_ctx {
     int csel = -1, ntags = 0;
     std::vector<double> alpha_tag;           // reference area of every sub-domain (frozen at first use, like stress_alpha)
     double* gradbuf = nullptr;
+    double* eq = nullptr;                    // option "equilibrate": the factorisation is that of D K D, D = diag(eq) (allocated on first use)
     double* fp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // force -> pressure solve: x, r, z, p, Ap, diag (3 nn each, on first use)
     // element-partitioned driver (femo_dist_*): replicated separator entries, dot weights, gradient scatter map
     struct Dist {
@@ -112,7 +113,9 @@ struct femo_ctx {
         int lookahead = 1, lookahead_cnt = 16;
         int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
         int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
+        int rows_fine_wg = 768;               // k_panel_rows launches of at most this many (64-row) workgroups run k_panel_rows_fine (16 rows per workgroup)
         int narrow_split = 1, narrow_split_wg = 1024;
+        int narrow_fine_wg = 512;             // narrow updates of at most this many 64 x 64 tiles run k_trailing_fine (32 x 32 tiles, a 16 x 16 block per wave)
         int fuse_rows = 1, fuse_rows_cnt = 4096;    // single-panel fronts of non-wide levels with at least that many fronts: rows in k_diag_block
         int sweep_graph = 0;                        // the preconditioner application of the PCG loop replayed as a HIP graph
         int diag_v1_cnt = 512;                      // levels of at least this many fronts: k_diag_block (80 KB of LDS, two workgroups per CU)
@@ -120,6 +123,10 @@ struct femo_ctx {
         int super_tiles = 0, super_tiles_min = 8;   // rank-k updates of few large fronts: 4 x 4 super-tiles per XCD from this many 64-row tiles
         int diag_ahead = 0;                   // super-panel levels: the next diagonal block runs beside the rest of this panel's rows and updates
         int fused_schur = 1;          // left-looking levels: the Schur update gathers its block from the children
+        // Experiment: factorise D K D with D = diag(K)^-1/2 (1) or its nearest powers of two (2) and apply
+        // D (L L^T)^-1 D.  Measured: no change in what one application of the factor leaves -- every operation of
+        // a Cholesky factorisation and of the sweeps commutes with a power-of-two scaling, so mode 2 reproduces mode 0 bit for bit
+        int equilibrate = 0;
         int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
         int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
@@ -592,16 +599,26 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
               hipLaunchKernelGGL(k_zero_fronts, dim3(nt0 * (nt0 + 1) / 2, n), dim3(256), 0, c->stream, fd, fr.level_nodes, off); }
         HIPCHK(c, hipMemsetAsync(fr.info, 0, sizeof(int), c->stream));
         if (refresh_penalty(c)) return 1;
+        const double* eq = nullptr;
+        if (c->opt.equilibrate) {
+            if (c->op_aM != 0.0 || c->op_aK != 1.0 || l1 != fr.nlevels || l0 != 0)
+                return fail(c, "option equilibrate: static operator and whole factorisations only (an experiment)");
+            if (!c->eq) HIPCHK(c, hipMalloc((void**)&c->eq, (size_t)c->ndof * sizeof(double)));
+            c->jacobi_dirty = true;
+            if (refresh_diag(c)) return 1;
+            hipLaunchKernelGGL(k_eq_scale, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->eq, (const double*)c->dinv, mask, c->opt.equilibrate, (int64_t)c->ndof);
+            eq = c->eq;
+        }
         { ProfScope ps(c, 4);
         if (c->op_aM != 0.0)
             ELEM_LAUNCH_S(c, k_front_assemble, COMMA_TRUE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
-                          fr.elem_map, mask);
+                          fr.elem_map, mask, eq);
         else
             ELEM_LAUNCH_S(c, k_front_assemble, COMMA_FALSE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
-                          fr.elem_map, mask); }
+                          fr.elem_map, mask, eq); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
-                               fr.elem_map, c->ld, c->npc, c->nvc, mask);
+                               fr.elem_map, c->ld, c->npc, c->nvc, mask, eq);
         if (mask) hipLaunchKernelGGL(k_front_mask_diag, dim3(fr.ntree), dim3(64), 0, c->stream, fd, mask);
         HIPCHK(c, hipGetLastError());
     }
@@ -739,7 +756,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // rows below a diagonal block: launches of few workgroups (what one workgroup takes is what the launch takes) use the
         // kernel that brings all of S into LDS at once (option "rows_preload_wg": up to that many workgroups per launch)
         auto launch_rows = [&](int ntiles, int off, int n, int C0_, const double* sw_, int tile_first, hipStream_t st) {
-            if ((long long)ntiles * n <= c->opt.rows_preload_wg)
+            if ((long long)ntiles * n <= c->opt.rows_fine_wg)
+                hipLaunchKernelGGL(k_panel_rows_fine, dim3(4 * ntiles, n), dim3(256), 0, st, fd, lev, off, C0_, sw_, tile_first);
+            else if ((long long)ntiles * n <= c->opt.rows_preload_wg)
                 hipLaunchKernelGGL(k_panel_rows_preload, dim3(ntiles, n), dim3(256), PANEL_ROWS_PRELOAD_LDS, st, fd, lev, off, C0_, sw_, tile_first);
             else
                 hipLaunchKernelGGL(k_panel_rows, dim3(ntiles, n), dim3(256), 0, st, fd, lev, off, C0_, sw_, tile_first);
@@ -797,9 +816,15 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                 const bool gather_panel = fused_schur && K0 == 0;
                 // diagonal look-ahead: only the tiles of the diagonal block here, the others were issued on stream_m behind the previous rows
                 const int gx = diag_ahead ? std::min(DIAG_TILES, ntr * (NBO / TS)) : ntr * (NBO / TS);
+                // few tiles (the top of the tree): the fine kernel -- a quarter of the MFMA chain per wave, four times the workgroups
+                const bool fine = !diag_ahead && (C0 - K0) % 64 == 0 && (long long)gx * cnt <= c->opt.narrow_fine_wg;
                 if (ntr > 0)
                 FOR_FRONT_CHUNKS(cnt, off, n) {
-                    if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, st, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
+                    if (fine) {
+                        const int gx32 = 2 * ntr * (NBO / 32);           // 32-row tiles from the even column anchor down, four column tiles
+                        if (gather_panel) hipLaunchKernelGGL(k_trailing_fine<true>, dim3(gx32, 1, n), dim3(256), 0, st, fd, lev, off, C0, K0, mask, 0);
+                        else hipLaunchKernelGGL(k_trailing_fine<false>, dim3(gx32, 1, n), dim3(256), 0, st, fd, lev, off, C0, K0, mask, 0);
+                    } else if (gather_panel) hipLaunchKernelGGL(k_trailing_mfma<true>, dim3(gx, 1, n), dim3(256), 0, st, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
                     else hipLaunchKernelGGL(k_trailing_mfma<false>, dim3(gx, narrow_slices(gx, n, C0 - K0), n), dim3(256), 0, st, fd, lev, off, C0, 0, K0, NBO, mask, 0, 0);
                 }
             }
@@ -1097,8 +1122,12 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
 }
 
 static int frontal_solve(femo_ctx* c, double* v) {
+    const bool eq = c->opt.equilibrate && c->eq;                    // the factor is that of D K D:  K^-1 ~ D (L L^T)^-1 D
+    if (eq) hipLaunchKernelGGL(k_mul, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, v, (const double*)c->eq, (int64_t)c->ndof);
     if (int rc = frontal_fwd(c, v, 0, c->fr.nlevels)) return rc;
-    return frontal_bwd(c, v, 0, c->fr.nlevels);
+    if (int rc = frontal_bwd(c, v, 0, c->fr.nlevels)) return rc;
+    if (eq) hipLaunchKernelGGL(k_mul, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, v, (const double*)c->eq, (int64_t)c->ndof);
+    return 0;
 }
 
 // The preconditioner application of the PCG loop (always on c->z: ~56 dependent launches whose arguments depend on the plan and the
@@ -1487,6 +1516,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     for (double* p : c->fp)
         if (p) hipFree(p);
+    if (c->eq) hipFree(c->eq);
     void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
@@ -1814,6 +1844,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "super_panel_cnt") o.super_panel_cnt = v;
     else if (k == "super_panel_ahead") o.super_panel_ahead = v != 0;
     else if (k == "diag_ahead") o.diag_ahead = v != 0;
+    else if (k == "rows_fine_wg") o.rows_fine_wg = v;
+    else if (k == "narrow_fine_wg") o.narrow_fine_wg = v;
     else if (k == "rows_preload_wg") o.rows_preload_wg = v;
     else if (k == "narrow_split") { if (v < 1 || v > 32) return fail(c, "narrow_split: 1..32 slices of the K range"); o.narrow_split = v; }
     else if (k == "narrow_split_wg") o.narrow_split_wg = v;
@@ -1826,6 +1858,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;
     else if (k == "fused_schur") o.fused_schur = v != 0;
+    else if (k == "equilibrate") { if (v < 0 || v > 2) return fail(c, "equilibrate: 0 off, 1 diag^-1/2, 2 nearest powers of two"); o.equilibrate = v; operator_changed(c); }
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {
         if (c->fr.ready) return fail(c, "wide_np / wide_cnt shape the plan: set them before femo_set_frontal_plan");

@@ -82,7 +82,8 @@ __device__ __host__ inline int ldx_of(int np) { return (np + SPD - 1) / SPD * SP
 template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS>
 __global__ void __launch_bounds__(64)          // 239 registers, two waves per SIMD; capped at 167 (three waves, 52 B of scratch): 1.33 against 1.07 ms
 k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double aK, double aM, FrontDev fd,
-                 const int* __restrict__ elem_front, const int* __restrict__ elem_map, const unsigned char* __restrict__ mask) {
+                 const int* __restrict__ elem_front, const int* __restrict__ elem_map, const unsigned char* __restrict__ mask,
+                 const double* __restrict__ eq) {
     constexpr int LD = 3 * NPC + 3 * NVC;
     const int e = blockIdx.x;
     const int j = threadIdx.x;
@@ -139,16 +140,18 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
     // instruction hit one column of the front (a few cache lines) instead of 39 different columns.
     const int pj = map[j];
     if (mask && mask[gd[pj]]) return;
+    // eq (option "equilibrate", an experiment): the matrix factorised is D K D with D = diag(eq)
+    const double sj = eq ? eq[gd[pj]] : 1.0;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
         const int pi = map[i];
-        if (pj >= pi && !(mask && mask[gd[pi]])) atomicAdd(fv.col(pi) + pj, ye[i]);
+        if (pj >= pi && !(mask && mask[gd[pi]])) atomicAdd(fv.col(pi) + pj, eq ? ye[i] * sj * eq[gd[pi]] : ye[i]);
     }
 }
 
 // penalty facet blocks into the leaf front of the facet's element
 __global__ void k_front_penalty(FacetDev pf, FrontDev fd, const int* __restrict__ elem_front, const int* __restrict__ elem_map,
-                                int ld, int npc, int nvc, const unsigned char* __restrict__ mask) {
+                                int ld, int npc, int nvc, const unsigned char* __restrict__ mask, const double* __restrict__ eq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pf.nf) return;
     const int e = pf.cell[i], k = pf.ledge[i];
@@ -163,12 +166,14 @@ __global__ void k_front_penalty(FacetDev pf, FrontDev fd, const int* __restrict_
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 const int pa = map[3 * un[a] + c], pb = map[3 * un[b] + c];
-                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]]))) atomicAdd(fv.col(pb) + pa, pf.M2[9 * i + 3 * a + b]);
+                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]])))
+                    atomicAdd(fv.col(pb) + pa, pf.M2[9 * i + 3 * a + b] * (eq ? eq[gd[pa]] * eq[gd[pb]] : 1.0));
             }
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) {
                 const int pa = map[3 * npc + 3 * vn[a] + c], pb = map[3 * npc + 3 * vn[b] + c];
-                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]]))) atomicAdd(fv.col(pb) + pa, pf.M1[4 * i + 2 * a + b]);
+                if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]])))
+                    atomicAdd(fv.col(pb) + pa, pf.M1[4 * i + 2 * a + b] * (eq ? eq[gd[pa]] * eq[gd[pb]] : 1.0));
             }
     }
 }
@@ -1139,6 +1144,64 @@ k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first
     }
 }
 
+// The same product cut finer, for launches that do not fill the chip (the top of the tree: a launch lasts as long as ONE workgroup
+// does, and k_panel_rows gives a wave 144 dependent MFMAs behind eight staged loads of S).  A workgroup takes 16 rows; wave w
+// forms their output column blocks w and 7 - w (4 w + 4 and 32 - 4 w MFMAs: 36 per wave, a quarter of k_panel_rows' chain).  No
+// LDS: the MFMA A operand S[c][k] (16 consecutive c per k: one 128-byte segment) and the rows travel straight to registers, all
+// loads of a wave in flight at once.  The product overwrites the rows in place and the four waves share them, so every wave
+// has ALL its loads back before any wave stores (the barrier).
+__global__ void __launch_bounds__(256, 2)
+k_panel_rows_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
+    const int slot = first + blockIdx.y;
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t];
+    if (C0 >= np) return;                                     // (uniform per workgroup: no barrier is skipped by part of it)
+    const int kw = min(NBO, np - C0);
+    const int nf = fd.nf[t];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = C0 + kw + (blockIdx.x + 4 * tile_first) * 16;     // tile_first counts 64-row tiles, as in k_panel_rows
+    if (row0 >= nf) return;
+    double* F = fd.P + fd.poff[t];
+    const int ldp = ldp_of(nf);
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
+    constexpr int NCB = NBO / 16;
+    const int ncb = (kw + 15) / 16;
+    const int cbs[2] = {wv, NCB - 1 - wv};                    // this wave's two column blocks
+    const int row = row0 + l15;
+    const bool rok = row < nf;
+    double a[NBO / 4];
+#pragma unroll
+    for (int kk = 0; kk < NBO / 4; ++kk) {
+        const int k = 4 * kk + l4;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+    }
+    // S operands of both blocks: block cb needs k < 16 cb + 16; the second block (cb >= 4) the longer chain
+    double s0[4 * (NCB / 2)], s1[4 * NCB];
+#pragma unroll
+    for (int kk = 0; kk < 4 * (NCB / 2); ++kk)
+        s0[kk] = (cbs[0] < ncb && kk < 4 * cbs[0] + 4) ? S[(16 * cbs[0] + l15) + (size_t)lds_ * (4 * kk + l4)] : 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 4 * NCB; ++kk)
+        s1[kk] = (cbs[1] < ncb && kk < 4 * cbs[1] + 4) ? S[(16 * cbs[1] + l15) + (size_t)lds_ * (4 * kk + l4)] : 0.0;
+    mfma_d4 acc0 = (mfma_d4){0.0, 0.0, 0.0, 0.0}, acc1 = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4 * (NCB / 2); ++kk)
+        if (kk < 4 * cbs[0] + 4) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(s0[kk], a[kk], acc0, 0, 0, 0);      // D[i = column][j = row]
+#pragma unroll
+    for (int kk = 0; kk < 4 * NCB; ++kk)
+        if (kk < 4 * cbs[1] + 4) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s1[kk], a[kk], acc1, 0, 0, 0);
+    // every load of this workgroup has been consumed by an MFMA above: the rows may be overwritten once all waves are here
+    __syncthreads();
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int c0 = 16 * cbs[0] + l4 + 4 * reg, c1 = 16 * cbs[1] + l4 + 4 * reg;
+        if (rok && c0 < kw) F[row + (size_t)ldp * (C0 + c0)] = acc0[reg];
+        if (rok && c1 < kw) F[row + (size_t)ldp * (C0 + c1)] = acc1[reg];
+    }
+}
+
 // P2: rank-k update  C[r][c] -= sum_m L[r][m] L[c][m]  of lower-triangle 64x64 tiles with v_mfma_f64_16x16x4_f64.
 // Workgroup = 4 waves = one 64x64 tile of the front; wave w owns the 32x32 quarter (w&1 rows, w>>1 columns) as
 // 2x2 MFMA blocks.  To make the stores run along rows of the column-major front (coalesced), the product is
@@ -1447,6 +1510,108 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
                 const int r = ri + wr + 16 * b + l15;
                 if (cok[a][reg] && r < nf && r >= cc) col_ptr(a, reg)[r] = cv[a][b][reg] - acc[a][b][reg];
             }
+}
+
+// ---- the narrow (schur 0) update cut finer, for launches that do not fill the chip.  At the top of the tree a narrow update is a
+// few dozen 64 x 64 tiles whose waves each walk K MFMAs behind K / 16 staged loads: the launch lasts as long as that one chain
+// (12 us at K = 128, 30 at K = 512, whatever the number of tiles).  Here a workgroup takes a 32 x 32 tile and a wave ONE 16 x 16
+// block: K / 4 MFMAs, a quarter of the chain, four times the workgroups.  No LDS: both MFMA operands are 16 consecutive rows of a
+// factor column per k (one 128-byte segment), loaded straight to registers in batches of 32 factor columns (two batches, 32 loads,
+// in flight per lane), the next batch requested before the products of the current one.  K range, column range and the gathering epilogue
+// are those of k_trailing_mfma with schur == 0; the host takes this kernel when the K range is a multiple of 64.
+template <bool GATHER>
+__global__ void __launch_bounds__(256, 2)
+k_trailing_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int K0, const unsigned char* __restrict__ mask, int bx_first) {
+    const int t = level_nodes[first + blockIdx.z];
+    const int np = fd.npiv[t];
+    const int nf = fd.nf[t];
+    const TrailRange tr = trail_range(0, C0, K0, NBO, np, nf);
+    const int kc0 = tr.kc0, kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
+    if (kw <= 0) return;
+    constexpr int FT = 32;                                       // tile edge
+    const int bxv = (int)blockIdx.x + bx_first;
+    const int by = bxv & 3, bx = bxv >> 2;                       // four column tiles per panel
+    const int cj = (col_lo & ~1) + by * FT;
+    if (cj >= col_hi) return;
+    const int ri = cj + bx * FT;                                 // row tiles start at the column tile (lower triangle)
+    if (ri >= nf) return;
+    const FrontView fv = front_view(fd, t);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (wv & 1) * 16, wc = (wv >> 1) * 16;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ldp = ldp_of(nf);
+    // operand rows: A = tile columns (D index i), B = tile rows (D index j); rows past the front are clamped (never stored)
+    const double* pa = fv.P + min(cj + wc + l15, nf - 1) + (size_t)ldp * (kc0 + l4);
+    const double* pb = fv.P + min(ri + wr + l15, nf - 1) + (size_t)ldp * (kc0 + l4);
+    const size_t kstep = (size_t)ldp * 4;
+    constexpr int KB = 32, NS = KB / 4;                          // factor columns per batch, k-steps per batch (two batches in flight)
+    double a0[NS], b0[NS], a1[NS], b1[NS];
+    mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+    const int nbatch = kw / KB;                                  // the host guarantees kw % KB == 0
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) { a0[s_] = pa[kstep * s_]; b0[s_] = pb[kstep * s_]; }
+    for (int bt = 0; bt < nbatch; bt += 2) {
+        const bool more1 = bt + 1 < nbatch, more2 = bt + 2 < nbatch;
+        if (more1) {
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) { a1[s_] = pa[kstep * (NS * (bt + 1) + s_)]; b1[s_] = pb[kstep * (NS * (bt + 1) + s_)]; }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s_], b0[s_], acc, 0, 0, 0);
+        if (more2) {
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) { a0[s_] = pa[kstep * (NS * (bt + 2) + s_)]; b0[s_] = pb[kstep * (NS * (bt + 2) + s_)]; }
+        }
+        if (more1) {
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s_], b1[s_], acc, 0, 0, 0);
+        }
+    }
+    // epilogue: D[i = l4 + 4 reg -> column][j = l15 -> row]
+    const int r = ri + wr + l15;
+    bool cok[4];
+    double* cp[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int cc = cj + wc + l4 + 4 * reg;
+        cok[reg] = cc >= col_lo && cc < col_hi && r < nf && r >= cc;
+        cp[reg] = cok[reg] ? fv.col(cc) + r : fv.P;              // safe address for the lanes that store nothing
+    }
+    double cv[4];
+    if (!GATHER) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cv[reg] = *cp[reg];
+    } else {
+        const long long dp = fd.doff[t];
+        double g[2][4];
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int ch = fd.child[sd][t];
+            const int chs = ch >= 0 ? ch : t;
+            const int npc = fd.npiv[chs], nbc = fd.nf[chs] - npc;
+            const double* Sc = fd.S + fd.soff[chs];
+            const int x = (ch >= 0 && r < nf) ? fd.cinv[sd][dp + r] : -1;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + wc + l4 + 4 * reg;
+                const int y = (ch >= 0 && cok[reg]) ? fd.cinv[sd][dp + cc] : -1;
+                const bool ok = cok[reg] && x >= 0 && y >= 0;
+                const int lo = min(x, y) - npc, hi = max(x, y) - npc;
+                g[sd][reg] = Sc[ok ? hi + (size_t)nbc * lo : 0];
+                if (!ok) g[sd][reg] = 0.0;
+            }
+        }
+        const int* gd = fd.dofs + dp;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = cj + wc + l4 + 4 * reg;
+            cv[reg] = g[0][reg] + g[1][reg];
+            if (mask && r == cc && cok[reg] && cc < np && mask[gd[r]]) cv[reg] = 1.0;
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+        if (cok[reg]) *cp[reg] = cv[reg] - acc[reg];
 }
 
 // ---- the same rank-k update on 128 x 128 tiles (schur 1, 2, 5: the updates of whole Schur complements / trailing matrices).

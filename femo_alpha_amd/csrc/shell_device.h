@@ -1526,6 +1526,15 @@ __global__ void k_invert_diag(double* __restrict__ d, const unsigned char* __res
         d[i] = (mask && mask[i]) ? 1.0 : 1.0 / d[i];
 }
 
+// eq = dinv^(1/2) (mode 1) or the nearest power of two (mode 2) -- the symmetric diagonal scaling of option "equilibrate"
+__global__ void k_eq_scale(double* __restrict__ eq, const double* __restrict__ dinv, const unsigned char* __restrict__ mask, int mode, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = (mask && mask[i]) ? 1.0 : sqrt(dinv[i]);
+        if (mode == 2) s = ldexp(1.0, (int)nearbyint(log2(s)));
+        eq[i] = s;
+    }
+}
+
 __global__ void k_axpby(double* __restrict__ y, double a, const double* __restrict__ x, double b, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = a * x[i] + b * y[i];

@@ -75,7 +75,7 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
     while (((int64_t)leaf_size << fixed_depth) < (int64_t)nel) ++fixed_depth;
     fixed_depth = std::max(fixed_depth, min_depth);
     const bool gap_mode = gap_coeff > 0.0;
-    constexpr int32_t GAP_NMIN = 64;           // smaller pieces are halved exactly (a row is a large share of them)
+    constexpr int32_t GAP_NMIN = 128;          // smaller pieces are halved exactly (a row is a large share of them)
     std::vector<int32_t> lo{0}, hi{nel}, left{-1}, right{-1}, parent{-1}, depth{0};
     std::vector<int32_t> eorder(nel);
     std::iota(eorder.begin(), eorder.end(), 0);

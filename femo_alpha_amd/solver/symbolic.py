@@ -81,7 +81,7 @@ def _tree_from_native(A) -> Tree:
 # 210 GFLOP, the Schur traffic from 9.3 to 7.2 GB and the panel steps of levels >= 6 from 60 to 49.
 AXIS_RULE = 1
 GAP = 0.75
-GAP_NMIN = 64
+GAP_NMIN = 128
 
 
 def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=None) -> Tree:

@@ -36,7 +36,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
                     const double* cent, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth);
 /* The same with the two rules of the bisection exposed (femo_plan_build = axis_rule 0, gap_coeff 0: the plain median cut along the
  * longest centroid extent).
- *   gap_coeff > 0: a piece of n >= 64 cells is cut at the largest gap between consecutive sorted centroid coordinates within
+ *   gap_coeff > 0: a piece of n >= 128 cells is cut at the largest gap between consecutive sorted centroid coordinates within
  *     n/2 +- min(1/8, gap_coeff / sqrt(n)) n (about one row of cells either way), so that the cut follows a mesh line where the mesh
  *     has any row structure; the tree then has the fixed depth max(min_depth, ceil(log2(nel / leaf_size))).
  *   axis_rule 1: cut across the axis along which the piece is longest in CELLS (centroid extent / mean cell extent; cext: nel x 3

@@ -161,6 +161,41 @@ class CpuShell:
                 K = o._apply_strong(K)
         return K
 
+    def assemble_K_extended(self, nthreads=1):
+        """(rowptr, colidx, values) of K = elastic stiffness + penalty blocks with the values in numpy.longdouble: element mathematics
+        and sums in x87 extended precision (cpu_assemble_csr_ld).  The operator of the goldens -- a float64-assembled matrix carries
+        rounding of its own that moves the 1 M-DOF solution by ~1e-7.  Penalty clamp only (what the golden workloads use)."""
+        if np.finfo(np.longdouble).nmant < 63:
+            raise RuntimeError("numpy longdouble is not the x87 80-bit type on this machine")
+        m, o = self.mesh, self.o
+        if o.strong_dofs.size:
+            raise NotImplementedError("extended-precision assembly handles the penalty clamp")
+        base = self.pattern()
+        # the penalty blocks couple DOFs of one cell edge: inside the pattern already
+        rowptr, colidx = base
+        vals = np.zeros(colidx.size, dtype=np.longdouble)
+        rc = self.lib.cpu_assemble_csr_ld(*self._common(), _i(self.cell_p2), m.ndof_u, self._u(), *self._tables(), *self._fields(),
+                                          _i(rowptr), _i(colidx), vals.ctypes.data_as(C.c_void_p), int(nthreads))
+        assert rc == 0, "CSR pattern does not hold an element entry"
+        for d, blk in o._penalty_blocks():
+            for a in range(d.size):
+                row = colidx[rowptr[d[a]]:rowptr[d[a] + 1]]
+                pos = rowptr[d[a]] + np.searchsorted(row, d)
+                assert np.array_equal(colidx[pos], d)
+                vals[pos] += blk[a].astype(np.longdouble)
+        return rowptr, colidx, vals
+
+    def load_vector_extended(self):
+        """F in numpy.longdouble (cpu_load_vector_ld)."""
+        m, o = self.mesh, self.o
+        F = np.zeros(m.ndof, dtype=np.longdouble)
+        f = np.ascontiguousarray(o.f, dtype=np.float64)
+        N2 = np.ascontiguousarray(o.N2)
+        rc = self.lib.cpu_load_vector_ld(*self._common(), _i(self.cell_p2), self._u(), _d(self.N1), _d(self.dN1), _d(self.dN2), _d(N2),
+                                         _d(self.w), _d(f), int(o.ewp), int(m.is_quad), F.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return F
+
     def load_vector(self, nthreads=1):
         """F = int f . v J dx through the C++ vector assembly (strong rows zeroed like the numpy oracle)."""
         m, o = self.mesh, self.o

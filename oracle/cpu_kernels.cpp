@@ -31,186 +31,19 @@ struct Tables {
     const double *N1, *dN1, *dN2, *w, *wS;   // (nq,nvc) (nq,nvc,2) (nq,npc,2) (nq) (nq)
 };
 
-inline void cross(const double* a, const double* b, double* c) {
-    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
-}
-inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline void inv3(const double F[3][3], double Fi[3][3], double& det) {
-    const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1], c01 = F[1][2] * F[2][0] - F[1][0] * F[2][2],
-                 c02 = F[1][0] * F[2][1] - F[1][1] * F[2][0];
-    det = F[0][0] * c00 + F[0][1] * c01 + F[0][2] * c02;
-    const double id = 1.0 / det;
-    Fi[0][0] = c00 * id; Fi[1][0] = c01 * id; Fi[2][0] = c02 * id;
-    Fi[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id;
-    Fi[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id;
-    Fi[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id;
-    Fi[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id;
-    Fi[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
-    Fi[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
-}
+}  // namespace
 
-// strain-displacement matrix B (9 x ld) and measure data at one quadrature point (oracle _geometry + _B)
-struct QP { double det, Ju; };
-void qp_B(const Tables& T, int q, const double X[][3], const double U[][3], bool quad, double B[9][MAXLD], QP& out) {
-    const int nvc = T.nvc, npc = T.npc, ld = 3 * npc + 3 * nvc;
-    const double* dN1 = T.dN1 + (size_t)q * nvc * 2;
-    const double* dN2 = T.dN2 + (size_t)q * npc * 2;
-    const double* N1 = T.N1 + (size_t)q * nvc;
-    double J0[3] = {0, 0, 0}, J1[3] = {0, 0, 0};
-    for (int b = 0; b < nvc; ++b)
-        for (int i = 0; i < 3; ++i) { J0[i] += X[b][i] * dN1[2 * b]; J1[i] += X[b][i] * dN1[2 * b + 1]; }
-    double a[3];
-    cross(J0, J1, a);
-    const double det = std::sqrt(dot3(a, a));
-    double E0[3], E1[3], E2[3];
-    const double n0 = std::sqrt(dot3(J0, J0));
-    for (int i = 0; i < 3; ++i) { E2[i] = a[i] / det; E0[i] = J0[i] / n0; }
-    cross(E2, E0, E1);
-    // pseudo-inverse Kinv (2 x 3) = G^-1 J^T
-    const double g00 = dot3(J0, J0), g01 = dot3(J0, J1), g11 = dot3(J1, J1), gd = g00 * g11 - g01 * g01;
-    double Kinv[2][3];
-    for (int i = 0; i < 3; ++i) {
-        Kinv[0][i] = (g11 * J0[i] - g01 * J1[i]) / gd;
-        Kinv[1][i] = (-g01 * J0[i] + g00 * J1[i]) / gd;
-    }
-    // derivative of the unit normal (warped quads)
-    double W[3][3] = {{0}};
-    if (quad) {
-        double c[3], da0[3], da1[3];
-        for (int i = 0; i < 3; ++i) c[i] = 0.25 * (X[0][i] - X[1][i] + X[2][i] - X[3][i]);
-        cross(J0, c, da0); cross(c, J1, da1);
-        const double p0 = dot3(E2, da0), p1 = dot3(E2, da1);
-        double dn[3][2];
-        for (int i = 0; i < 3; ++i) { dn[i][0] = (da0[i] - E2[i] * p0) / det; dn[i][1] = (da1[i] - E2[i] * p1) / det; }
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) W[i][j] = dn[i][0] * Kinv[0][j] + dn[i][1] * Kinv[1][j];
-    }
-    // mesh motion F = I + grad(uhat)
-    double gradM[4][3];
-    for (int b = 0; b < nvc; ++b)
-        for (int i = 0; i < 3; ++i) gradM[b][i] = Kinv[0][i] * dN1[2 * b] + Kinv[1][i] * dN1[2 * b + 1];
-    double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, Fi[3][3], Ju;
-    if (U)
-        for (int b = 0; b < nvc; ++b)
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) F[i][j] += U[b][i] * gradM[b][j];
-    inv3(F, Fi, Ju);
-    out.det = det; out.Ju = Ju;
-    double Wp[3][3], wl0[3], wl1[3];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Wp[i][j] = W[i][0] * Fi[0][j] + W[i][1] * Fi[1][j] + W[i][2] * Fi[2][j];
-    for (int i = 0; i < 3; ++i) { wl0[i] = dot3(E0, Wp[i]); wl1[i] = dot3(E1, Wp[i]); }
-    double x00[3], x01[3], x10[3], x11[3];
-    cross(E0, wl0, x00); cross(E0, wl1, x01); cross(E1, wl0, x10); cross(E1, wl1, x11);
-    for (int r = 0; r < 9; ++r) std::memset(B[r], 0, sizeof(double) * ld);
-    for (int n = 0; n < npc; ++n) {
-        double gN[3], gx[3];
-        for (int i = 0; i < 3; ++i) gN[i] = Kinv[0][i] * dN2[2 * n] + Kinv[1][i] * dN2[2 * n + 1];
-        for (int j = 0; j < 3; ++j) gx[j] = gN[0] * Fi[0][j] + gN[1] * Fi[1][j] + gN[2] * Fi[2][j];
-        const double d0 = dot3(E0, gx), d1 = dot3(E1, gx);
-        for (int c = 0; c < 3; ++c) {
-            const int k = 3 * n + c;
-            B[0][k] = E0[c] * d0;
-            B[1][k] = E1[c] * d1;
-            B[2][k] = E0[c] * d1 + E1[c] * d0;
-            B[6][k] = E2[c] * d0;
-            B[7][k] = E2[c] * d1;
-            B[8][k] = 0.5 * (E0[c] * d1 - E1[c] * d0);
-        }
-    }
-    for (int b = 0; b < nvc; ++b) {
-        double gx[3];
-        for (int j = 0; j < 3; ++j) gx[j] = gradM[b][0] * Fi[0][j] + gradM[b][1] * Fi[1][j] + gradM[b][2] * Fi[2][j];
-        const double m0 = dot3(E0, gx), m1 = dot3(E1, gx), M = N1[b];
-        for (int c = 0; c < 3; ++c) {
-            const int k = 3 * npc + 3 * b + c;
-            const double c00 = -E1[c] * m0 + M * x00[c], c01 = -E1[c] * m1 + M * x01[c];
-            const double c10 = E0[c] * m0 + M * x10[c], c11 = E0[c] * m1 + M * x11[c];
-            B[3][k] = c00;
-            B[4][k] = c11;
-            B[5][k] = c01 + c10;
-            B[6][k] = M * E1[c];
-            B[7][k] = -M * E0[c];
-            B[8][k] = M * E2[c];
-        }
-    }
-}
+namespace f64 {
+typedef double REAL;
+#include "cpu_core.inc"
+}  // namespace f64
+namespace f80 {
+typedef long double REAL;
+#include "cpu_core.inc"
+}  // namespace f80
+using namespace f64;
 
-// diagonal blocks of C x weights (oracle _C): membrane 3x3, bending 3x3, shear, drilling; deriv: 0 none, 1 h, 2 E, 3 nu
-struct CQ { double Cm[3][3], Cb[3][3], cs, cd; };
-void qp_C(double h, double E, double nu, double hK, double wdet, double wdetS, double Ju, int deriv, CQ& o) {
-    const double P[3][3] = {{1, nu, 0}, {nu, 1, 0}, {0, 0, 0.5 * (1 - nu)}};
-    const double dP[3][3] = {{0, 1, 0}, {1, 0, 0}, {0, 0, -0.5}};
-    const double c = E / (1 - nu * nu), G = E / 2 / (1 + nu), hK2 = hK * hK;
-    double fm, fb, cs, cd, gm = 0, gb = 0;
-    if (deriv == 0) { fm = c * h; fb = c * h * h * h / 12; cs = SHEAR_K * G * h; cd = E * h * h * h / hK2; }
-    else if (deriv == 1) { fm = c; fb = c * h * h / 4; cs = SHEAR_K * G; cd = 3 * E * h * h / hK2; }
-    else if (deriv == 2) { fm = h / (1 - nu * nu); fb = h * h * h / 12 / (1 - nu * nu); cs = SHEAR_K * h / 2 / (1 + nu); cd = h * h * h / hK2; }
-    else {
-        const double dc = E * 2 * nu / ((1 - nu * nu) * (1 - nu * nu));
-        fm = h * dc; fb = h * h * h / 12 * dc; gm = h * c; gb = h * h * h / 12 * c;
-        cs = -SHEAR_K * h * E / 2 / ((1 + nu) * (1 + nu)); cd = 0;
-    }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            o.Cm[i][j] = (fm * P[i][j] + gm * dP[i][j]) * wdetS;
-            o.Cb[i][j] = (fb * P[i][j] + gb * dP[i][j]) * wdetS;
-        }
-    o.cs = cs * Ju * wdetS;
-    o.cd = cd * Ju * wdet;
-}
-
-struct ElemIn {
-    double X[4][3], U[4][3], h[4], E[4], nu[4], hK;
-    bool has_u;
-};
-
-void load_elem(int e, int nvc, const double* nodes, const int32_t* cells, const double* uhat, const double* h, const double* E,
-               const double* nu, int ewm, const double* hK, ElemIn& el) {
-    el.has_u = false;
-    for (int b = 0; b < nvc; ++b) {
-        const int v = cells[(size_t)e * nvc + b];
-        for (int i = 0; i < 3; ++i) {
-            el.X[b][i] = nodes[3 * (size_t)v + i];
-            el.U[b][i] = uhat ? uhat[3 * (size_t)v + i] : 0.0;
-            if (el.U[b][i] != 0.0) el.has_u = true;
-        }
-        const int k = ewm ? e : v;
-        el.h[b] = h[k]; el.E[b] = E[k]; el.nu[b] = nu[k];
-    }
-    el.hK = hK[e];
-}
-
-// K_e (ld x ld, row-major, symmetric) = sum_q B^T C B
-void element_matrix(const Tables& T, const ElemIn& el, bool quad, int deriv, double* Ke) {
-    const int ld = 3 * T.npc + 3 * T.nvc;
-    std::memset(Ke, 0, sizeof(double) * ld * ld);
-    double B[9][MAXLD], CB[9][MAXLD];
-    for (int q = 0; q < T.nq; ++q) {
-        QP g;
-        qp_B(T, q, el.X, el.has_u ? el.U : nullptr, quad, B, g);
-        double hq = 0, Eq = 0, nq_ = 0;
-        for (int b = 0; b < T.nvc; ++b) { const double N = T.N1[(size_t)q * T.nvc + b]; hq += N * el.h[b]; Eq += N * el.E[b]; nq_ += N * el.nu[b]; }
-        CQ C;
-        qp_C(hq, Eq, nq_, el.hK, T.w[q] * g.det, T.wS[q] * g.det, g.Ju, deriv, C);
-        for (int k = 0; k < ld; ++k) {
-            for (int i = 0; i < 3; ++i) {
-                CB[i][k] = C.Cm[i][0] * B[0][k] + C.Cm[i][1] * B[1][k] + C.Cm[i][2] * B[2][k];
-                CB[3 + i][k] = C.Cb[i][0] * B[3][k] + C.Cb[i][1] * B[4][k] + C.Cb[i][2] * B[5][k];
-            }
-            CB[6][k] = C.cs * B[6][k]; CB[7][k] = C.cs * B[7][k]; CB[8][k] = C.cd * B[8][k];
-        }
-        for (int i = 0; i < ld; ++i) {
-            double* row = Ke + (size_t)i * ld;
-            for (int r = 0; r < 9; ++r) {
-                const double bi = B[r][i];
-                if (bi == 0.0) continue;
-                const double* cb = CB[r];
-                for (int j = 0; j < ld; ++j) row[j] += bi * cb[j];
-            }
-        }
-    }
-}
+namespace {
 
 inline void element_dofs(int e, int nvc, int npc, const int32_t* cells, const int32_t* cell_p2, int ndof_u, int* dofs) {
     for (int n = 0; n < npc; ++n)
@@ -255,6 +88,77 @@ int cpu_assemble_csr(int nel, int nvc, int npc, int nq, const double* nodes, con
         }
     }
     return bad;
+}
+
+// ---- the same assembly with the element mathematics in long double (x87 extended precision) and the sums kept in long double:
+// the operator of the GOLDENS.  vals_ld / F_ld: long double arrays (numpy.longdouble on x86-64 Linux).  Element matrices are formed
+// in parallel into a scratch block, the scatter is serial (no atomics on 16-byte values).
+int cpu_assemble_csr_ld(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
+                        int ndof_u, const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* w,
+                        const double* wS, const double* h, const double* E, const double* nu, int ewm, const double* hK, int quad,
+                        const int32_t* rowptr, const int32_t* colidx, long double* vals_ld, int nthreads) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
+    const int ld = 3 * npc + 3 * nvc;
+    if (ld > MAXLD || nq > MAXQ) return 1;
+    const int chunk = 4096;
+    std::vector<long double> Ke((size_t)chunk * ld * ld);
+    int bad = 0;
+    for (int e0 = 0; e0 < nel; e0 += chunk) {
+        const int ne = std::min(chunk, nel - e0);
+#pragma omp parallel for schedule(static, 16) num_threads(nthreads)
+        for (int k = 0; k < ne; ++k) {
+            f80::ElemIn el;
+            f80::load_elem(e0 + k, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
+            f80::element_matrix(T, el, quad != 0, 0, Ke.data() + (size_t)k * ld * ld);
+        }
+        int dofs[MAXLD];
+        for (int k = 0; k < ne; ++k) {
+            element_dofs(e0 + k, nvc, npc, cells, cell_p2, ndof_u, dofs);
+            const long double* K = Ke.data() + (size_t)k * ld * ld;
+            for (int i = 0; i < ld; ++i) {
+                const int32_t* cb = colidx + rowptr[dofs[i]];
+                const int32_t* ce = colidx + rowptr[dofs[i] + 1];
+                for (int j = 0; j < ld; ++j) {
+                    const int32_t* p = std::lower_bound(cb, ce, dofs[j]);
+                    if (p == ce || *p != dofs[j]) { bad = 1; continue; }
+                    vals_ld[p - colidx] += K[(size_t)i * ld + j];
+                }
+            }
+        }
+    }
+    return bad;
+}
+
+// F_a = int f . N2_a J det dS in long double (cpu_load_vector's twin for the goldens)
+int cpu_load_vector_ld(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
+                       const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* N2, const double* w,
+                       const double* f, int ewp, int quad, long double* F_ld) {
+    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, w};
+    if (3 * npc + 3 * nvc > MAXLD || nq > MAXQ) return 1;
+    for (int e = 0; e < nel; ++e) {
+        long double X[4][3], U[4][3], fe[4][3], B[9][MAXLD];
+        bool has_u = false;
+        for (int b = 0; b < nvc; ++b) {
+            const int v = cells[(size_t)e * nvc + b];
+            for (int i = 0; i < 3; ++i) {
+                X[b][i] = nodes[3 * (size_t)v + i];
+                U[b][i] = uhat ? uhat[3 * (size_t)v + i] : 0.0;
+                has_u = has_u || U[b][i] != 0.0L;
+                fe[b][i] = f[3 * (size_t)(ewp ? e : v) + i];
+            }
+        }
+        for (int q = 0; q < nq; ++q) {
+            f80::QP g;
+            f80::qp_B(T, q, X, has_u ? U : nullptr, quad != 0, B, g);
+            long double fq[3] = {0, 0, 0};
+            for (int b = 0; b < nvc; ++b)
+                for (int i = 0; i < 3; ++i) fq[i] += (ewp ? (b == 0 ? 1.0L : 0.0L) : (long double)N1[(size_t)q * nvc + b]) * fe[b][i];
+            const long double wj = (long double)w[q] * g.det * g.Ju;
+            for (int a = 0; a < npc; ++a)
+                for (int i = 0; i < 3; ++i) F_ld[3 * (size_t)cell_p2[(size_t)e * npc + a] + i] += wj * N2[(size_t)q * npc + a] * fq[i];
+        }
+    }
+    return 0;
 }
 
 // element matrices only (nel x ld x ld), for cross-checks against the numpy oracle

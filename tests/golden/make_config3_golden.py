@@ -7,10 +7,10 @@ this skin -- the reference integrates its static forms (nearly) exactly, linear_
 1e-9 of that limit here, n = 4 is 7.5e-8 away in the gradient).  ``4`` writes config3_wing1m_n4.npz, the round-1..3 golden
 kept as the secondary rule.
 
-SuperLU cannot factorise this matrix (32-bit fill indices), so the state and the adjoint come from the CPU restatement's
-own multifrontal Cholesky (oracle/cpu_baseline.py: C++/OpenMP element matrices, LAPACK/BLAS on dense fronts) and are then
-polished by iterative refinement with the residual b - K x accumulated in x87 extended precision on the CSR matrix the C++
-restatement assembles -- the same recipe as make_fullsize_goldens.py.  ``w_correction`` / ``lam_correction`` record the
+SuperLU cannot factorise this matrix (32-bit fill indices), so the preconditioner of the refinement is the CPU restatement's own
+multifrontal Cholesky (oracle/cpu_baseline.py: C++/OpenMP element matrices, LAPACK/BLAS on dense fronts); the operator the residual
+b - K x is formed with is assembled in x87 extended precision (tests/golden/_extended.py) -- the same recipe as
+make_fullsize_goldens.py: the stored numbers are the solution of the discrete problem, not of a float64-rounded matrix.  ``w_correction`` / ``lam_correction`` record the
 size of the last correction relative to the solution.  Stored: compliance, mass, max |w|, 4096 seeded samples of the state,
 and the full d compliance / d thickness vector: the north-star triple at the north-star size.
 
@@ -32,24 +32,8 @@ from bench import make_workload                                  # noqa: E402
 from femo_alpha_amd.solver.symbolic import build_plan            # noqa: E402
 from oracle import cpu_baseline as cb                            # noqa: E402
 from oracle.rm_shell_oracle import ShellOracle                   # noqa: E402
-
-
-def refine(K, solve, b, x, steps=10, tol=2e-16):
-    if np.finfo(np.longdouble).nmant < 63:
-        raise RuntimeError("numpy longdouble is not the x87 80-bit type on this machine")
-    data = K.data.astype(np.longdouble)
-    xl = x.astype(np.longdouble)
-    bl = b.astype(np.longdouble)
-    rel = np.inf
-    for k in range(steps):
-        r = bl - np.add.reduceat(data * xl[K.indices], K.indptr[:-1])
-        dx = solve(np.asarray(r, dtype=np.float64))
-        xl += dx
-        rel = float(np.abs(dx).max() / np.abs(xl).max())
-        print(f"    refinement {k}: correction {rel:.1e}", flush=True)
-        if rel < tol:
-            break
-    return np.asarray(xl, dtype=np.float64), rel
+sys.path.insert(0, HERE)
+from _extended import extended_system, refine                    # noqa: E402
 
 
 def main():
@@ -60,24 +44,29 @@ def main():
     o = ShellOracle(m, nquad=nquad, penalty_facets=m.penalty_facets(marker))
     o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
     cs = cb.CpuShell(o)
-    cs.pattern()
-    K = cs.assemble_K(cores).tocsr()
-    K.sort_indices()
-    b = cs.load_vector(cores)
+    Kx, bx = extended_system(cs, cores)
     mf = cb.CpuMultifrontal(cs, build_plan(m, 12), cores)
     mf.factorize()
-    print(f"{desc}\nassembled and factorised in {time.time() - t0:.0f} s", flush=True)
-    w, cw = refine(K, mf.solve, b, mf.solve(b))
+    print(f"{desc}\nassembled (extended precision) and factorised in {time.time() - t0:.0f} s", flush=True)
+    say = lambda msg: print(msg, flush=True)
+    w, cw = refine(Kx, mf.solve, bx, mf.solve(np.asarray(bx, dtype=np.float64)), log=say)
     J = o.compliance(w)
     rhs = o.dcompliance_du(w)
-    lam, cl = refine(K, mf.solve, rhs, mf.solve(rhs))
+    lam, cl = refine(Kx, mf.solve, rhs, mf.solve(rhs), log=say)
     dJ = o.dcompliance_dh(w) - cs.assemble_drdfield("h", w, cores).T @ lam
+    # for the record: the solution of the FLOAT64-assembled matrix (the round 1-3 goldens) against the one above
+    K64 = cs.assemble_K(cores).tocsr(); K64.sort_indices()
+    b64 = cs.load_vector(cores)
+    w64, _ = refine((K64.indptr, K64.indices, K64.data.astype(np.longdouble)), mf.solve, b64, mf.solve(b64), steps=6)
+    d64 = (float(np.abs(w64 - w).max() / np.abs(w).max()), float(abs(o.compliance(w64) - J) / abs(J)))
+    print(f"float64-assembled matrix: solution off by {d64[0]:.1e} (displacement) {d64[1]:.1e} (compliance)", flush=True)
     sample = np.sort(np.random.default_rng(7).choice(m.ndof, size=4096, replace=False))
     print(f"ndof {m.ndof}  J={J:.15e}  corrections w {cw:.1e} lam {cl:.1e}  total {time.time() - t0:.0f} s")
     name = "config3_wing1m.npz" if nquad == m.recommended_nquad() else f"config3_wing1m_n{nquad}.npz"
     np.savez_compressed(os.path.join(os.environ.get("FEMO_GOLDEN_OUT", HERE), name), ndof=m.ndof, nn=m.nn, nel=m.nel, nquad=nquad, compliance=J, mass=o.mass(),
                         w_maxabs=np.abs(w).max(), w_sample_index=sample, w_sample=w[sample],
-                        dcompliance_dthickness=dJ, w_correction=cw, lam_correction=cl)
+                        dcompliance_dthickness=dJ, w_correction=cw, lam_correction=cl,
+                        float64_matrix_distance_w=d64[0], float64_matrix_distance_compliance=d64[1])
 
 
 if __name__ == "__main__":
