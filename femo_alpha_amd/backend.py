@@ -188,6 +188,9 @@ class ShellContext:
         out = {n: dict(ms=t[i], launches=int(t[8 + i])) for i, n in enumerate(names)}
         out["trailing_flops"], out["panel_rows_flops"], out["panel_diag_flops"] = t[18], t[16], t[17]
         out["trailing_bytes"], out["panel_rows_bytes"], out["panel_diag_bytes"] = t[26], t[24], t[25]
+        # the rank-k launches above / below the ridge of the chip (9.8 flop per compulsory byte): bounded by the matrix cores / by HBM
+        out["trailing_mfma_bound"] = dict(ms=t[7], launches=int(t[15]), flops=t[23], bytes=t[31])
+        out["trailing_hbm_bound"] = dict(ms=t[2] - t[7], launches=int(t[10]) - int(t[15]), flops=t[18] - t[23], bytes=t[26] - t[31])
         return out
 
     def sweep_profile(self, detail=False):

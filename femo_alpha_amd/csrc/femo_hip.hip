@@ -49,6 +49,7 @@ struct femo_ctx {
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
     int nghost = 0;
     bool quad = true, ewm = false, ewp = false, has_uhat = false;
+    bool cg1 = false;                        // element CG1CG1 (linear_shell_model.py:74-79): displacement on the vertices too (nP2 == nn)
     int64_t nT = 0, nF = 0;
     // mesh
     double* xyz = nullptr;
@@ -113,9 +114,13 @@ struct femo_ctx {
         int lookahead = 1, lookahead_cnt = 16;
         int super_panel = 512, super_panel_cnt = 64, super_panel_ahead = 0;
         int rows_preload_wg = 0;              // k_panel_rows launches of at most this many workgroups preload S into LDS
-        int rows_fine_wg = 768;               // k_panel_rows launches of at most this many (64-row) workgroups run k_panel_rows_fine (16 rows per workgroup)
+        // k_panel_rows launches of at most this many (64-row) workgroups run k_panel_rows_fine (16 rows per workgroup).  Measured at 1 M DOF
+        // (scripts/r4_ab.py, one process, interleaved): rows per panel of the two top levels 16 -> 10 us; factorisation 12.73 ms without the
+        // fine kernels, 12.61 with this one at 96 or 256, 12.72 at 768 (levels of 8-32 fronts lose), 12.52 with both at (96, 128)
+        int rows_fine_wg = 96;
         int narrow_split = 1, narrow_split_wg = 1024;
-        int narrow_fine_wg = 512;             // narrow updates of at most this many 64 x 64 tiles run k_trailing_fine (32 x 32 tiles, a 16 x 16 block per wave)
+        int narrow_fine_wg = 128;             // narrow updates of at most this many 64 x 64 tiles run k_trailing_fine (32 x 32 tiles, a 16 x 16 block per wave): the
+                                              // root's updates 24 -> 18 us each; levels of four fronts and more lose (512: +5 % on level 11)
         int fuse_rows = 1, fuse_rows_cnt = 4096;    // single-panel fronts of non-wide levels with at least that many fronts: rows in k_diag_block
         int sweep_graph = 0;                        // the preconditioner application of the PCG loop replayed as a HIP graph
         int diag_v1_cnt = 512;                      // levels of at least this many fronts: k_diag_block (80 KB of LDS, two workgroups per CU)
@@ -265,7 +270,7 @@ static void lag1(double t, double* v, double* d) {
 
 // nred > 0 (quads): the membrane / bending / shear energies are integrated with nred x nred Gauss points, everything
 // else with nquad x nquad: the table then lists both point sets, each with a zero weight for the terms of the other
-static void build_tables(bool quad, int nquad, Tables& T, int nred = 0) {
+static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1 = false) {
     memset(&T, 0, sizeof T);
     if (quad) {
         static const int Q2I[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
@@ -330,6 +335,16 @@ static void build_tables(bool quad, int nquad, Tables& T, int nred = 0) {
             }
         }
     }
+    if (cg1) {
+        // CG1CG1: the displacement is interpolated with the vertex functions -- its tables are those of the rotation
+        const int nv = quad ? 4 : 3;
+        for (int q = 0; q < T.nq; ++q)
+            for (int n = 0; n < 9; ++n) {
+                T.N2[q][n] = n < nv ? T.N1[q][n] : 0.0;
+                T.dN2[q][n][0] = n < nv ? T.dN1[q][n][0] : 0.0;
+                T.dN2[q][n][1] = n < nv ? T.dN1[q][n][1] : 0.0;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
@@ -359,9 +374,13 @@ static FacetDev facet_dev(const femo_ctx* c) {
     return fd;
 }
 
-// KERNEL is a template <NPC,NVC,QUAD,UHAT>; EXTRA may carry more template args (leading comma)
+// KERNEL is a template <NPC,NVC,QUAD,UHAT>; EXTRA may carry more template args (leading comma).
+// Two families: the _CORE macros also instantiate the CG1CG1 element (NPC == NVC: the displacement lives on the vertices,
+// linear_shell_model.py:74-79) -- the forward solve, the outputs and the adjoint chain; the plain macros serve what is built for the
+// reference's own element choice CG2CG1 only (rm_shell_pde.py:27) and refuse a CG1CG1 context.
 #define ELEM_LAUNCH(c, KERNEL, EXTRA, grid, block, ...)                                                       \
     do {                                                                                                      \
+        if ((c)->cg1) return fail((c), "this operation is not provided for the CG1CG1 element (" #KERNEL ")"); \
         if ((c)->quad) {                                                                                      \
             if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
             else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
@@ -373,6 +392,7 @@ static FacetDev facet_dev(const femo_ctx* c) {
 // the same with dynamic LDS (kernels that stage their quadrature points: stage_qpoints)
 #define ELEM_LAUNCH_S(c, KERNEL, EXTRA, grid, block, shm, ...)                                                \
     do {                                                                                                      \
+        if ((c)->cg1) return fail((c), "this operation is not provided for the CG1CG1 element (" #KERNEL ")"); \
         if ((c)->quad) {                                                                                      \
             if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
             else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
@@ -381,7 +401,48 @@ static FacetDev facet_dev(const femo_ctx* c) {
             else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
         }                                                                                                     \
     } while (0)
-#define QPOINT_LDS(c) ((size_t)(c)->tab_nq * ((c)->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>)))
+#define ELEM_LAUNCH_CORE(c, KERNEL, EXTRA, grid, block, ...)                                                  \
+    do {                                                                                                      \
+        if ((c)->cg1) {                                                                                       \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<4, 4, true, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<4, 4, true, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<3, 3, false, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<3, 3, false, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+        } else {                                                                                              \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+        }                                                                                                     \
+    } while (0)
+#define ELEM_LAUNCH_S_CORE(c, KERNEL, EXTRA, grid, block, shm, ...)                                           \
+    do {                                                                                                      \
+        if ((c)->cg1) {                                                                                       \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<4, 4, true, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<4, 4, true, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<3, 3, false, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<3, 3, false, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+        } else {                                                                                              \
+        if ((c)->quad) {                                                                                      \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        } else {                                                                                              \
+            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
+        }                                                                                                     \
+        }                                                                                                     \
+    } while (0)
+#define QPOINT_LDS(c) ((size_t)(c)->tab_nq * ((c)->cg1 ? ((c)->quad ? sizeof(QPoint<4, 4>) : sizeof(QPoint<3, 3>)) \
+                                                        : ((c)->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>))))
 #define NOEXTRA
 #define COMMA_H , DERIV_H
 #define COMMA_E , DERIV_E
@@ -406,15 +467,15 @@ static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, do
         const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
 #define COMMA_TRUE , true
 #define COMMA_FALSE , false
-        if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
-        else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        if (aM != 0.0) ELEM_LAUNCH_CORE(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        else ELEM_LAUNCH_CORE(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
         const int nthreads = c->nP2 + c->nghost;
-        if (c->quad)
-            hipLaunchKernelGGL((k_gather_sum<9, 4>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,
-                               c->n2e_off, c->n2e_ent, c->ybuf, y);
-        else
-            hipLaunchKernelGGL((k_gather_sum<6, 3>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, c->ndof_u, c->ndof,
-                               c->n2e_off, c->n2e_ent, c->ybuf, y);
+#define GATHER_SUM(NPC_, NVC_) hipLaunchKernelGGL((k_gather_sum<NPC_, NVC_>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, \
+                                                  c->ndof_u, c->ndof, c->n2e_off, c->n2e_ent, c->ybuf, y)
+        if (c->cg1) { if (c->quad) GATHER_SUM(4, 4); else GATHER_SUM(3, 3); }
+        else if (c->quad) GATHER_SUM(9, 4);
+        else GATHER_SUM(6, 3);
+#undef GATHER_SUM
     }
     if (with_penalty && c->nf > 0) {
         if (refresh_penalty(c)) return 1;
@@ -429,7 +490,7 @@ static int refresh_diag(femo_ctx* c) {
     if (!c->jacobi_dirty) return 0;
     const int64_t n = c->ndof;
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv, 0.0, n);
-    ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
+    ELEM_LAUNCH_CORE(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
     if (c->nf > 0) {
         if (refresh_penalty(c)) return 1;
         hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 1,
@@ -447,7 +508,7 @@ static int load_vector_dev(femo_ctx* c, double* F, const double* f_override = nu
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, 0.0, n);
     FieldsDev fdv = fields_dev(c);
     if (f_override) fdv.f = const_cast<double*>(f_override);        // a level of the resident force history (femo_newmark_*)
-    ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
+    ELEM_LAUNCH_CORE(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
     if (c->has_g && c->nf > 0) {
         // penalty with prescribed values: R = ... + P (w - g)  ->  the right-hand side gains P g
         if (refresh_penalty(c)) return 1;
@@ -611,10 +672,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         }
         { ProfScope ps(c, 4);
         if (c->op_aM != 0.0)
-            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_TRUE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_TRUE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq);
         else
-            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_FALSE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_FALSE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
@@ -1026,6 +1087,13 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const int tag = (int)(intptr_t)fr.pev[i + 2];
         const int cls = tag % 16;
         fr.prof_ms[cls] += ms; fr.prof_calls[cls] += 1;
+        if (cls == 2) {
+            // class 7: the rank-k launches whose arithmetic intensity (algorithmic flops / compulsory bytes) lies above the ridge of
+            // the chip, 78.6 TFLOP/s / 8 TB/s = 9.8 flop per byte -- the ones the matrix cores can bound; the rest of class 2 is
+            // bounded by HBM whatever the kernel does
+            const double fl = fr.pmeta[i / 3 * 2], by = fr.pmeta[i / 3 * 2 + 1];
+            if (by > 0 && fl / by >= 78.6e12 / 8.0e12) { fr.prof_ms[7] += ms; fr.prof_calls[7] += 1; fr.prof_flops[7] += fl; fr.prof_bytes[7] += by; }
+        }
         if (c->opt.profile_verbose) {
             if (cls == 2) fprintf(stderr, "prof level %d class %d %.1f us flops %.6e bytes %.6e\n", tag / 16, cls, ms * 1e3, fr.pmeta[i / 3 * 2], fr.pmeta[i / 3 * 2 + 1]);
             else fprintf(stderr, "prof level %d class %d %.1f us\n", tag / 16, cls, ms * 1e3);
@@ -1434,12 +1502,12 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
     Tables T;
     c->nquad = nquad;
-    build_tables(c->quad, nquad, T);
+    build_tables(c->quad, nquad, T, 0, c->cg1);
     HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
     c->tab_nq = T.nq;
     Tables TS_;
-    build_tables(c->quad, 3, TS_);               // quadrature_degree 4 (rm_shell_model.py:200-201)
+    build_tables(c->quad, 3, TS_, 0, c->cg1);    // quadrature_degree 4 (rm_shell_model.py:200-201)
     HIPCHK(c, hipMalloc((void**)&c->tab_s, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab_s, &TS_, sizeof(Tables), hipMemcpyHostToDevice));
     c->nT = c->ewm ? nel : c->nn;
@@ -1480,7 +1548,10 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
     if (nvc != 3 && nvc != 4) { g_create_error = "nvc must be 3 (triangles) or 4 (quads)"; return 2; }
     if (nn <= 0 || nel <= 0 || !xyz || !cells || !cell_p2) { g_create_error = "empty mesh or null pointer"; return 2; }
     if (nvc == 4 && (nquad < 2 || nquad > 5)) { g_create_error = "nquad must be in 2..5"; return 2; }
-    const int npc = nvc == 4 ? 9 : 6;
+    // CG1CG1 (linear_shell_model.py:74-79): the caller's "P2 node" set is the vertex set itself and cell_p2 holds nvc entries per
+    // cell -- told apart by nP2 == nn (a CG2CG1 mesh always has nP2 = nn + edges [+ cells] > nn)
+    const bool cg1 = nP2 == nn;
+    const int npc = cg1 ? nvc : (nvc == 4 ? 9 : 6);
     for (int64_t i = 0; i < (int64_t)nel * nvc; ++i)
         if (cells[i] < 0 || cells[i] >= nn) { g_create_error = "cells refers to a vertex outside 0..nn-1"; return 2; }
     for (int64_t i = 0; i < (int64_t)nel * npc; ++i)
@@ -1492,6 +1563,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
     c->device = device;
     c->nn = nn; c->nel = nel; c->nvc = nvc; c->npc = npc; c->nP2 = nP2;
     c->quad = nvc == 4;
+    c->cg1 = cg1;
     c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * nn + nghost; c->nghost = nghost; c->ld = 3 * npc + 3 * nvc;
     c->ewm = elementwise_material != 0; c->ewp = elementwise_pressure != 0;
     if (create_impl(c, xyz, cells, cell_p2, nquad)) {
@@ -1571,6 +1643,7 @@ int64_t femo_field_size(const femo_ctx* c, const char* name) {
 }
 
 int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double beta) {
+    if (c && c->cg1 && nf > 0) return fail(c, "the CG1CG1 element takes strong Dirichlet conditions (femo_set_strong_dofs); the penalty clamp is built for CG2CG1");
     HIPCHK(c, hipSetDevice(c->device));
     if (nf < 0 || (nf > 0 && !cl)) return fail(c, "bad facet list");
     void* old[] = {c->fcell, c->fledge, c->funode, c->fvnode, c->fM2, c->fM1};
@@ -1907,7 +1980,7 @@ static MeshDev mesh_dev_all(const femo_ctx* c) { MeshDev m = mesh_dev(c); m.csel
 
 static int functionals_dev(femo_ctx* c, double* out3, int nout = 3, bool subdomain = false) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
-    ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, subdomain ? mesh_dev(c) : mesh_dev_all(c), fields_dev(c), c->tab, c->w, c->scal);
+    ELEM_LAUNCH_CORE(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, subdomain ? mesh_dev(c) : mesh_dev_all(c), fields_dev(c), c->tab, c->w, c->scal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2029,23 +2102,23 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
     if (fn == "tip_disp") {               // 0.5 int u.u J over the selected sub-domain
-        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out, 0.5);
+        if (wrt == "disp_solid") ELEM_LAUNCH_CORE(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out, 0.5);
     } else if (fn == "area") {
     } else if (fn == "regularization") {         // the thickness term of the compliance (its only explicit thickness dependence)
-        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "compliance") {
-        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, mesh_dev_all(c), f, c->tab, c->w, out, 1.0);
-        else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+        if (wrt == "disp_solid") ELEM_LAUNCH_CORE(c, k_dcompliance_du, NOEXTRA, g, EB, mesh_dev_all(c), f, c->tab, c->w, out, 1.0);
+        else if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "mass") {
-        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
-        else if (wrt == "density") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
+        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
+        else if (wrt == "density") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
     } else if (fn == "volume") {
-        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 3, out);
+        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 3, out);
     } else if (fn == "elastic_energy") {
         if (wrt == "disp_solid") { if (op_apply(c, c->w, out, nullptr, nullptr, nullptr, false)) return 1; }
-        else if (wrt == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
-        else if (wrt == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
-        else if (wrt == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "E") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "nu") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
     } else if (fn == "pnorm_stress") {
         if (stress_alpha_ref(c) < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
         const int mode = wrt == "disp_solid" ? 1 : wrt == "thickness" ? 2 : wrt == "E" ? 3 : wrt == "nu" ? 4 : 0;
@@ -2066,10 +2139,10 @@ static int dRdarg_T_dev(femo_ctx* c, const std::string& arg, const double* lam, 
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
-    if (arg == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "F_solid") ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
+    if (arg == "thickness") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "E") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "nu") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "F_solid") ELEM_LAUNCH_CORE(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
     else if (arg == "density") { /* R does not depend on density */ }
     else if (arg == "uhat") { if (shape_gradient_dev(c, 0, c->w, lam, scale, out)) return 1; }
     else return fail(c, "(dR/d" + arg + ")^T is not implemented in this build");
@@ -2342,7 +2415,8 @@ int femo_factorize(femo_ctx* c) {
 /* Run one factorisation with a HIP event pair around every kernel launch and report, per kernel class
  * (0 panel rows, 1 diagonal blocks, 2 trailing, 3 extend_add, 4 front_assemble, 5 memset): total ms and launches;
  * also the algorithmic flop counts (lower triangles only) of what the launches of classes 2, 0, 1 execute.
- * out32 = ms[8], calls[8], flops[8], bytes[8], indexed by class (class 6: inversion of L11, 7 unused). */
+ * out32 = ms[8], calls[8], flops[8], bytes[8], indexed by class (class 6: inversion of L11; class 7: the subset of class 2 whose
+ * flops / compulsory bytes lie above the chip's ridge of 9.8 flop per byte, i.e. the launches the matrix cores can bound). */
 int femo_factorize_profile(femo_ctx* c, double* out32) {
     HIPCHK(c, hipSetDevice(c->device));
     c->fr.profile = true;
@@ -2718,7 +2792,7 @@ int femo_set_strain_quadrature(femo_ctx* c, int32_t nred) {
     if (!c->quad) return fail(c, "reduced strain quadrature is implemented for quadrilaterals only");
     if (nred < 0 || nred > 5 || nred * nred + c->nquad * c->nquad > MAXQ) return fail(c, "unsupported reduced rule");
     Tables T;
-    build_tables(true, c->nquad, T, nred);
+    build_tables(true, c->nquad, T, nred, c->cg1);
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
     c->tab_nq = T.nq;
     c->nred = nred; operator_changed(c);
@@ -2768,7 +2842,7 @@ int femo_grad_add(femo_ctx* c, int kind, int32_t x, int32_t y, double scale) {
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
-    if (kind == 0) ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
+    if (kind == 0) ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
     else if (kind == 1) ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
     else return fail(c, "kind must be 0 (stiffness) or 1 (inertia)");
     HIPCHK(c, hipGetLastError());
@@ -2959,9 +3033,9 @@ int femo_newmark_residual_T(femo_ctx* c, int32_t levels, double* g_t, double* dF
         const double *wi = nm.W + (size_t)i * n, *wo = nm.W + (size_t)(i - 1) * n, *li = nm.Lam + (size_t)i * n;
         hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, wi, 1.0, wo, 0.0, (const double*)nullptr, n);         // w_i + w_{i-1}
         hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->z, nm.a, wi, -nm.a, wo, -nm.b, (const double*)wdv, n);     // a (w_i - w_{i-1}) - b wdot_{i-1}
-        ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->p, li, 0.5, c->gradbuf);
+        ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->p, li, 0.5, c->gradbuf);
         ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, c->z, li, 1.0, c->gradbuf);
-        ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, li, -1.0, dFd + (size_t)i * fl);
+        ELEM_LAUNCH_CORE(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, li, -1.0, dFd + (size_t)i * fl);
         hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, wdv, wi, wo, nm.b, n);
     }
     hipError_t e = hipGetLastError();
@@ -3033,7 +3107,7 @@ int femo_newmark_jvp(femo_ctx* c, int32_t levels, const double* dY, const double
         if (dFd) {
             FieldsDev fdv = f;
             fdv.f = dFd + (size_t)i * fl;
-            ELEM_LAUNCH(c, k_load, NOEXTRA, g, EB, m, fdv, c->tab, out, -1.0);                               // (dR_i/df) df_i = - load(df_i)
+            ELEM_LAUNCH_CORE(c, k_load, NOEXTRA, g, EB, m, fdv, c->tab, out, -1.0);                               // (dR_i/df) df_i = - load(df_i)
         }
         if (mask) {
             if (dY) hipLaunchKernelGGL(k_mask_identity, dim3(vg), dim3(256), 0, c->stream, out, (const double*)(nm.Gh + (size_t)i * n), mask, n);
@@ -3263,7 +3337,7 @@ int femo_bench_kernel(femo_ctx* c, const char* name, int32_t reps, double* avg_m
         if (s == "apply") return op_apply(c, c->p, c->Ap, c->scal + 7, nullptr, nullptr, false);
         if (s == "pcg_update") { hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, c->tmp, c->r, c->z, c->p, c->Ap, c->dinv, (const unsigned char*)nullptr, n, c->scal, 0); return 0; }
         if (s == "pcg_direction") { hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, 0); return 0; }
-        if (s == "diag") { ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
+        if (s == "diag") { ELEM_LAUNCH_CORE(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
         return fail(c, "unknown kernel '" + s + "'");
     };
     for (int i = 0; i < 3; ++i)

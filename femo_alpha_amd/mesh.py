@@ -32,7 +32,14 @@ __all__ = ["ShellMesh", "plate_mesh", "wing_skin_mesh", "quads_to_triangles"]
 class ShellMesh:
     """Linear-geometry surface mesh of quads (4 CCW vertices) or triangles in R^3."""
 
-    def __init__(self, nodes, cells):
+    def __init__(self, nodes, cells, element="CG2CG1"):
+        # element: the mixed space of the state (ShellElement.setUpFunctionSpace, linear_shell_model.py:47-86).  'CG2CG1' -- the
+        # one RMShellPDE selects (rm_shell_pde.py:27): displacement on the P2 nodes, rotation on the vertices; 'CG1CG1'
+        # (:74-79): both on the vertices -- the "P2 node" set then IS the vertex set and every table of the displacement is the
+        # bilinear / linear one.  ('CG2CR1', triangles only, :68-73, is not provided.)
+        if element not in ("CG2CG1", "CG1CG1"):
+            raise ValueError("Invalid element type.")
+        self.element = element
         nodes = np.ascontiguousarray(np.asarray(nodes, dtype=np.float64))
         cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int32))
         if nodes.ndim != 2 or nodes.shape[1] not in (2, 3):
@@ -98,10 +105,16 @@ class ShellMesh:
 
     def _build_p2(self):
         nV, nE, nC = self.nn, self.nE, (self.nel if self.is_quad else 0)
+        if self.element == "CG1CG1":
+            nE_p2, nC = 0, 0
+        else:
+            nE_p2 = nE
         self.nV, self.nC = nV, nC
-        self.nP2 = nV + nE + nC
-        cols = [self.cells, nV + self.cell_edges]
-        if self.is_quad:
+        self.nP2 = nV + nE_p2 + nC
+        cols = [self.cells]
+        if self.element != "CG1CG1":
+            cols.append(nV + self.cell_edges)
+        if self.is_quad and self.element != "CG1CG1":
             cols.append((nV + nE + np.arange(self.nel, dtype=np.int32))[:, None])
         # (nel, 9) quads: 4 vertices, 4 edge midpoints, centre; (nel, 6) triangles
         self.cell_p2 = np.ascontiguousarray(np.hstack(cols).astype(np.int32))
@@ -115,6 +128,8 @@ class ShellMesh:
     def p2_coords(self):
         """Coordinates of the P2 nodes under the (bi)linear geometry map."""
         x = self.nodes
+        if self.element == "CG1CG1":
+            return x
         parts = [x, 0.5 * (x[self.edges[:, 0]] + x[self.edges[:, 1]])]
         if self.is_quad:
             parts.append(x[self.cells].mean(axis=1))
@@ -250,7 +265,7 @@ class ShellMesh:
         new_of_vertex[vertex_of_new] = np.arange(self.nn)
         if vertex_of_new.size != self.nn:
             raise ValueError("mesh has vertices that belong to no cell")
-        return ShellMesh(self.nodes[vertex_of_new], new_of_vertex[self.cells[cell_of_new]]), vertex_of_new, cell_of_new
+        return ShellMesh(self.nodes[vertex_of_new], new_of_vertex[self.cells[cell_of_new]], self.element), vertex_of_new, cell_of_new
 
     def partition_cells(self, nparts):
         """Deterministic recursive coordinate bisection of cell centroids into
@@ -276,7 +291,7 @@ class ShellMesh:
 
 
 # ---------------------------------------------------------------------- generators
-def plate_mesh(width=2.0, length=10.0, nw=4, nl=20):
+def plate_mesh(width=2.0, length=10.0, nw=4, nl=20, element="CG2CG1"):
     """Flat rectangular plate, ``nl`` quads along x in [0,length], ``nw`` along y in
     [0,width]; the regenerable stand-in for the reference's LFS-only
     ``plate_2_10_quad_{nw}_{nl}`` meshes (ex_simple_shell_opt.py:27-30,42-43), clamped
@@ -288,11 +303,11 @@ def plate_mesh(width=2.0, length=10.0, nw=4, nl=20):
     idx = np.arange((nl + 1) * (nw + 1)).reshape(nl + 1, nw + 1)
     cells = np.stack([idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(),
                       idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()], axis=1)
-    return ShellMesh(nodes, cells)
+    return ShellMesh(nodes, cells, element)
 
 
 def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True,
-                   seed_jitter=1, seed_perm=2):
+                   seed_jitter=1, seed_perm=2, element="CG2CG1"):
     """Synthetic 'wing-skin' surface: an ``nc x ns``
     quad grid mapped to a cambered, tapered, twisted surface z = c(x,y), interior
     vertices jittered by ``jitter * h_cell * U(-1,1)``, then cells and nodes randomly
@@ -326,7 +341,7 @@ def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True
         nodes = nodes[inv]
         cells = pn[cells]
         cells = cells[rng.permutation(cells.shape[0])]
-    return ShellMesh(nodes, cells)
+    return ShellMesh(nodes, cells, element)
 
 
 def tee_beam_mesh(width=1.0, height=0.5, length=5.0, nw=4, nh=2, nl=10):
@@ -354,4 +369,4 @@ def quads_to_triangles(mesh: ShellMesh):
     """Split every quad along its 0-2 diagonal (triangle variant of a config)."""
     c = mesh.cells
     tri = np.vstack([c[:, [0, 1, 2]], c[:, [0, 2, 3]]])
-    return ShellMesh(mesh.nodes, tri)
+    return ShellMesh(mesh.nodes, tri, mesh.element)

@@ -22,7 +22,13 @@ class FacetSet:
 
 
 class RMShellPDE:
-    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=None, device=0, solver="direct"):
+    def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False, nquad=None, device=0, solver="direct",
+                 element_type=None):
+        # element_type: 'CG2CG1' (what the reference's RMShellPDE hard-codes, rm_shell_pde.py:27) or 'CG1CG1' (the other quadrilateral /
+        # triangle choice of ShellElement.setUpFunctionSpace, linear_shell_model.py:74-79); None: the element the mesh object carries
+        if element_type is not None and element_type != mesh.element:
+            from ..mesh import ShellMesh
+            mesh = ShellMesh(mesh.nodes, mesh.cells, element_type)
         self.mesh = mesh
         self.element_wise_material = element_wise_material
         self.elementwise_pressure = elementwise_pressure

@@ -312,7 +312,7 @@ def rank_plan(mesh, T: Tree, rank, nranks):
     verts_g = np.unique(mesh.cells[cells_g])
     g2l_v = -np.ones(mesh.nn, dtype=np.int64)
     g2l_v[verts_g] = np.arange(verts_g.size)
-    sub = ShellMesh(mesh.nodes[verts_g], g2l_v[mesh.cells[cells_g]])
+    sub = ShellMesh(mesh.nodes[verts_g], g2l_v[mesh.cells[cells_g]], mesh.element)
     l2g_p2 = np.empty(sub.nP2, dtype=np.int64)
     l2g_p2[sub.cell_p2.ravel()] = mesh.cell_p2[cells_g].ravel()
     l2g_dof = np.empty(sub.ndof, dtype=np.int64)

@@ -177,6 +177,9 @@ class ShellOracle:
             self.pts, self.wts = tri_rule() if rule is None else rule
             self.wts_strain = self.wts
             self.N2, self.dN2, self.N1, self.dN1 = tri_tables(self.pts)
+        if getattr(mesh, "element", "CG2CG1") == "CG1CG1":
+            # ShellElement 'CG1CG1' (linear_shell_model.py:74-79): the displacement is interpolated on the vertices as well
+            self.N2, self.dN2 = self.N1, self.dN1
         self.nq = self.pts.shape[0]
         self.npc = mesh.cell_p2.shape[1]
         self.nvc = mesh.cells.shape[1]
@@ -339,6 +342,8 @@ class ShellOracle:
         out = []
         if self.penalty_facets.shape[0] == 0:
             return out
+        if getattr(self.mesh, "element", "CG2CG1") != "CG2CG1":
+            raise NotImplementedError("penalty blocks are restated for the CG2CG1 element")
         x, w = gauss_legendre(3)                                # degree 4 measure, utils_dolfinx.py:556
         L2, _ = _lag2(x); L1, _ = _lag1(x)
         mesh = self.mesh

@@ -154,3 +154,30 @@ def test_bench_distributed_path_over_rccl_with_one_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "DOF/s"
     assert line["config"]["pcg_iterations_forward"] <= 4 and line["config"]["relres_forward"] < 1e-9
     assert line["roofline"]["bound"] == "mfma" and line["roofline_spmv"]["bound"] == "hbm"
+
+
+def test_bench_with_four_ranks_at_full_size_on_one_card():
+    """``python bench.py --gpus 4 --share-gpu`` at the FULL size of BASELINE config 4 (FEMO_BENCH_NS = 580: the 1 015 470-DOF skin in
+    four element partitions): bench.py starts its own four ranks (torch.distributed.run --standalone), they share the one card of the
+    box (a box admits six GPU processes; collectives over gloo), and the JSON line must carry what the single-GPU solve of the same
+    skin gives -- 2 PCG iterations forward and adjoint at rtol 1e-10 (the config-3 golden test) -- and both roofline objects.  What is
+    rehearsed: the launcher, the rendezvous, the partitioned driver of four processes with the HIP engine, the max-over-ranks timing.
+    Not measured: anything about scaling (one card)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEMO_BENCH_NS="580")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FEMO_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["unit"] == "DOF/s" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["ndof"] == 1015470 and cfg["gauss_points_per_direction"] == 5
+    # the single-GPU solve of this skin takes 2 + 2 iterations at rtol 1e-10; a partitioned run may sit on the threshold (+1)
+    assert 2 <= cfg["pcg_iterations_forward"] <= 3 and 2 <= cfg["pcg_iterations_adjoint"] <= 3
+    assert cfg["relres_forward"] < 1e-10 and cfg["relres_adjoint"] < 1e-10
+    assert line["roofline"]["bound"] == "mfma" and line["roofline_spmv"]["bound"] == "hbm"

@@ -703,3 +703,64 @@ def test_pnorm_stress_with_the_thickness_regularisation(ewm, uhat):
         o3.set_fields(uhat=u0)
         assert abs(np.sum(gu * d) - (fp - fm) / (2 * eps)) < 1e-5 * abs((fp - fm) / (2 * eps))
     c.set_option("stress_regularization", 0.0)
+
+
+@pytest.mark.parametrize("kind,uhat", [("warped", False), ("tri", False), ("warped", True)])
+def test_cg1cg1_element(kind, uhat):
+    """ShellElement 'CG1CG1' (linear_shell_model.py:74-79: displacement AND rotation on the vertices; the reference's RMShellPDE
+    never selects it, rm_shell_pde.py:27): the element kernels instantiated with the vertex tables for the displacement, against the
+    oracle's CG1CG1 branch -- operator, load, functionals, partial gradients at 1e-11; forward solve and adjoint gradient through the
+    multifrontal Cholesky; strong Dirichlet conditions (the penalty clamp and the stress outputs are built for CG2CG1 and say so)."""
+    from femo_alpha_amd._lib import FemoHipError
+    from femo_alpha_amd.backend import ShellContext
+    from oracle.rm_shell_oracle import ShellOracle
+    base = _mesh(kind)
+    m = ShellMesh(base.nodes, base.cells, "CG1CG1")
+    assert m.ndof == 6 * m.nn and m.ldof == 6 * m.nvc
+    rng = np.random.default_rng(5)
+    fields = dict(thickness=0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)), E=3e7 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)),
+                  nu=0.3 + 0.05 * rng.uniform(-1, 1, m.nn), density=10 * (1 + 0.1 * rng.uniform(-1, 1, m.nn)),
+                  F_solid=rng.uniform(-1, 1, (m.nn, 3)))
+    if uhat:
+        fields["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
+    sd = m.locate_dofs_geometrical(lambda x: np.less(x[1], 1e-12))
+    o = ShellOracle(m, strong_dofs=sd)
+    o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"], uhat=fields.get("uhat"))
+    c = ShellContext(m)
+    for k, v in fields.items():
+        c.set_field(k, v)
+    c.set_strong_dofs(sd)
+    tol = 1e-11
+    x = rng.uniform(-1, 1, m.ndof)
+    K = o.assemble_K()
+    assert rel(c.apply_K(x), K @ x) < tol
+    assert rel(c.diagonal(), K.diagonal()) < tol
+    assert rel(c.load_vector(), o.load_vector()) < tol
+    w = rng.uniform(-1, 1, m.ndof) * 1e-3
+    w[o.strong_dofs] = 0.0
+    c.set_state(w)
+    assert abs(c.functional("compliance") - o.compliance(w)) < tol * abs(o.compliance(w))
+    assert abs(c.functional("mass") - o.mass()) < tol * abs(o.mass())
+    assert abs(c.functional("elastic_energy") - o.elastic_energy(w)) < tol * abs(o.elastic_energy(w))
+    assert rel(c.dfunctional("compliance", "disp_solid"), o.dcompliance_du(w)) < tol
+    assert rel(c.dfunctional("compliance", "thickness"), o.dcompliance_dh(w)) < tol
+    assert rel(c.dfunctional("elastic_energy", "thickness"), 0.5 * o.dRdfield_T("h", w, w)) < tol
+    lam = rng.uniform(-1, 1, m.ndof)
+    for arg, name in (("thickness", "h"), ("E", "E"), ("nu", "nu")):
+        assert rel(c.dRdarg_T(arg, lam), o.dRdfield_T(name, w, lam)) < tol
+    assert rel(c.dRdarg_T("F_solid", lam), o.dRdf_T(lam)) < tol
+    # forward + adjoint through the direct solver
+    w_ref, J_ref, dJ_ref = o.forward_adjoint()
+    c.use_direct_solver(leaf_size=4)
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 4 and rr <= 1e-12
+    assert rel(c.get_state(), w_ref) < 1e-8
+    assert abs(c.functional("compliance") - J_ref) < 1e-8 * abs(J_ref)
+    dJ, it2, _ = c.total_gradient("compliance", "thickness")
+    assert it2 <= 4 and rel(dJ, dJ_ref) < 1e-8
+    # what is built for CG2CG1 only refuses loudly
+    with pytest.raises(FemoHipError):
+        c.set_penalty_facets(m.penalty_facets(lambda x: np.less(x[1], 1e-12)))
+    with pytest.raises(FemoHipError):
+        c.field_output("stress")
+    c.close()

@@ -349,3 +349,22 @@ def test_stress_surfaces_and_component_sums_of_the_oracle():
     top, mid, bot = (o.stress_dg1(w, s) for s in ("Top", "Mid", "Bot"))
     assert np.abs(mid).max() < 1e-9 * np.abs(top).max()
     assert np.allclose(top, bot, rtol=1e-10) and top.min() > 0
+
+
+def test_cg1cg1_branch_of_the_oracle():
+    """ShellElement 'CG1CG1' (linear_shell_model.py:74-79): symmetric element matrices, exactly six zero-energy rigid-body modes on
+    a warped unconstrained patch, and the C++ restatement agrees with the numpy one."""
+    from femo_alpha_amd.mesh import ShellMesh, quads_to_triangles, wing_skin_mesh
+    from oracle import cpu_baseline as cb
+    from oracle.rm_shell_oracle import ShellOracle
+    for base in (wing_skin_mesh(4, 6), quads_to_triangles(wing_skin_mesh(4, 6))):
+        m = ShellMesh(base.nodes, base.cells, "CG1CG1")
+        assert m.ndof == 6 * m.nn
+        o = ShellOracle(m)
+        o.set_fields(h=0.02, E=7e10, nu=0.3, rho=2700.0)
+        Ke = o.element_matrices()
+        assert np.abs(Ke - Ke.transpose(0, 2, 1)).max() < 1e-13 * np.abs(Ke).max()
+        assert np.abs(Ke - cb.CpuShell(o).element_matrices(0, 2)).max() < 1e-13 * np.abs(Ke).max()
+        K = o.assemble_K(with_penalty=False, with_strong=False).toarray()
+        ev = np.linalg.eigvalsh(K)
+        assert np.sum(np.abs(ev) < 1e-9 * ev.max()) == 6, ev[:8] / ev.max()
