@@ -57,7 +57,7 @@ def spmv_roofline(apply_ms, ndof, nel, traffic, where="", nq=16):
             "binding": "fp64 vector ALU latency at two waves per SIMD (242 VGPRs); neither roof is reached"}
 
 
-def trailing_roofline(prof, traffic):
+def trailing_roofline(prof, traffic, traffic_by_class=None):
     """The dominant kernel of the step: the rank-k updates of the multifrontal Cholesky, k_trailing_mfma / k_trailing_fine (fp64 MFMA).
     Flops and compulsory bytes are summed over the launches from each launch's own K / column ranges (femo_hip.hip, count_trailing):
     lower triangles only, C read + written once, the factor rows of the K panel read once.  One kernel, two roofs: a launch whose
@@ -92,8 +92,8 @@ def trailing_roofline(prof, traffic):
         return dict(allk, kernel="k_trailing_mfma, all launches"), None, allk
     main = max(both.values(), key=lambda o: o["ms_per_factorisation"])
     other = [o for o in both.values() if o is not main]
-    if main["bound"] == "mfma":
-        main["traffic"] = traffic          # the counter passes cover all launches of the kernel: quoted with the class that dominates them
+    for o in both.values():                 # counter bytes per launch of each class (scripts/r4_pmc_levels.py), when the committed passes are current
+        o["traffic"] = (traffic_by_class or {}).get(o["bound"])
     return main, (other[0] if other else None), allk
 
 
@@ -104,13 +104,15 @@ def pmc_traffic(workload):
     from femo_alpha_amd import _build
     pmc = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
     if not os.path.exists(pmc):
-        return None, None
+        return None, None, {}
     pj = json.load(open(pmc))
     if pj.get("source_digest") != _build.source_digest():
         print(f"warning: {os.path.relpath(pmc, ROOT)} was measured on other kernel sources (digest mismatch): roofline.traffic = null; "
-              "re-run scripts/r3_rocprof.sh", file=sys.stderr)
-        return None, None
-    return pj.get("apply_hbm_bytes_per_launch"), pj.get("trailing_hbm_bytes_per_launch")
+              "re-run scripts/r4_rocprof.sh", file=sys.stderr)
+        return None, None, {}
+    # per-class figures of the rank-k updates (scripts/r4_pmc_levels.py): launches above / below the ridge of the chip
+    by_class = {"mfma": pj.get("trailing_mfma_bound_hbm_bytes_per_launch"), "hbm": pj.get("trailing_hbm_bound_hbm_bytes_per_launch")}
+    return pj.get("apply_hbm_bytes_per_launch"), pj.get("trailing_hbm_bytes_per_launch"), by_class
 
 
 def make_workload(name, renumber=True, timings=None):
@@ -492,11 +494,11 @@ def launch_ranks(args):
     set) bench.py is a rank and never comes here.  No process that has initialised the GPU is ever replaced by another."""
     import subprocess
     env = dict(os.environ)
+    # early refusal only: the topology lists the HOST's devices, a container may be allowed fewer of them -- the ranks, which
+    # initialise the GPU anyway, count what they can really use and pick the collective backend (main(): --share-gpu -> gloo)
     ndev = visible_gpus()
-    if ndev is not None and ndev < args.gpus:
-        if not args.share_gpu:
-            raise SystemExit(f"--gpus {args.gpus} but {ndev} device(s) visible (a rehearsal on fewer cards: --share-gpu)")
-        env.setdefault("FEMO_BENCH_BACKEND", "gloo")
+    if ndev is not None and ndev < args.gpus and not args.share_gpu:
+        raise SystemExit(f"--gpus {args.gpus} but {ndev} device(s) visible (a rehearsal on fewer cards: --share-gpu)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={args.gpus}", os.path.abspath(__file__), *sys.argv[1:]]
     res = subprocess.run(cmd, env=env)
@@ -547,10 +549,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_dist:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank if torch.cuda.device_count() > local_rank else 0)
-        backend = os.environ.get("FEMO_BENCH_BACKEND", "nccl")     # "gloo" only to rehearse ranks that share one GPU
+        ndev = torch.cuda.device_count()
+        if ndev < world and not args.share_gpu and "FEMO_BENCH_BACKEND" not in os.environ and not force_dist:
+            raise SystemExit(f"{world} ranks but {ndev} device(s) visible (a rehearsal on fewer cards: --share-gpu)")
+        torch.cuda.set_device(local_rank if ndev > local_rank else 0)
+        # RCCL wants one device per rank: ranks that share a card (rehearsals, --share-gpu) talk over gloo
+        backend = os.environ.get("FEMO_BENCH_BACKEND", "gloo" if ndev < world else "nccl")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank if ndev > local_rank else 0))
         else:
             dist.init_process_group(backend=backend)
     if args.gpus != world and rank == 0 and world > 1:
@@ -622,7 +628,7 @@ def main():
 
     # the matrix-free element operator (the SpMV of the north star), HIP events around back-to-back launches
     apply_ms = ctx.bench_kernel("apply", 100)
-    traffic, traffic_trailing = pmc_traffic(args.workload)
+    traffic, traffic_trailing, traffic_by_class = pmc_traffic(args.workload)
     roof_spmv = spmv_roofline(apply_ms, m.ndof, m.nel, traffic, nq=nquad ** 2)
     roof = roof_spmv
     prof = None
@@ -630,7 +636,7 @@ def main():
         # dominant kernel of the frontal path: the trailing update of the partial Cholesky (fp64 rank-k updates);
         # one instrumented factorisation with a HIP event pair around every launch on the context's stream
         prof = ctx.factorize_profile()
-        roof, roof_other, roof_all = trailing_roofline(prof, traffic_trailing)
+        roof, roof_other, roof_all = trailing_roofline(prof, traffic_trailing, traffic_by_class)
         kernels = {}
         for cls, fk in (("trailing", "trailing"), ("panel_rows", "panel_rows"), ("panel_diag", "panel_diag")):
             ms = prof[cls]["ms"]
