@@ -454,7 +454,7 @@ static void operator_changed(femo_ctx* c) { c->jacobi_dirty = true; c->fr.factor
 
 static int refresh_penalty(femo_ctx* c) {
     if (c->nf == 0 || !c->penalty_dirty) return 0;
-    ELEM_LAUNCH(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
+    ELEM_LAUNCH_CORE(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
     HIPCHK(c, hipGetLastError());
     c->penalty_dirty = false;
     return 0;
@@ -1643,7 +1643,6 @@ int64_t femo_field_size(const femo_ctx* c, const char* name) {
 }
 
 int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double beta) {
-    if (c && c->cg1 && nf > 0) return fail(c, "the CG1CG1 element takes strong Dirichlet conditions (femo_set_strong_dofs); the penalty clamp is built for CG2CG1");
     HIPCHK(c, hipSetDevice(c->device));
     if (nf < 0 || (nf > 0 && !cl)) return fail(c, "bad facet list");
     void* old[] = {c->fcell, c->fledge, c->funode, c->fvnode, c->fM2, c->fM1};
@@ -1666,7 +1665,7 @@ int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double b
         cell[i] = e; le[i] = k;
         const int kb = (k + 1) % c->nvc;
         un[3 * i] = hp[(size_t)k * c->nel + e];
-        un[3 * i + 1] = hp[(size_t)(c->nvc + k) * c->nel + e];
+        un[3 * i + 1] = hp[(size_t)(c->cg1 ? k : c->nvc + k) * c->nel + e];      // CG1CG1: no mid-edge node (its rows of M2 are empty)
         un[3 * i + 2] = hp[(size_t)kb * c->nel + e];
         vn[2 * i] = hc[(size_t)k * c->nel + e];
         vn[2 * i + 1] = hc[(size_t)kb * c->nel + e];

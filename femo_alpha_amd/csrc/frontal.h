@@ -160,7 +160,7 @@ __global__ void k_front_penalty(FacetDev pf, FrontDev fd, const int* __restrict_
     const int* map = elem_map + (size_t)e * ld;
     const int* gd = fd.dofs + fd.doff[t];
     const int kb = (k + 1) % nvc;
-    const int un[3] = {k, nvc + k, kb};          // element-local P2 nodes (a, mid, b)
+    const int un[3] = {k, npc == nvc ? k : nvc + k, kb};          // element-local P2 nodes (a, mid, b); CG1CG1: no mid node, its slot of M2 is empty
     const int vn[2] = {k, kb};                   // element-local vertices
     for (int c = 0; c < 3; ++c) {
         for (int a = 0; a < 3; ++a)

@@ -1458,8 +1458,11 @@ __global__ void k_penalty_setup(MeshDev m, FieldsDev f, FacetDev fd, double beta
         const double wq = gw[q] * 0.5 * len * nanson * beta / m.hK[e];
         const double L2[3] = {0.5 * s * (s - 1.0), 1.0 - s * s, 0.5 * s * (s + 1.0)};
         const double L1[2] = {0.5 * (1.0 - s), 0.5 * (1.0 + s)};
+        // CG1CG1 (NPC == NVC): the displacement has no mid-edge node -- its edge block is the linear one, kept in the 3 x 3 slot
+        // with an empty middle row and column (the host sets the "mid" node to the first vertex)
+        const double U3[3] = {NPC == NVC ? L1[0] : L2[0], NPC == NVC ? 0.0 : L2[1], NPC == NVC ? L1[1] : L2[2]};
         for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) M2[3 * a + b] += wq * L2[a] * L2[b];
+            for (int b = 0; b < 3; ++b) M2[3 * a + b] += wq * U3[a] * U3[b];
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) M1[2 * a + b] += wq * L1[a] * L1[b];
     }

@@ -342,22 +342,25 @@ class ShellOracle:
         out = []
         if self.penalty_facets.shape[0] == 0:
             return out
-        if getattr(self.mesh, "element", "CG2CG1") != "CG2CG1":
-            raise NotImplementedError("penalty blocks are restated for the CG2CG1 element")
+        cg1 = getattr(self.mesh, "element", "CG2CG1") == "CG1CG1"
         x, w = gauss_legendre(3)                                # degree 4 measure, utils_dolfinx.py:556
         L2, _ = _lag2(x); L1, _ = _lag1(x)
         mesh = self.mesh
         for cell, k in self.penalty_facets:
             nv = self.nvc
             va, vb = mesh.cells[cell, k], mesh.cells[cell, (k + 1) % nv]
-            pa, pb, pm = mesh.cell_p2[cell, k], mesh.cell_p2[cell, (k + 1) % nv], mesh.cell_p2[cell, nv + k]
+            pa, pb = mesh.cell_p2[cell, k], mesh.cell_p2[cell, (k + 1) % nv]
+            pm = None if cg1 else mesh.cell_p2[cell, nv + k]
             length = np.linalg.norm(mesh.nodes[vb] - mesh.nodes[va])
             nanson = self._nanson(cell, k, x)
             wq = w * 0.5 * length * nanson * self.beta / self.hK[cell]
             M2 = np.einsum("q,qi,qj->ij", wq, L2, L2)           # nodes (a, mid, b)
             M1 = np.einsum("q,qi,qj->ij", wq, L1, L1)           # nodes (a, b)
             for c in range(3):
-                out.append((np.array([3 * pa + c, 3 * pm + c, 3 * pb + c]), M2))
+                if cg1:                                   # displacement on the vertices: the linear edge functions
+                    out.append((np.array([3 * pa + c, 3 * pb + c]), M1))
+                else:
+                    out.append((np.array([3 * pa + c, 3 * pm + c, 3 * pb + c]), M2))
                 out.append((mesh.ndof_u + np.array([3 * va + c, 3 * vb + c]), M1))
         return out
 

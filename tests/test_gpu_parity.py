@@ -705,12 +705,14 @@ def test_pnorm_stress_with_the_thickness_regularisation(ewm, uhat):
     c.set_option("stress_regularization", 0.0)
 
 
-@pytest.mark.parametrize("kind,uhat", [("warped", False), ("tri", False), ("warped", True)])
-def test_cg1cg1_element(kind, uhat):
+@pytest.mark.parametrize("kind,uhat,bc", [("warped", False, "strong"), ("tri", False, "strong"), ("warped", True, "strong"), ("warped", False, "penalty"),
+                                          ("tri", True, "penalty")])
+def test_cg1cg1_element(kind, uhat, bc):
     """ShellElement 'CG1CG1' (linear_shell_model.py:74-79: displacement AND rotation on the vertices; the reference's RMShellPDE
     never selects it, rm_shell_pde.py:27): the element kernels instantiated with the vertex tables for the displacement, against the
     oracle's CG1CG1 branch -- operator, load, functionals, partial gradients at 1e-11; forward solve and adjoint gradient through the
-    multifrontal Cholesky; strong Dirichlet conditions (the penalty clamp and the stress outputs are built for CG2CG1 and say so)."""
+    multifrontal Cholesky; strong Dirichlet conditions and the penalty clamp (the linear edge block for the displacement too); the stress
+    outputs are built for CG2CG1 and say so."""
     from femo_alpha_amd._lib import FemoHipError
     from femo_alpha_amd.backend import ShellContext
     from oracle.rm_shell_oracle import ShellOracle
@@ -723,13 +725,18 @@ def test_cg1cg1_element(kind, uhat):
                   F_solid=rng.uniform(-1, 1, (m.nn, 3)))
     if uhat:
         fields["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
-    sd = m.locate_dofs_geometrical(lambda x: np.less(x[1], 1e-12))
-    o = ShellOracle(m, strong_dofs=sd)
+    marker = lambda x: np.less(x[1], 1e-12)
+    sd = m.locate_dofs_geometrical(marker) if bc == "strong" else None
+    pf = m.penalty_facets(marker) if bc == "penalty" else None
+    o = ShellOracle(m, strong_dofs=sd, penalty_facets=pf)
     o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"], uhat=fields.get("uhat"))
     c = ShellContext(m)
     for k, v in fields.items():
         c.set_field(k, v)
-    c.set_strong_dofs(sd)
+    if sd is not None:
+        c.set_strong_dofs(sd)
+    else:
+        c.set_penalty_facets(pf)
     tol = 1e-11
     x = rng.uniform(-1, 1, m.ndof)
     K = o.assemble_K()
@@ -737,7 +744,8 @@ def test_cg1cg1_element(kind, uhat):
     assert rel(c.diagonal(), K.diagonal()) < tol
     assert rel(c.load_vector(), o.load_vector()) < tol
     w = rng.uniform(-1, 1, m.ndof) * 1e-3
-    w[o.strong_dofs] = 0.0
+    if sd is not None:
+        w[o.strong_dofs] = 0.0
     c.set_state(w)
     assert abs(c.functional("compliance") - o.compliance(w)) < tol * abs(o.compliance(w))
     assert abs(c.functional("mass") - o.mass()) < tol * abs(o.mass())
@@ -759,8 +767,6 @@ def test_cg1cg1_element(kind, uhat):
     dJ, it2, _ = c.total_gradient("compliance", "thickness")
     assert it2 <= 4 and rel(dJ, dJ_ref) < 1e-8
     # what is built for CG2CG1 only refuses loudly
-    with pytest.raises(FemoHipError):
-        c.set_penalty_facets(m.penalty_facets(lambda x: np.less(x[1], 1e-12)))
     with pytest.raises(FemoHipError):
         c.field_output("stress")
     c.close()
