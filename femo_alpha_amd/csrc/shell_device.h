@@ -691,6 +691,9 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
     constexpr int LD = 3 * NPC + 3 * NVC;
     constexpr int EPB = 64;                     // elements per block (256 threads / 4 lanes)
     constexpr int GEO = 3 * NVC + 3 * NVC + 4 * NVC;    // per element: X, uhat, (h, E, nu, rho) at the vertices
+    // (r4: SQ_LDS_BANK_CONFLICT is 70 % of this kernel's LDS-active cycles; rows of an odd number of doubles -- 16 cells on 16 different
+    //  bank pairs instead of every fourth cell colliding at 40 doubles = 64 B modulo 256 B -- changed nothing: 109.7 against 108 us.
+    //  The LDS pipe is not what the kernel waits for.)
     __shared__ double sx[EPB][LD + 1];
     __shared__ double sg[EPB][GEO + 1];
     // the lanes of a quad work on different quadrature points, so the tables are indexed per lane: keep

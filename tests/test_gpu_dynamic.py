@@ -171,7 +171,20 @@ def test_forward_mode_of_the_transient_operator(ewt, self_weight):
     # J J^-1 = identity
     R = rng.uniform(-1, 1, W0.shape)
     back = ps.jacobian_products_fwd(dY=ps.tangent_history(R))
-    assert np.abs(back - R).max() < 1e-6 * np.abs(R).max()          # J scales like 2/dt^2 M: the solve tolerance, amplified
+    defect = np.abs(back - R).max() / np.abs(R).max()
+    assert defect < 1e-6          # not 1e-8: see below
+    if not ewt and not self_weight:
+        # WHY not 1e-8, tested.  J (J^-1 R) is evaluated level by level as a difference of terms of size
+        # |A| |dY| that cancel down to R: its rounding is eps times the condition number of the step operator A = 2/dt^2 M + K/2.  The mass
+        # shift regularises K/2, so the defect GROWS with the time step (round 3's comment had it falling like 2/dt^2, which this
+        # measurement refuted): 1.1e-7 at dt = 0.01, 2.5e-7 at dt = 0.04.
+        ps4 = PlateSim(mesh, E, nu, rho, 4 * dt, N, element_wise_thickness=ewt, add_self_weight=self_weight, quad_deg=3, leaf_size=8, rtol=1e-12)
+        ps4.update_f_history(F); ps4.update_t(t0); ps4.solve_dynamic_problem()
+        back4 = ps4.jacobian_products_fwd(dY=ps4.tangent_history(R))
+        defect4 = np.abs(back4 - R).max() / np.abs(R).max()
+        print(f"J J^-1 - I: {defect:.2e} at dt = {dt}, {defect4:.2e} at dt = {4 * dt}")
+        assert defect < defect4 < 1e-5, (defect, defect4)
+        ps4.ctx.close()
     # forward against reverse mode
     # (on the free rows: the adjoint keeps the Dirichlet entries of Lambda at zero -- they multiply rows of dR/dt and dR/df that are
     #  zero -- so the transpose relation is the one of the free-free blocks)
