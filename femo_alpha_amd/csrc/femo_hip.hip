@@ -61,6 +61,8 @@ struct femo_ctx {
     double* hK = nullptr;
     Tables* tab = nullptr;
     Tables* tab_s = nullptr;     // degree-4 rule of the p-norm stress measure (3x3 Gauss on quads)
+    Tables* tab_pre = nullptr;   // rule of the front assembly when the operator's has more than 4 x 4 points (option "precond_nquad"); null: c->tab
+    int tab_pre_nq = 0;
     double stress_m = 1e-6, stress_rho = 100.0, stress_alpha = -1.0, stress_reg = 0.0;
     int* ctag = nullptr;                     // sub-domain index per cell
     int csel = -1, ntags = 0;
@@ -132,6 +134,12 @@ struct femo_ctx {
         // D (L L^T)^-1 D.  Measured: no change in what one application of the factor leaves -- every operation of
         // a Cholesky factorisation and of the sweeps commutes with a power-of-two scaling, so mode 2 reproduces mode 0 bit for bit
         int equilibrate = 0;
+        // Gauss points per direction of the FRONT ASSEMBLY on quadrilaterals (0: the operator's rule, the default).  The factor is only a
+        // preconditioner, so a lighter rule is legitimate -- but it does not pay on thin shells: on the 1 M DOF wing skin (operator
+        // 5 x 5) fronts assembled with 4 x 4 points take 4 + 4 PCG iterations instead of 2 + 2 (3 x 3: 6 + 6), i.e. 1.93 -> 1.51 ms of
+        // assembly bought with +2.7 ms of forward solve and +3.1 ms of adjoint (profiles/r4_precond_nquad.txt).  Results are the same
+        // to 1e-11 either way (PCG iterates on the operator's residual); kept as an option for meshes where assembly dominates.
+        int precond_nquad = 0;
         int grid_chunk = 32768;       // fronts per launch along grid y / z (extent limit 65535)
         int wide_np = WIDE_NP_DEFAULT, wide_cnt = WIDE_CNT_DEFAULT;   // read when the plan is uploaded
         int strict = 1;               // a Krylov solve that stops at maxit without reaching rtol is an error
@@ -670,12 +678,28 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             hipLaunchKernelGGL(k_eq_scale, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->eq, (const double*)c->dinv, mask, c->opt.equilibrate, (int64_t)c->ndof);
             eq = c->eq;
         }
+        // the rule of the front assembly (option "precond_nquad"): a lighter one than the operator's on quadrilaterals with the plain
+        // (un-split) quadrature -- the transient path's reduced strain rule keeps the operator's tables
+        const Tables* atab = c->tab;
+        int anq = c->tab_nq;
+        if (c->quad && c->nred == 0 && c->opt.precond_nquad > 0 && c->opt.precond_nquad < c->nquad) {
+            if (!c->tab_pre || c->tab_pre_nq != c->opt.precond_nquad * c->opt.precond_nquad) {
+                Tables TP;                                           // 8 KB on this thread's stack (contexts of several threads factorise at once)
+                build_tables(true, c->opt.precond_nquad, TP, 0, c->cg1);
+                if (!c->tab_pre) HIPCHK(c, hipMalloc((void**)&c->tab_pre, sizeof(Tables)));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipMemcpy(c->tab_pre, &TP, sizeof(Tables), hipMemcpyHostToDevice));
+                c->tab_pre_nq = TP.nq;
+            }
+            atab = c->tab_pre; anq = c->tab_pre_nq;
+        }
+        const size_t qlds = (size_t)anq * (c->cg1 ? (c->quad ? sizeof(QPoint<4, 4>) : sizeof(QPoint<3, 3>)) : (c->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>)));
         { ProfScope ps(c, 4);
         if (c->op_aM != 0.0)
-            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_TRUE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_TRUE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq);
         else
-            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_FALSE, c->nel, 64, QPOINT_LDS(c), mesh_dev(c), fields_dev(c), c->tab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_FALSE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
@@ -1589,7 +1613,7 @@ void femo_destroy(femo_ctx* c) {
     for (double* p : c->fp)
         if (p) hipFree(p);
     if (c->eq) hipFree(c->eq);
-    void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
+    void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->tab_pre, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
                     c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
@@ -1930,6 +1954,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;
     else if (k == "fused_schur") o.fused_schur = v != 0;
+    else if (k == "precond_nquad") { if (v != 0 && (v < 2 || v > 5)) return fail(c, "precond_nquad: 0 (the operator's rule) or 2..5"); o.precond_nquad = v; operator_changed(c); }
     else if (k == "equilibrate") { if (v < 0 || v > 2) return fail(c, "equilibrate: 0 off, 1 diag^-1/2, 2 nearest powers of two"); o.equilibrate = v; operator_changed(c); }
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {

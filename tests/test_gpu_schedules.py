@@ -91,3 +91,18 @@ def test_diagonal_look_ahead_inside_super_panels(sp, fused, case):
         assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
         assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
     assert np.abs(res[0][1] - res[1][1]).max() < 1e-10 * np.abs(w0).max()
+
+
+def test_lighter_quadrature_rule_of_the_front_assembly():
+    """Option "precond_nquad": the fronts are assembled with fewer Gauss points than the operator (wing skin: 5 x 5).  The factor
+    is then the factor of a slightly different matrix -- still a preconditioner: the solution is the same (PCG iterates on the
+    operator's residual), it only takes more iterations, which is why the option is off by default (profiles/r4_precond_nquad.txt)."""
+    m, marker = wing_skin_mesh(32, 96, shuffle=True).renumbered()[0], (lambda x: np.less(x[1], 1e-9))
+    assert m.recommended_nquad() == 5
+    it0, w0, g0 = _solve(m, marker, True, 8, {}, {})
+    it4, w4, g4 = _solve(m, marker, True, 8, {}, dict(precond_nquad=4))
+    it3, w3, g3 = _solve(m, marker, True, 8, {}, dict(precond_nquad=3))
+    assert it0 <= it4 <= it3 and it3 > it0
+    for w, g in ((w4, g4), (w3, g3)):
+        assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
+        assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
