@@ -382,34 +382,10 @@ static FacetDev facet_dev(const femo_ctx* c) {
     return fd;
 }
 
-// KERNEL is a template <NPC,NVC,QUAD,UHAT>; EXTRA may carry more template args (leading comma).
-// Two families: the _CORE macros also instantiate the CG1CG1 element (NPC == NVC: the displacement lives on the vertices,
-// linear_shell_model.py:74-79) -- the forward solve, the outputs and the adjoint chain; the plain macros serve what is built for the
-// reference's own element choice CG2CG1 only (rm_shell_pde.py:27) and refuse a CG1CG1 context.
-#define ELEM_LAUNCH(c, KERNEL, EXTRA, grid, block, ...)                                                       \
-    do {                                                                                                      \
-        if ((c)->cg1) return fail((c), "this operation is not provided for the CG1CG1 element (" #KERNEL ")"); \
-        if ((c)->quad) {                                                                                      \
-            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
-        } else {                                                                                              \
-            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);              \
-        }                                                                                                     \
-    } while (0)
-// the same with dynamic LDS (kernels that stage their quadrature points: stage_qpoints)
-#define ELEM_LAUNCH_S(c, KERNEL, EXTRA, grid, block, shm, ...)                                                \
-    do {                                                                                                      \
-        if ((c)->cg1) return fail((c), "this operation is not provided for the CG1CG1 element (" #KERNEL ")"); \
-        if ((c)->quad) {                                                                                      \
-            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<9, 4, true, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<9, 4, true, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
-        } else {                                                                                              \
-            if ((c)->has_uhat) hipLaunchKernelGGL((KERNEL<6, 3, false, true EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<6, 3, false, false EXTRA>), dim3(grid), dim3(block), shm, (c)->stream, __VA_ARGS__);              \
-        }                                                                                                     \
-    } while (0)
-#define ELEM_LAUNCH_CORE(c, KERNEL, EXTRA, grid, block, ...)                                                  \
+// KERNEL is a template <NPC,NVC,QUAD,UHAT>; EXTRA may carry more template args (leading comma).  Every element kernel is instantiated
+// for the reference's own element choice CG2CG1 (rm_shell_pde.py:27; NPC = 9 / 6) and for CG1CG1 (NPC == NVC: the displacement lives
+// on the vertices, linear_shell_model.py:74-79).
+#define ELEM_LAUNCH(c, KERNEL, EXTRA, grid, block, ...)                                                  \
     do {                                                                                                      \
         if ((c)->cg1) {                                                                                       \
         if ((c)->quad) {                                                                                      \
@@ -429,7 +405,7 @@ static FacetDev facet_dev(const femo_ctx* c) {
         }                                                                                                     \
         }                                                                                                     \
     } while (0)
-#define ELEM_LAUNCH_S_CORE(c, KERNEL, EXTRA, grid, block, shm, ...)                                           \
+#define ELEM_LAUNCH_S(c, KERNEL, EXTRA, grid, block, shm, ...)                                           \
     do {                                                                                                      \
         if ((c)->cg1) {                                                                                       \
         if ((c)->quad) {                                                                                      \
@@ -462,7 +438,7 @@ static void operator_changed(femo_ctx* c) { c->jacobi_dirty = true; c->fr.factor
 
 static int refresh_penalty(femo_ctx* c) {
     if (c->nf == 0 || !c->penalty_dirty) return 0;
-    ELEM_LAUNCH_CORE(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
+    ELEM_LAUNCH(c, k_penalty_setup, NOEXTRA, nblk(c->nf, 64), 64, mesh_dev(c), fields_dev(c), facet_dev(c), c->beta);
     HIPCHK(c, hipGetLastError());
     c->penalty_dirty = false;
     return 0;
@@ -475,8 +451,8 @@ static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, do
         const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
 #define COMMA_TRUE , true
 #define COMMA_FALSE , false
-        if (aM != 0.0) ELEM_LAUNCH_CORE(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
-        else ELEM_LAUNCH_CORE(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
         const int nthreads = c->nP2 + c->nghost;
 #define GATHER_SUM(NPC_, NVC_) hipLaunchKernelGGL((k_gather_sum<NPC_, NVC_>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, \
                                                   c->ndof_u, c->ndof, c->n2e_off, c->n2e_ent, c->ybuf, y)
@@ -498,7 +474,7 @@ static int refresh_diag(femo_ctx* c) {
     if (!c->jacobi_dirty) return 0;
     const int64_t n = c->ndof;
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, c->dinv, 0.0, n);
-    ELEM_LAUNCH_CORE(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
+    ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->dinv);
     if (c->nf > 0) {
         if (refresh_penalty(c)) return 1;
         hipLaunchKernelGGL(k_penalty_apply, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), c->ndof_u, 1,
@@ -516,7 +492,7 @@ static int load_vector_dev(femo_ctx* c, double* F, const double* f_override = nu
     hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, F, 0.0, n);
     FieldsDev fdv = fields_dev(c);
     if (f_override) fdv.f = const_cast<double*>(f_override);        // a level of the resident force history (femo_newmark_*)
-    ELEM_LAUNCH_CORE(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
+    ELEM_LAUNCH(c, k_load, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fdv, c->tab, F, 1.0);
     if (c->has_g && c->nf > 0) {
         // penalty with prescribed values: R = ... + P (w - g)  ->  the right-hand side gains P g
         if (refresh_penalty(c)) return 1;
@@ -696,10 +672,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         const size_t qlds = (size_t)anq * (c->cg1 ? (c->quad ? sizeof(QPoint<4, 4>) : sizeof(QPoint<3, 3>)) : (c->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>)));
         { ProfScope ps(c, 4);
         if (c->op_aM != 0.0)
-            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_TRUE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_TRUE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq);
         else
-            ELEM_LAUNCH_S_CORE(c, k_front_assemble, COMMA_FALSE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
+            ELEM_LAUNCH_S(c, k_front_assemble, COMMA_FALSE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq); }
         if (c->nf > 0)
             hipLaunchKernelGGL(k_front_penalty, dim3(nblk(c->nf, 64)), dim3(64), 0, c->stream, facet_dev(c), fd, fr.elem_front,
@@ -2004,7 +1980,7 @@ static MeshDev mesh_dev_all(const femo_ctx* c) { MeshDev m = mesh_dev(c); m.csel
 
 static int functionals_dev(femo_ctx* c, double* out3, int nout = 3, bool subdomain = false) {
     HIPCHK(c, hipMemsetAsync(c->scal, 0, 8 * sizeof(double), c->stream));
-    ELEM_LAUNCH_CORE(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, subdomain ? mesh_dev(c) : mesh_dev_all(c), fields_dev(c), c->tab, c->w, c->scal);
+    ELEM_LAUNCH(c, k_functionals, NOEXTRA, nblk(c->nel, EB), EB, subdomain ? mesh_dev(c) : mesh_dev_all(c), fields_dev(c), c->tab, c->w, c->scal);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->scal, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2081,12 +2057,14 @@ static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const doub
     const FieldsDev f = fields_dev(c);
     const int nthreads = c->nel * 3 * c->nvc;
     const Tables* tb = mode == 4 ? c->tab_s : c->tab;
-    if (c->quad)
-        hipLaunchKernelGGL((k_shape_gradient<9, 4, true>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w, lam,
-                           scale, c->stress_m, c->stress_rho, c->stress_reg, out);
-    else
-        hipLaunchKernelGGL((k_shape_gradient<6, 3, false>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w,
-                           lam, scale, c->stress_m, c->stress_rho, c->stress_reg, out);
+#define SHAPE_LAUNCH(NPC, NVC, QUAD)                                                                                              \
+    hipLaunchKernelGGL((k_shape_gradient<NPC, NVC, QUAD>), dim3(nblk(nthreads, 128)), dim3(128), 0, c->stream, m, f, tb, mode, w, lam, \
+                       scale, c->stress_m, c->stress_rho, c->stress_reg, out)
+    if (c->cg1) { if (c->quad) SHAPE_LAUNCH(4, 4, true); else SHAPE_LAUNCH(3, 3, false); }
+    else        { if (c->quad) SHAPE_LAUNCH(9, 4, true); else SHAPE_LAUNCH(6, 3, false); }
+#undef SHAPE_LAUNCH
+    if (mode == 0 && c->nf > 0 && c->cg1)
+        return fail(c, "the shape derivative of the penalty clamp is not provided for the CG1CG1 element (use strong Dirichlet conditions)");
     if (mode == 0 && c->nf > 0) {
         if (c->has_g) {           // the penalty term is P(uhat) (w - g)
             hipLaunchKernelGGL(k_lincomb3, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->tmp, 1.0, w, -1.0, (const double*)c->gdir, 0.0,
@@ -2126,23 +2104,23 @@ static int dfunctional_dev(femo_ctx* c, const std::string& fn, const std::string
         return shape_gradient_dev(c, mode, c->w, nullptr, 1.0, out);
     }
     if (fn == "tip_disp") {               // 0.5 int u.u J over the selected sub-domain
-        if (wrt == "disp_solid") ELEM_LAUNCH_CORE(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out, 0.5);
+        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, m, f, c->tab, c->w, out, 0.5);
     } else if (fn == "area") {
     } else if (fn == "regularization") {         // the thickness term of the compliance (its only explicit thickness dependence)
-        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "compliance") {
-        if (wrt == "disp_solid") ELEM_LAUNCH_CORE(c, k_dcompliance_du, NOEXTRA, g, EB, mesh_dev_all(c), f, c->tab, c->w, out, 1.0);
-        else if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
+        if (wrt == "disp_solid") ELEM_LAUNCH(c, k_dcompliance_du, NOEXTRA, g, EB, mesh_dev_all(c), f, c->tab, c->w, out, 1.0);
+        else if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 0, out);
     } else if (fn == "mass") {
-        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
-        else if (wrt == "density") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 1, out);
+        else if (wrt == "density") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 2, out);
     } else if (fn == "volume") {
-        if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 3, out);
+        if (wrt == "thickness") ELEM_LAUNCH(c, k_field_grad, NOEXTRA, g, EB, m, f, c->tab, 3, out);
     } else if (fn == "elastic_energy") {
         if (wrt == "disp_solid") { if (op_apply(c, c->w, out, nullptr, nullptr, nullptr, false)) return 1; }
-        else if (wrt == "thickness") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
-        else if (wrt == "E") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
-        else if (wrt == "nu") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
+        else if (wrt == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, c->w, 0.5, out);
     } else if (fn == "pnorm_stress") {
         if (stress_alpha_ref(c) < 0) { double v[2]; if (pnorm_dev(c, v)) return 1; hipLaunchKernelGGL(k_fill, dim3(vec_grid(n)), dim3(256), 0, c->stream, out, 0.0, n); }
         const int mode = wrt == "disp_solid" ? 1 : wrt == "thickness" ? 2 : wrt == "E" ? 3 : wrt == "nu" ? 4 : 0;
@@ -2163,10 +2141,10 @@ static int dRdarg_T_dev(femo_ctx* c, const std::string& arg, const double* lam, 
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
-    if (arg == "thickness") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "E") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "nu") ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
-    else if (arg == "F_solid") ELEM_LAUNCH_CORE(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
+    if (arg == "thickness") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "E") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_E, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "nu") ELEM_LAUNCH(c, k_dRdfield_T, COMMA_NU, g, EB, m, f, c->tab, c->w, lam, scale, out);
+    else if (arg == "F_solid") ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, lam, -scale, out);
     else if (arg == "density") { /* R does not depend on density */ }
     else if (arg == "uhat") { if (shape_gradient_dev(c, 0, c->w, lam, scale, out)) return 1; }
     else return fail(c, "(dR/d" + arg + ")^T is not implemented in this build");
@@ -2866,7 +2844,7 @@ int femo_grad_add(femo_ctx* c, int kind, int32_t x, int32_t y, double scale) {
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int g = nblk(c->nel, EB);
-    if (kind == 0) ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
+    if (kind == 0) ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
     else if (kind == 1) ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, vx, vy, scale, c->gradbuf);
     else return fail(c, "kind must be 0 (stiffness) or 1 (inertia)");
     HIPCHK(c, hipGetLastError());
@@ -3057,9 +3035,9 @@ int femo_newmark_residual_T(femo_ctx* c, int32_t levels, double* g_t, double* dF
         const double *wi = nm.W + (size_t)i * n, *wo = nm.W + (size_t)(i - 1) * n, *li = nm.Lam + (size_t)i * n;
         hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->p, 1.0, wi, 1.0, wo, 0.0, (const double*)nullptr, n);         // w_i + w_{i-1}
         hipLaunchKernelGGL(k_lincomb3, dim3(vg), dim3(256), 0, c->stream, c->z, nm.a, wi, -nm.a, wo, -nm.b, (const double*)wdv, n);     // a (w_i - w_{i-1}) - b wdot_{i-1}
-        ELEM_LAUNCH_CORE(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->p, li, 0.5, c->gradbuf);
+        ELEM_LAUNCH(c, k_dRdfield_T, COMMA_H, g, EB, m, f, c->tab, c->p, li, 0.5, c->gradbuf);
         ELEM_LAUNCH(c, k_dMdh_T, NOEXTRA, g, EB, m, f, c->tab, c->z, li, 1.0, c->gradbuf);
-        ELEM_LAUNCH_CORE(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, li, -1.0, dFd + (size_t)i * fl);
+        ELEM_LAUNCH(c, k_dRdf_T, NOEXTRA, g, EB, m, f, c->tab, li, -1.0, dFd + (size_t)i * fl);
         hipLaunchKernelGGL(k_newmark_wdot, dim3(vg), dim3(256), 0, c->stream, wdv, wi, wo, nm.b, n);
     }
     hipError_t e = hipGetLastError();
@@ -3131,7 +3109,7 @@ int femo_newmark_jvp(femo_ctx* c, int32_t levels, const double* dY, const double
         if (dFd) {
             FieldsDev fdv = f;
             fdv.f = dFd + (size_t)i * fl;
-            ELEM_LAUNCH_CORE(c, k_load, NOEXTRA, g, EB, m, fdv, c->tab, out, -1.0);                               // (dR_i/df) df_i = - load(df_i)
+            ELEM_LAUNCH(c, k_load, NOEXTRA, g, EB, m, fdv, c->tab, out, -1.0);                               // (dR_i/df) df_i = - load(df_i)
         }
         if (mask) {
             if (dY) hipLaunchKernelGGL(k_mask_identity, dim3(vg), dim3(256), 0, c->stream, out, (const double*)(nm.Gh + (size_t)i * n), mask, n);
@@ -3361,7 +3339,7 @@ int femo_bench_kernel(femo_ctx* c, const char* name, int32_t reps, double* avg_m
         if (s == "apply") return op_apply(c, c->p, c->Ap, c->scal + 7, nullptr, nullptr, false);
         if (s == "pcg_update") { hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, c->tmp, c->r, c->z, c->p, c->Ap, c->dinv, (const unsigned char*)nullptr, n, c->scal, 0); return 0; }
         if (s == "pcg_direction") { hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, 0); return 0; }
-        if (s == "diag") { ELEM_LAUNCH_CORE(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
+        if (s == "diag") { ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
         return fail(c, "unknown kernel '" + s + "'");
     };
     for (int i = 0; i < 3; ++i)
