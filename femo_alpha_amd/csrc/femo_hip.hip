@@ -2063,8 +2063,6 @@ static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const doub
     if (c->cg1) { if (c->quad) SHAPE_LAUNCH(4, 4, true); else SHAPE_LAUNCH(3, 3, false); }
     else        { if (c->quad) SHAPE_LAUNCH(9, 4, true); else SHAPE_LAUNCH(6, 3, false); }
 #undef SHAPE_LAUNCH
-    if (mode == 0 && c->nf > 0 && c->cg1)
-        return fail(c, "the shape derivative of the penalty clamp is not provided for the CG1CG1 element (use strong Dirichlet conditions)");
     if (mode == 0 && c->nf > 0) {
         if (c->has_g) {           // the penalty term is P(uhat) (w - g)
             hipLaunchKernelGGL(k_lincomb3, dim3(vec_grid(c->ndof)), dim3(256), 0, c->stream, c->tmp, 1.0, w, -1.0, (const double*)c->gdir, 0.0,
@@ -2072,12 +2070,12 @@ static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const doub
             w = c->tmp;
         }
         const int nt = c->nf * 3 * c->nvc;
-        if (c->quad)
-            hipLaunchKernelGGL((k_shape_gradient_penalty<4, true>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta,
-                               w, lam, scale, out);
-        else
-            hipLaunchKernelGGL((k_shape_gradient_penalty<3, false>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta,
-                               w, lam, scale, out);
+#define SHAPE_PENALTY(NVC, QUAD, CG1)                                                                                                  \
+    hipLaunchKernelGGL((k_shape_gradient_penalty<NVC, QUAD, CG1>), dim3(nblk(nt, 64)), dim3(64), 0, c->stream, m, f, facet_dev(c), c->beta, \
+                       w, lam, scale, out)
+        if (c->cg1) { if (c->quad) SHAPE_PENALTY(4, true, true); else SHAPE_PENALTY(3, false, true); }
+        else        { if (c->quad) SHAPE_PENALTY(4, true, false); else SHAPE_PENALTY(3, false, false); }
+#undef SHAPE_PENALTY
     }
     HIPCHK(c, hipGetLastError());
     return 0;

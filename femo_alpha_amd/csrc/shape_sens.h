@@ -268,7 +268,8 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
 }
 
 // penalty term: lam . P(uhat) w  with  P = beta/h_K int |J F^-T N| (.,.) ds  per tagged facet
-template <int NVC, bool QUAD>
+// CG1: the CG1CG1 element -- the displacement's edge block is the linear one (k_penalty_setup's U3)
+template <int NVC, bool QUAD, bool CG1>
 __global__ void k_shape_gradient_penalty(MeshDev m, FieldsDev f, FacetDev fd, double beta, const double* __restrict__ w,
                                          const double* __restrict__ lam, double scale, double* __restrict__ out) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,8 +315,8 @@ __global__ void k_shape_gradient_penalty(MeshDev m, FieldsDev f, FacetDev fd, do
         D1 v[3];
         for (int a = 0; a < 3; ++a) v[a] = sd.cof[a][0] * Nf[0] + sd.cof[a][1] * Nf[1] + sd.cof[a][2] * Nf[2];
         const D1 nanson = dsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        const double L2[3] = {0.5 * s * (s - 1.0), 1.0 - s * s, 0.5 * s * (s + 1.0)};
         const double L1[2] = {0.5 * (1.0 - s), 0.5 * (1.0 + s)};
+        const double L2[3] = {CG1 ? L1[0] : 0.5 * s * (s - 1.0), CG1 ? 0.0 : 1.0 - s * s, CG1 ? L1[1] : 0.5 * s * (s + 1.0)};
         double wl = 0.0;
         for (int c = 0; c < 3; ++c) {
             double wu = 0, lu = 0, wt = 0, lt = 0;

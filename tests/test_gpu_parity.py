@@ -771,9 +771,7 @@ def test_cg1cg1_element(kind, uhat, bc):
 def test_cg1cg1_stress_csr_and_shape_outputs(kind):
     """The rest of the operator surface on the CG1CG1 element: p-norm stress aggregate with its partial gradients, the DG1 stress
     field, the CSR export and the shape derivatives (d/d uhat of the outputs and (dR/d uhat)^T lambda), each against the oracle's
-    CG1CG1 branch (values) or its central finite differences (shape, stress gradients).  Only the shape derivative of the PENALTY
-    clamp is missing for this element, and says so."""
-    from femo_alpha_amd._lib import FemoHipError
+    CG1CG1 branch (values) or its central finite differences (shape, stress gradients), the penalty clamp's shape term included."""
     from femo_alpha_amd.backend import ShellContext
     from oracle.rm_shell_oracle import ShellOracle
     base = _mesh(kind)
@@ -851,12 +849,27 @@ def test_cg1cg1_stress_csr_and_shape_outputs(kind):
             for g, d, name in ((g_c, fd[0], "compliance"), (g_m, fd[1], "mass"), (g_e, fd[2], "energy"), (g_s, fd[3], "pnorm"), (g_r, fd[4], "residual")):
                 assert abs(g[v, comp] - d) <= 5e-6 * np.abs(g).max() + 1e-7 * abs(d), (name, v, comp, g[v, comp], d)
     c.close()
-    # the one gap: shape derivative of the penalty clamp
+    # the shape derivative of the penalty clamp (linear edge block for the displacement)
+    pf = m.penalty_facets(lambda x: np.less(x[1], 1e-12))
+    op = ShellOracle(m, penalty_facets=pf, beta=1e6)
+    op.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"], uhat=fields["uhat"])
     c = ShellContext(m)
     for k, v in fields.items():
         c.set_field(k, v)
-    c.set_penalty_facets(m.penalty_facets(lambda x: np.less(x[1], 1e-12)), 1e6)
+    c.set_penalty_facets(pf, 1e6)
+    w = rng.uniform(-1, 1, m.ndof) * 1e-3
+    lam = rng.uniform(-1, 1, m.ndof)
     c.set_state(w)
-    with pytest.raises(FemoHipError):
-        c.dRdarg_T("uhat", lam)
+    g_r = c.dRdarg_T("uhat", lam).reshape(-1, 3)
+    on_clamp = np.nonzero(np.abs(m.nodes[:, 1]) < 1e-12)[0]
+    for v in list(rng.choice(on_clamp, 2, replace=False)) + list(rng.choice(m.nn, 1)):
+        for comp in range(3):
+            vals = []
+            for sgn in (1, -1):
+                u = u0.copy(); u[v, comp] += sgn * step
+                op.set_fields(uhat=u)
+                vals.append(lam @ (op.assemble_K() @ w - op.load_vector()))
+            op.set_fields(uhat=u0)
+            d = (vals[0] - vals[1]) / (2 * step)
+            assert abs(g_r[v, comp] - d) <= 5e-6 * np.abs(g_r).max() + 1e-7 * abs(d), ("penalty", v, comp, g_r[v, comp], d)
     c.close()
