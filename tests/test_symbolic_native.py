@@ -69,3 +69,18 @@ def test_every_dof_is_eliminated_exactly_once_and_maps_are_consistent():
 def test_too_few_cells_for_the_requested_depth_is_an_error():
     with pytest.raises(ValueError):
         symbolic.analyse(plate_mesh(1.0, 1.0, 1, 2), 1, min_depth=3)
+
+
+def test_separators_follow_the_mesh_lines_of_the_config3_skin():
+    """The bisection of round 4 (cut at the largest gap of the sorted centroid coordinates near the middle, across the axis along which
+    the piece is longest in CELLS, fixed tree depth): on the 116 x 580 wing skin of BASELINE config 3 no separator is wider than
+    one chordwise mesh line (1 050 DOFs: 117 vertices x 6 + 116 edge nodes x 3), where cutting every piece at its middle element
+    drags both neighbouring lines in (1 455).  A third of the factorisation's flops depends on it."""
+    m = wing_skin_mesh(116, 580).renumbered()[0]
+    line = 117 * 6 + 116 * 3
+    new = symbolic.build_plan(m, 12).summary()
+    old = symbolic.build_plan(m, 12, axis_rule=0, gap=0.0).summary()
+    assert new["max_pivots"] == line and new["max_front"] == 3 * line
+    assert old["max_pivots"] > 1.3 * line
+    assert new["factor_gflop"] < 0.72 * old["factor_gflop"]
+    assert 205.0 < new["factor_gflop"] < 220.0
