@@ -147,13 +147,14 @@ class ShellContext:
         return Ke
 
     # ------------------------------------------------------------------ multifrontal preconditioner
-    def enable_frontal(self, leaf_size=12, plan=None, **options):
+    def enable_frontal(self, leaf_size=None, plan=None, **options):
         """Run the symbolic analysis on the host (mesh only) and upload it; afterwards
         ``set_solver(preconditioner=2)`` selects the multifrontal Cholesky preconditioner.
         ``plan`` may carry a ready-made plan (the multi-GPU driver passes rank-local plans);
         ``options`` are plan-shaping switches set before the upload (``wide_np``, ``wide_cnt``)."""
         import time
         from .solver.symbolic import build_plan
+        leaf_size = self.mesh.recommended_leaf_size() if leaf_size is None else int(leaf_size)
         for k, v in options.items():
             self.set_option(k, v)
         t0 = time.perf_counter()
@@ -211,7 +212,7 @@ class ShellContext:
     def set_solver(self, preconditioner=0, rtol=1e-10, maxit=200000, check_every=50):
         self._chk(self.lib.femo_set_solver(self._h, preconditioner, rtol, maxit, check_every))
 
-    def use_direct_solver(self, leaf_size=12, rtol=1e-12, maxit=40):
+    def use_direct_solver(self, leaf_size=None, rtol=1e-12, maxit=40):
         """What the reference's LU stands for (fea/utils_dolfinx.py:466,514-531): symbolic analysis once, then every
         solve = multifrontal Cholesky of the current operator + a few refinement steps of PCG on the true residual."""
         if getattr(self, "plan", None) is None:

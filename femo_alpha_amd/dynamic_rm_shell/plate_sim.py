@@ -31,7 +31,7 @@ from ..backend import ShellContext
 
 class PlateSim:
     def __init__(self, mesh, E, nu, rho, dt, Nsteps, element_wise_thickness=False, custom_bc_func=None,
-                 add_self_weight=False, g_factor=None, quad_deg=3, comm=None, device=0, leaf_size=12, rtol=1e-8):
+                 add_self_weight=False, g_factor=None, quad_deg=3, comm=None, device=0, leaf_size=None, rtol=1e-8):
         import torch
         self.torch = torch
         self.mesh, self.E, self.nu, self.rho, self.dt = mesh, E, nu, rho, dt

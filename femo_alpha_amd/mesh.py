@@ -176,6 +176,12 @@ class ShellMesh:
                 d = np.maximum(d, np.linalg.norm(x[:, i] - x[:, j], axis=1))
         return d
 
+    def recommended_leaf_size(self):
+        """Cells per leaf of the nested dissection (ShellContext.enable_frontal / use_direct_solver, DistributedShell): 12 quadrilaterals;
+        24 triangles -- two triangles cover one quadrilateral's area and DOFs, and leaves of 12 triangles add a tree level of small fronts
+        (1 M-DOF triangle skin: forward 20.8 ms with 12, 20.3 with 24, scripts/r4_tri.py)."""
+        return 12 if self.is_quad else 24
+
     def recommended_nquad(self):
         """Gauss points per direction that reproduce the reference's integration of the static forms.  The reference leaves
         the degree to UFL (plain ``dx``, linear_shell_model.py:88-103), whose estimate is 43-53 on quadrilaterals

@@ -166,7 +166,7 @@ class HipEngine:
 class DistributedShell:
     """Forward solve, scalar outputs and the adjoint gradient on an element partition."""
 
-    def __init__(self, mesh, comm: Comm, bc_marker=None, beta=1.0e15, leaf_size=12, engine_factory=None,
+    def __init__(self, mesh, comm: Comm, bc_marker=None, beta=1.0e15, leaf_size=None, engine_factory=None,
                  element_wise_material=False, device=0, tree=None, nquad=None, strict=True):
         import torch
         self.torch = torch
@@ -174,6 +174,7 @@ class DistributedShell:
         self.mesh, self.comm = mesh, comm
         self.ewm = bool(element_wise_material)
         d = int(np.log2(comm.size))
+        leaf_size = mesh.recommended_leaf_size() if leaf_size is None else int(leaf_size)
         self.tree = analyse(mesh, leaf_size, min_depth=d) if tree is None else tree
         self.sub, self.plan, self.info = rank_plan(mesh, self.tree, comm.rank, comm.size)
         self.nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
