@@ -350,6 +350,44 @@ def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True
     return ShellMesh(nodes, cells, element)
 
 
+def unstructured_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.35, shuffle=True, seed_jitter=1, seed_perm=2,
+                           element="CG2CG1"):
+    """The wing-skin surface of ``wing_skin_mesh`` with an UNSTRUCTURED triangulation: the (nc + 1) x (ns + 1) parameter points are
+    jittered by ``jitter`` cells and Delaunay-triangulated in the parameter plane (vertex valences 4..9, no mesh lines), then mapped to
+    the cambered, tapered, twisted surface and renumbered at random.  Same vertex count as the quadrilateral skin (1 015 470 DOF at the
+    default size, 134 560 triangles).  Needs scipy (a mesh generator for tests and benchmarks, not part of the solver path)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed_jitter)
+    S, T = np.meshgrid(np.linspace(0.0, 1.0, nc + 1), np.linspace(0.0, 1.0, ns + 1), indexing="ij")
+    dS = jitter / nc * rng.uniform(-1, 1, S.shape)
+    dT = jitter / ns * rng.uniform(-1, 1, T.shape)
+    dS[[0, -1], :] = 0; dT[:, [0, -1]] = 0                 # boundary points slide along their edge only
+    S, T = S + dS, T + dT
+    # triangulate in cell units (isotropic), so that the Delaunay criterion sees the cells' real aspect
+    tri = Delaunay(np.stack([S.ravel() * nc, T.ravel() * ns], axis=1)).simplices.astype(np.int64)
+    st = np.stack([S.ravel(), T.ravel()], axis=1)
+    a, b = st[tri[:, 1]] - st[tri[:, 0]], st[tri[:, 2]] - st[tri[:, 0]]
+    area = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    tri = tri[np.abs(area) > 1e-14 / (nc * ns)]             # slivers between collinear boundary points
+    cw = area[np.abs(area) > 1e-14 / (nc * ns)] < 0
+    tri[cw] = tri[cw][:, [0, 2, 1]]
+    taper = 1.0 - 0.55 * T
+    xloc = (S - 0.25) * chord * taper
+    camber = 0.06 * chord * taper * 4.0 * S * (1.0 - S)
+    twist = np.deg2rad(-4.0) * T
+    x = 0.35 * span * T * 0.25 + xloc * np.cos(twist) + camber * np.sin(twist)
+    z = -xloc * np.sin(twist) + camber * np.cos(twist) + 0.03 * span * T ** 2
+    nodes = np.stack([x.ravel(), (span * T).ravel(), z.ravel()], axis=1)
+    if shuffle:
+        rng = np.random.default_rng(seed_perm)
+        pn = rng.permutation(nodes.shape[0])
+        inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+        nodes = nodes[inv]
+        tri = pn[tri]
+        tri = tri[rng.permutation(tri.shape[0])]
+    return ShellMesh(nodes, tri, element)
+
+
 def tee_beam_mesh(width=1.0, height=0.5, length=5.0, nw=4, nh=2, nl=10):
     """A T-section: a flange plate (x along the length, y across the width, z = 0) with a web standing on its centre
     line (y = 0, 0 <= z <= height).  The edges along the junction are shared by three cells -- the smallest instance

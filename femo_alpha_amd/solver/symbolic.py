@@ -77,9 +77,10 @@ def _tree_from_native(A) -> Tree:
 
 # Rules of the bisection (csrc/symbolic.cpp, femo_plan_build_ex).  AXIS_RULE 1: cut across the axis along which a piece is longest in
 # cells; GAP > 0: cut at the largest gap of the sorted centroid coordinates within about one row of cells of the middle, fixed tree
-# depth.  (0, 0.0) is the plain median cut of rounds 1-3.  At BASELINE config 3 the pair below takes the factorisation from 310 to
+# depth.  AXIS_RULE 2: pieces of >= GAP_NMIN cells are cut along every axis and the smallest separator wins (sheared pieces of
+# unstructured meshes mislead rule 1: 275 -> 218 GFLOP on the unstructured skin; config 3: 212 -> 204).  (0, 0.0) is the plain median cut of rounds 1-3.  At BASELINE config 3 the pair below takes the factorisation from 310 to
 # 210 GFLOP, the Schur traffic from 9.3 to 7.2 GB and the panel steps of levels >= 6 from 60 to 49.
-AXIS_RULE = 1
+AXIS_RULE = 2
 GAP = 0.75
 GAP_NMIN = 128
 
@@ -117,21 +118,39 @@ def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=
                 continue
             idx = eorder[lo:hi]
             c = cent[idx]
-            score = c.max(axis=0) - c.min(axis=0)
-            if axis_rule == 1:
+            ext = c.max(axis=0) - c.min(axis=0)
+            score = ext
+            if axis_rule >= 1:
                 mean = np.cumsum(cext[idx], axis=0)[-1] / n              # sequential sums, as the C++ loop forms them
                 score = np.where(mean > 0.0, score / np.where(mean > 0.0, mean, 1.0), 0.0)
-            ax = int(np.argmax(score))
-            o = np.argsort(c[:, ax], kind="stable")
+
+            def sort_and_cut(ax):
+                o = np.argsort(c[:, ax], kind="stable")
+                m = n // 2
+                if gap > 0 and n >= GAP_NMIN:
+                    v = c[o, ax]
+                    w = max(1, int(min(0.125, gap / np.sqrt(float(n))) * n))
+                    ka, kb = max(1, m - w), min(n - 1, m + w)
+                    g = v[ka:kb + 1] - v[ka - 1:kb]
+                    cand = np.nonzero(g == g.max())[0] + ka
+                    m = int(cand[np.argmin(np.abs(cand - m))])          # nearest the middle; of two equally near ones the lower
+                return o, m
+            if axis_rule == 2 and n >= GAP_NMIN:
+                # every axis the piece extends in, in the order of rule 1's scores; the smallest separator (in DOFs) wins, the first of equals
+                best = None
+                for ax in np.argsort(-score, kind="stable"):
+                    if not ext[ax] > 0.0:
+                        continue
+                    o, m = sort_and_cut(int(ax))
+                    cells = mesh.cell_p2[idx[o]]
+                    both = np.intersect1d(cells[:m].ravel(), cells[m:].ravel())
+                    sep = int(np.where(both < mesh.nV, 6, 3).sum())
+                    if best is None or sep < best[0]:
+                        best = (sep, o, m)
+                _, o, mid = best
+            else:
+                o, mid = sort_and_cut(int(np.argmax(score)))
             eorder[lo:hi] = idx[o]
-            mid = n // 2
-            if gap > 0 and n >= GAP_NMIN:
-                v = c[o, ax]
-                w = max(1, int(min(0.125, gap / np.sqrt(float(n))) * n))
-                ka, kb = max(1, mid - w), min(n - 1, mid + w)
-                g = v[ka:kb + 1] - v[ka - 1:kb]
-                cand = np.nonzero(g == g.max())[0] + ka
-                mid = int(cand[np.argmin(np.abs(cand - mid))])          # nearest the middle; of two equally near ones the lower
             mid += lo
             for (a, b), store in (((lo, mid), left_l), ((mid, hi), right_l)):
                 lo_l.append(a); hi_l.append(b); left_l.append(-1); right_l.append(-1)

@@ -11,7 +11,7 @@ from bench import make_workload
 from femo_alpha_amd.backend import ShellContext
 from femo_alpha_amd.solver.symbolic import build_plan
 m, fields, marker, desc = make_workload(which)
-settings = [(12, 1, 0.75), (12, 0, 0.0), (12, 0, 0.75), (12, 1, 0.5), (12, 1, 1.0), (8, 1, 0.75), (16, 1, 0.75), (20, 1, 0.75), (24, 1, 0.75), (32, 1, 0.75)]
+settings = [(12, 2, 0.75), (12, 1, 0.75), (12, 2, 0.75), (12, 1, 0.75)] if os.environ.get("FEMO_PLAN_SWEEP") == "rule2" else [(12, 2, 0.75), (12, 1, 0.75), (12, 0, 0.0), (12, 0, 0.75), (12, 1, 0.5), (12, 1, 1.0), (8, 1, 0.75), (16, 1, 0.75), (20, 1, 0.75), (24, 1, 0.75), (32, 1, 0.75)]
 for leaf, ar, gap in settings:
     c = ShellContext(m)
     for k, v in fields.items():

@@ -161,7 +161,9 @@ def test_bench_distributed_path_over_rccl_with_one_rank():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "DOF/s"
     assert line["config"]["pcg_iterations_forward"] <= 4 and line["config"]["relres_forward"] < 1e-9
-    assert line["roofline"]["bound"] == "mfma" and line["roofline_spmv"]["bound"] == "hbm"
+    # the rank-k updates are reported by the roof that binds the class of launches taking more time: on a skin this small that may be either
+    rf = line["roofline"]
+    assert (rf["bound"], rf["unit"]) in (("mfma", "TFLOP/s"), ("hbm", "GB/s")) and 0 < rf["frac"] < 1 and line["roofline_spmv"]["bound"] == "hbm"
 
 
 def test_bench_with_four_ranks_at_full_size_on_one_card():
@@ -188,4 +190,6 @@ def test_bench_with_four_ranks_at_full_size_on_one_card():
     # the single-GPU solve of this skin takes 2 + 2 iterations at rtol 1e-10; a partitioned run may sit on the threshold (+1)
     assert 2 <= cfg["pcg_iterations_forward"] <= 3 and 2 <= cfg["pcg_iterations_adjoint"] <= 3
     assert cfg["relres_forward"] < 1e-10 and cfg["relres_adjoint"] < 1e-10
-    assert line["roofline"]["bound"] == "mfma" and line["roofline_spmv"]["bound"] == "hbm"
+    # the rank-k updates are reported by the roof that binds the class of launches taking more time: on a skin this small that may be either
+    rf = line["roofline"]
+    assert (rf["bound"], rf["unit"]) in (("mfma", "TFLOP/s"), ("hbm", "GB/s")) and 0 < rf["frac"] < 1 and line["roofline_spmv"]["bound"] == "hbm"
