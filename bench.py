@@ -142,6 +142,13 @@ def make_workload(name, renumber=True, timings=None):
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
         desc = f"synthetic wing skin 116x{580 * mult} quads, {m.ndof} DOF"
+    elif name == "uskin1m":      # the config-3 surface with an UNSTRUCTURED triangulation (Delaunay of jittered points): same vertices, same DOF count
+        from femo_alpha_amd.mesh import unstructured_skin_mesh
+        m = unstructured_skin_mesh(116, 580)
+        fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
+                      F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
+        marker = lambda x: np.less(x[1], 1e-9)
+        desc = f"synthetic wing skin, unstructured: {m.nel} CG2xCG1 triangles (Delaunay of 117 x 581 jittered points, renumbered), {m.ndof} DOF"
     elif name == "plate8k":      # BASELINE.json configs[0] (plumbing size)
         m = plate_mesh(2.0, 10.0, 10, 50)
         fields = dict(thickness=[0.1], E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
@@ -307,6 +314,7 @@ def main_dynamic(args, torch):
     warmup = 1 if args.warmup is None else args.warmup
     t0 = time.perf_counter()
     mesh, dt, F = dynamic_case(nsteps=nsteps)
+    args.leaf = mesh.recommended_leaf_size() if args.leaf is None else args.leaf
     ps = PlateSim(mesh, 1e8, 0.3, 10.0, dt, nsteps, quad_deg=3, leaf_size=args.leaf)
     thickness = np.full(mesh.nn, 0.1)
     ps.update_t(thickness)
@@ -393,6 +401,7 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
     mult = world if args.scaling == "weak" else 1
     m = wing_skin_mesh(116, ns * mult, span=6.0 * mult * ns / 580.0).renumbered()[0]
     marker = lambda x: np.less(x[1], 1e-9)
+    args.leaf = m.recommended_leaf_size() if args.leaf is None else args.leaf
     comm = Comm(dist)
     shared_gpu = torch.cuda.device_count() < world                 # rehearsal: several ranks on one card
     ds = DistributedShell(m, comm, bc_marker=marker, leaf_size=args.leaf, device=0 if shared_gpu else local_rank, nquad=args.nquad)
@@ -515,7 +524,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("FEMO_BENCH_WORKLOAD", "wing1m"))
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--solver", default="frontal", choices=["frontal", "jacobi"])
-    ap.add_argument("--leaf", type=int, default=12, help="cells per leaf of the nested dissection (all bench workloads are quadrilateral: 12)")
+    ap.add_argument("--leaf", type=int, default=None, help="cells per leaf of the nested dissection (default: ShellMesh.recommended_leaf_size, 12 quadrilaterals / 24 triangles)")
     ap.add_argument("--nquad", type=int, default=None, help="n x n Gauss points per quadrilateral (2..5).  Default: what the mesh asks for "
                     "(ShellMesh.recommended_nquad) -- the reference integrates (nearly) exactly, scripts/ufl_degree_estimate.py; n = 4 is exact "
                     "on flat cells, on the warped wing skin n = 5 is within 1e-9 of the limit and n = 4 7.5e-8 away in the gradient")
@@ -574,6 +583,7 @@ def main():
         return main_distributed(args, rank, local_rank, world, torch, dist)
     setup = {}
     m, fields, marker, desc = make_workload(args.workload, renumber=not args.keep_numbering, timings=setup)
+    args.leaf = m.recommended_leaf_size() if args.leaf is None else args.leaf
     t0 = time.perf_counter()
     ctx = ShellContext(m, device=local_rank, nquad=args.nquad)
     nquad = ctx.nquad                                   # the rule in use: --nquad, or what the mesh asks for

@@ -77,12 +77,13 @@ def _tree_from_native(A) -> Tree:
 
 # Rules of the bisection (csrc/symbolic.cpp, femo_plan_build_ex).  AXIS_RULE 1: cut across the axis along which a piece is longest in
 # cells; GAP > 0: cut at the largest gap of the sorted centroid coordinates within about one row of cells of the middle, fixed tree
-# depth.  AXIS_RULE 2: pieces of >= GAP_NMIN cells are cut along every axis and the smallest separator wins (sheared pieces of
+# depth.  AXIS_RULE 2: pieces of >= AXIS_NMIN cells are cut along every axis and the smallest separator wins (sheared pieces of
 # unstructured meshes mislead rule 1: 275 -> 218 GFLOP on the unstructured skin; config 3: 212 -> 204).  (0, 0.0) is the plain median cut of rounds 1-3.  At BASELINE config 3 the pair below takes the factorisation from 310 to
 # 210 GFLOP, the Schur traffic from 9.3 to 7.2 GB and the panel steps of levels >= 6 from 60 to 49.
 AXIS_RULE = 2
 GAP = 0.75
 GAP_NMIN = 128
+AXIS_NMIN = 16         # rule 2 measures the separators of pieces of at least this many cells
 
 
 def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=None) -> Tree:
@@ -135,16 +136,31 @@ def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=
                     cand = np.nonzero(g == g.max())[0] + ka
                     m = int(cand[np.argmin(np.abs(cand - m))])          # nearest the middle; of two equally near ones the lower
                 return o, m
-            if axis_rule == 2 and n >= GAP_NMIN:
+            if axis_rule == 2 and n >= AXIS_NMIN:
                 # every axis the piece extends in, in the order of rule 1's scores; the smallest separator (in DOFs) wins, the first of equals
                 best = None
                 for ax in np.argsort(-score, kind="stable"):
                     if not ext[ax] > 0.0:
                         continue
-                    o, m = sort_and_cut(int(ax))
-                    cells = mesh.cell_p2[idx[o]]
-                    both = np.intersect1d(cells[:m].ravel(), cells[m:].ravel())
-                    sep = int(np.where(both < mesh.nV, 6, 3).sum())
+                    o, m0 = sort_and_cut(int(ax))
+                    # sep(m) for every cut position of this order: a node is in the separator of m iff the first cell touching it sits
+                    # before m and the last one at or after m
+                    nodes = mesh.cell_p2[idx[o]].ravel()
+                    pos = np.repeat(np.arange(n), mesh.cell_p2.shape[1])
+                    u, inv = np.unique(nodes, return_inverse=True)
+                    first = np.full(u.size, n); np.minimum.at(first, inv, pos)
+                    last = np.full(u.size, -1); np.maximum.at(last, inv, pos)
+                    wgt = np.where(u < mesh.nV, 6, 3) * (last > first)
+                    diff = np.zeros(n + 2, dtype=np.int64)
+                    np.add.at(diff, first + 1, wgt); np.add.at(diff, last + 1, -wgt)
+                    sepm = np.cumsum(diff)
+                    m = m0
+                    if gap > 0 and n >= GAP_NMIN:
+                        w = max(1, int(min(0.125, gap / np.sqrt(float(n))) * n))
+                        win = np.arange(max(1, n // 2 - w), min(n - 1, n // 2 + w) + 1)
+                        cand = win[sepm[win] == sepm[win].min()]
+                        m = int(cand[np.argmin(np.abs(cand - m0))])        # smallest separator; of equal ones nearest the largest gap, then the lower
+                    sep = int(sepm[m])
                     if best is None or sep < best[0]:
                         best = (sep, o, m)
                 _, o, mid = best

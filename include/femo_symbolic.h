@@ -41,7 +41,7 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
  *     has any row structure; the tree then has the fixed depth max(min_depth, ceil(log2(nel / leaf_size))).
  *   axis_rule 1: cut across the axis along which the piece is longest in CELLS (centroid extent / mean cell extent; cext: nel x 3
  *     extents of the cells' bounding boxes), not in length units.
- *   axis_rule 2 (the package's default): a piece of n >= 128 cells is cut along every axis it extends in (in the order of rule 1's
+ *   axis_rule 2 (the package's default): a piece of n >= 16 cells is cut along every axis it extends in (in the order of rule 1's
  *     scores), the DOFs of the nodes that cells of both halves touch are counted, and the axis with the smallest separator is taken
  *     (the first of equal ones); smaller pieces follow rule 1. */
 int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,

@@ -28,6 +28,9 @@ def _mesh(kind):
         return wing_skin_mesh(6, 14, shuffle=True)
     if kind == "tri":
         return quads_to_triangles(wing_skin_mesh(5, 9, shuffle=True))
+    if kind == "delaunay":           # unstructured triangulation (valences 3..9, no mesh lines)
+        from femo_alpha_amd.mesh import unstructured_skin_mesh
+        return unstructured_skin_mesh(7, 15)
     if kind == "tee":                # branching surface: flange + web, edges shared by three cells
         from femo_alpha_amd.mesh import tee_beam_mesh
         return tee_beam_mesh(1.0, 0.5, 5.0, 4, 2, 10)
@@ -65,7 +68,7 @@ def _pair(kind, ewm=False, ewp=False, uhat=False, bc="penalty", beta=1e15, seed=
 CASES = [("plate", False, False, False, "penalty"), ("warped", False, False, False, "penalty"),
          ("warped", True, True, False, "strong"), ("warped", False, False, True, "penalty"),
          ("tri", False, False, False, "penalty"), ("tri", True, False, True, "strong"),
-         ("tee", False, False, True, "penalty")]
+         ("tee", False, False, True, "penalty"), ("delaunay", False, False, True, "penalty"), ("delaunay", True, True, False, "strong")]
 
 
 @pytest.mark.parametrize("kind,ewm,ewp,uhat,bc", CASES)
@@ -141,7 +144,8 @@ def test_errors_are_loud():
                                                        ("warped", False, "penalty", True, None), ("tri", False, "penalty", False, 0),
                                                        ("plate24", False, "penalty", False, 0), ("plate", False, "strong", False, 0),
                                                        ("tee", False, "penalty", False, None), ("tee", True, "strong", True, 0),
-                                                       ("plate24", False, "strong", False, None)])
+                                                       ("plate24", False, "strong", False, None), ("delaunay", False, "penalty", True, None),
+                                                       ("delaunay", True, "strong", False, 0)])
 def test_multifrontal_preconditioner(kind, ewm, bc, uhat, wide_cnt):
     """PCG preconditioned by the multifrontal Cholesky factorisation: a handful of iterations and
     the same parity triple as the reference's direct (MUMPS LU) solve.  Levels with few fronts take the wide

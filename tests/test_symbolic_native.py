@@ -87,7 +87,7 @@ def test_separators_follow_the_mesh_lines_of_the_config3_skin():
 
 
 def test_the_cut_direction_is_measured_on_sheared_pieces():
-    """axis_rule 2 (the default): a piece of at least 128 cells is cut along every axis it extends in and the smallest separator wins.
+    """axis_rule 2 (the default): a piece of at least 16 cells is cut along every axis it extends in and the smallest separator wins.
     On an unstructured triangulation of the swept, tapered skin the bounding box misleads rule 1 (a quarter wing is 155 "cells" wide
     and 145 long): one cut the wrong way puts 2 058 DOFs into a separator where a mesh line has 1 050."""
     from femo_alpha_amd.mesh import unstructured_skin_mesh
@@ -96,7 +96,8 @@ def test_the_cut_direction_is_measured_on_sheared_pieces():
     r2 = symbolic.build_plan(m, 24).summary()
     assert r1["max_pivots"] > 2000 and r2["max_pivots"] < 1100
     assert r2["factor_gflop"] < 0.82 * r1["factor_gflop"]
-    # structured meshes lose nothing: the plates of configs 2 and 5 get the same tree either way
+    # structured meshes lose nothing: the plate of config 2 keeps its separators of one mesh line, flops and fronts do not grow
     p = plate_mesh(2.0, 10.0, 58, 290)
-    a, b = symbolic.build_plan(p, 12, axis_rule=1), symbolic.build_plan(p, 12)
-    assert np.array_equal(a.nf, b.nf) and np.array_equal(a.npiv, b.npiv)
+    a, b = symbolic.build_plan(p, 12, axis_rule=1).summary(), symbolic.build_plan(p, 12).summary()
+    assert b["max_pivots"] == a["max_pivots"] == 59 * 6 + 58 * 3
+    assert b["factor_gflop"] <= a["factor_gflop"] and b["front_doubles"] <= a["front_doubles"]
