@@ -123,7 +123,13 @@ struct femo_ctx {
         int narrow_split = 1, narrow_split_wg = 1024;
         int narrow_fine_wg = 128;             // narrow updates of at most this many 64 x 64 tiles run k_trailing_fine (32 x 32 tiles, a 16 x 16 block per wave): the
                                               // root's updates 24 -> 18 us each; levels of four fronts and more lose (512: +5 % on level 11)
-        int fuse_rows = 1, fuse_rows_cnt = 4096;    // single-panel fronts of non-wide levels with at least that many fronts: rows in k_diag_block
+        // fronts of non-wide levels with at least fuse_rows_cnt fronts whose widest front has at most fuse_rows_np pivots: the rows under a
+        // diagonal block are formed inside k_diag_block.  Up to round 4 only single-panel levels (np <= 128) of >= 4096 fronts took this
+        // path, and a handful of leaves with 129-150 pivots sent the whole leaf level through separate row launches (config 2 and 5
+        // always, config 3 with the measured bisection: +0.18 ms).  In-process A/B (scripts/r4_ab.py): (128, 4096) -> (256, 2048)
+        // factorisation 11.93 -> 11.77 ms at 1 M DOF, 3.235 -> 3.205 on the 255 k plate, 41.6 -> 41.0 at 4 M DOF
+        int fuse_rows = 1, fuse_rows_cnt = 2048;
+        int fuse_rows_np = 2 * NBO;
         int sweep_graph = 0;                        // the preconditioner application of the PCG loop replayed as a HIP graph
         int diag_v1_cnt = 512;                      // levels of at least this many fronts: k_diag_block (80 KB of LDS, two workgroups per CU)
         int split_cnt = 0, split_groups = 2;        // levels of 2..split_cnt fronts: dealt to two streams in split_groups groups (off: no gain measured)
@@ -859,7 +865,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         constexpr int DIAG_TILES = 3, NEXT_ROW_TILES = NBO / TS;
         bool rest_pending = false;
         // single-panel fronts on a level that keeps no S: rows inside the diagonal-block kernel (option "fuse_rows")
-        const bool fuse_rows = !wide && max_np_level <= NBO && c->opt.fuse_rows != 0 && cnt_level >= c->opt.fuse_rows_cnt;
+        const bool fuse_rows = !wide && max_np_level <= std::max(NBO, c->opt.fuse_rows_np) && c->opt.fuse_rows != 0 && cnt_level >= c->opt.fuse_rows_cnt;
         for (int C0 = 0; C0 < max_np; C0 += NBO) {
             double* sw = wide ? nullptr : fr.Swork;
             const int S0 = C0 / SP * SP;                 // start of this panel's super-panel (== C0 when SP == NBO)
@@ -1926,6 +1932,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "sweep_graph") o.sweep_graph = v != 0;
     else if (k == "fuse_rows") o.fuse_rows = v != 0;
     else if (k == "fuse_rows_cnt") o.fuse_rows_cnt = v;
+    else if (k == "fuse_rows_np") o.fuse_rows_np = v;
     else if (k == "split_groups") { if (v < 2) return fail(c, "split_groups: at least 2"); o.split_groups = v; }
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;

@@ -21,8 +21,9 @@ def _context(kind):
                       nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
         marker = lambda x: np.less(x[0], 3e-16)
         return m, fields, marker, rng
-    if kind == "wing1m":
-        m = wing_skin_mesh(116, 580)
+    if kind in ("wing1m", "uskin1m"):          # uskin1m: the same surface with an unstructured triangulation (Delaunay, valences 3..9)
+        from femo_alpha_amd.mesh import unstructured_skin_mesh
+        m = wing_skin_mesh(116, 580) if kind == "wing1m" else unstructured_skin_mesh(116, 580)
         rng = np.random.default_rng(5)
         fields = dict(thickness=1.27e-3 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=[73.1e9], nu=[0.33], density=[2780.0],
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
@@ -50,10 +51,10 @@ def _solver(m, fields, marker, ewm=False, strong=False):
     return c
 
 
-@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k"])
+@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k", "uskin1m"])
 def test_full_size_properties(kind):
     m, fields, marker, rng = _context(kind)
-    assert m.ndof == {"wing1m": 1015470, "plate250k": 255438}.get(kind, m.ndof)
+    assert m.ndof == {"wing1m": 1015470, "uskin1m": 1015470, "plate250k": 255438}.get(kind, m.ndof)
     c = _solver(m, fields, marker, ewm=kind == "tri170k", strong=kind == "tri170k")
     it, rr = c.solve_state(zero_guess=True)
     assert it <= 4 and rr <= 1e-11
