@@ -135,6 +135,10 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   super-panel's panels; "lookahead" 0/1, "lookahead_cnt": the same for the 128-column schedule;
  *   "fused_schur" (default 1): Schur complements are gathered from the children by the rank-k update that touches them
  *   first instead of by the extend-add;
+ *   "fuse_rows" (default 1), "fuse_rows_cnt" (2048), "fuse_rows_np" (256): levels of at least that many fronts whose widest front has at most
+ *   that many pivots form the rows under a diagonal block inside the diagonal-block kernel;
+ *   "rows_fine_wg" (96), "narrow_fine_wg" (128): launches of at most that many workgroups take the kernels with 16 rows / a 16 x 16 block per wave;
+ *   "equilibrate" (0), "precond_nquad" (0): measured experiments, off;
  *   "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
  *   "swork_slots" (default 8192; before femo_set_frontal_plan): 128 x 128 scratch blocks for the diagonal-block inverses of
