@@ -696,6 +696,7 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
     //  The LDS pipe is not what the kernel waits for.)
     __shared__ double sx[EPB][LD + 1];
     __shared__ double sg[EPB][GEO + 1];
+    __shared__ double scm[MASS ? EPB : 1][MASS ? MAXQ : 1];     // inertia coefficient per (element, point); written and read by the same lane
     // the lanes of a quad work on different quadrature points, so the tables are indexed per lane: keep
     // them in LDS (a per-lane global/scalar load would park ~40 doubles of table data in VGPRs)
     __shared__ Tables stab;
@@ -776,9 +777,16 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
             const Gen s = strains_q<NPC, NVC>(stab, q, g, xe);
             const Gen t = stress_of(s, mat);
             strains_T_q<NPC, NVC>(stab, q, g, t, ye);
-            if (MASS) {          // compiled out of the static operator: keeps its register budget
-                const double rq = interp<NVC>(stab.N1[q], ge + 9 * NVC);
-                mass_qp<NPC, NVC>(stab, q, aM * rq * hq * stab.w[q] * g.det * g.Ju, hK, xe, ye);
+            if (MASS)            // the inertia term's coefficient at this point, parked in LDS for the loop below
+                scm[row][q] = aM * interp<NVC>(stab.N1[q], ge + 9 * NVC) * hq * stab.w[q] * g.det * g.Ju;
+        }
+        if (MASS) {
+            // The inertia term in a loop of its own (compiled out of the static operator): inside the stiffness loop its interpolated
+            // vectors pushed the kernel from 242 registers to 256 + 148 B of scratch
+            for (int q = sub; q < nq; q += 4) {
+                int row = le;
+                asm volatile("" : "+v"(row));
+                mass_qp<NPC, NVC>(stab, q, scm[row][q], hK, sx[row], ye);
             }
         }
 #pragma unroll
