@@ -180,8 +180,12 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
                         const long long sep = sc.diff[m];
                         if (sep_best < 0 || sep < sep_best) { sep_best = sep; ord_best.swap(oc); mid_best = m; ax = c; }
                     }
-                    ord.swap(ord_best);
-                    mid = mid_best;
+                    if (sep_best < 0) {                  // no axis with an extent (coincident centroids): halve the piece as it stands
+                        mid = n / 2;
+                    } else {
+                        ord.swap(ord_best);
+                        mid = mid_best;
+                    }
                 } else {
                     mid = sort_and_cut(ax, ord);
                 }

@@ -163,7 +163,10 @@ def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=
                     sep = int(sepm[m])
                     if best is None or sep < best[0]:
                         best = (sep, o, m)
-                _, o, mid = best
+                if best is None:                      # no axis with an extent (coincident centroids): halve the piece as it stands
+                    o, mid = np.arange(n), n // 2
+                else:
+                    _, o, mid = best
             else:
                 o, mid = sort_and_cut(int(np.argmax(score)))
             eorder[lo:hi] = idx[o]

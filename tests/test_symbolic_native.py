@@ -101,3 +101,11 @@ def test_the_cut_direction_is_measured_on_sheared_pieces():
     a, b = symbolic.build_plan(p, 12, axis_rule=1).summary(), symbolic.build_plan(p, 12).summary()
     assert b["max_pivots"] == a["max_pivots"] == 59 * 6 + 58 * 3
     assert b["factor_gflop"] <= a["factor_gflop"] and b["front_doubles"] <= a["front_doubles"]
+
+
+def test_coincident_centroids_do_not_break_the_measured_bisection():
+    """A piece none of whose axes has an extent (here: twenty copies of one cell) offers no direction to measure: both implementations
+    halve it as it stands and agree."""
+    from femo_alpha_amd.mesh import ShellMesh
+    m = ShellMesh(np.array([[0.0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]), np.tile([[0, 1, 2, 3]], (20, 1)))
+    _same_plan(symbolic.build_plan(m, 2), symbolic.build_plan(m, 2, impl="python"))
