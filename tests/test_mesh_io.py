@@ -151,3 +151,24 @@ def test_hdf5_reader_reports_what_it_cannot_read(tmp_path):
     p.write_bytes(b"this is not an hdf5 file" * 40)
     with pytest.raises(HDF5FormatError):
         read_dataset(str(p), "/Mesh/Grid/topology")
+
+
+def test_unstructured_skin_generator_gives_a_valid_triangulation():
+    """``unstructured_skin_mesh``: every vertex used, counter-clockwise cells (positive area in the parameter plane is positive area on
+    the gently curved surface seen from +z), every interior edge shared by exactly two triangles, a boundary of 2 (nc + ns) edges, vertex
+    valences that no structured mesh has, and the DOF count of the quadrilateral skin of the same vertex grid."""
+    import numpy as np
+    from femo_alpha_amd.mesh import unstructured_skin_mesh, wing_skin_mesh
+    nc, ns = 12, 30
+    m = unstructured_skin_mesh(nc, ns)
+    assert m.nn == (nc + 1) * (ns + 1) and np.unique(m.cells).size == m.nn
+    x = m.nodes[m.cells]
+    nz = np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0])[:, 2]
+    assert np.all(nz > 0)
+    e = np.sort(np.concatenate([m.cells[:, [0, 1]], m.cells[:, [1, 2]], m.cells[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert set(cnt.tolist()) == {1, 2} and int((cnt == 1).sum()) == 2 * (nc + ns)
+    val = np.bincount(m.cells.ravel())
+    assert val.min() >= 1 and val.max() >= 7             # a corner may belong to one triangle only
+    assert len(m.penalty_facets(lambda p: np.less(p[1], 1e-9))) == nc
+    assert unstructured_skin_mesh().ndof == wing_skin_mesh().ndof == 1015470
