@@ -142,6 +142,13 @@ def make_workload(name, renumber=True, timings=None):
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
         desc = f"synthetic wing skin 116x{580 * mult} quads, {m.ndof} DOF"
+    elif name == "wing1m_tri":   # SURVEY.md section 8d, config 3, triangle variant: 183 x 365 x 2 = 133 590 triangles, 1 006 863 DOF
+        from femo_alpha_amd.mesh import quads_to_triangles
+        m = quads_to_triangles(wing_skin_mesh(183, 365))
+        fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
+                      F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
+        marker = lambda x: np.less(x[1], 1e-9)
+        desc = f"synthetic wing skin 183x365 quads split into {m.nel} CG2xCG1 triangles (cambered, tapered, twisted, jittered, renumbered), {m.ndof} DOF"
     elif name == "uskin1m":      # the config-3 surface with an UNSTRUCTURED triangulation (Delaunay of jittered points): same vertices, same DOF count
         from femo_alpha_amd.mesh import unstructured_skin_mesh
         m = unstructured_skin_mesh(116, 580)

@@ -21,9 +21,12 @@ def _context(kind):
                       nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
         marker = lambda x: np.less(x[0], 3e-16)
         return m, fields, marker, rng
-    if kind in ("wing1m", "uskin1m"):          # uskin1m: the same surface with an unstructured triangulation (Delaunay, valences 3..9)
-        from femo_alpha_amd.mesh import unstructured_skin_mesh
-        m = wing_skin_mesh(116, 580) if kind == "wing1m" else unstructured_skin_mesh(116, 580)
+    if kind in ("wing1m", "uskin1m", "wing1m_tri"):
+        # uskin1m: the same surface with an unstructured triangulation (Delaunay, valences 3..9); wing1m_tri: the triangle variant of
+        # config 3 that SURVEY.md section 8d defines (183 x 365 quads split: 133 590 triangles, 1 006 863 DOF)
+        from femo_alpha_amd.mesh import quads_to_triangles, unstructured_skin_mesh
+        m = {"wing1m": lambda: wing_skin_mesh(116, 580), "uskin1m": lambda: unstructured_skin_mesh(116, 580),
+             "wing1m_tri": lambda: quads_to_triangles(wing_skin_mesh(183, 365))}[kind]()
         rng = np.random.default_rng(5)
         fields = dict(thickness=1.27e-3 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=[73.1e9], nu=[0.33], density=[2780.0],
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
@@ -51,10 +54,10 @@ def _solver(m, fields, marker, ewm=False, strong=False):
     return c
 
 
-@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k", "uskin1m"])
+@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k", "uskin1m", "wing1m_tri"])
 def test_full_size_properties(kind):
     m, fields, marker, rng = _context(kind)
-    assert m.ndof == {"wing1m": 1015470, "uskin1m": 1015470, "plate250k": 255438}.get(kind, m.ndof)
+    assert m.ndof == {"wing1m": 1015470, "uskin1m": 1015470, "wing1m_tri": 1006863, "plate250k": 255438}.get(kind, m.ndof)
     c = _solver(m, fields, marker, ewm=kind == "tri170k", strong=kind == "tri170k")
     it, rr = c.solve_state(zero_guess=True)
     assert it <= 4 and rr <= 1e-11
@@ -64,7 +67,8 @@ def test_full_size_properties(kind):
     #    set by cancellation, not by the solver: the membrane terms of K w are ~1e10 times larger than the load they
     #    sum to, so eps * |K| |w| ~ 1e-7 |F| in float64 (a direct solver's residual sits at the same level).
     r = c.residual(w)
-    assert np.linalg.norm(r) <= 5e-6 * np.linalg.norm(F), np.linalg.norm(r) / np.linalg.norm(F)
+    #    (the 183 x 365 triangle variant has cells twice as slender spanwise: measured 7.6e-6)
+    assert np.linalg.norm(r) <= (2e-5 if kind == "wing1m_tri" else 5e-6) * np.linalg.norm(F), np.linalg.norm(r) / np.linalg.norm(F)
     # 2. energy identity of the discrete system: w.K w = F.w, and the energy output is half of it
     Kw = c.apply_K(w)
     assert abs(w @ Kw - F @ w) <= 1e-9 * abs(F @ w)
