@@ -1,6 +1,10 @@
 """Generator of the full-size golden for BASELINE config 3: the 1 015 470-DOF wing skin of bench.py (workload "wing1m").
 
-    python tests/golden/make_config3_golden.py [nquad]    (a few minutes of the host's cores, ~20 GB)
+    python tests/golden/make_config3_golden.py [nquad] [workload]    (a few minutes of the host's cores, ~20 GB)
+
+``workload`` (default wing1m): any single-mesh workload of bench.py -- ``uskin1m`` writes config3_uskin1m.npz, the same surface with an
+unstructured (Delaunay) triangulation; that file also stores a checksum of the connectivity, because the triangulation comes from
+scipy / qhull and the golden is only valid for the very same mesh.
 
 ``nquad`` Gauss points per direction; default: what the mesh asks for (ShellMesh.recommended_nquad: 5 on the warped cells of
 this skin -- the reference integrates its static forms (nearly) exactly, linear_shell_model.py:88-103, and n = 5 is within
@@ -25,7 +29,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-NQUAD = int(sys.argv[1]) if len(sys.argv) > 1 else None
+NQUAD = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] not in ("", "auto") else None
+WORKLOAD = sys.argv[2] if len(sys.argv) > 2 else "wing1m"
 sys.argv = [sys.argv[0]]
 
 from bench import make_workload                                  # noqa: E402
@@ -38,14 +43,14 @@ from _extended import extended_system, refine                    # noqa: E402
 
 def main():
     t0 = time.time()
-    m, fields, marker, desc = make_workload("wing1m")
+    m, fields, marker, desc = make_workload(WORKLOAD)
     cores = cb.host_cores()
     nquad = m.recommended_nquad() if NQUAD is None else NQUAD
     o = ShellOracle(m, nquad=nquad, penalty_facets=m.penalty_facets(marker))
     o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
     cs = cb.CpuShell(o)
     Kx, bx = extended_system(cs, cores)
-    mf = cb.CpuMultifrontal(cs, build_plan(m, 12), cores)
+    mf = cb.CpuMultifrontal(cs, build_plan(m, m.recommended_leaf_size()), cores)
     mf.factorize()
     print(f"{desc}\nassembled (extended precision) and factorised in {time.time() - t0:.0f} s", flush=True)
     say = lambda msg: print(msg, flush=True)
@@ -62,11 +67,13 @@ def main():
     print(f"float64-assembled matrix: solution off by {d64[0]:.1e} (displacement) {d64[1]:.1e} (compliance)", flush=True)
     sample = np.sort(np.random.default_rng(7).choice(m.ndof, size=4096, replace=False))
     print(f"ndof {m.ndof}  J={J:.15e}  corrections w {cw:.1e} lam {cl:.1e}  total {time.time() - t0:.0f} s")
-    name = "config3_wing1m.npz" if nquad == m.recommended_nquad() else f"config3_wing1m_n{nquad}.npz"
+    name = f"config3_{WORKLOAD}.npz" if nquad == m.recommended_nquad() else f"config3_{WORKLOAD}_n{nquad}.npz"
+    import hashlib
+    mesh_sha = hashlib.sha256(np.ascontiguousarray(m.cells, dtype=np.int64).tobytes() + np.ascontiguousarray(m.nodes).tobytes()).hexdigest()
     np.savez_compressed(os.path.join(os.environ.get("FEMO_GOLDEN_OUT", HERE), name), ndof=m.ndof, nn=m.nn, nel=m.nel, nquad=nquad, compliance=J, mass=o.mass(),
                         w_maxabs=np.abs(w).max(), w_sample_index=sample, w_sample=w[sample],
                         dcompliance_dthickness=dJ, w_correction=cw, lam_correction=cl,
-                        float64_matrix_distance_w=d64[0], float64_matrix_distance_compliance=d64[1])
+                        float64_matrix_distance_w=d64[0], float64_matrix_distance_compliance=d64[1], mesh_sha256=mesh_sha)
 
 
 if __name__ == "__main__":

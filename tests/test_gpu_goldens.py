@@ -94,3 +94,38 @@ def test_parity_triple_against_the_one_million_dof_golden(nquad):
     assert it2 <= 4
     assert np.abs(dJ - ref).max() < tol * np.abs(ref).max()
     c.close()
+
+
+def test_parity_triple_on_the_unstructured_skin():
+    """The surface of config 3 with an UNSTRUCTURED triangulation (134 560 CG2xCG1 triangles by Delaunay, vertex valences 3..9,
+    1 015 470 DOF; workload uskin1m) against the exact discrete solution (tests/golden/make_config3_golden.py auto uskin1m: the C++
+    oracle's triangle operator assembled in x87 extended precision, refined to 1e-10): displacement, compliance and the full
+    d compliance / d thickness vector at 1e-8.  The triangulation comes from scipy / qhull: the golden carries a checksum of the mesh and
+    the test is skipped, not failed, where another qhull gives another (equally valid) triangulation."""
+    import hashlib
+    from bench import make_workload
+    from femo_alpha_amd.backend import ShellContext
+    g = np.load(os.path.join(GOLDEN, "config3_uskin1m.npz"))
+    m, fields, marker, _ = make_workload("uskin1m")
+    sha = hashlib.sha256(np.ascontiguousarray(m.cells, dtype=np.int64).tobytes() + np.ascontiguousarray(m.nodes).tobytes()).hexdigest()
+    if sha != str(g["mesh_sha256"]):
+        pytest.skip("this scipy / qhull triangulates the point set differently: the golden belongs to another mesh")
+    assert m.ndof == int(g["ndof"]) == 1015470 and not m.is_quad
+    assert max(float(g["w_correction"]), float(g["lam_correction"])) < 1e-2 * TOL
+    c = ShellContext(m)
+    for k, v in fields.items():
+        c.set_field(k, v)
+    c.set_penalty_facets(m.penalty_facets(marker))
+    c.use_direct_solver()
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 4 and rr <= 1e-12
+    w = c.get_state()
+    assert abs(np.abs(w).max() - float(g["w_maxabs"])) < TOL * float(g["w_maxabs"])
+    assert np.abs(w[g["w_sample_index"]] - g["w_sample"]).max() < TOL * float(g["w_maxabs"])
+    J = c.functional("compliance")
+    assert abs(J - float(g["compliance"])) < TOL * abs(float(g["compliance"]))
+    assert abs(c.functional("mass") - float(g["mass"])) < 1e-12 * float(g["mass"])
+    dJ, it2, _ = c.total_gradient("compliance", "thickness")
+    ref = g["dcompliance_dthickness"]
+    assert it2 <= 4 and np.abs(dJ - ref).max() < TOL * np.abs(ref).max()
+    c.close()
