@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT && . scripts/r4_lib.sh && mkdir -p gpurun_out
-run 600 gpurun_out/r4_golden_uskin.log python -m pytest tests/test_gpu_goldens.py -q -m gpu -k unstructured -rs
+run 600 gpurun_out/r4_golden_uskin.log python -m pytest tests/test_gpu_goldens.py -q -m gpu -k triangle_skins -rs
 tail -5 gpurun_out/r4_golden_uskin.log

@@ -96,22 +96,27 @@ def test_parity_triple_against_the_one_million_dof_golden(nquad):
     c.close()
 
 
-def test_parity_triple_on_the_unstructured_skin():
-    """The surface of config 3 with an UNSTRUCTURED triangulation (134 560 CG2xCG1 triangles by Delaunay, vertex valences 3..9,
-    1 015 470 DOF; workload uskin1m) against the exact discrete solution (tests/golden/make_config3_golden.py auto uskin1m: the C++
-    oracle's triangle operator assembled in x87 extended precision, refined to 1e-10): displacement, compliance and the full
-    d compliance / d thickness vector at 1e-8.  The triangulation comes from scipy / qhull: the golden carries a checksum of the mesh and
-    the test is skipped, not failed, where another qhull gives another (equally valid) triangulation."""
+@pytest.mark.parametrize("workload", ["uskin1m", "wing1m_tri"])
+def test_parity_triple_on_the_triangle_skins(workload):
+    """The surface of config 3 on triangles, against the exact discrete solution (tests/golden/make_config3_golden.py auto <workload>: the
+    C++ oracle's triangle operator assembled in x87 extended precision, refined to ~1e-10): displacement, compliance and the full
+    d compliance / d thickness vector at 1e-8.
+      uskin1m     an UNSTRUCTURED triangulation (134 560 CG2xCG1 triangles by Delaunay, vertex valences 3..9, 1 015 470 DOF).  It comes
+                  from scipy / qhull: the golden carries a checksum of the mesh and the test is skipped, not failed, where another
+                  qhull gives another (equally valid) triangulation;
+      wing1m_tri  the triangle variant SURVEY.md section 8d defines (183 x 365 quads split: 133 590 triangles, 1 006 863 DOF)."""
     import hashlib
     from bench import make_workload
     from femo_alpha_amd.backend import ShellContext
-    g = np.load(os.path.join(GOLDEN, "config3_uskin1m.npz"))
-    m, fields, marker, _ = make_workload("uskin1m")
+    g = np.load(os.path.join(GOLDEN, f"config3_{workload}.npz"))
+    m, fields, marker, _ = make_workload(workload)
     sha = hashlib.sha256(np.ascontiguousarray(m.cells, dtype=np.int64).tobytes() + np.ascontiguousarray(m.nodes).tobytes()).hexdigest()
     if sha != str(g["mesh_sha256"]):
-        pytest.skip("this scipy / qhull triangulates the point set differently: the golden belongs to another mesh")
-    assert m.ndof == int(g["ndof"]) == 1015470 and not m.is_quad
-    assert max(float(g["w_correction"]), float(g["lam_correction"])) < 1e-2 * TOL
+        if workload == "uskin1m":
+            pytest.skip("this scipy / qhull triangulates the point set differently: the golden belongs to another mesh")
+        raise AssertionError("the mesh generator no longer produces the mesh of the golden")
+    assert m.ndof == int(g["ndof"]) == {"uskin1m": 1015470, "wing1m_tri": 1006863}[workload] and not m.is_quad
+    assert max(float(g["w_correction"]), float(g["lam_correction"])) < 0.05 * TOL        # the golden is sharper than the bar (3e-10 on the slender cells)
     c = ShellContext(m)
     for k, v in fields.items():
         c.set_field(k, v)
