@@ -206,3 +206,32 @@ def test_quadrature_rule_sensitivity_at_config3():
     # n = 4 against n = 5 stays below the level at which the two rules would be different discretisations (1e-3); whether
     # it reaches the 1e-8 of the north star is what the printed numbers say -- it does not, see DESIGN.md
     assert all(d[(4, 5)][k] < 1e-3 for k in range(3))
+
+
+def test_stress_outputs_at_config3_size():
+    """The stress outputs of RMShellPDE (p-norm aggregate with the reference's defaults m = 1e-6, rho = 100 and with rho = 6, DG1 von
+    Mises field on the top surface, rm_shell_pde.py:112-166) on the solved 1 015 470-DOF skin, against the oracle's quadrature evaluated
+    at the SAME state on the host: the accumulation over 67 280 cells, the sub-domain selection and the reference area at full size."""
+    from bench import make_workload
+    from femo_alpha_amd.backend import ShellContext
+    from oracle.rm_shell_oracle import ShellOracle
+    m, fields, marker, _ = make_workload("wing1m")
+    c = ShellContext(m)
+    for k, v in fields.items():
+        c.set_field(k, v)
+    c.set_penalty_facets(m.penalty_facets(marker))
+    c.use_direct_solver()
+    c.solve_state(zero_guess=True)
+    w = c.get_state()
+    o3 = ShellOracle(m, nquad=3)                                     # the degree-4 measure of the aggregate (rm_shell_model.py:200-205)
+    o3.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
+    for mval, rho in ((1e-6, 100.0), (1e-6, 6.0)):
+        c.set_stress_params(mval, rho)
+        ref = o3.pnorm_stress(w, mval, rho)
+        assert abs(c.functional("pnorm_stress") - ref) < 1e-9 * abs(ref), (mval, rho)
+    o = ShellOracle(m)
+    o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
+    s_ref = o.stress_dg1(w)
+    s = c.field_output("stress").reshape(m.nel, -1)
+    assert np.abs(s - s_ref).max() < 1e-9 * np.abs(s_ref).max()
+    c.close()
