@@ -235,3 +235,35 @@ def test_stress_outputs_at_config3_size():
     s = c.field_output("stress").reshape(m.nel, -1)
     assert np.abs(s - s_ref).max() < 1e-9 * np.abs(s_ref).max()
     c.close()
+
+
+def test_shape_gradient_at_config3_size():
+    """d compliance / d uhat (the mesh-displacement design variable of the shape optimisation examples) at full size: the adjoint
+    total gradient  dJ/duhat - (dR/duhat)^T lambda  against a central difference of the solved compliance along a random smooth
+    direction of nodal displacements -- the forward-mode dual kernels of csrc/shape_sens.h on 67 280 warped cells."""
+    from bench import make_workload
+    from femo_alpha_amd.backend import ShellContext
+    m, fields, marker, _ = make_workload("wing1m")
+    c = ShellContext(m)
+    for k, v in fields.items():
+        c.set_field(k, v)
+    c.set_field("uhat", np.zeros((m.nn, 3)))
+    c.set_penalty_facets(m.penalty_facets(marker))
+    c.use_direct_solver()
+    c.solve_state(zero_guess=True)
+    g, it, rr = c.total_gradient("compliance", "uhat")
+    g = g.reshape(m.nn, 3)
+    x = m.nodes
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (3, 3))
+    # smooth field of amplitude 1e-6 m (a thousandth of the thickness), zero at the clamped root
+    d = 1e-6 * np.stack([np.sin(2.0 * x[:, 1] + a[k, 0]) * np.cos(3.0 * x[:, 0] + a[k, 1]) * x[:, 1] / 6.0 for k in range(3)], axis=1)
+    Jp = []
+    for sgn in (1.0, -1.0):
+        c.set_field("uhat", sgn * d)
+        c.solve_state(zero_guess=True)
+        Jp.append(c.functional("compliance"))
+    fd = (Jp[0] - Jp[1]) / 2.0
+    lin = float(np.sum(g * d))
+    assert abs(lin - fd) <= 1e-5 * abs(fd), (lin, fd)
+    c.close()
