@@ -64,8 +64,9 @@ def trailing_roofline(prof, traffic, traffic_by_class=None):
     lower triangles only, C read + written once, the factor rows of the K panel read once.  One kernel, two roofs: a launch whose
     algorithmic flops / compulsory bytes lie above the ridge of the chip (78.6 TFLOP/s / 8 TB/s = 9.8 flop per byte) can be bounded by
     the matrix cores, one below it is bounded by HBM whatever the kernel does (the small-K updates of the lower tree levels).  The
-    instrumented factorisation classifies every launch; ``roofline`` is the class that takes more time, the other class and the
-    all-launch average (the figure of rounds 1-3) ride along."""
+    instrumented factorisation classifies every launch.  Returns (all launches, the class that takes more time, the other class):
+    the top-level ``roofline`` of the JSON line is ALL launches against the MFMA peak (one definition for every round), with the two
+    classes inside it (``by_binding_roof``) and beside it (``roofline_trailing_mfma_class`` / ``roofline_trailing_hbm_class``)."""
     tr = prof["trailing"]
     tf_all = prof["trailing_flops"] / (tr["ms"] * 1e-3) / 1e12
     both = {}
@@ -84,18 +85,20 @@ def trailing_roofline(prof, traffic, traffic_by_class=None):
              "avg_launch_ms": p["ms"] / p["launches"], "launches_per_factorisation": p["launches"], "ms_per_factorisation": p["ms"],
              "achieved_TFLOPs": tf, "achieved_compulsory_GBs": gbs}
         both[bound] = o
-    allk = {"bound": "mfma", "achieved": tf_all, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_all / FP64_PEAK_TFLOPS, "traffic": traffic,
+    allk = {"bound": "mfma", "kernel": "k_trailing_mfma / k_trailing_fine / k_schur_strip (fp64 rank-k updates of the multifrontal Cholesky), ALL launches",
+            "achieved": tf_all, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf_all / FP64_PEAK_TFLOPS, "traffic": traffic,
             "algorithmic_flops_per_launch": prof["trailing_flops"] / tr["launches"],
             "algorithmic_bytes_per_launch": prof["trailing_bytes"] / tr["launches"],
             "avg_launch_ms": tr["ms"] / tr["launches"], "launches_per_factorisation": tr["launches"], "ms_per_factorisation": tr["ms"],
-            "what": "all rank-k launches against the fp64 MFMA peak, whichever roof binds them (the figure of rounds 1-3)"}
-    if not both:
-        return dict(allk, kernel="k_trailing_mfma, all launches"), None, allk
-    main = max(both.values(), key=lambda o: o["ms_per_factorisation"])
-    other = [o for o in both.values() if o is not main]
+            "what": "all rank-k launches of one factorisation against the fp64 MFMA peak, whichever roof binds the single launch: the same "
+                    "definition every round (rounds 1-3: `roofline`; round 4: `roofline_trailing_all_launches`).  `by_binding_roof` splits the "
+                    "launches by the roof that binds them (flops / compulsory bytes above or below the ridge of 9.8)"}
     for o in both.values():                 # counter bytes per launch of each class (scripts/r4_pmc_levels.py), when the committed passes are current
         o["traffic"] = (traffic_by_class or {}).get(o["bound"])
-    return main, (other[0] if other else None), allk
+    allk["by_binding_roof"] = both
+    main = max(both.values(), key=lambda o: o["ms_per_factorisation"]) if both else None
+    other = [o for o in both.values() if o is not main]
+    return allk, main, (other[0] if other else None)
 
 
 def pmc_traffic(workload):
@@ -156,6 +159,14 @@ def make_workload(name, renumber=True, timings=None):
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
         marker = lambda x: np.less(x[1], 1e-9)
         desc = f"synthetic wing skin, unstructured: {m.nel} CG2xCG1 triangles (Delaunay of 117 x 581 jittered points, renumbered), {m.ndof} DOF"
+    elif name == "uquad1m":      # an UNSTRUCTURED ALL-QUADRILATERAL skin of the config-3 surface and size: what the reference's real wings are
+        from femo_alpha_amd.mesh import unstructured_quad_skin_mesh
+        m = unstructured_quad_skin_mesh(47, 239)
+        fields = dict(thickness=[1.27e-3], E=[73.1e9], nu=[0.33], density=[2780.0],
+                      F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
+        marker = lambda x: np.less(x[1], 1e-9)
+        desc = (f"synthetic wing skin, unstructured quadrilaterals: {m.nel} CG2xCG1 quads (Delaunay of 48 x 240 jittered points, every triangle "
+                f"cut into three kites; vertex valences 3..9, shuffled numbering), {m.ndof} DOF")
     elif name == "plate8k":      # BASELINE.json configs[0] (plumbing size)
         m = plate_mesh(2.0, 10.0, 10, 50)
         fields = dict(thickness=[0.1], E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
@@ -356,7 +367,7 @@ def main_dynamic(args, torch):
     # dominant kernel of the march as worded: the rank-k updates of the per-step factorisation (one instrumented factorisation of
     # the step operator, HIP event pairs on the context's stream); of the factor-once march: the triangular sweeps (HBM)
     prof = ctx.factorize_profile()
-    roof, roof_other, roof_all = trailing_roofline(prof, None)
+    roof, roof_main, roof_other = trailing_roofline(prof, None)
     sw = np.min([ctx.sweep_profile() for _ in range(3)], axis=0)
     fac_bytes = float(np.sum(ctx.plan.nf.astype(np.float64) * ctx.plan.npiv) * 8)
     out = {
@@ -377,7 +388,7 @@ def main_dynamic(args, torch):
                         "what": "the same march with the step operator factorised once per thickness (the product default: the operator "
                                 "does not change along the march)"},
         "roofline": roof,
-        "roofline_trailing_other_class": roof_other, "roofline_trailing_all_launches": roof_all,
+        **{f"roofline_trailing_{o['bound']}_class": o for o in (roof_main, roof_other) if o is not None},
         "roofline_sweeps": {"bound": "hbm", "kernel": "triangular sweeps of one preconditioner application (the solve of a factor-once time step)",
                             "achieved": 2 * fac_bytes / (sw.sum() * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": 2 * fac_bytes / (sw.sum() * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -654,7 +665,7 @@ def main():
         # dominant kernel of the frontal path: the trailing update of the partial Cholesky (fp64 rank-k updates);
         # one instrumented factorisation with a HIP event pair around every launch on the context's stream
         prof = ctx.factorize_profile()
-        roof, roof_other, roof_all = trailing_roofline(prof, traffic_trailing, traffic_by_class)
+        roof, roof_main, roof_other = trailing_roofline(prof, traffic_trailing, traffic_by_class)
         kernels = {}
         for cls, fk in (("trailing", "trailing"), ("panel_rows", "panel_rows"), ("panel_diag", "panel_diag")):
             ms = prof[cls]["ms"]
@@ -736,11 +747,11 @@ def main():
                                              "ShellMesh.recommended_nquad: 4 on affine cells (exact), 5 when a cell is warped"),
                        "true_relres_forward": true_relres,
                        "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
-                                  f"(nested dissection, leaves of <= {args.leaf} cells)" if args.solver == "frontal"
+                                  f"(nested dissection, leaves of about {args.leaf} cells)" if args.solver == "frontal"
                                   else "Jacobi-PCG, matrix-free element-by-element operator"), "rtol": args.rtol,
                        "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
                        "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],
-                       "parallelism": "replicas" if world > 1 else "single"},
+                       "parallelism": "single"},
             "roofline": roof,
             "roofline_spmv": roof_spmv,
             "forward_split_ms": {"assemble_factorise": step.timing["setup_ms"], "pcg": step.timing["krylov_ms"]},
@@ -752,9 +763,9 @@ def main():
         if rule4 is not None:
             out["secondary_rule_4x4"] = rule4
         if prof is not None:
-            if roof_other is not None:
-                out["roofline_trailing_other_class"] = roof_other
-            out["roofline_trailing_all_launches"] = roof_all
+            for o in (roof_main, roof_other):
+                if o is not None:
+                    out[f"roofline_trailing_{o['bound']}_class"] = o
             out["factorisation_profile_ms"] = {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)}
             out["factorisation_kernels"] = kernels
             sw = np.min([ctx.sweep_profile() for _ in range(3)], axis=0)

@@ -156,6 +156,11 @@ struct femo_ctx {
         // 26-38 against 33-43 TFLOP/s): two waves per SIMD instead of four hide the stage barriers worse, and diagonal / edge tiles waste
         // twice as much.  Off by default.
         int big_tiles = 0, big_min_wg = 512;
+        // rank-k updates with K <= strip_kmax on levels of at least strip_cnt fronts: k_schur_strip (a workgroup per 64-row strip of a front,
+        // panel rows, maps and metadata once per strip, the next block's operands and child entries in flight behind the current one)
+        // Measured (profiles/r5_strip_ab.txt): parity on the leaves, 1.4-1.7 x SLOWER than the tile kernel on the gathering levels 1-5, and more
+        // look-ahead makes it worse -- off by default (strip_cnt 0), kept as a validated alternative schedule
+        int strip_cnt = 0, strip_kmax = STRIP_KMAX, strip_depth = 1;     // strip_depth: blocks the children's entries are requested ahead (1..2)
         int diag_v1 = 0;              // diagonal-block kernel: 0 auto (see the launch), 1 round-2 kernel (sequential phases), 2 overlapped kernel
         int swork_slots = 8192;       // cap of the diagonal-block scratch (1 GB); larger levels are factorised in chunks (read at plan upload)
         int xinv_small_cnt = 32;      // inversion of L11: levels with at most this many fronts use 64 x 32 tiles
@@ -798,6 +803,29 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // Triangular-grid updates (schur 1, 2, 5): 128 x 128 tiles where that still fills the chip (at least "big_min_wg" workgroups
         // over the launch), 64 x 64 tiles otherwise.  `ntr`: 64-row tiles the launch needs (trail_tiles).
         auto launch_tri = [&](bool gather, int ntr, int off, int n, int C0_, int mode, int K0_, int KW_, hipStream_t st) {
+            // levels of many small fronts with a short K range (HBM-bound updates): one workgroup per 64-row strip of a front
+            // (k_schur_strip; option "strip_cnt": levels of at least that many fronts, 0 = never)
+            if (c->opt.strip_cnt > 0 && cnt_level >= c->opt.strip_cnt) {
+                int kmax = 0, gx = 0;
+                for (int i = b; i < e; ++i) {
+                    const int t = fr.h_level_nodes[i], nf = fr.h_nf[t];
+                    const TrailRange tr = trail_range(mode, C0_, K0_, KW_, fr.h_npiv[t], nf);
+                    if (tr.kw <= 0 || tr.col_lo >= tr.col_hi) continue;
+                    kmax = std::max(kmax, tr.kw);
+                    const int anchor = tr.col_lo & ~1;
+                    gx = std::max(gx, strip_wgs(nf - anchor, tr.col_hi - anchor));
+                }
+                if (kmax > 0 && kmax <= std::min(c->opt.strip_kmax, STRIP_KMAX)) {
+                    const dim3 grid(gx, 1, n);
+#define STRIP_LAUNCH(G_, KQ_, D_) hipLaunchKernelGGL((k_schur_strip<G_, KQ_, D_>), grid, dim3(256), 0, st, fd, lev, off, C0_, mode, K0_, KW_, mask)
+#define STRIP_DEPTHS(G_, KQ_) do { if (c->opt.strip_depth <= 1) STRIP_LAUNCH(G_, KQ_, 1); else STRIP_LAUNCH(G_, KQ_, 2); } while (0)
+                    if (gather) { if (kmax <= 64) STRIP_DEPTHS(true, 16); else if (kmax <= 112) STRIP_DEPTHS(true, 28); else if (kmax <= 128) STRIP_DEPTHS(true, 32); else STRIP_DEPTHS(true, 40); }
+                    else        { if (kmax <= 64) STRIP_DEPTHS(false, 16); else if (kmax <= 128) STRIP_DEPTHS(false, 32); else STRIP_DEPTHS(false, 40); }
+#undef STRIP_DEPTHS
+#undef STRIP_LAUNCH
+                    return;
+                }
+            }
             const int ntb = (ntr + 1) / 2;
             const long long big_wgs = (long long)ntb * (ntb + 1) / 2 * n;
             if (c->opt.big_tiles && big_wgs >= c->opt.big_min_wg) {
@@ -1951,6 +1979,9 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "profile_verbose") o.profile_verbose = v != 0;
     else if (k == "big_tiles") o.big_tiles = v != 0;
     else if (k == "big_min_wg") o.big_min_wg = v;
+    else if (k == "strip_cnt") o.strip_cnt = v;
+    else if (k == "strip_kmax") o.strip_kmax = v;
+    else if (k == "strip_depth") { if (v < 1 || v > 2) return fail(c, "strip_depth: 1..2 blocks of look-ahead"); o.strip_depth = v; }
     else if (k == "diag_v1") { if (v < 0 || v > 3) return fail(c, "diag_v1: 0 auto, 1 round-2 kernel, 2 overlapped kernel, 3 the rule before the LDS diet"); o.diag_v1 = v; }
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;

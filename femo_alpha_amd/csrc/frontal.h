@@ -1631,6 +1631,210 @@ k_trailing_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         if (cok[reg]) *cp[reg] = cv[reg] - acc[reg];
 }
 
+// ---- the rank-k update of the levels of many small fronts (K <= 160: the leaves and the four or five levels above them), where
+// the update moves its compulsory bytes only and is bound by HBM, not by the matrix cores.  k_trailing_mfma runs those levels at
+// 0.31 of the HBM peak: a 64 x 64 tile there is a chain of dependent round trips -- front metadata, two to nine staged K steps with
+// one step of look-ahead, the index maps of the gather, the children's entries, the store -- about 13 us with three workgroups
+// per CU, and every tile reads its own 2 x 64 rows of the K panel and its own maps.  Here a workgroup takes a 64-ROW STRIP of a
+// front's update (all updated columns up to the diagonal, in chunks of at most STRIP_CH blocks of 16 columns):
+//   * front metadata, the row maps of the gather (one register per child and lane) and the strip's own 64 rows of the K panel
+//     (the MFMA B operand: 16 rows x K per wave, in registers, k_panel_rows' layout) are loaded ONCE per strip;
+//   * the column maps of the chunk go to LDS once (2 x 256 entries);
+//   * per block of 16 columns the other operand (16 rows of the panel x K: 16 KB at K = 128) is staged through LDS, double
+//     buffered, and while the matrix cores work on block n the panel rows AND the children's entries of block n + 1 are already in
+//     flight: a stage is one barrier, K / 4 MFMAs per wave and one epilogue of four entries per lane whose loads were issued a stage
+//     earlier -- no dependent round trip inside the loop.
+// The product is formed as in k_panel_rows (D[i = column][j = row]: a lane stores along the rows of the column-major front).
+// K range, column range and the gather are those of k_trailing_mfma (trail_range); KQ = K steps of 4 the B operand has room for.
+constexpr int STRIP_CH = 16;           // blocks of 16 columns per workgroup at most
+constexpr int STRIP_KMAX = 160;        // the widest K range the kernel is instantiated for
+
+// workgroups the update of one front needs: rows and updated columns counted from the even column anchor
+__device__ __host__ inline int strip_wgs(int nrows, int ncols) {
+    const int nstrips = (nrows + 63) / 64, ncb = (ncols + 15) / 16;
+    int n = 0;
+    for (int s = 0; s < nstrips; ++s) {
+        const int nbk = 4 * (s + 1) < ncb ? 4 * (s + 1) : ncb;
+        n += (nbk + STRIP_CH - 1) / STRIP_CH;
+    }
+    return n;
+}
+
+template <bool GATHER, int KQ, int DEPTH>
+__global__ void __launch_bounds__(256, KQ > 32 ? 2 : 3)
+k_schur_strip(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, int schur, int K0, int KW,
+              const unsigned char* __restrict__ mask) {
+    // whole fronts per XCD on levels of many fronts (the strips of a front read the same panel rows): k_trailing_mfma's map
+    int bxv = blockIdx.x, zv = blockIdx.z;
+    {
+        const int G = gridDim.x, n = gridDim.z;
+        if (n >= 256 && (n & 7) == 0) {
+            const int flat = bxv + G * zv, x = flat & 7, q = flat >> 3;
+            zv = (q / G) * 8 + x; bxv = q % G;
+        }
+    }
+    const int t = level_nodes[first + zv];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const TrailRange tr = trail_range(schur, C0, K0, KW, np, nf);
+    const int kc0 = tr.kc0, kw = tr.kw, col_lo = tr.col_lo, col_hi = tr.col_hi;
+    if (kw <= 0 || col_lo >= col_hi) return;
+    const int anchor = col_lo & ~1;
+    const int nstrips = (nf - anchor + 63) / 64, ncb = (col_hi - anchor + 15) / 16;
+    // strip s (rows anchor + 64 s ..) and chunk of its column blocks; the longest strips come first in launch order
+    int s = nstrips - 1, chunk = -1;
+    for (int lin = bxv; s >= 0; --s) {
+        const int nbk = min(4 * (s + 1), ncb), n = (nbk + STRIP_CH - 1) / STRIP_CH;
+        if (lin < n) { chunk = lin; break; }
+        lin -= n;
+    }
+    if (chunk < 0) return;
+    const int cb_lo = STRIP_CH * chunk, cb_hi = min(min(4 * (s + 1), ncb), cb_lo + STRIP_CH);
+    __shared__ __attribute__((aligned(16))) double sA[2][4 * KQ][16];      // sA[.][k][c] = L[anchor + 16 cb + c][kc0 + k]
+    __shared__ int cmap[2][16 * STRIP_CH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const FrontView fv = front_view(fd, t);
+    const int ldp = ldp_of(nf);
+    const int rw = anchor + 64 * s + 16 * wv;                  // this wave's 16 rows
+    const int r = rw + l15;
+    const bool rok = r < nf;
+    const double* Lk = fv.P + (size_t)ldp * kc0;               // the K panel: always pivot columns
+    // B operand: the wave's rows, every k, in registers.  Addresses are clamped and NOTHING is masked: rows past the front give
+    // products that are never stored, and the K range is cut off by the other operand (zero beyond kw).  (A select on the loaded
+    // value makes the compiler sink every load into a branch of its own with a full wait behind it: 32 dependent round trips.)
+    double b[KQ];
+    {
+        const double* rowp = Lk + min(r, nf - 1);
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) b[kk] = rowp[(size_t)ldp * min(4 * kk + l4, kw - 1)];
+    }
+    // staging of the other operand: thread (row pair cp, k slot kq) loads rows 2 cp, 2 cp + 1 of the block at k = kq + 32 q
+    const int cp = tid & 7, kq = tid >> 3;
+    constexpr int NQ = (4 * KQ + 31) / 32;
+    constexpr int NSET = DEPTH + 1;
+    // A wave's vector-memory operations retire in ISSUE order: waiting for the panel rows of the next block waits for every load
+    // issued before them.  So the panel rows (L2 hits) are requested one block FURTHER ahead than the children's entries (HBM) and
+    // always before them -- DEPTH + 1 register sets -- or the entries would have one stage to arrive whatever their look-ahead.
+    d2 pa[NSET][NQ];
+    auto fetchA = [&](int cb, d2 (&dst)[NQ]) {
+        const double* p = Lk + min(anchor + 16 * cb + 2 * cp, ldp - 2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int k = kq + 32 * q;
+            const d2 v = *reinterpret_cast<const d2*>(p + (size_t)ldp * min(k, kw - 1));
+            const d2 z = {0.0, 0.0};
+            dst[q] = k < kw ? v : z;
+        }
+    };
+    auto stashA = [&](int buf, const d2 (&src)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int k = kq + 32 * q;
+            if (k < 4 * KQ) *reinterpret_cast<d2*>(&sA[buf][k][2 * cp]) = src[q];
+        }
+    };
+    // the gather: rows of the children's fronts that land on this lane's row (registers) and on the chunk's columns (LDS)
+    const long long dp = fd.doff[t];
+    int xrow[2] = {-1, -1}, npc[2] = {0, 0}, nbc[2] = {0, 0};
+    const double* Sc[2] = {fd.S, fd.S};
+    if (GATHER) {
+        int chd[2];
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            const int ch = fd.child[sd][t];
+            const int chs = ch >= 0 ? ch : t;
+            chd[sd] = ch;
+            npc[sd] = fd.npiv[chs]; nbc[sd] = fd.nf[chs] - npc[sd];
+            Sc[sd] = fd.S + fd.soff[chs];
+            const int x = fd.cinv[sd][dp + min(r, nf - 1)];
+            xrow[sd] = (ch >= 0 && rok) ? x : -1;
+        }
+        for (int i = tid; i < 2 * 16 * STRIP_CH; i += 256) {
+            const int sd = i / (16 * STRIP_CH), j = i % (16 * STRIP_CH);
+            const int cc = anchor + 16 * cb_lo + j;
+            const int y = fd.cinv[sd][dp + min(cc, nf - 1)];
+            cmap[sd][j] = (chd[sd] >= 0 && cc >= col_lo && cc < col_hi) ? y : -1;
+        }
+    }
+    fetchA(cb_lo, pa[0]);
+    stashA(0, pa[0]);
+    __syncthreads();
+    // entries of C this lane's epilogue needs for block cb: the children's (GATHER) or the front's own -- requested a stage ahead;
+    // `okm` keeps which of them exist (the select waits for the data, so it is left to the epilogue)
+    constexpr int NG = GATHER ? 8 : 4;
+    auto request = [&](int cb, double (&g)[NG], unsigned& okm) {
+        okm = 0;
+        const int j0 = 16 * (cb - cb_lo);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = anchor + 16 * cb + l4 + 4 * reg;
+            const bool tri = rok && r >= cc && cc >= col_lo && cc < col_hi;
+            if (GATHER) {
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    const int x = xrow[sd], y = cmap[sd][j0 + l4 + 4 * reg];
+                    const bool ok = tri && x >= 0 && y >= 0;
+                    const int lo = min(x, y) - npc[sd], hi = max(x, y) - npc[sd];
+                    g[2 * reg + sd] = Sc[sd][ok ? hi + (size_t)nbc[sd] * lo : 0];
+                    okm |= (ok ? 1u : 0u) << (2 * reg + sd);
+                }
+            } else {
+                const double* src = tri ? fv.col(cc) + r : fv.P;      // (one load from a selected address, not a load in a branch)
+                g[reg] = *src;
+                okm |= (tri ? 1u : 0u) << reg;
+            }
+        }
+    };
+    const int* gd = fd.dofs + dp;
+    // one stage: block cb with the entries `g` requested DEPTH stages earlier; the next block's panel rows and the entries of block
+    // cb + DEPTH go on their way first
+    auto stage = [&](int cb, const double (&g)[NG], unsigned okm, double (&gnext)[NG], unsigned& oknext, d2 (&anew)[NQ], const d2 (&anext)[NQ]) {
+        const int buf = (cb - cb_lo) & 1;
+        if (cb + DEPTH + 1 < cb_hi) fetchA(cb + DEPTH + 1, anew);
+        if (cb + DEPTH < cb_hi) request(cb + DEPTH, gnext, oknext);
+        const int cj = anchor + 16 * cb;
+        // the wave has entries in this block if its last row reaches the block's first column (lower triangle)
+        if (rw < nf && rw + 15 >= cj) {
+            mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk)
+                if (4 * kk < kw) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[buf][4 * kk + l4][l15], b[kk], acc, 0, 0, 0);   // D[i = column][j = row]
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = cj + l4 + 4 * reg;
+                const bool tri = rok && r >= cc && cc >= col_lo && cc < col_hi;
+                double cv;
+                if (GATHER) {
+                    cv = (((okm >> (2 * reg)) & 1u) ? g[2 * reg] : 0.0) + (((okm >> (2 * reg + 1)) & 1u) ? g[2 * reg + 1] : 0.0);
+                    if (mask && tri && r == cc && cc < np && mask[gd[r]]) cv = 1.0;      // strong-BC pivots: unit diagonal, as in the extend-add
+                } else {
+                    cv = g[reg];
+                }
+                if (tri) fv.col(cc)[r] = cv - acc[reg];
+            }
+        }
+        if (cb + 1 < cb_hi) stashA(buf ^ 1, anext);
+        __syncthreads();
+    };
+    // DEPTH + 1 register sets each for the requested entries and for the panel rows, rotated by unrolling (a copy would wait for the
+    // loads just issued): at stage n the panel rows of block n + DEPTH + 1 are requested, then the entries of block n + DEPTH.
+    // A stage lasts K / 4 MFMAs (0.35-0.9 us), a load of the children's entries from HBM 2-3 us under load.
+    double g[NSET][NG];
+    unsigned okm[NSET];
+#pragma unroll
+    for (int d = 1; d <= DEPTH; ++d)
+        if (cb_lo + d < cb_hi) fetchA(cb_lo + d, pa[d % NSET]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        okm[d] = 0;
+        if (cb_lo + d < cb_hi) request(cb_lo + d, g[d], okm[d]);
+    }
+    for (int cb = cb_lo; cb < cb_hi; cb += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            if (cb + u < cb_hi) stage(cb + u, g[u], okm[u], g[(u + DEPTH) % NSET], okm[(u + DEPTH) % NSET], pa[u], pa[(u + 1) % NSET]);
+    }
+}
+
 // ---- the same rank-k update on 128 x 128 tiles (schur 1, 2, 5: the updates of whole Schur complements / trailing matrices).
 // The per-level counter table (profiles/r3_pmc_trailing_levels.md) shows where the 64 x 64 kernel loses: on the MFMA-bound
 // levels (6 and up) it moves 2.2-3 x its compulsory bytes at ~4 TB/s -- every tile re-reads 2 x 64 rows of the K panel, and

@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["ShellMesh", "plate_mesh", "wing_skin_mesh", "quads_to_triangles"]
+__all__ = ["ShellMesh", "plate_mesh", "wing_skin_mesh", "unstructured_skin_mesh", "unstructured_quad_skin_mesh", "quads_to_triangles"]
 
 
 class ShellMesh:
@@ -350,42 +350,82 @@ def wing_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.2, shuffle=True
     return ShellMesh(nodes, cells, element)
 
 
-def unstructured_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.35, shuffle=True, seed_jitter=1, seed_perm=2,
-                           element="CG2CG1"):
-    """The wing-skin surface of ``wing_skin_mesh`` with an UNSTRUCTURED triangulation: the (nc + 1) x (ns + 1) parameter points are
-    jittered by ``jitter`` cells and Delaunay-triangulated in the parameter plane (vertex valences 4..9, no mesh lines), then mapped to
-    the cambered, tapered, twisted surface and renumbered at random.  Same vertex count as the quadrilateral skin (1 015 470 DOF at the
-    default size, 134 560 triangles).  Needs scipy (a mesh generator for tests and benchmarks, not part of the solver path)."""
-    from scipy.spatial import Delaunay
-    rng = np.random.default_rng(seed_jitter)
-    S, T = np.meshgrid(np.linspace(0.0, 1.0, nc + 1), np.linspace(0.0, 1.0, ns + 1), indexing="ij")
-    dS = jitter / nc * rng.uniform(-1, 1, S.shape)
-    dT = jitter / ns * rng.uniform(-1, 1, T.shape)
-    dS[[0, -1], :] = 0; dT[:, [0, -1]] = 0                 # boundary points slide along their edge only
-    S, T = S + dS, T + dT
-    # triangulate in cell units (isotropic), so that the Delaunay criterion sees the cells' real aspect
-    tri = Delaunay(np.stack([S.ravel() * nc, T.ravel() * ns], axis=1)).simplices.astype(np.int64)
-    st = np.stack([S.ravel(), T.ravel()], axis=1)
-    a, b = st[tri[:, 1]] - st[tri[:, 0]], st[tri[:, 2]] - st[tri[:, 0]]
-    area = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
-    tri = tri[np.abs(area) > 1e-14 / (nc * ns)]             # slivers between collinear boundary points
-    cw = area[np.abs(area) > 1e-14 / (nc * ns)] < 0
-    tri[cw] = tri[cw][:, [0, 2, 1]]
+def _wing_surface(S, T, chord, span):
+    """The cambered, tapered, twisted, swept surface of ``wing_skin_mesh`` at the parameter points (S chordwise, T spanwise)."""
     taper = 1.0 - 0.55 * T
     xloc = (S - 0.25) * chord * taper
     camber = 0.06 * chord * taper * 4.0 * S * (1.0 - S)
     twist = np.deg2rad(-4.0) * T
     x = 0.35 * span * T * 0.25 + xloc * np.cos(twist) + camber * np.sin(twist)
     z = -xloc * np.sin(twist) + camber * np.cos(twist) + 0.03 * span * T ** 2
-    nodes = np.stack([x.ravel(), (span * T).ravel(), z.ravel()], axis=1)
-    if shuffle:
-        rng = np.random.default_rng(seed_perm)
-        pn = rng.permutation(nodes.shape[0])
-        inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
-        nodes = nodes[inv]
-        tri = pn[tri]
-        tri = tri[rng.permutation(tri.shape[0])]
-    return ShellMesh(nodes, tri, element)
+    return np.stack([np.ravel(x), np.ravel(span * T), np.ravel(z)], axis=1)
+
+
+def skin_triangulation(nc, ns, jitter=0.35, seed_jitter=1, tri=None):
+    """Parameter points (S, T) of an (nc + 1) x (ns + 1) grid jittered by ``jitter`` cells (boundary points slide along their edge
+    only) and their Delaunay triangulation in cell units, counter-clockwise, slivers between collinear boundary points dropped.
+    ``tri``: a triangulation of these points computed earlier (the goldens carry theirs: qhull's output may differ between
+    versions, the points do not)."""
+    rng = np.random.default_rng(seed_jitter)
+    S, T = np.meshgrid(np.linspace(0.0, 1.0, nc + 1), np.linspace(0.0, 1.0, ns + 1), indexing="ij")
+    dS = jitter / nc * rng.uniform(-1, 1, S.shape)
+    dT = jitter / ns * rng.uniform(-1, 1, T.shape)
+    dS[[0, -1], :] = 0; dT[:, [0, -1]] = 0                 # boundary points slide along their edge only
+    S, T = S + dS, T + dT
+    if tri is None:
+        from scipy.spatial import Delaunay
+        # triangulate in cell units (isotropic), so that the Delaunay criterion sees the cells' real aspect
+        tri = Delaunay(np.stack([S.ravel() * nc, T.ravel() * ns], axis=1)).simplices.astype(np.int64)
+        st = np.stack([S.ravel(), T.ravel()], axis=1)
+        a, b = st[tri[:, 1]] - st[tri[:, 0]], st[tri[:, 2]] - st[tri[:, 0]]
+        area = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        tri = tri[np.abs(area) > 1e-14 / (nc * ns)]             # slivers between collinear boundary points
+        cw = area[np.abs(area) > 1e-14 / (nc * ns)] < 0
+        tri[cw] = tri[cw][:, [0, 2, 1]]
+    return S.ravel(), T.ravel(), np.asarray(tri, dtype=np.int64)
+
+
+def _shuffled(nodes, cells, seed_perm, element):
+    rng = np.random.default_rng(seed_perm)
+    pn = rng.permutation(nodes.shape[0])                    # new id of old node i
+    inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+    cells = pn[cells]
+    return ShellMesh(nodes[inv], cells[rng.permutation(cells.shape[0])], element)
+
+
+def unstructured_skin_mesh(nc=116, ns=580, chord=1.2, span=6.0, jitter=0.35, shuffle=True, seed_jitter=1, seed_perm=2,
+                           element="CG2CG1", tri=None):
+    """The wing-skin surface of ``wing_skin_mesh`` with an UNSTRUCTURED triangulation: the (nc + 1) x (ns + 1) parameter points are
+    jittered by ``jitter`` cells and Delaunay-triangulated in the parameter plane (vertex valences 4..9, no mesh lines), then mapped to
+    the cambered, tapered, twisted surface and renumbered at random.  Same vertex count as the quadrilateral skin (1 015 470 DOF at the
+    default size, 134 560 triangles).  Needs scipy unless ``tri`` (``skin_triangulation``) is given -- a mesh generator for tests and
+    benchmarks, not part of the solver path."""
+    S, T, tri = skin_triangulation(nc, ns, jitter, seed_jitter, tri)
+    nodes = _wing_surface(S, T, chord, span)
+    return _shuffled(nodes, tri, seed_perm, element) if shuffle else ShellMesh(nodes, tri, element)
+
+
+def unstructured_quad_skin_mesh(nc=47, ns=239, chord=1.2, span=6.0, jitter=0.35, shuffle=True, seed_jitter=1, seed_perm=2,
+                                element="CG2CG1", tri=None):
+    """An UNSTRUCTURED ALL-QUADRILATERAL wing skin -- what the reference's real shells are
+    (examples/advanced_examples/lpc_gust_response_opt/ex_lpc_gust_response_opt.py:142-153: 39 488 quadrilaterals from a CAD mesher):
+    the Delaunay triangulation of ``skin_triangulation`` with every triangle cut into three quadrilaterals (vertex, edge midpoint,
+    centroid, edge midpoint).  Vertex valences 3 (the centroids), 4 (the edge midpoints) and 8..18 (the triangulation's vertices), no
+    mesh lines, every cell a kite (strongly non-affine: the bilinear map's Jacobian varies by a factor ~2 over a cell), new points placed
+    ON the cambered / twisted surface (so the cells are warped as well), numbering shuffled.  At the default size: 67 398 cells,
+    1 016 124 DOF -- the size of BASELINE config 3."""
+    S, T, tri = skin_triangulation(nc, ns, jitter, seed_jitter, tri)
+    nV = S.size
+    e = np.sort(np.stack([tri, np.roll(tri, -1, axis=1)], axis=2).reshape(-1, 2), axis=1)       # edge k of a triangle: vertex k -> k + 1
+    ue, inv = np.unique(e[:, 0] * nV + e[:, 1], return_inverse=True)
+    ea, eb = ue // nV, ue % nV
+    mid = nV + inv.reshape(-1, 3)                                                                 # midpoint node of every triangle edge
+    ctr = nV + ue.size + np.arange(tri.shape[0])
+    Sx = np.concatenate([S, 0.5 * (S[ea] + S[eb]), S[tri].mean(axis=1)])
+    Tx = np.concatenate([T, 0.5 * (T[ea] + T[eb]), T[tri].mean(axis=1)])
+    quads = np.concatenate([np.stack([tri[:, k], mid[:, k], ctr, mid[:, (k + 2) % 3]], axis=1) for k in range(3)])
+    nodes = _wing_surface(Sx, Tx, chord, span)
+    return _shuffled(nodes, quads, seed_perm, element) if shuffle else ShellMesh(nodes, quads, element)
 
 
 def tee_beam_mesh(width=1.0, height=0.5, length=5.0, nw=4, nh=2, nl=10):

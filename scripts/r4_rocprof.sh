@@ -1,7 +1,10 @@
 # Round-4 profiles on the GPU box (through gpurun): rocprofv3 kernel-trace statistics of the bench command, two counter passes
 # (FETCH_SIZE, WRITE_SIZE; separate runs, no tracing domains beside them) on bench.py for the per-kernel HBM bytes, SQ counter
 # passes for the element operator.  The program itself follows `--`.
-cd $GRAFT_REPO_ROOT && . scripts/r4_lib.sh && mkdir -p gpurun_out
+set -eu
+cd "${GRAFT_REPO_ROOT:?not on a GPU box: GRAFT_REPO_ROOT is unset}"
+. scripts/r4_lib.sh
+mkdir -p gpurun_out
 export TMPDIR=/tmp
 for d in prof_r4 pmc_r4f pmc_r4w pmc_r4lf pmc_r4lw pmc_r4s1 pmc_r4s2 pmc_r4s3; do rm -rf gpurun_out/$d; mkdir -p gpurun_out/$d; done
 BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-keep-numbering-leg"

@@ -1,4 +1,4 @@
-# helpers of the round-4 GPU-box scripts: every step runs under its own time limit; after a step that was killed at its limit
+# helpers of the round-5 GPU-box scripts: every step runs under its own time limit; after a step that was killed at its limit
 # no further GPU step is started (a hung kernel must not be followed by more launches on the same box)
 run() {   # run <seconds> <log> <command...>
     local lim=$1 log=$2 rc=0; shift 2

@@ -19,15 +19,20 @@ def _prof(mfma_ms, hbm_ms):
             "trailing_mfma_bound": mf, "trailing_hbm_bound": hb}
 
 
-def test_roofline_reports_the_class_that_takes_more_time():
-    main, other, allk = bench.trailing_roofline(_prof(4.0, 2.8), 3.5e8, {"mfma": 3.4e8, "hbm": 3.8e8})
+def test_roofline_is_all_launches_with_the_two_classes_inside():
+    allk, main, other = bench.trailing_roofline(_prof(4.0, 2.8), 3.5e8, {"mfma": 3.4e8, "hbm": 3.8e8})
+    # the top-level object: every rank-k launch against the MFMA peak (the same definition every round)
+    assert allk["bound"] == "mfma" and allk["unit"] == "TFLOP/s" and allk["peak"] == bench.FP64_PEAK_TFLOPS
+    assert allk["frac"] == pytest.approx(186e9 / 6.8e-3 / 1e12 / 78.6) and allk["traffic"] == 3.5e8
+    assert allk["launches_per_factorisation"] == 58 and allk["algorithmic_flops_per_launch"] == pytest.approx(186e9 / 58)
+    assert set(allk["by_binding_roof"]) == {"mfma", "hbm"} and allk["by_binding_roof"]["mfma"] is main
+    # the class that takes more time, then the other one
     assert main["bound"] == "mfma" and main["unit"] == "TFLOP/s" and main["peak"] == bench.FP64_PEAK_TFLOPS
     assert main["achieved"] == pytest.approx(150e9 / 4.0e-3 / 1e12) and main["frac"] == pytest.approx(main["achieved"] / 78.6)
     assert main["traffic"] == 3.4e8 and main["algorithmic_bytes_per_launch"] == pytest.approx(5.8e9 / 40)
     assert other["bound"] == "hbm" and other["unit"] == "GB/s" and other["peak"] == bench.HBM_PEAK_GBS and other["traffic"] == 3.8e8
     assert other["achieved"] == pytest.approx(6.5e9 / 2.8e-3 / 1e9)
-    assert allk["frac"] == pytest.approx(186e9 / 6.8e-3 / 1e12 / 78.6) and allk["traffic"] == 3.5e8
-    main2, other2, _ = bench.trailing_roofline(_prof(1.0, 2.8), None)          # a mesh of small fronts: HBM is the roof that binds
+    _, main2, other2 = bench.trailing_roofline(_prof(1.0, 2.8), None)          # a mesh of small fronts: HBM is the roof that binds
     assert main2["bound"] == "hbm" and other2["bound"] == "mfma" and main2["traffic"] is None
     # the ridge the launches are classified by (femo_hip.hip, profile class 7) is the ratio of the two peaks the line quotes
     assert bench.FP64_PEAK_TFLOPS * 1e12 / (bench.HBM_PEAK_GBS * 1e9) == pytest.approx(9.8, abs=0.05)
@@ -60,6 +65,8 @@ def test_workload_table():
     assert m.ndof == 8046 and "8046 DOF" in desc
     m, fields, marker, desc = bench.make_workload("plate250k", renumber=False)
     assert m.ndof == 255438 and fields["thickness"].shape == (m.nn,)
+    m, fields, marker, desc = bench.make_workload("uquad1m", renumber=False)
+    assert m.is_quad and m.ndof == 1016124 and m.recommended_nquad() == 5
     with pytest.raises(SystemExit):
         bench.make_workload("wing0m")
     with pytest.raises(SystemExit):
