@@ -231,23 +231,27 @@ static void operator_changed(femo_ctx* c);
 
 // ------------------------------------------------------------------------------------------ tables
 static void gauss_legendre(int n, double* x, double* w) {
-    // The rules the element kernels use (n <= 5) as decimal literals, i.e. the CORRECTLY ROUNDED doubles of the exact nodes and
+    // The rules the element kernels use (n <= 6) as decimal literals, i.e. the CORRECTLY ROUNDED doubles of the exact nodes and
     // weights.  Not pedantry: at BASELINE config 3 (1 M DOF, 1.27 mm skin) replacing the 5-point weights by values that differ in
     // the last place (<= 4e-16: this routine's own Newton iteration below against numpy's leggauss) moves the displacement, the
     // compliance and d compliance / d thickness by 3.5e-7, 2.8e-7 and 3.5e-7 (tests/golden/make_config3_golden.py with either
     // table; a weight error is the same relative stiffness error in every cell, and the thin skin amplifies it).  The oracle keeps
     // its own copy of the same literals, so the two sides integrate with bit-identical tables.
-    static const double GX[6][5] = {{0}, {0.0},
+    static const double GX[7][6] = {{0}, {0.0},
         {-0.5773502691896257645091488, 0.5773502691896257645091488},
         {-0.7745966692414833770358531, 0.0, 0.7745966692414833770358531},
         {-0.8611363115940525752239465, -0.3399810435848562648026658, 0.3399810435848562648026658, 0.8611363115940525752239465},
-        {-0.9061798459386639927976269, -0.5384693101056830910363144, 0.0, 0.5384693101056830910363144, 0.9061798459386639927976269}};
-    static const double GW[6][5] = {{0}, {2.0}, {1.0, 1.0},
+        {-0.9061798459386639927976269, -0.5384693101056830910363144, 0.0, 0.5384693101056830910363144, 0.9061798459386639927976269},
+        {-0.9324695142031520278123015545, -0.661209386466264513661399595, -0.2386191860831969086305017217, 0.2386191860831969086305017217,
+         0.661209386466264513661399595, 0.9324695142031520278123015545}};
+    static const double GW[7][6] = {{0}, {2.0}, {1.0, 1.0},
         {0.5555555555555555555555556, 0.8888888888888888888888889, 0.5555555555555555555555556},
         {0.3478548451374538573730639, 0.6521451548625461426269361, 0.6521451548625461426269361, 0.3478548451374538573730639},
         {0.236926885056189087514264, 0.4786286704993664680412915, 0.5688888888888888888888889, 0.4786286704993664680412915,
-         0.236926885056189087514264}};
-    if (n >= 1 && n <= 5) {
+         0.236926885056189087514264},
+        {0.1713244923791703450402961422, 0.3607615730481386075698335138, 0.467913934572691047389870344, 0.467913934572691047389870344,
+         0.3607615730481386075698335138, 0.1713244923791703450402961422}};
+    if (n >= 1 && n <= 6) {
         for (int i = 0; i < n; ++i) { x[i] = GX[n][i]; w[i] = GW[n][i]; }
         return;
     }
@@ -1581,7 +1585,7 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
     *out = nullptr;
     if (nvc != 3 && nvc != 4) { g_create_error = "nvc must be 3 (triangles) or 4 (quads)"; return 2; }
     if (nn <= 0 || nel <= 0 || !xyz || !cells || !cell_p2) { g_create_error = "empty mesh or null pointer"; return 2; }
-    if (nvc == 4 && (nquad < 2 || nquad > 5)) { g_create_error = "nquad must be in 2..5"; return 2; }
+    if (nvc == 4 && (nquad < 2 || nquad > 6)) { g_create_error = "nquad must be in 2..6"; return 2; }
     // CG1CG1 (linear_shell_model.py:74-79): the caller's "P2 node" set is the vertex set itself and cell_p2 holds nvc entries per
     // cell -- told apart by nP2 == nn (a CG2CG1 mesh always has nP2 = nn + edges [+ cells] > nn)
     const bool cg1 = nP2 == nn;
@@ -1965,7 +1969,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "super_tiles") o.super_tiles = v != 0;
     else if (k == "super_tiles_min") o.super_tiles_min = v;
     else if (k == "fused_schur") o.fused_schur = v != 0;
-    else if (k == "precond_nquad") { if (v != 0 && (v < 2 || v > 5)) return fail(c, "precond_nquad: 0 (the operator's rule) or 2..5"); o.precond_nquad = v; operator_changed(c); }
+    else if (k == "precond_nquad") { if (v != 0 && (v < 2 || v > 6)) return fail(c, "precond_nquad: 0 (the operator's rule) or 2..6"); o.precond_nquad = v; operator_changed(c); }
     else if (k == "equilibrate") { if (v < 0 || v > 2) return fail(c, "equilibrate: 0 off, 1 diag^-1/2, 2 nearest powers of two"); o.equilibrate = v; operator_changed(c); }
     else if (k == "grid_chunk") { if (v < 1 || v > 65535) return fail(c, "grid_chunk must be in 1..65535"); o.grid_chunk = v; }
     else if (k == "wide_np" || k == "wide_cnt") {

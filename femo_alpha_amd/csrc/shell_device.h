@@ -18,7 +18,7 @@
 
 namespace femo {
 
-constexpr int MAXQ = 25;
+constexpr int MAXQ = 36;     // 6 x 6 Gauss points: strongly non-affine quadrilaterals (ShellMesh.recommended_nquad)
 constexpr double K_SHEAR = 0.833;       // linear_shell_model.py:146
 constexpr double REG_ALPHA1 = 1.0e-2;   // rm_shell_pde.py:67
 

@@ -187,14 +187,27 @@ class ShellMesh:
         the degree to UFL (plain ``dx``, linear_shell_model.py:88-103), whose estimate is 43-53 on quadrilaterals
         (scripts/ufl_degree_estimate.py): (nearly) exact integration.  On affine cells (parallelograms) the integrand is a
         polynomial of degree <= 7 per direction and 4 points are exact; on any other quadrilateral the frame, the
-        derivative map and the differentiated normal are rational in the reference coordinates and 4 points are 7.5e-8 away
-        from the limit in d compliance / d thickness at BASELINE config 3, 5 points 1e-9
-        (tests/test_gpu_fullsize.py::test_quadrature_rule_sensitivity_at_config3).  Triangles are affine: one rule."""
+        derivative map and the differentiated normal are rational in the reference coordinates and the answer converges in n:
+          * mildly non-affine cells (BASELINE config 3: a jittered grid, the Jacobian of the bilinear map varies by a factor 1.4
+            across the typical cell): 4 points are 7.5e-8 away from the limit in d compliance / d thickness, 5 points 1e-9
+            (tests/test_gpu_fullsize.py::test_quadrature_rule_sensitivity_at_config3) -> 5;
+          * strongly non-affine cells (an unstructured quadrilateral mesh whose typical cell is a kite: factor 3; workload
+            uquad1m): 5 points are 2.1e-8 away in the gradient (9e-10 displacement, 1.1e-9 compliance), 6 points 3.6e-10
+            (profiles/r5_quadrature_uquad1m.txt: exact discrete solutions at n = 5, 6, 7) -> 6.
+        The measure is the MEDIAN over the cells of max / min of the Jacobian at the four corners (wing1m 1.43, uquad1m 3.00; the
+        worst cells of the jittered grid reach 4.9, but what moves the solution is the typical cell); 6 from 2.0 on.
+        Triangles are affine: one rule."""
         if not self.is_quad:
             return 4
         x = self.nodes[self.cells]
         defect = np.linalg.norm(x[:, 0] - x[:, 1] + x[:, 2] - x[:, 3], axis=1)       # zero for a parallelogram
-        return 4 if np.all(defect <= 1e-10 * self.cell_diameters()) else 5
+        if np.all(defect <= 1e-10 * self.cell_diameters()):
+            return 4
+        e = [x[:, 1] - x[:, 0], x[:, 2] - x[:, 1], x[:, 2] - x[:, 3], x[:, 3] - x[:, 0]]     # edges 01, 12, 32, 03
+        area = lambda u, v: np.linalg.norm(np.cross(u, v), axis=1)
+        J = np.stack([area(e[0], e[3]), area(e[0], e[1]), area(e[2], e[1]), area(e[2], e[3])], axis=1)
+        ratio = J.max(axis=1) / np.maximum(J.min(axis=1), 1e-300)
+        return 6 if np.median(ratio) >= 2.0 else 5
 
     # ------------------------------------------------------------------ Dirichlet sets
     @staticmethod

@@ -39,7 +39,7 @@ const char* femo_last_error(const femo_ctx* ctx);
  *   cells          nel*nvc vertex ids
  *   cell_p2        nel*npc P2 node ids (npc = 9 quads / 6 triangles: vertices, edge midpoints, centre)
  *   elementwise_material / elementwise_pressure   DG0 instead of CG1 for VT / VF (rm_shell_pde.py:37-44)
- *   nquad          Gauss points per direction on quads (2..5); ignored on triangles (12-point rule) */
+ *   nquad          Gauss points per direction on quads (2..6); ignored on triangles (12-point rule) */
 int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                 const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                 int elementwise_material, int elementwise_pressure, int nquad);

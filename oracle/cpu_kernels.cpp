@@ -24,7 +24,7 @@
 namespace {
 
 constexpr double SHEAR_K = 0.833;          // linear_shell_model.py:146
-constexpr int MAXLD = 39, MAXQ = 32;
+constexpr int MAXLD = 39, MAXQ = 64;     // up to 8 x 8 Gauss points (the quadrature-convergence studies; the product kernels stop at 5 x 5)
 
 struct Tables {
     int nq, nvc, npc;

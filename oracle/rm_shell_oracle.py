@@ -41,7 +41,7 @@ REG_ALPHA1 = 1.0e-2          # rm_shell_pde.py:67
 
 
 # ----------------------------------------------------------------------------- tables
-# Gauss-Legendre rules up to 5 points from decimal literals of the exact nodes and weights (computed with mpmath at 50 digits):
+# Gauss-Legendre rules up to 7 points from decimal literals of the exact nodes and weights (computed with mpmath at 50 digits):
 # the correctly rounded doubles.  numpy's leggauss is up to 4e-16 away from them, and at BASELINE config 3 (1 M DOF) a change of
 # that size in the 5-point weights moves displacement / compliance / gradient by 3.5e-7 / 2.8e-7 / 3.5e-7
 # (tests/golden/make_config3_golden.py with either table): the tables are part of the definition of the discrete problem at that
@@ -56,6 +56,16 @@ _GL = {
     5: ([-0.9061798459386639927976269, -0.5384693101056830910363144, 0.0, 0.5384693101056830910363144, 0.9061798459386639927976269],
         [0.236926885056189087514264, 0.4786286704993664680412915, 0.5688888888888888888888889, 0.4786286704993664680412915,
          0.236926885056189087514264]),
+    # 6 and 7 points: only the quadrature-convergence study of the unstructured quadrilateral skin uses them (is n = 5 within 1e-8 of the
+    # limit on kites?  profiles/r5_quadrature_uquad1m.txt); numpy's tables are up to 9e-16 away from these
+    6: ([-0.9324695142031520278123015545, -0.661209386466264513661399595, -0.2386191860831969086305017217, 0.2386191860831969086305017217,
+         0.661209386466264513661399595, 0.9324695142031520278123015545],
+        [0.1713244923791703450402961422, 0.3607615730481386075698335138, 0.467913934572691047389870344, 0.467913934572691047389870344,
+         0.3607615730481386075698335138, 0.1713244923791703450402961422]),
+    7: ([-0.949107912342758524526189684, -0.7415311855993944398638647733, -0.4058451513773971669066064121, 0.0, 0.4058451513773971669066064121,
+         0.7415311855993944398638647733, 0.949107912342758524526189684],
+        [0.1294849661688696932706114327, 0.2797053914892766679014677714, 0.3818300505051189449503697755, 0.4179591836734693877551020408,
+         0.3818300505051189449503697755, 0.2797053914892766679014677714, 0.1294849661688696932706114327]),
 }
 
 

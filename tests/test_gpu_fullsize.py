@@ -21,12 +21,14 @@ def _context(kind):
                       nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1)))
         marker = lambda x: np.less(x[0], 3e-16)
         return m, fields, marker, rng
-    if kind in ("wing1m", "uskin1m", "wing1m_tri"):
+    if kind in ("wing1m", "uskin1m", "wing1m_tri", "uquad1m"):
         # uskin1m: the same surface with an unstructured triangulation (Delaunay, valences 3..9); wing1m_tri: the triangle variant of
-        # config 3 that SURVEY.md section 8d defines (183 x 365 quads split: 133 590 triangles, 1 006 863 DOF)
-        from femo_alpha_amd.mesh import quads_to_triangles, unstructured_skin_mesh
+        # config 3 that SURVEY.md section 8d defines (183 x 365 quads split: 133 590 triangles, 1 006 863 DOF); uquad1m: the surface as an
+        # unstructured ALL-QUADRILATERAL mesh (every Delaunay triangle cut into three kites: valences 3..9, strongly non-affine cells)
+        from femo_alpha_amd.mesh import quads_to_triangles, unstructured_quad_skin_mesh, unstructured_skin_mesh
         m = {"wing1m": lambda: wing_skin_mesh(116, 580), "uskin1m": lambda: unstructured_skin_mesh(116, 580),
-             "wing1m_tri": lambda: quads_to_triangles(wing_skin_mesh(183, 365))}[kind]()
+             "wing1m_tri": lambda: quads_to_triangles(wing_skin_mesh(183, 365)),
+             "uquad1m": lambda: unstructured_quad_skin_mesh(47, 239)}[kind]()
         rng = np.random.default_rng(5)
         fields = dict(thickness=1.27e-3 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=[73.1e9], nu=[0.33], density=[2780.0],
                       F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
@@ -54,10 +56,12 @@ def _solver(m, fields, marker, ewm=False, strong=False):
     return c
 
 
-@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k", "uskin1m", "wing1m_tri"])
+@pytest.mark.parametrize("kind", ["plate250k", "wing1m", "tri170k", "uskin1m", "wing1m_tri", "uquad1m"])
 def test_full_size_properties(kind):
     m, fields, marker, rng = _context(kind)
     assert m.ndof == {"wing1m": 1015470, "uskin1m": 1015470, "wing1m_tri": 1006863, "plate250k": 255438}.get(kind, m.ndof)
+    if kind == "uquad1m":          # (the exact count depends on how qhull treats the collinear boundary points: the golden test pins it)
+        assert m.is_quad and abs(m.ndof - 1016124) < 2000
     c = _solver(m, fields, marker, ewm=kind == "tri170k", strong=kind == "tri170k")
     it, rr = c.solve_state(zero_guess=True)
     assert it <= 4 and rr <= 1e-11
@@ -175,17 +179,22 @@ def test_config5_full_size_properties():
     assert abs(g @ d - fd) < 2e-6 * abs(fd), (g @ d, fd)
 
 
-def test_quadrature_rule_sensitivity_at_config3():
+@pytest.mark.parametrize("workload", ["wing1m", "uquad1m"])
+def test_quadrature_rule_sensitivity_at_config3(workload):
     """What the quadrature rule is worth on the warped cells of BASELINE config 3.  The reference lets UFL estimate the degree
     of its static forms; on quadrilaterals the published rules give ~47 (scripts/ufl_degree_estimate.py), i.e. exact
     integration, while this repository integrates with n x n Gauss, n = 4 by default (exact on flat cells).  The wing skin's
     cells are warped and its integrand rational: the solution converges in n, and the step 4 -> 5 bounds what parity with
-    FEniCSx on this mesh can be claimed at n = 4.  Measured numbers are printed and quoted in DESIGN.md section 2."""
+    FEniCSx on this mesh can be claimed at n = 4.  Measured numbers are printed and quoted in DESIGN.md section 2.
+    ``uquad1m``: the same question on the unstructured quadrilateral skin, whose cells are kites (the Jacobian of the bilinear map
+    varies by a factor ~2 across a cell) -- far from affine, where the jittered grid of ``wing1m`` is nearly so."""
     from bench import make_workload
     from femo_alpha_amd.backend import ShellContext
-    m, fields, marker, _ = make_workload("wing1m")
+    m, fields, marker, _ = make_workload(workload)
+    rule = m.recommended_nquad()
+    assert rule == {"wing1m": 5, "uquad1m": 6}[workload]
     res = {}
-    for n in (3, 4, 5):
+    for n in range(rule - 2, rule + 1):
         c = ShellContext(m, nquad=n)
         for k, v in fields.items():
             c.set_field(k, v)
@@ -197,15 +206,18 @@ def test_quadrature_rule_sensitivity_at_config3():
         res[n] = (c.get_state(), c.functional("compliance"), g)
         c.close()
     d = {}
-    for a, b in ((3, 4), (4, 5)):
+    for a, b in ((rule - 2, rule - 1), (rule - 1, rule)):
         wa, Ja, ga = res[a]; wb, Jb, gb = res[b]
         d[(a, b)] = (np.abs(wa - wb).max() / np.abs(wb).max(), abs(Ja - Jb) / abs(Jb), np.abs(ga - gb).max() / np.abs(gb).max())
-        print(f"n = {a} -> {b}: displacement {d[(a, b)][0]:.3e}, compliance {d[(a, b)][1]:.3e}, d compliance / d thickness {d[(a, b)][2]:.3e}")
+        print(f"{workload}: n = {a} -> {b}: displacement {d[(a, b)][0]:.3e}, compliance {d[(a, b)][1]:.3e}, d compliance / d thickness {d[(a, b)][2]:.3e}")
     # convergence in n: every step smaller than the one before
-    assert all(d[(4, 5)][k] < d[(3, 4)][k] for k in range(3))
+    assert all(d[(rule - 1, rule)][k] < d[(rule - 2, rule - 1)][k] for k in range(3))
     # n = 4 against n = 5 stays below the level at which the two rules would be different discretisations (1e-3); whether
     # it reaches the 1e-8 of the north star is what the printed numbers say -- it does not, see DESIGN.md
-    assert all(d[(4, 5)][k] < 1e-3 for k in range(3))
+    assert all(d[(rule - 1, rule)][k] < 1e-3 for k in range(3))
+    # the last step of the recommended rule: below 1e-7 in every quantity (its own distance from the limit is a further factor
+    # ~50 smaller: wing1m ~1e-9, uquad1m 3.6e-10 in the gradient -- profiles/r5_quadrature_uquad1m.txt)
+    assert all(d[(rule - 1, rule)][k] < 1e-7 for k in range(3))
 
 
 def test_stress_outputs_at_config3_size():
