@@ -168,6 +168,14 @@ struct femo_ctx {
         // Measured at 1M DOF: one workgroup per 32 columns wins on every level (43-57 us against 49-115), so the default is never
         int bnd_tiled_nb = 1 << 30;
         int sweep_butterfly = 3;              // backward sweep column sums in one butterfly: bit 0 k_front_bwd_small, bit 1 k_sweep_bnd_cols
+        // wide levels: every run of consecutive wide levels is ONE launch per sweep direction, tiles ordered by per-front counters
+        // instead of launch boundaries (k_sweep_wide_fwd / k_sweep_wide_bwd).  Measured at 1 M DOF (profiles/r5_sweep_fuse_ab.txt): the ten
+        // wide levels take 517-546 us forward and 437-492 us backward in one launch each against 397 / 380 us as twenty launches -- what a
+        // launch boundary costs (~10 us per level and phase) is less than what replaces it: every tile waits for the acknowledgement of its
+        // own atomics before it may signal, and a tile in flight holds one of 512 slots for ~17 us instead of ~9.  Off; kept as a validated
+        // alternative schedule (schedule fuzz)
+        int sweep_fuse = 0;
+        int sweep_read_mode = 0;              // how a fused sweep reads what other workgroups of the launch wrote: 0 returning atomic, 1 agent-scope load, 2 plain (experiment)
     } opt;
     // solver
     int precond = 0;
@@ -188,6 +196,12 @@ struct femo_ctx {
             *cinv0 = nullptr, *cinv1 = nullptr;
         long long *poff = nullptr, *soff = nullptr, *doff = nullptr, *linvoff = nullptr, *xoff = nullptr;
         double *P = nullptr, *S = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
+        // fused sweeps of the wide levels (option "sweep_fuse"): tiles as tasks of one launch per run of consecutive wide levels
+        int* slot_of = nullptr;               // position of every front in level_nodes
+        int* sweep_cnt = nullptr;             // two counters per position (k_sweep_wide_fwd / _bwd)
+        SweepTask *ftasks = nullptr, *btasks = nullptr;
+        std::vector<long long> h_ft_off;      // forward table (levels ascending): tasks of level L at [h_ft_off[L], h_ft_off[L + 1])
+        std::vector<long long> h_bt_begin, h_bt_end;   // backward table (levels descending): tasks of level L at [begin, end)
         hipGraphExec_t sweep_graph = nullptr; // one preconditioner application on c->z, captured (option "sweep_graph")
         long long sweep_graph_key = -1;       // options version the graph was captured under
         std::vector<long long> h_soff;        // host copy of the Schur offsets (femo_front_schur_get / block_set)
@@ -1160,6 +1174,24 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
+        if (fr.h_level_wide[L] && c->opt.sweep_fuse) {
+            // the run of consecutive wide levels from here: one launch, tiles ordered by per-front counters
+            if (join_xinv(c)) return 1;
+            int Le = L;
+            while (Le < l1 && fr.h_level_wide[Le]) ++Le;
+            const long long t0 = fr.h_ft_off[L], t1 = fr.h_ft_off[Le];
+            const int s0 = fr.h_level_off[L], s1 = fr.h_level_off[Le];
+            if (t1 > t0) {
+                HIPCHK(c, hipMemsetAsync(fr.sweep_cnt + 2 * (size_t)s0, 0, (size_t)(s1 - s0) * 2 * sizeof(int), c->stream));
+#define FWD_LAUNCH(RM_) hipLaunchKernelGGL(k_sweep_wide_fwd<RM_>, dim3((unsigned)(t1 - t0)), dim3(256), 0, c->stream, fd, (const int*)fr.level_nodes, \
+                                   (const SweepTask*)(fr.ftasks + t0), s0, (const int*)fr.slot_of, fr.sweep_cnt, v, y)
+                if (c->opt.sweep_read_mode == 0) FWD_LAUNCH(0); else if (c->opt.sweep_read_mode == 1) FWD_LAUNCH(1); else FWD_LAUNCH(2);
+#undef FWD_LAUNCH
+            }
+            for (int k = L; k < Le; ++k) { mark(); mark(); }        // the profile books the whole run under its first level
+            L = Le - 1;
+            continue;
+        }
         if (fr.h_level_wide[L]) {
             if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
@@ -1195,6 +1227,25 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
+        if (fr.h_level_wide[L] && c->opt.sweep_fuse) {
+            if (join_xinv(c)) return 1;
+            int Lb = L;                                            // the run of consecutive wide levels from L down to Lb
+            while (Lb > l0 && fr.h_level_wide[Lb - 1]) --Lb;
+            const long long t0 = fr.h_bt_begin[L], t1 = fr.h_bt_end[Lb];
+            const int s0 = fr.h_level_off[Lb], s1 = fr.h_level_off[L + 1];
+            if (t1 > t0) {
+                int mxnb = 128;
+                for (int k = Lb; k <= L; ++k) mxnb = std::max(mxnb, fr.h_level_maxnb[k]);
+                HIPCHK(c, hipMemsetAsync(fr.sweep_cnt + 2 * (size_t)s0, 0, (size_t)(s1 - s0) * 2 * sizeof(int), c->stream));
+#define BWD_LAUNCH(RM_) hipLaunchKernelGGL(k_sweep_wide_bwd<RM_>, dim3((unsigned)(t1 - t0)), dim3(256), (size_t)mxnb * sizeof(double), c->stream, fd, \
+                                   (const int*)fr.level_nodes, (const SweepTask*)(fr.btasks + t0), s1, (const int*)fr.slot_of, fr.sweep_cnt, y, v)
+                if (c->opt.sweep_read_mode == 0) BWD_LAUNCH(0); else if (c->opt.sweep_read_mode == 1) BWD_LAUNCH(1); else BWD_LAUNCH(2);
+#undef BWD_LAUNCH
+            }
+            for (int k = Lb; k <= L; ++k) { mark(); mark(); }
+            L = Lb;
+            continue;
+        }
         if (fr.h_level_wide[L]) {
             if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
@@ -1634,7 +1685,8 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.poff, c->fr.soff, c->fr.doff, c->fr.linvoff, c->fr.P, c->fr.S, c->fr.Linv,
-                     c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1};
+                     c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1, c->fr.slot_of, c->fr.sweep_cnt, c->fr.ftasks,
+                     c->fr.btasks};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->fr.sweep_graph) hipGraphExecDestroy(c->fr.sweep_graph);
@@ -1990,6 +2042,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "profile") c->fr.profile = v != 0;      // event pair around every factorisation launch until switched off (femo_factorize_profile_get)
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
+    else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
+    else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }
     else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
     else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;
     else return fail(c, "unknown option '" + k + "'");
@@ -2412,6 +2466,44 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         }
         UPI(fr.cinv0, inv0.data(), ndofs_total); UPI(fr.cinv1, inv1.data(), ndofs_total);
     }
+    {
+        // task tables of the fused wide sweeps (k_sweep_wide_fwd / _bwd): per wide level the first-phase tiles of its fronts (in level
+        // order), then the second-phase tiles; forward table by ascending level, backward table by descending level
+        std::vector<int> slot_of(ntree, 0);
+        for (int i = 0; i < ntree; ++i) slot_of[level_nodes[i]] = i;
+        std::vector<SweepTask> ft, bt;
+        fr.h_ft_off.assign(nlevels + 1, 0); fr.h_bt_begin.assign(nlevels, 0); fr.h_bt_end.assign(nlevels, 0);
+        for (int L = 0; L < nlevels; ++L) {
+            fr.h_ft_off[L] = (long long)ft.size();
+            // (first-phase tiles of ALL fronts of the level, then the second-phase tiles: with a front's two phases next to each other
+            //  the workgroups in flight are the waiting second-phase tiles of a few fronts while the other fronts' first phase queues)
+            if (fr.h_level_wide[L]) {
+                for (int i = level_off[L]; i < level_off[L + 1]; ++i)
+                    for (int k = 0; k < sweep_xtiles(npiv[level_nodes[i]]); ++k) ft.push_back({i, k});
+                for (int i = level_off[L]; i < level_off[L + 1]; ++i) {
+                    const int t = level_nodes[i];
+                    for (int k = 0; k < sweep_ltiles(npiv[t], nf[t] - npiv[t]); ++k) ft.push_back({i, (1 << 24) | k});
+                }
+            }
+        }
+        fr.h_ft_off[nlevels] = (long long)ft.size();
+        for (int L = nlevels - 1; L >= 0; --L) {
+            fr.h_bt_begin[L] = (long long)bt.size();
+            if (fr.h_level_wide[L]) {
+                for (int i = level_off[L]; i < level_off[L + 1]; ++i) {
+                    const int t = level_nodes[i];
+                    for (int k = 0; k < sweep_bblocks(npiv[t], nf[t] - npiv[t]); ++k) bt.push_back({i, k});
+                }
+                for (int i = level_off[L]; i < level_off[L + 1]; ++i)
+                    for (int k = 0; k < sweep_xtiles(npiv[level_nodes[i]]); ++k) bt.push_back({i, (1 << 24) | k});
+            }
+            fr.h_bt_end[L] = (long long)bt.size();
+        }
+        if (sweep_xtiles(fr.max_nf) >= (1 << 24)) return fail(c, "front too large for the fused sweep task table");
+        UPI(fr.slot_of, slot_of.data(), ntree);
+        UPI(fr.ftasks, ft.data(), ft.size()); UPI(fr.btasks, bt.data(), bt.size());
+        HIPCHK(c, hipMalloc((void**)&fr.sweep_cnt, (size_t)std::max(ntree, 1) * 2 * sizeof(int)));
+    }
     HIPCHK(c, hipMalloc((void**)&fr.P, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));
     HIPCHK(c, hipMemset(fr.P, 0, (size_t)std::max<long long>(fr.p_doubles, 1) * sizeof(double)));   // once: the upper triangles of L11 are never written
     // two doubles of padding: the gathering updates read Sc[0] of a child without a Schur block (or of the front itself when a
@@ -2431,6 +2523,9 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));

@@ -2435,6 +2435,235 @@ k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, do
     }
 }
 
+// ---- the wide levels as ONE launch per sweep direction: tiles as tasks with per-front dependencies.
+// Level by level, a sweep pays two dependent launches per wide level, and the first of the two (the product with X) lasts ~10 us
+// whatever it moves: at 1 M DOF twenty launches per sweep, 0.2 ms of an application of 1.5 ms, with the chip mostly idle.  Here every
+// 128 x 128 tile of X and of L21 (every block of 16 columns in the backward sweep) of ALL consecutive wide levels is one workgroup of
+// one grid, listed in the order the level-wise schedule would run them, and what a launch boundary used to enforce is a counter:
+//   forward    X tiles of front t wait until both children are complete; the L21 tiles of t wait until all X tiles of t have added
+//              their part of y_p -- with their own first 32 loads per thread already in flight;
+//   backward   the column blocks of L21^T x_B of front t wait until the parent is complete, the X^T tiles of t until all column
+//              blocks of t have subtracted their part.
+// Workgroups are dispatched in grid order and every dependency points to an EARLIER workgroup, so a waiting workgroup never
+// waits for one that cannot start.  Memory model (MI355X_MICROARCH.md, inter-workgroup visibility: the per-XCD L2s are not
+// coherent, a CU's L1 is never refreshed): every value that crosses workgroups inside the launch is WRITTEN by an agent-scope
+// atomic add and READ by a returning agent-scope atomic (add of zero) -- both execute at the memory side, never in a cache;
+// a workgroup signals (one lane, agent-scope atomic add on the front's counter) only after every one of its waves has waited
+// for its own atomics (s_waitcnt vmcnt(0)) and a workgroup barrier; the consumer polls the counter with agent-scope loads.
+struct SweepTask { int slot, kt; };                       // position of the front in level_nodes; kind << 24 | tile
+__device__ __host__ inline int sweep_nct(int np) { return (np + 127) / 128; }
+__device__ __host__ inline int sweep_xtiles(int np) { const int n = sweep_nct(np); return n * (n + 1) / 2; }
+__device__ __host__ inline int sweep_ltiles(int np, int nb) { return ((nb + 127) / 128) * sweep_nct(np); }
+constexpr int BB_COLS_F = 16;                             // columns per workgroup of the fused L21^T x_B (== BB_COLS)
+__device__ __host__ inline int sweep_bblocks(int np, int nb) { return nb > 0 ? (np + BB_COLS_F - 1) / BB_COLS_F : 0; }
+
+__device__ __forceinline__ void sweep_wait(const int* cnt, int want) {
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+}
+// RM 0: a returning atomic (add of zero): the value as the memory side holds it; RM 1: an agent-scope load (global_load sc1: past
+// this CU's L1); RM 2: a plain load (an experiment: NOT safe across workgroups)
+template <int RM>
+__device__ __forceinline__ double sweep_read(double* p) {
+    if (RM == 0) return __hip_atomic_fetch_add(p, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (RM == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+__device__ __forceinline__ void sweep_add(double* p, double v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every wave's atomics have been acknowledged, then one lane counts the workgroup in
+__device__ __forceinline__ void sweep_signal(int* c0, int* c1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (c0) __hip_atomic_fetch_add(c0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c1) __hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// forward: y_p = X b_p (kind 0), v_B -= L21 y_p (kind 1).  cnt[2 slot]: X tiles of the front done; cnt[2 slot + 1]: all tiles done.
+template <int RM>
+__global__ void __launch_bounds__(256)
+k_sweep_wide_fwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTask* __restrict__ tasks, int slot_lo,
+                 const int* __restrict__ slot_of, int* __restrict__ cnt, double* __restrict__ v, double* __restrict__ y) {
+    const SweepTask tk = tasks[blockIdx.x];
+    const int slot = tk.slot, kind = tk.kt >> 24, tile = tk.kt & 0xffffff;
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int nct = sweep_nct(np);
+    const int* gd = fd.dofs + fd.doff[t];
+    int* xdone = cnt + 2 * slot;
+    int* fin = xdone + 1;
+    __shared__ double xs[128];
+    __shared__ double part[128];
+    const int tid = threadIdx.x, lr = tid & 127, ch = tid >> 7;
+    if (kind == 0) {
+        int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        while (ti * (ti + 1) / 2 > tile) --ti;
+        const int tj = tile - ti * (ti + 1) / 2;
+        const int ld = ldx_of(np);
+        const double* M = fd.X + fd.xoff[t];
+        const int r0 = 128 * ti, c0 = 128 * tj, r = r0 + lr;
+        const double* row = M + r;                                 // (r < ld: inside X whatever np is)
+        const int cb0 = c0 + 64 * ch;                              // first column of this thread's half
+        const int cmax = min(np - cb0, 64);
+        const int clim = ti == tj ? min(cmax, lr - 64 * ch + 1) : cmax;
+        // the tile's own entries first (they depend on nothing), then the wait for the children; addresses are clamped into the
+        // front's columns and the values masked where they are used (no load sits in a branch)
+        double a[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + k, np - 1)];
+        if (tid == 0) {
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const int c = fd.child[sd][t];
+                if (c < 0) continue;
+                const int cs = slot_of[c];
+                if (cs < slot_lo) continue;                    // finished by an earlier launch
+                const int cnp = fd.npiv[c];
+                sweep_wait(cnt + 2 * cs + 1, sweep_xtiles(cnp) + sweep_ltiles(cnp, fd.nf[c] - cnp));
+            }
+        }
+        __syncthreads();
+        if (tid < 128) xs[tid] = c0 + tid < np ? sweep_read<RM>(&v[gd[c0 + tid]]) : 0.0;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += (r < np && k < clim ? a[k] : 0.0) * xs[64 * ch + k];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + 32 + k, np - 1)];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += (r < np && 32 + k < clim ? a[k] : 0.0) * xs[64 * ch + 32 + k];
+        if (ch) part[lr] = s;
+        __syncthreads();
+        if (!ch && r < np) sweep_add(&y[gd[r]], s + part[lr]);
+        sweep_signal(xdone, fin);
+    } else {
+        const int nb = nf - np;
+        const int ti = tile / nct, tj = tile % nct;
+        const int ld = ldp_of(nf);
+        const double* M = fd.P + fd.poff[t] + np;                  // L21 starts at row np of the pivot columns
+        const int cw = ((np + nct - 1) / nct + 1) & ~1, hw = cw / 2;
+        const int r0 = 128 * ti, c0 = cw * tj, r = r0 + lr;
+        const double* row = M + min(r, nb - 1);
+        const int cb0 = c0 + hw * ch;
+        const int clim = min(np - cb0, hw);
+        double a[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + k, np - 1)];
+        if (tid == 0) sweep_wait(xdone, sweep_xtiles(np));
+        __syncthreads();
+        if (tid < 128) xs[tid] = (tid < cw && c0 + tid < np) ? sweep_read<RM>(&y[gd[c0 + tid]]) : 0.0;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += (k < clim ? a[k] : 0.0) * xs[hw * ch + k];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + 32 + k, np - 1)];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += (32 + k < clim ? a[k] : 0.0) * xs[hw * ch + 32 + k];
+        if (ch) part[lr] = s;
+        __syncthreads();
+        if (!ch && r < nb) sweep_add(&v[gd[np + r]], -(s + part[lr]));
+        sweep_signal(nullptr, fin);
+    }
+}
+
+// backward: s_p = y_p - L21^T x_B (kind 0, one workgroup per 16 pivot columns), x_p = X^T s_p (kind 1).
+// cnt[2 slot]: column blocks of the front done; cnt[2 slot + 1]: X^T tiles done (the front is complete when all are).
+template <int RM>
+__global__ void __launch_bounds__(256)
+k_sweep_wide_bwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTask* __restrict__ tasks, int slot_hi,
+                 const int* __restrict__ slot_of, int* __restrict__ cnt, double* __restrict__ sv, double* __restrict__ xv) {
+    const SweepTask tk = tasks[blockIdx.x];
+    const int slot = tk.slot, kind = tk.kt >> 24, tile = tk.kt & 0xffffff;
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t], nf = fd.nf[t];
+    const int nb = nf - np;
+    const int* gd = fd.dofs + fd.doff[t];
+    int* bdone = cnt + 2 * slot;
+    int* xfin = bdone + 1;
+    extern __shared__ double xsd[];                       // kind 0: nb doubles (x_B); kind 1: 128
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (kind == 0) {
+        const int c0 = tile * BB_COLS_F;
+        const int ldp = ldp_of(nf);
+        const double* L21 = fd.P + fd.poff[t] + np;
+        const int cb = c0 + 4 * wv;
+        const double* col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[k] = L21 + (size_t)ldp * min(cb + k, np - 1);
+        // the first 512 rows of the wave's four columns are requested before the wait
+        double a[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[k][u] = col[k][min(lane + 64 * u, nb - 1)];
+        if (tid == 0) {
+            const int p = fd.parent[t];
+            if (p >= 0 && slot_of[p] < slot_hi) sweep_wait(cnt + 2 * slot_of[p] + 1, sweep_xtiles(fd.npiv[p]));
+        }
+        __syncthreads();
+        for (int r = tid; r < nb; r += 256) xsd[r] = sweep_read<RM>(&xv[gd[np + r]]);
+        __syncthreads();
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int rb = 0; rb < nb; rb += 512) {
+            if (rb > 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[k][u] = col[k][min(rb + lane + 64 * u, nb - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + lane + 64 * u;
+                const double xr = r < nb ? xsd[r] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += a[k][u] * xr;
+            }
+        }
+        int k;
+        const double tot = wave_sum_cols<4>(s, lane, k);
+        if (!(lane & 15) && cb + k < np) sweep_add(&sv[gd[cb + k]], -tot);
+        sweep_signal(bdone, nullptr);
+    } else {
+        int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+        while (ti * (ti + 1) / 2 > tile) --ti;
+        const int tj = tile - ti * (ti + 1) / 2;
+        const int ld = ldx_of(np);
+        const double* M = fd.X + fd.xoff[t];
+        const int r0 = 128 * ti, c0 = 128 * tj;
+        const int ra = r0 + lane, rb = r0 + lane + 64;
+        double a0[32], a1[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int c = c0 + 32 * wv + k;
+            const double* colp = M + (size_t)ld * min(c, np - 1);
+            a0[k] = colp[min(ra, np - 1)];
+            a1[k] = colp[min(rb, np - 1)];
+        }
+        if (tid == 0) sweep_wait(bdone, sweep_bblocks(np, nb));
+        __syncthreads();
+        if (tid < 128) xsd[tid] = r0 + tid < np ? sweep_read<RM>(&sv[gd[r0 + tid]]) : 0.0;
+        __syncthreads();
+        const double x0 = xsd[lane], x1 = xsd[lane + 64];
+        double p[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int c = c0 + 32 * wv + k;
+            const bool ca = c < np && ra < np && ra >= c, cbb = c < np && rb < np && rb >= c;     // triangular: rows >= column
+            p[k] = (ca ? a0[k] : 0.0) * x0 + (cbb ? a1[k] : 0.0) * x1;
+        }
+        int colw;
+        const double sum = wave_sum_cols<32>(p, lane, colw);
+        const int c = c0 + 32 * wv + colw;
+        if (!(lane & 1) && c < np) sweep_add(&xv[gd[c]], sum);
+        sweep_signal(nullptr, xfin);
+    }
+}
+
 // X = L11^-1 beyond its 128 x 128 diagonal blocks (which k_diag_block leaves in place), by recursive doubling: at block
 // size bs = 128, 256, 512, ... the inverse of every aligned 2 bs block [[A, 0], [C, B]] of L11 is completed from the
 // inverses XA, XB of its halves,  X_BA = -XB (C XA):
