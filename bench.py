@@ -197,15 +197,18 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m", nqua
     needs FEniCSx/PETSc and cannot run here, so this is oracle/cpu_baseline.py, the repository's float64 restatement of
     its algorithm: C++/OpenMP element assembly + a multifrontal Cholesky on dense fronts with LAPACK/BLAS (what MUMPS is
     algorithmically), on the SAME mesh, fields and quadrature rule as the GPU run.  Bounded sample: the best-effort forward
-    solve (1 assembly + 1 factorisation + 3 solves), median of up to 3 runs inside ``budget_s``, at TWO thread counts: 16 (the
-    CPU share of a one-GPU box) and every core this process may run on (at most 64: scipy's OpenBLAS is built for 64
-    threads); ``value`` is the FASTER of the two, the other one is reported beside it; plus one single-core run if the
-    budget allows.  The full protocol of BASELINE.md section 3 (both core counts, "as the reference runs it" with SuperLU,
+    solve (1 assembly + 1 factorisation + 3 solves), median of up to 3 runs inside ``budget_s``, at 16 threads (the CPU share of a
+    one-GPU box) and, where the job is GRANTED more, at every core (at most 64: scipy's OpenBLAS is built for 64 threads) -- the
+    control group's CPU quota counts, not the affinity mask: a one-GPU box lists 256 hardware threads and grants 16, and round 4's
+    "all cores" leg of 64 threads was throttled by the scheduler into being 5 x slower than 16 (``cpu_quota_cores``,
+    ``throttled_periods_during_cpu_legs`` in the output; profiles/r5_cpu_levels.txt).  ``value`` is the FASTEST leg; plus one
+    single-core run if the budget allows.  The full protocol of BASELINE.md section 3 (both core counts, "as the reference runs it" with SuperLU,
     5 repeats) is scripts/cpu_baseline_full.py -> profiles/."""
     from femo_alpha_amd.solver.symbolic import build_plan
     from oracle import cpu_baseline as cb
     from oracle.rm_shell_oracle import ShellOracle
     t_begin = time.perf_counter()
+    throttled0 = cb.cpu_throttled_periods()
     o = ShellOracle(m, nquad=nquad, penalty_facets=m.penalty_facets(marker))
     o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
     plan = build_plan(m, leaf)
@@ -256,7 +259,7 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m", nqua
                       f"residuals (all executed) = {best['forward_s']:.2f} s, median of {best['runs']} after 1 warm-up, {best['cores']} threads "
                       f"(the faster of {[l['cores'] for l in legs]} threads); adjoint gradient with the same factor (C++/OpenMP quadrature of "
                       f"dJ/du, dJ/dh and (dR/dh)^T lambda, 2 solves + 1 residual) {best['adjoint_ms'] / 1e3:.3f} s, median of 3",
-               forward_s=best["forward_s"], adjoint_ms=best["adjoint_ms"], visible_hardware_threads=os.cpu_count())
+               forward_s=best["forward_s"], adjoint_ms=best["adjoint_ms"], **cpu_allowance(cb, throttled0))
     for l in legs:
         out["gpu_share_16_threads" if l["cores"] == share else "all_cores"] = l
     if time.perf_counter() - t_begin + 1.2 * share * legs[0]["forward_s"] < 2 * budget_s + 30.0:    # one single-core run, if it fits (same, already touched, fronts)
@@ -267,6 +270,15 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m", nqua
             out["full_protocol"] = full
             break
     return out
+
+
+def cpu_allowance(cb, throttled0):
+    """What "all cores" means for this job: the hardware threads the affinity mask lists, the CPUs the control group grants time on
+    (a one-GPU box of this pool: 256 listed, 16 granted -- threads beyond the quota are throttled, so the quota IS every core this
+    job has), and how many scheduling periods the CPU legs were throttled in (0 when the thread count respects the quota)."""
+    t1 = cb.cpu_throttled_periods()
+    return dict(visible_hardware_threads=os.cpu_count(), cpu_quota_cores=cb.cpu_quota_cores(),
+                throttled_periods_during_cpu_legs=None if t1 is None or throttled0 is None else t1 - throttled0)
 
 
 def dynamic_case(nx=82, ny=410, nsteps=100):
@@ -291,6 +303,7 @@ def cpu_baseline_dynamic(mesh, dt, F, leaf, nsteps):
     from femo_alpha_amd.solver.symbolic import build_plan
     from oracle import cpu_baseline as cb
     from oracle.rm_shell_oracle import ShellOracle
+    throttled0 = cb.cpu_throttled_periods()
     strong = mesh.locate_dofs_geometrical(lambda x: np.isclose(x[0], 0.0, atol=1e-6))
     o = ShellOracle(mesh, strong_dofs=strong, nred=2)
     o.set_fields(h=0.1, E=1e8, nu=0.3, rho=10.0)
@@ -316,7 +329,7 @@ def cpu_baseline_dynamic(mesh, dt, F, leaf, nsteps):
                       f"({best['s_per_time_step_factor_once']:.3f} s per time step); {best['cores']} threads (the faster of "
                       f"{[l['cores'] for l in legs]})",
                time_steps_per_s=1.0 / best["s_per_time_step_reassembled"],
-               time_steps_per_s_factor_once=1.0 / best["s_per_time_step_factor_once"], visible_hardware_threads=os.cpu_count())
+               time_steps_per_s_factor_once=1.0 / best["s_per_time_step_factor_once"], **cpu_allowance(cb, throttled0))
     for l in legs:
         out["gpu_share_16_threads" if l["cores"] == share else "all_cores"] = l
     return out

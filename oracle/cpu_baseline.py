@@ -325,7 +325,11 @@ class CpuMultifrontal:
         self._dirichlet()
         t1 = time.perf_counter()
         for lev in self.levels:
-            many = lev.size >= 2 * self.nthreads or self.nthreads == 1
+            # one front per OpenMP thread (BLAS single-threaded) from half as many fronts as threads on; the few fronts above run one after
+            # the other with threaded BLAS.  Measured on the GPU box's host at 16 threads (profiles/r5_cpu_levels.txt): the level of 16 fronts
+            # 26 against 126 ms, of 8 fronts 55 against 84, of 4 fronts 82 against 56 -- round 4's rule (2 x threads) sent the levels of 16
+            # and 8 fronts through the slow branch: factorisation 0.53 -> 0.39 s
+            many = lev.size >= max(2, self.nthreads // 2) or self.nthreads == 1
             with threadpool_limits(limits=1 if many else self.nthreads):
                 rc = lib.cpu_fronts_factor_level(lev.size, _i(lev), _i(self.nf), _i(self.npiv), _l(self.front_off), _l(self.dof_off),
                                                  _i(self.left), _i(self.right), _i(self.up_map), _d(self.F), self.ptr["potrf"],
@@ -433,13 +437,51 @@ def cpu_model_name():
     return "unknown"
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time the control group of this process may use per scheduling period (cgroup v2 ``cpu.max``, v1
+    ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``), or None without a quota.  A one-GPU box of this pool lists 256 hardware threads in
+    ``sched_getaffinity`` and grants 16: more runnable threads than that are throttled by the scheduler for the rest of every 100 ms
+    period -- which is why round 4's "all cores" leg (64 threads) took 3.7 s for a factorisation that 16 threads do in 0.5 s
+    (profiles/r5_cpu_levels.txt: stalls of 70-100 ms per parallel region, at random)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            return max(1, int(quota) // int(period))
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            quota, period = int(fq.read()), int(fp.read())
+        return max(1, quota // period) if quota > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_throttled_periods():
+    """Scheduling periods in which this control group was throttled so far (cgroup v2 ``cpu.stat``), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            for line in fh:
+                if line.startswith("nr_throttled"):
+                    return int(line.split()[1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def host_cores(cap=None):
-    """Threads the baseline may use: the cores this process can run on, capped at the CPU share a one-GPU box gives a
-    job (16; ``FEMO_CPU_CORES`` overrides).  scipy's OpenBLAS is built for at most 64 threads and crashes beyond."""
+    """Threads the baseline may use: the cores this process can run on AND is granted time on (affinity mask, then the control
+    group's CPU quota), capped at the CPU share a one-GPU box gives a job (16; ``FEMO_CPU_CORES`` overrides; ``cap`` = 64 asks for
+    "every core").  scipy's OpenBLAS is built for at most 64 threads and crashes beyond."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    if quota is not None:
+        n = min(n, quota)
     cap = int(os.environ.get("FEMO_CPU_CORES", 16)) if cap is None else cap
     return max(1, min(n, cap, 64))
 
