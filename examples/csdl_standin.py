@@ -4,7 +4,8 @@ The reference's operators subclass ``csdl.CustomExplicitOperation`` /
 ``csdl.experimental.CustomImplicitOperation`` and are driven by a CSDL simulator
 (reference femo_alpha/csdl_alpha_opt/state_operation.py:8, output_operation.py:6,72).
 ``csdl_alpha`` is not installable here; when it *is* importable the
-package uses the real thing (see ``femo_alpha_amd.csdl``), otherwise this module provides the
+package uses the real thing (see ``femo_alpha_amd.csdl``), otherwise this module -- scaffolding for the tests and examples,
+not part of the product package -- provides the
 same protocol -- ``declare_input / create_output / declare_derivative_parameters``, inline
 execution as with ``csdl.Recorder(inline=True)`` (ex_simple_shell_opt.py:58), and a small
 reverse-mode driver (``Recorder.compute_totals`` / ``check_totals``) that calls

@@ -523,7 +523,7 @@ class ShellContext:
     def last_timing(self):
         t = np.zeros(5)
         self._chk(self.lib.femo_last_timing(self._h, dptr(t)))
-        return dict(setup_ms=t[0], krylov_ms=t[1], total_ms=t[2], operator_launches=int(t[4]))
+        return dict(setup_ms=t[0], krylov_ms=t[1], total_ms=t[2], factor_state=int(t[3]), operator_launches=int(t[4]))
 
     def bench_kernel(self, name, reps=50):
         v = C.c_double()

@@ -175,6 +175,15 @@ struct femo_ctx {
         // own atomics before it may signal, and a tile in flight holds one of 512 slots for ~17 us instead of ~9.  Off; kept as a validated
         // alternative schedule (schedule fuzz)
         int sweep_fuse = 0;
+        // Optimisation loops: when only FIELDS changed since the last factorisation (a new thickness), keep that factor as the PCG
+        // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
+        // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
+        // reference never refreshes its derivative matrices at all (quirk Q2, csdl_alpha_opt/state_operation.py:130-131)
+        int stale_factor = 0;
+        // ... and only while no field has moved further than this from the factor's design (relative L2 norm).  Measured at 1 M DOF
+        // (profiles/r5_stale_factor.txt): forward + adjoint with the kept factor 12.8 / 15.7 / 18.7 / 24.7 ms at a relative nodal change of
+        // 1e-4 / 1e-3 / 3e-3 / 1e-2 (L2: 0.58 of that) against 20.0 ms re-factorised -- the break-even sits at ~2.5e-3
+        double stale_rel = 2e-3;
         int sweep_read_mode = 0;              // how a fused sweep reads what other workgroups of the launch wrote: 0 returning atomic, 1 agent-scope load, 2 plain (experiment)
     } opt;
     // solver
@@ -187,6 +196,9 @@ struct femo_ctx {
     // multifrontal preconditioner (precond == 2)
     struct Frontal {
         bool ready = false, factored = false;
+        bool have_factor = false;             // a complete factorisation of SOME earlier operator sits in the panel store (option "stale_factor")
+        double* snap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // thickness, E, nu, density, uhat as they were when that factor was made
+        bool snap_valid = false;
         bool x_inflight = false;              // k_xinv launches on stream3 that the main stream has not waited for yet (event ev_x[1])
         int ntree = 0, nlevels = 0;
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
@@ -241,7 +253,7 @@ static int fail(femo_ctx* c, const std::string& msg) {
 }
 
 // whatever the operator A = aK K + aM M (+ Dirichlet treatment) depends on has changed: both preconditioners are stale
-static void operator_changed(femo_ctx* c);
+static void operator_changed(femo_ctx* c, bool fields_only = false);
 
 // ------------------------------------------------------------------------------------------ tables
 static void gauss_legendre(int n, double* x, double* w) {
@@ -463,7 +475,13 @@ static FacetDev facet_dev(const femo_ctx* c) {
 
 static const int EB = 128;   // element kernels: threads per block (one element per thread)
 
-static void operator_changed(femo_ctx* c) { c->jacobi_dirty = true; c->fr.factored = false; }
+// fields_only: a material / thickness / geometry field was re-uploaded -- the old factor no longer belongs to the operator, but it is still the
+// factor of a NEARBY symmetric positive definite operator on the same pattern and may serve as the PCG preconditioner (option "stale_factor");
+// any other change (Dirichlet data, operator coefficients, quadrature, scaling) discards it
+static void operator_changed(femo_ctx* c, bool fields_only) {
+    c->jacobi_dirty = true; c->fr.factored = false;
+    if (!fields_only) c->fr.have_factor = false;
+}
 
 static int refresh_penalty(femo_ctx* c) {
     if (c->nf == 0 || !c->penalty_dirty) return 0;
@@ -1122,6 +1140,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     if (assemble) { fr.t_assemble_ms = ta; fr.t_factor_ms = 0; }
     fr.t_factor_ms += tf; fr.pivots_fixed = info;
     fr.factored = (l1 == fr.nlevels);
+    fr.have_factor = fr.factored;
     int pivot_rc = 0;
     if (info > 0 && !c->opt.allow_pivot_repair) {
         // the reference's LU would factorise an indefinite matrix; a Cholesky factor of one does not exist, and a silently
@@ -1130,7 +1149,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         snprintf(buf, sizeof buf, "multifrontal Cholesky: %d non-positive pivot(s) -- the operator is not positive definite "
                  "(negative thickness / modulus, or no Dirichlet data?)", info);
         c->err = buf;
-        fr.factored = false;
+        fr.factored = false; fr.have_factor = false;
         pivot_rc = 5;
     }
     for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
@@ -1309,14 +1328,49 @@ static int frontal_solve_z(femo_ctx* c) {
     return 0;
 }
 
+// option "stale_factor": remember the fields the factor just made belongs to
+static int snapshot_fields(femo_ctx* c) {
+    if (c->opt.stale_factor <= 0) { c->fr.snap_valid = false; return 0; }
+    double* cur[5] = {c->h, c->E, c->nu, c->rho, c->has_uhat ? c->uhat : nullptr};
+    const int64_t len[5] = {c->nT, c->nT, c->nT, c->nT, 3 * (int64_t)c->nn};
+    for (int i = 0; i < 5; ++i) {
+        if (!cur[i]) { if (c->fr.snap[i]) { hipFree(c->fr.snap[i]); c->fr.snap[i] = nullptr; } continue; }
+        if (!c->fr.snap[i]) HIPCHK(c, hipMalloc((void**)&c->fr.snap[i], (size_t)len[i] * sizeof(double)));
+        HIPCHK(c, hipMemcpyAsync(c->fr.snap[i], cur[i], (size_t)len[i] * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->fr.snap_valid = true;
+    return 0;
+}
+
 // PCG preconditioned by the multifrontal factorisation (a handful of iterations)
 static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iters, double* relres) {
     const int64_t n = c->ndof;
     const int vg = vec_grid(n);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    if (!c->fr.factored)
+    // option "stale_factor": the factor of an earlier design preconditions this solve; refreshed below if the iteration drags
+    bool stale = !c->fr.factored && c->opt.stale_factor > 0 && c->fr.have_factor && c->fr.snap_valid;
+    if (stale) {
+        // how far the design has moved from the one the factor belongs to: beyond stale_rel the iterations a kept factor needs cost
+        // more than a factorisation (profiles/r5_stale_factor.txt), so it is refreshed at once
+        double* cur[5] = {c->h, c->E, c->nu, c->rho, c->has_uhat ? c->uhat : nullptr};
+        const int64_t len[5] = {c->nT, c->nT, c->nT, c->nT, 3 * (int64_t)c->nn};
+        for (int i = 0; i < 5 && stale; ++i) {
+            if (!cur[i] || !c->fr.snap[i]) continue;
+            HIPCHK(c, hipMemsetAsync(c->scal + 5, 0, 2 * sizeof(double), c->stream));
+            hipLaunchKernelGGL(k_sq_change, dim3(red_grid(len[i])), dim3(256), 0, c->stream, (const double*)cur[i], (const double*)c->fr.snap[i], len[i], c->scal + 5);
+            HIPCHK(c, hipMemcpyAsync(c->scal_host + 5, c->scal + 5, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const double d2 = c->scal_host[5], r2 = c->scal_host[6];
+            if (!(d2 <= c->opt.stale_rel * c->opt.stale_rel * r2)) stale = false;
+        }
+    }
+    int factor_state = stale ? 1 : 0;
+    if (stale) { c->fr.t_assemble_ms = 0; c->fr.t_factor_ms = 0; }
+    if (!c->fr.factored && !stale) {
         if (int rc = frontal_factorize(c)) return rc;
+        if (snapshot_fields(c)) return 1;
+    }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     auto dot = [&](const double* a, const double* bb, double* out) -> int {
         HIPCHK(c, hipMemsetAsync(c->scal + 7, 0, sizeof(double), c->stream));
@@ -1346,12 +1400,27 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     int k = 0, napply = 0;
     const double target = c->rtol * c->rtol * bb;
     // device scalars: [0] r.z of the previous iteration, [1] r.z, [2] p.Ap, [3] r.r -- one host synchronisation per iteration
+    int k_restart = 0;                             // iteration at which the search directions start afresh
     while (bb > 0 && rr > target && k < c->maxit) {
+        if (stale && k >= c->opt.stale_factor) {
+            // the kept factor is too far from this operator: factorise the current one and restart from the iterate reached so far
+            if (int rc = frontal_factorize(c)) return rc;
+            if (snapshot_fields(c)) return 1;
+            stale = false; factor_state = 2; k_restart = k;
+            hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
+            if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
+            ++napply;
+            HIPCHK(c, hipMemcpyAsync(c->r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            hipLaunchKernelGGL(k_axpby, dim3(vg), dim3(256), 0, c->stream, c->r, -1.0, c->Ap, 1.0, n);
+            if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, c->r, mask, n);
+            if (dot(c->r, c->r, &rr)) return 1;
+            if (!(rr > target)) break;
+        }
         HIPCHK(c, hipMemsetAsync(c->scal + 1, 0, 3 * sizeof(double), c->stream));
         HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (frontal_solve_z(c)) return 1;
         hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, c->r, c->z, n, c->scal + 1);
-        hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->scal, k == 0 ? 1 : 0, n);
+        hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->scal, k == k_restart ? 1 : 0, n);
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
         if (op_apply(c, c->p, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
         ++napply;
@@ -1370,7 +1439,9 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     float t_loop = 0;
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
     c->timing[0] = c->fr.t_assemble_ms + c->fr.t_factor_ms; c->timing[1] = t_loop; c->timing[2] = c->timing[0] + t_loop;
-    c->timing[4] = napply;
+    if (factor_state == 2) c->timing[1] = std::max(0.0, (double)t_loop - c->timing[0]);      // the refresh happened inside the loop's event pair
+    c->timing[2] = c->timing[0] + c->timing[1];
+    c->timing[3] = factor_state; c->timing[4] = napply;
     return finish_solve(c, "PCG (multifrontal preconditioner)", k, rr, bb, target, iters, relres);
 }
 
@@ -1686,7 +1757,7 @@ void femo_destroy(femo_ctx* c) {
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.poff, c->fr.soff, c->fr.doff, c->fr.linvoff, c->fr.P, c->fr.S, c->fr.Linv,
                      c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1, c->fr.slot_of, c->fr.sweep_cnt, c->fr.ftasks,
-                     c->fr.btasks};
+                     c->fr.btasks, c->fr.snap[0], c->fr.snap[1], c->fr.snap[2], c->fr.snap[3], c->fr.snap[4]};
     for (void* p : fptrs)
         if (p) hipFree(p);
     if (c->fr.sweep_graph) hipGraphExecDestroy(c->fr.sweep_graph);
@@ -1822,7 +1893,7 @@ int femo_set_field(femo_ctx* c, const char* name, const double* v, int64_t n) {
         return 0;                                   // the prescribed values enter the right-hand side only
     }
     // the load never enters the operator; the density only through the inertia term aM M
-    if (d != c->f && (d != c->rho || c->op_aM != 0.0)) operator_changed(c);
+    if (d != c->f && (d != c->rho || c->op_aM != 0.0)) operator_changed(c, true);
     return 0;
 }
 
@@ -2043,6 +2114,8 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
+    else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
+    else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
     else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }
     else if (k == "swork_slots") { if (c->fr.ready || v < 1) return fail(c, "swork_slots >= 1, before femo_set_frontal_plan"); o.swork_slots = v; }
     else if (k == "xinv_small_cnt") o.xinv_small_cnt = v;

@@ -1594,6 +1594,18 @@ __global__ void k_dot(const double* __restrict__ a, const double* __restrict__ b
     block_accumulate((s0 + s1) + (s2 + s3), slot);
 }
 
+// slot[0] += sum (a - b)^2, slot[1] += sum b^2: how far a field has moved from a snapshot (option "stale_factor")
+__global__ void k_sq_change(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* slot) {
+    double d = 0.0, r = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double x = a[i] - b[i];
+        d += x * x; r += b[i] * b[i];
+    }
+    block_accumulate(d, slot);
+    block_accumulate(r, slot + 1);
+}
+
 // ---- consistent mass matrix of the pressure space [CG1]^3, matrix-free: y += A x (diag != null: diag += diag(A) instead), one thread
 // per cell, node-major xyz vectors of length 3 nn.  A = int Pv . w dx on the undeformed surface (rm_shell_pde.py:194-209): 3 x 3
 // Gauss points on quadrilaterals, the 3-point rule on triangles (exact for the bilinear / linear basis on affine cells).

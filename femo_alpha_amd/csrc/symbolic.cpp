@@ -99,6 +99,8 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
                 const int32_t t = frontier[k], a = lo[t], b = hi[t], n = b - a;
                 const bool want = gap_mode ? depth[t] < fixed_depth : (n > leaf_size || depth[t] < min_depth);
                 if (!want) continue;
+                // a piece of one cell cannot be cut: an error below the depth the caller asked for (2^d partitions), otherwise a leaf that
+                // hangs higher in the tree -- levels are assigned by height (section 4 of the header comment), so the schedule does not mind
                 if (n < 2) { if (depth[t] < min_depth) bad |= 1; continue; }
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, cs[3] = {0.0, 0.0, 0.0};
                 for (int32_t i = a; i < b; ++i)
@@ -152,7 +154,7 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
                         const int32_t m0 = sort_and_cut(c, oc);
                         // sep(m) for EVERY cut position m of this order in one pass: a node lies in the separator of m iff the first cell
                         // that touches it sits before m and the last one at or after m -- a difference array over the positions
-                        const int32_t sid = 4 * t + q;
+                        const int32_t sid = 4 * t + q;               // (int32: trees of up to 5e8 nodes, i.e. ~3e9 cells -- beyond one device by far)
                         sc.touched.clear();
                         for (int32_t i = 0; i < n; ++i)
                             for (int al = 0; al < npc; ++al) {

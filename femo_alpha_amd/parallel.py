@@ -250,6 +250,7 @@ class DistributedShell:
             if not self.factored:
                 self.factorize()
             eng.pcg_start(b, x)
+            self.last["converged"] = True          # of THIS solve; the maxit branch below flips it
             k, bb, rr = 0, None, None
             while True:
                 # z = r and the forward sweep over the rank's subtree; its contributions to the replicated entries and the

@@ -17,13 +17,16 @@ from ..mesh import ShellMesh
 from .rm_shell_pde import FacetSet, RMShellPDE
 
 
-def solve_linear(A, b, ctx=None):
+def solve_linear(A, b, ctx):
     """pressure = A^-1 force as a differentiable node: ``csdl.solve_linear`` when csdl_alpha is installed (what the
     reference calls, rm_shell_model.py:420); otherwise an explicit operation whose solve runs on the device
     (``femo_force_to_pressure``: Jacobi-PCG with the consistent [CG1]^3 mass matrix applied cell by cell -- the matrix ``A`` of
-    ``construct_force_to_pressure_map`` is the same operator and is not touched)."""
+    ``construct_force_to_pressure_map`` is the same operator and is not touched).  ``ctx``: the shell context whose device runs
+    that solve (required: there is no host fallback)."""
     if csdl.HAVE_CSDL_ALPHA:
         return csdl.solve_linear(A.toarray(), b)
+    if ctx is None:
+        raise ValueError("solve_linear: without csdl_alpha the force -> pressure solve runs on the device and needs the shell context")
 
     class _Solve(csdl.CustomExplicitOperation):
         def evaluate(self, rhs):
@@ -195,6 +198,8 @@ class RMShellModel:
         else:
             # nodal forces -> nodal pressures through the consistent mass matrix (rm_shell_model.py:414-421)
             # the matrix itself is only needed by csdl_alpha's solve_linear; the stand-in solves on the device
+            if self.elementwise_pressure:          # as construct_force_to_pressure_map says, with or without csdl_alpha
+                raise NotImplementedError("force -> pressure conversion is defined for nodal pressures")
             A = self.shell_pde.construct_force_to_pressure_map() if csdl.HAVE_CSDL_ALPHA else None
             shell_inputs.F_solid = solve_linear(A, reshaped_force, ctx=self.shell_pde.ctx)
         shell_inputs.F_solid.add_name("F_solid")

@@ -138,6 +138,18 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "fuse_rows" (default 1), "fuse_rows_cnt" (2048), "fuse_rows_np" (256): levels of at least that many fronts whose widest front has at most
  *   that many pivots form the rows under a diagonal block inside the diagonal-block kernel;
  *   "rows_fine_wg" (96), "narrow_fine_wg" (128): launches of at most that many workgroups take the kernels with 16 rows / a 16 x 16 block per wave;
+ *   "stale_factor" (default 0)       n > 0: when only FIELDS (thickness, E, nu, density, uhat) changed since the last factorisation, that
+ *                                    factor is kept as the PCG preconditioner and the operator is re-factorised only if a solve has not
+ *                                    converged after n iterations (the iteration then restarts from the iterate it reached), and at once
+ *                                    if a field has moved more than "stale_rel" (default 2e-3, relative L2 norm) from the factor's design:
+ *                                    beyond that the extra iterations cost more than the factorisation (profiles/r5_stale_factor.txt).  PCG works on
+ *                                    the current matrix-free operator: the solution is the same.  For optimisation loops, where successive
+ *                                    designs are close; the reference itself never refreshes its derivative matrices
+ *                                    (csdl_alpha_opt/state_operation.py:130-131).  femo_last_timing [3] says which factor a solve used;
+ *   "strip_cnt" (0), "strip_kmax" (160), "strip_depth" (1): rank-k updates with K <= strip_kmax on levels of at least strip_cnt fronts by
+ *   one workgroup per 64-row strip of a front (k_schur_strip) -- measured slower than the tile kernel, off (profiles/r5_strip_ab.txt);
+ *   "sweep_fuse" (0): all consecutive wide levels of a triangular sweep as ONE launch, tiles ordered by per-front counters -- measured
+ *   slower than the level-wise launches, off (profiles/r5_sweep_fuse_ab.txt); "sweep_read_mode" (its read of other workgroups' values);
  *   "equilibrate" (0), "precond_nquad" (0): measured experiments, off;
  *   "grid_chunk" (fronts per launch, <= 65535);
  *   "wide_np", "wide_cnt" (which tree levels take the wide triangular-solve kernels; before femo_set_frontal_plan);
@@ -239,8 +251,9 @@ int femo_total_gradient(femo_ctx* ctx, const char* functional, const char* arg, 
                         int32_t* iters, double* relres);
 
 /* Timing of the most recent solve, measured with HIP events on the context's stream (ms):
- * [0] setup (diagonal / preconditioner), [1] Krylov loop, [2] total, [3] element-operator kernel
- * average launch duration (ms), [4] number of element-operator launches. */
+ * [0] setup (diagonal / preconditioner), [1] Krylov loop (with option "stale_factor": a factorisation inside the loop included),
+ * [2] total, [3] the multifrontal factor that preconditioned the solve: 0 the current operator's, 1 one kept from an earlier
+ * design (option "stale_factor"), 2 a kept one that was refreshed inside the solve; [4] number of element-operator launches. */
 int femo_last_timing(const femo_ctx* ctx, double* out5);
 
 /* Average duration (ms) of `reps` back-to-back launches of one kernel, timed with HIP events on

@@ -38,7 +38,10 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
  * longest centroid extent).
  *   gap_coeff > 0: a piece of n >= 128 cells is cut at the largest gap between consecutive sorted centroid coordinates within
  *     n/2 +- min(1/8, gap_coeff / sqrt(n)) n (about one row of cells either way), so that the cut follows a mesh line where the mesh
- *     has any row structure; the tree then has the fixed depth max(min_depth, ceil(log2(nel / leaf_size))).
+ *     has any row structure; the tree then has the fixed depth max(min_depth, ceil(log2(nel / leaf_size))).  leaf_size is then the
+ *     AVERAGE number of cells per leaf, not a bound: every cut may sit up to the window's width off the middle and the imbalance compounds
+ *     (leaves of up to ~1.5 leaf_size cells).  A piece that runs out of cells above that depth (fewer than two) stays a leaf there: levels
+ *     are assigned by HEIGHT (a leaf is level 0 wherever it hangs), so the schedule is unaffected.
  *   axis_rule 1: cut across the axis along which the piece is longest in CELLS (centroid extent / mean cell extent; cext: nel x 3
  *     extents of the cells' bounding boxes), not in length units.
  *   axis_rule 2 (the package's default): a piece of n >= 16 cells is cut along every axis it extends in (in the order of rule 1's

@@ -261,7 +261,9 @@ def test_thickness_optimisation_loop():
     """The reference's example end to end (ex_simple_shell_opt.py:114-131): thickness design variable with bounds,
     mass held at its initial value, an SLSQP loop in which every function evaluation is a forward solve and every
     gradient an adjoint solve on the GPU.  A few iterations must lower the compliance markedly at constant mass."""
-    from femo_alpha_amd.optimize import slsqp
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from optimize import slsqp
     from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
     mesh = plate_mesh(2.0, 10.0, 4, 20)
     nn = mesh.nn
@@ -290,3 +292,58 @@ def test_thickness_optimisation_loop():
     # material moved towards the clamped root, as it must for a cantilever
     x = mesh.nodes[:, 0]
     assert thickness.value[x < 2.0].mean() > thickness.value[x > 8.0].mean()
+
+
+def test_stale_factor_policy_gives_the_same_answers():
+    """Option "stale_factor" (for optimisation loops): after a change of FIELDS only, the previous design's factor stays the PCG
+    preconditioner; the operator is re-factorised at once if a field has moved more than "stale_rel" from the factor's design, and
+    inside the solve if it has not converged after "stale_factor" iterations.  PCG iterates on the current matrix-free operator, so
+    displacement, compliance and gradient must equal the always-refactorise run's (1e-8) whichever path a solve takes:
+    femo_last_timing [3] = 0 fresh factor, 1 kept factor, 2 kept, then refreshed inside the solve.  A change of the Dirichlet data must
+    discard the kept factor altogether."""
+    from femo_alpha_amd.backend import ShellContext
+    m = plate_mesh(2.0, 10.0, 24, 120)
+    rng = np.random.default_rng(3)
+    h0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn))
+    steps = (1e-3, 1e-2, 5e-2, 0.5)
+    designs = [h0 * (1 + d * rng.uniform(-1, 1, m.nn)) for d in steps]
+
+    def run(stale, rel=None):
+        c = ShellContext(m)
+        for k, v in dict(thickness=h0, E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1))).items():
+            c.set_field(k, v)
+        c.set_penalty_facets(m.penalty_facets(ClampedBoundary))
+        c.enable_frontal()
+        c.set_solver(preconditioner=2, rtol=1e-12, maxit=60, check_every=1)
+        c.set_option("stale_factor", stale)
+        if rel is not None:
+            c.set_option("stale_rel", rel)
+        c.solve_state(zero_guess=True)
+        assert c.last_timing()["factor_state"] == 0              # nothing to keep yet
+        rows = []
+        for h in designs:
+            c.set_field("thickness", h)
+            it, rr = c.solve_state(zero_guess=True)
+            st = c.last_timing()["factor_state"]
+            w = c.get_state()
+            J = c.functional("compliance")
+            g, it2, _ = c.total_gradient("compliance", "thickness")
+            rows.append((it, st, it2, c.last_timing()["factor_state"], w, J, g))
+        # Dirichlet data changed: the kept factor belongs to another problem and must not be used
+        c.set_penalty_facets(m.penalty_facets(lambda x: np.less(x[0], 0.5)))
+        c.solve_state(zero_guess=True)
+        assert c.last_timing()["factor_state"] == 0
+        c.close()
+        return rows
+
+    ref = run(0)
+    assert all(r[1] == 0 for r in ref)
+    for got in (run(6, rel=10.0), run(6)):                     # the gate off (every design tries the kept factor), then at its default 2e-3
+        for (_, _, _, _, w0, J0, g0), (it, st, it2, st2, w, J, g), d in zip(ref, got, steps):
+            assert np.abs(w - w0).max() < 1e-8 * np.abs(w0).max(), (d, st)
+            assert abs(J - J0) < 1e-8 * abs(J0), (d, st)
+            assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max(), (d, st)
+        assert got[0][1] == 1 and got[0][0] <= 6 and got[0][3] == 1      # 0.1 % change: absorbed by the kept factor, forward and adjoint
+    gate_off, gated = run(6, rel=10.0), run(6)
+    assert gate_off[-1][1] == 2 and gate_off[-1][3] == 0 and gate_off[-1][2] <= 3     # 50 % change: refreshed INSIDE the solve, the adjoint finds the fresh factor
+    assert gated[-1][1] == 0 and gated[-1][0] <= 3                                    # with the gate: refreshed at once, no wasted iterations
