@@ -462,73 +462,120 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
     element partitions (the N subtrees at depth log2 N of the nested-dissection tree), one per GPU.  ``--scaling weak``: N
     times the span, N times the cells.  Collectives over RCCL (backend nccl): one all-reduce of the replicated separator
     entries per operator / preconditioner application, one packed scalar all-reduce per dot, one all-gather of the
-    subtree roots' Schur complements (packed lower triangles) per factorisation."""
+    subtree roots' Schur complements (packed lower triangles) per factorisation.
+
+    The line's ``value`` is the scaling asked for; the OTHER scaling rides along as a sub-object (``weak`` beside a strong run,
+    ``strong`` beside a weak one) from a shorter timed region, because the two say different things: 1 M DOF is a small problem for
+    eight MI355X (the builder's own composition bounds strong scaling at 2.3 x, weak at 6.3 x; profiles/r4_amdahl_wing1m*.md) --
+    no curve has been measured.
+
+    ``--rehearsal-engine module:Class`` (tests only): the ranks run that engine in place of the HIP one, on the CPU over gloo --
+    launcher, rendezvous, collectives and the JSON line are exercised without a GPU; the line says so and is not a measurement."""
     from femo_alpha_amd.mesh import wing_skin_mesh
     from femo_alpha_amd.parallel import Comm, DistributedShell
     if world & (world - 1):
         raise SystemExit("the element partition needs a power-of-two number of GPUs")
     if args.workload != "wing1m":
         raise SystemExit("the multi-GPU bench runs the wing-skin workload")
-    ns = int(os.environ.get("FEMO_BENCH_NS", "580"))               # spanwise cells (580 = the 1M-DOF config); rehearsals shrink it
-    mult = world if args.scaling == "weak" else 1
-    m = wing_skin_mesh(116, ns * mult, span=6.0 * mult * ns / 580.0).renumbered()[0]
+    rehearsal = args.rehearsal_engine is not None
+    Engine = None
+    if rehearsal:
+        import importlib
+        mod, cls = args.rehearsal_engine.split(":")
+        Engine = getattr(importlib.import_module(mod), cls)
+    nc = int(os.environ.get("FEMO_BENCH_NC", "116"))               # chordwise / spanwise cells (116 x 580 = the 1M-DOF config); rehearsals shrink them
+    ns = int(os.environ.get("FEMO_BENCH_NS", "580"))
     marker = lambda x: np.less(x[1], 1e-9)
-    args.leaf = m.recommended_leaf_size() if args.leaf is None else args.leaf
     comm = Comm(dist)
-    shared_gpu = torch.cuda.device_count() < world                 # rehearsal: several ranks on one card
-    ds = DistributedShell(m, comm, bc_marker=marker, leaf_size=args.leaf, device=0 if shared_gpu else local_rank, nquad=args.nquad)
-    ds.rtol = args.rtol
-    fields = dict(thickness=np.array([1.27e-3]), E=np.array([73.1e9]), nu=np.array([0.33]), density=np.array([2780.0]),
-                  F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
-    ds.set_fields(**fields)
+    shared_gpu = (not rehearsal) and torch.cuda.device_count() < world        # rehearsal: several ranks on one card
+    dev = "cpu" if rehearsal else "cuda"
+    sync = (lambda: None) if rehearsal else torch.cuda.synchronize
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    def step():
-        ds.set_fields(thickness=fields["thickness"])         # new design: factorisation stale
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        it, rr = ds.solve_state()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        g, it2, rr2 = ds.total_gradient("compliance", "thickness")
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        return (t1 - t0, t2 - t1, it, rr, it2, rr2)
+    def run_case(scaling, steps, warmup):
+        mult = world if scaling == "weak" else 1
+        m = wing_skin_mesh(nc, ns * mult, span=6.0 * mult * ns / 580.0).renumbered()[0]
+        leaf = m.recommended_leaf_size() if args.leaf is None else args.leaf
+        nq = m.recommended_nquad() if args.nquad is None else args.nquad          # the rule of the WHOLE mesh on every rank
+        factory = (lambda sub, plan, info: Engine(sub, plan, info, nquad=nq)) if rehearsal else None
+        ds = DistributedShell(m, comm, bc_marker=marker, leaf_size=leaf, device=0 if shared_gpu else local_rank, nquad=args.nquad,
+                              engine_factory=factory)
+        ds.rtol = args.rtol
+        fields = dict(thickness=np.array([1.27e-3]), E=np.array([73.1e9]), nu=np.array([0.33]), density=np.array([2780.0]),
+                      F_solid=np.tile([0.0, 0.0, -2780.0 * 1.27e-3 * 9.81], (m.nn, 1)))
+        ds.set_fields(**fields)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t_start = time.perf_counter()
-    rows = [step() for _ in range(args.steps)]
-    barrier()
-    t_total = time.perf_counter() - t_start
-    tt = torch.tensor([t_total, sum(r[0] for r in rows), sum(r[1] for r in rows)], device="cuda", dtype=torch.float64)
-    comm.allreduce_(tt, op="max")
-    t_total, t_fwd, t_adj = tt.tolist()
-    # the same two roofline objects as the N = 1 line, measured on rank 0's partition: the rank-k updates of ITS factorisation
-    # (its subtree + the replicated top of the tree; one instrumented factorisation, HIP event pairs on the context's stream --
-    # every rank takes part, the Schur all-gather sits in the middle) and its element operator
-    ctx0 = ds.eng.ctx
-    ctx0.set_option("profile", 1)
-    with ds.eng.on_stream():
-        ds.factorize()
-    ctx0.set_option("profile", 0)
-    prof = ctx0.factorize_profile(run=False)
-    apply_ms = ctx0.bench_kernel("apply", 50)
+        def step():
+            ds.set_fields(thickness=fields["thickness"])         # new design: factorisation stale
+            sync()
+            t0 = time.perf_counter()
+            it, rr = ds.solve_state()
+            sync()
+            t1 = time.perf_counter()
+            g, it2, rr2 = ds.total_gradient("compliance", "thickness")
+            sync()
+            t2 = time.perf_counter()
+            return (t1 - t0, t2 - t1, it, rr, it2, rr2)
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t_start = time.perf_counter()
+        rows = [step() for _ in range(steps)]
+        barrier()
+        t_total = time.perf_counter() - t_start
+        tt = torch.tensor([t_total, sum(r[0] for r in rows), sum(r[1] for r in rows)], device=dev, dtype=torch.float64)
+        comm.allreduce_(tt, op="max")
+        t_total, t_fwd, t_adj = tt.tolist()
+        return dict(ds=ds, m=m, rows=rows, t_total=t_total, t_fwd=t_fwd, t_adj=t_adj, steps=steps, scaling=scaling)
+
+    def figures(r):
+        m, ds = r["m"], r["ds"]
+        return {"value": m.ndof * r["steps"] / r["t_fwd"], "unit": "DOF/s", "scaling": r["scaling"], "steps": r["steps"],
+                "ms_per_step": r["t_total"] / r["steps"] * 1e3, "forward_ms": r["t_fwd"] / r["steps"] * 1e3,
+                "adjoint_ms": r["t_adj"] / r["steps"] * 1e3, "ndof": m.ndof, "cells": m.nel, "ndof_per_gpu": ds.sub.ndof,
+                "replicated_separator_dofs": ds.info["n_top"], "pcg_iterations_forward": r["rows"][-1][2],
+                "pcg_iterations_adjoint": r["rows"][-1][4]}
+
+    main_run = run_case(args.scaling, args.steps, args.warmup)
+    ds, m, rows = main_run["ds"], main_run["m"], main_run["rows"]
+    prof = apply_ms = None
+    if not rehearsal:
+        # the same roofline object as the N = 1 line, measured on rank 0's partition: the rank-k updates of ITS factorisation
+        # (its subtree + the replicated top of the tree; one instrumented factorisation, HIP event pairs on the context's stream --
+        # every rank takes part, the Schur all-gather sits in the middle) and its element operator
+        ctx0 = ds.eng.ctx
+        ctx0.set_option("profile", 1)
+        with ds.eng.on_stream():
+            ds.factorize()
+        ctx0.set_option("profile", 0)
+        prof = ctx0.factorize_profile(run=False)
+        apply_ms = ctx0.bench_kernel("apply", 50)
+    other = "weak" if args.scaling == "strong" else "strong"
+    other_fig = None
+    if not args.no_other_scaling:
+        del main_run["ds"]
+        if not rehearsal:
+            ds.eng.ctx.close()
+        other_run = run_case(other, max(3, args.steps // 4), min(args.warmup, 2))
+        other_fig = figures(other_run)
+        if not rehearsal:
+            other_run["ds"].eng.ctx.close()
     if rank == 0:
+        t_total, t_fwd, t_adj = main_run["t_total"], main_run["t_fwd"], main_run["t_adj"]
         out = {
             "metric": "DOF/s (assembly+solve), forward solve of the RM shell; adjoint-gradient wallclock in adjoint_ms",
             "value": m.ndof * args.steps / t_fwd, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": t_total / args.steps * 1e3, "forward_ms": t_fwd / args.steps * 1e3,
             "adjoint_ms": t_adj / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"wing1m, strong scaling: the 116x{ns} wing skin ({m.ndof} DOF) in {world} element partitions of "
+            "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on the CPU (stand-in engine over gloo): launcher coverage, not a measurement",
+            "config": {"workload": (f"wing1m, strong scaling: the {nc}x{ns} wing skin ({m.ndof} DOF) in {world} element partitions of "
                                     f"{ds.sub.nel} cells" if args.scaling == "strong" else
-                                    f"wing1m x{world}, weak scaling: synthetic wing skin 116x{ns * world} quads (span x{world}), {m.ndof} DOF, "
+                                    f"wing1m x{world}, weak scaling: synthetic wing skin {nc}x{ns * world} quads (span x{world}), {m.ndof} DOF, "
                                     f"one element partition of {ds.sub.nel} cells per GPU"),
                        "ndof": m.ndof, "cells": m.nel, "ndof_per_gpu": ds.sub.ndof, "gauss_points_per_direction": ds.nquad,
                        "replicated_separator_dofs": ds.info["n_top"],
@@ -537,10 +584,13 @@ def main_distributed(args, rank, local_rank, world, torch, dist):
                        "rtol": args.rtol, "pcg_iterations_forward": rows[-1][2], "pcg_iterations_adjoint": rows[-1][4],
                        "relres_forward": rows[-1][3], "relres_adjoint": rows[-1][5],
                        "parallelism": f"element partition over {world} GPUs, RCCL all-reduce of separator DOFs"},
-            "roofline": dict(trailing_roofline(prof, None)[0], where=f"rank 0 of {world}: its subtree + the replicated top of the tree"),
-            "roofline_spmv": spmv_roofline(apply_ms, ds.sub.ndof, ds.sub.nel, None, where=f", rank 0 of {world}"),
-            "factorisation_profile_ms": {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)},
         }
+        if other_fig is not None:
+            out[other] = other_fig
+        if prof is not None:
+            out["roofline"] = dict(trailing_roofline(prof, None)[0], where=f"rank 0 of {world}: its subtree + the replicated top of the tree")
+            out["roofline_spmv"] = spmv_roofline(apply_ms, ds.sub.ndof, ds.sub.nel, None, where=f", rank 0 of {world}")
+            out["factorisation_profile_ms"] = {k: v["ms"] for k, v in prof.items() if isinstance(v, dict)}
         print(json.dumps(out))
     dist.destroy_process_group()
 
@@ -579,7 +629,7 @@ def launch_ranks(args):
     # early refusal only: the topology lists the HOST's devices, a container may be allowed fewer of them -- the ranks, which
     # initialise the GPU anyway, count what they can really use and pick the collective backend (main(): --share-gpu -> gloo)
     ndev = visible_gpus()
-    if ndev is not None and ndev < args.gpus and not args.share_gpu:
+    if ndev is not None and ndev < args.gpus and not args.share_gpu and args.rehearsal_engine is None:
         raise SystemExit(f"--gpus {args.gpus} but {ndev} device(s) visible (a rehearsal on fewer cards: --share-gpu)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={args.gpus}", os.path.abspath(__file__), *sys.argv[1:]]
@@ -605,6 +655,10 @@ def main():
     ap.add_argument("--no-keep-numbering-leg", action="store_true", help="skip the extra forward solve on the shuffled numbering")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: the same 1M-DOF skin split into N element partitions (BASELINE config 4), or N times the span")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: skip the shorter run of the other scaling (the 'weak' / 'strong' sub-object)")
+    ap.add_argument("--rehearsal-engine", default=None, metavar="MODULE:CLASS",
+                    help="tests only: N > 1 ranks run this engine in place of the HIP one, on the CPU over gloo (launcher coverage; the "
+                         "line says REHEARSAL and is not a measurement)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: allow --gpus N on a box with fewer cards (the ranks share them; collectives over gloo)")
     args = ap.parse_args()
@@ -629,6 +683,14 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    if args.rehearsal_engine is not None:
+        if world < 2:
+            raise SystemExit("--rehearsal-engine is for the N > 1 launcher path")
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        args.steps = 2 if args.steps is None else args.steps
+        args.warmup = 0 if args.warmup is None else args.warmup
+        return main_distributed(args, rank, local_rank, world, torch, dist)
     if world > 1 or force_dist:
         import torch.distributed as dist
         ndev = torch.cuda.device_count()

@@ -56,3 +56,32 @@ def test_rank_plans_partition_the_mesh():
         assert np.all(np.diff(info["l2g_dof"][info["top_local"]]) > 0)
     assert np.all(seen == 1)
     assert owned.max() == 1
+
+
+def test_bench_launcher_with_two_ranks_on_the_cpu():
+    """``python bench.py --gpus 2`` without a launcher and without a GPU: bench.py's own ``launch_ranks`` starts two ranks
+    (torch.distributed.run --standalone), the ranks rendezvous over gloo, run the partitioned forward + adjoint step of
+    ``main_distributed`` on a small skin with the numpy stand-in engine (``--rehearsal-engine``: a test hook, the line says
+    REHEARSAL) and rank 0 prints the one JSON line of the contract -- with the element-partition label, and with the OTHER scaling
+    as a sub-object (``weak`` beside the default strong run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEMO_BENCH_NC="8", FEMO_BENCH_NS="24", OMP_NUM_THREADS="2",
+               PYTHONPATH=os.pathsep.join([os.path.join(root, "tests"), root, os.environ.get("PYTHONPATH", "")]))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--rehearsal-engine", "dist_helpers:NumpyEngine"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["unit"] == "DOF/s" and j["value"] > 0 and j["steps"] == 1
+    assert "REHEARSAL" in j["data"] and "roofline" not in j
+    assert j["config"]["parallelism"].startswith("element partition over 2 GPUs")
+    assert j["config"]["pcg_iterations_forward"] <= 4 and j["config"]["pcg_iterations_adjoint"] <= 4
+    assert j["config"]["replicated_separator_dofs"] > 0
+    w = j["weak"]
+    assert w["scaling"] == "weak" and w["ndof"] > j["config"]["ndof"] and w["ndof_per_gpu"] >= 0.8 * j["config"]["ndof_per_gpu"]
+    assert w["pcg_iterations_forward"] <= 4
