@@ -1373,12 +1373,18 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
     }
     __syncthreads();
     int cur = 0;
+    // a tile on the diagonal of the front (row tile == column tile): the wave whose quarter lies entirely ABOVE the diagonal (rows 0..31,
+    // columns 32..63) has nothing to store -- it only helps with the staging.  On the levels of small fronts a third to a half of the
+    // tiles are diagonal ones (a Schur block of 174 rows: 3 of 6), so this is 8-12 % of their MFMA work, which is what those levels
+    // spend about half of their time on (the tile-quantised work is ~2.5 x the algorithmic flops there).
+    const bool idle_quarter = ri == cj && wr + 31 < wc;
     for (int k0 = 0; k0 < kw; k0 += KC) {
         const int left = kw - k0 - KC;             // factor columns behind this stage
         if (left > 0) {
             if (left >= KC) fetch(base); else fetch_tail(base, left);
             base += stage_bytes;
         }
+        if (!idle_quarter) {
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 4) {
             // A: tile columns (index i), B: tile rows (index j); k = kk + (lane >> 4)
@@ -1388,6 +1394,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
         }
         if (left > 0) {
 #pragma unroll
@@ -1399,6 +1406,7 @@ k_trailing_mfma(FrontDev fd, const int* __restrict__ level_nodes, int first, int
         __syncthreads();
         cur ^= 1;
     }
+    if (idle_quarter) return;                      // (behind the last barrier of the K loop: nothing of this quarter is stored)
     // C -= D with all of the tile's loads in flight at once (entries outside the tile's part of the lower triangle load
     // from a safe address and are not stored).  D[i][j]: i = l4 + 4*reg -> tile column, j = l15 -> tile row
     bool cok[2][4];
