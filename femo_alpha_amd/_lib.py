@@ -21,6 +21,8 @@ SIGNATURES = {
                               _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int]),
     "femo_create_ghost": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int, C.c_int32]),
+    "femo_create_element": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      _c_double_p, _c_int32_p, _c_int32_p, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int]),
     "femo_destroy": (None, [C.c_void_p]),
     "femo_ndof": (C.c_int64, [C.c_void_p]),
     "femo_field_size": (C.c_int64, [C.c_void_p, C.c_char_p]),

@@ -39,10 +39,17 @@ class ShellContext:
         xyz = np.ascontiguousarray(mesh.nodes, dtype=np.float64)
         cells = np.ascontiguousarray(mesh.cells, dtype=np.int32)
         cp2 = np.ascontiguousarray(mesh.cell_p2, dtype=np.int32)
-        rc = self.lib.femo_create_ghost(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
-                                        dptr(xyz), iptr(cells), iptr(cp2),
-                                        int(self.element_wise_material), int(self.elementwise_pressure), int(nquad),
-                                        int(nghost))
+        if getattr(mesh, "element", "CG2CG1") == "CG2CR1":
+            # rotation on the edge midpoints (Crouzeix-Raviart, linear_shell_model.py:68-73): the element is named explicitly
+            rc = self.lib.femo_create_element(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
+                                              dptr(xyz), iptr(cells), iptr(cp2),
+                                              int(self.element_wise_material), int(self.elementwise_pressure), int(nquad),
+                                              int(nghost), 1)
+        else:
+            rc = self.lib.femo_create_ghost(C.byref(h), int(device), mesh.nn, mesh.nel, mesh.nvc, mesh.nP2,
+                                            dptr(xyz), iptr(cells), iptr(cp2),
+                                            int(self.element_wise_material), int(self.elementwise_pressure), int(nquad),
+                                            int(nghost))
         if rc:
             raise FemoHipError(f"femo_create failed ({rc}): {self.lib.femo_last_error(None).decode()}")
         self._h = h

@@ -49,6 +49,9 @@ struct femo_ctx {
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
     int nghost = 0;
     bool quad = true, ewm = false, ewp = false, has_uhat = false;
+    bool cr = false;                         // element CG2CR1 (linear_shell_model.py:68-73, triangles): rotation on the edge midpoints (Crouzeix-Raviart)
+    int nrot = 0;                            // rotation nodes: nn, or the number of edges for CG2CR1
+    int* frnode = nullptr; double* fMR = nullptr;   // CG2CR1: rotation nodes and 3 x 3 rotation blocks of the penalty facets
     bool cg1 = false;                        // element CG1CG1 (linear_shell_model.py:74-79): displacement on the vertices too (nP2 == nn)
     int64_t nT = 0, nF = 0;
     // mesh
@@ -319,7 +322,7 @@ static void lag1(double t, double* v, double* d) {
 
 // nred > 0 (quads): the membrane / bending / shear energies are integrated with nred x nred Gauss points, everything
 // else with nquad x nquad: the table then lists both point sets, each with a zero weight for the terms of the other
-static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1 = false) {
+static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1 = false, bool cr = false) {
     memset(&T, 0, sizeof T);
     if (quad) {
         static const int Q2I[9][2] = {{0, 0}, {2, 0}, {2, 2}, {0, 2}, {1, 0}, {2, 1}, {1, 2}, {0, 1}, {1, 1}};
@@ -394,6 +397,21 @@ static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1
                 T.dN2[q][n][1] = n < nv ? T.dN1[q][n][1] : 0.0;
             }
     }
+    // the rotation's tables: the vertex functions, or (CG2CR1, triangles) the Crouzeix-Raviart functions NR_k = 1 - 2 lambda_(k+2) of the
+    // midpoint of edge k (vertex k -> k + 1): one on its own edge's midpoint, zero on the other two
+    for (int q = 0; q < T.nq; ++q)
+        for (int n = 0; n < 4; ++n) {
+            if (cr && !quad && n < 3) {
+                const int o = (n + 2) % 3;
+                T.NR[q][n] = 1.0 - 2.0 * T.N1[q][o];
+                T.dNR[q][n][0] = -2.0 * T.dN1[q][o][0];
+                T.dNR[q][n][1] = -2.0 * T.dN1[q][o][1];
+            } else {
+                T.NR[q][n] = T.N1[q][n];
+                T.dNR[q][n][0] = T.dN1[q][n][0];
+                T.dNR[q][n][1] = T.dN1[q][n][1];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------ launch helpers
@@ -407,7 +425,7 @@ static MeshDev mesh_dev(const femo_ctx* c) {
     MeshDev m;
     m.nn = c->nn; m.nel = c->nel; m.nP2 = c->nP2; m.ndof_u = c->ndof_u; m.ndof = c->ndof;
     m.xyz = c->xyz; m.cells = c->cells; m.cellp2 = c->cellp2; m.hK = c->hK;
-    m.ctag = c->ctag; m.csel = c->csel;
+    m.ctag = c->ctag; m.csel = c->csel; m.cr = c->cr ? 1 : 0;
     return m;
 }
 static FieldsDev fields_dev(const femo_ctx* c) {
@@ -419,7 +437,7 @@ static FieldsDev fields_dev(const femo_ctx* c) {
 static FacetDev facet_dev(const femo_ctx* c) {
     FacetDev fd;
     fd.nf = c->nf; fd.cell = c->fcell; fd.ledge = c->fledge; fd.unode = c->funode; fd.vnode = c->fvnode;
-    fd.M2 = c->fM2; fd.M1 = c->fM1;
+    fd.M2 = c->fM2; fd.M1 = c->fM1; fd.rnode = c->frnode; fd.MR = c->fMR;
     return fd;
 }
 
@@ -502,7 +520,7 @@ static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, do
         else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
         const int nthreads = c->nP2 + c->nghost;
 #define GATHER_SUM(NPC_, NVC_) hipLaunchKernelGGL((k_gather_sum<NPC_, NVC_>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, \
-                                                  c->ndof_u, c->ndof, c->n2e_off, c->n2e_ent, c->ybuf, y)
+                                                  c->ndof_u, c->ndof, c->n2e_off, c->n2e_ent, c->ybuf, y, c->cr ? 1 : 0, c->nrot)
         if (c->cg1) { if (c->quad) GATHER_SUM(4, 4); else GATHER_SUM(3, 3); }
         else if (c->quad) GATHER_SUM(9, 4);
         else GATHER_SUM(6, 3);
@@ -708,7 +726,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         if (c->quad && c->nred == 0 && c->opt.precond_nquad > 0 && c->opt.precond_nquad < c->nquad) {
             if (!c->tab_pre || c->tab_pre_nq != c->opt.precond_nquad * c->opt.precond_nquad) {
                 Tables TP;                                           // 8 KB on this thread's stack (contexts of several threads factorise at once)
-                build_tables(true, c->opt.precond_nquad, TP, 0, c->cg1);
+                build_tables(true, c->opt.precond_nquad, TP, 0, c->cg1, c->cr);
                 if (!c->tab_pre) HIPCHK(c, hipMalloc((void**)&c->tab_pre, sizeof(Tables)));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 HIPCHK(c, hipMemcpy(c->tab_pre, &TP, sizeof(Tables), hipMemcpyHostToDevice));
@@ -1662,12 +1680,12 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
     Tables T;
     c->nquad = nquad;
-    build_tables(c->quad, nquad, T, 0, c->cg1);
+    build_tables(c->quad, nquad, T, 0, c->cg1, c->cr);
     HIPCHK(c, hipMalloc((void**)&c->tab, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
     c->tab_nq = T.nq;
     Tables TS_;
-    build_tables(c->quad, 3, TS_, 0, c->cg1);    // quadrature_degree 4 (rm_shell_model.py:200-201)
+    build_tables(c->quad, 3, TS_, 0, c->cg1, c->cr);    // quadrature_degree 4 (rm_shell_model.py:200-201)
     HIPCHK(c, hipMalloc((void**)&c->tab_s, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab_s, &TS_, sizeof(Tables), hipMemcpyHostToDevice));
     c->nT = c->ewm ? nel : c->nn;
@@ -1702,6 +1720,13 @@ int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc
 int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2, const double* xyz,
                       const int32_t* cells, const int32_t* cell_p2, int elementwise_material, int elementwise_pressure,
                       int nquad, int32_t nghost) {
+    return femo_create_element(out, device, nn, nel, nvc, nP2, xyz, cells, cell_p2, elementwise_material, elementwise_pressure, nquad,
+                               nghost, 0);
+}
+
+int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2, const double* xyz,
+                        const int32_t* cells, const int32_t* cell_p2, int elementwise_material, int elementwise_pressure,
+                        int nquad, int32_t nghost, int element) {
     if (!out) return 2;
     if (nghost < 0) { g_create_error = "nghost must be >= 0"; return 2; }
     *out = nullptr;
@@ -1712,6 +1737,13 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
     // cell -- told apart by nP2 == nn (a CG2CG1 mesh always has nP2 = nn + edges [+ cells] > nn)
     const bool cg1 = nP2 == nn;
     const int npc = cg1 ? nvc : (nvc == 4 ? 9 : 6);
+    // element 1 = CG2CR1 (linear_shell_model.py:68-73): displacement on the P2 nodes, rotation on the EDGE MIDPOINTS (Crouzeix-Raviart);
+    // triangles only, as in the reference.  The rotation nodes are the P2 nodes nn .. nP2 - 1 (cell_p2 lists a cell's edge midpoints behind
+    // its vertices), so the state vector is [u(P2 nodes) | theta(edges)] with 3 nP2 + 3 (nP2 - nn) entries
+    if (element != 0 && element != 1) { g_create_error = "element: 0 (CG2CG1 / CG1CG1 by the node count) or 1 (CG2CR1)"; return 2; }
+    const bool cr = element == 1;
+    if (cr && (nvc != 3 || cg1)) { g_create_error = "Invalid element type: CG2CR1 is defined on triangles with P2 displacement"; return 2; }
+    if (cr && nghost != 0) { g_create_error = "CG2CR1: the element-partitioned driver is not provided for this element"; return 2; }
     for (int64_t i = 0; i < (int64_t)nel * nvc; ++i)
         if (cells[i] < 0 || cells[i] >= nn) { g_create_error = "cells refers to a vertex outside 0..nn-1"; return 2; }
     for (int64_t i = 0; i < (int64_t)nel * npc; ++i)
@@ -1723,8 +1755,9 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
     c->device = device;
     c->nn = nn; c->nel = nel; c->nvc = nvc; c->npc = npc; c->nP2 = nP2;
     c->quad = nvc == 4;
-    c->cg1 = cg1;
-    c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * nn + nghost; c->nghost = nghost; c->ld = 3 * npc + 3 * nvc;
+    c->cg1 = cg1; c->cr = cr;
+    c->nrot = cr ? nP2 - nn : nn;
+    c->ndof_u = 3 * nP2; c->ndof = 3 * nP2 + 3 * c->nrot + nghost; c->nghost = nghost; c->ld = 3 * npc + 3 * nvc;
     c->ewm = elementwise_material != 0; c->ewp = elementwise_pressure != 0;
     if (create_impl(c, xyz, cells, cell_p2, nquad)) {
         g_create_error = c->err;
@@ -1750,7 +1783,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     if (c->eq) hipFree(c->eq);
     void* ptrs[] = {c->bi[0], c->bi[1], c->bi[2], c->bi[3], c->bi[4], c->ctag, c->gradbuf, c->csr_perm, c->csr_dest, c->csr_rowptr, c->csr_colidx, c->csr_vals, c->csr_ke, c->xyz, c->cells, c->cellp2, c->eorder, c->n2e_off, c->n2e_ent, c->ybuf, c->hK, c->tab, c->tab_s, c->tab_pre, c->h, c->E, c->nu, c->rho, c->f, c->uhat, c->fcell, c->fledge,
-                    c->funode, c->fvnode, c->fM2, c->fM1, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
+                    c->funode, c->fvnode, c->fM2, c->fM1, c->frnode, c->fMR, c->mask, c->w, c->lam, c->r, c->z, c->p, c->Ap, c->dinv, c->b, c->tmp,
                     c->scal};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1806,11 +1839,11 @@ int64_t femo_field_size(const femo_ctx* c, const char* name) {
 int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double beta) {
     HIPCHK(c, hipSetDevice(c->device));
     if (nf < 0 || (nf > 0 && !cl)) return fail(c, "bad facet list");
-    void* old[] = {c->fcell, c->fledge, c->funode, c->fvnode, c->fM2, c->fM1};
+    void* old[] = {c->fcell, c->fledge, c->funode, c->fvnode, c->fM2, c->fM1, c->frnode, c->fMR};
     for (void* p : old)
         if (p) hipFree(p);
-    c->fcell = c->fledge = c->funode = c->fvnode = nullptr;
-    c->fM2 = c->fM1 = nullptr;
+    c->fcell = c->fledge = c->funode = c->fvnode = c->frnode = nullptr;
+    c->fM2 = c->fM1 = c->fMR = nullptr;
     c->nf = 0;
     c->beta = beta;
     c->penalty_dirty = true;
@@ -1841,6 +1874,15 @@ int femo_set_penalty_facets(femo_ctx* c, int32_t nf, const int32_t* cl, double b
     HIPCHK(c, hipMemcpy(c->fledge, le.data(), nf * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->funode, un.data(), un.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->fvnode, vn.data(), vn.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (c->cr) {
+        // CG2CR1: the three rotation nodes (edge midpoints) of the facet's cell and room for the 3 x 3 rotation block
+        std::vector<int> rn(3 * (size_t)nf);
+        for (int i = 0; i < nf; ++i)
+            for (int a = 0; a < 3; ++a) rn[3 * i + a] = hp[(size_t)(c->nvc + a) * c->nel + cl[2 * i]] - c->nn;
+        HIPCHK(c, hipMalloc((void**)&c->frnode, rn.size() * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->frnode, rn.data(), rn.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc((void**)&c->fMR, 9 * (size_t)nf * sizeof(double)));
+    }
     c->nf = nf;
     return 0;
 }
@@ -2222,6 +2264,7 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
 
 // out (3 nn) += scale * d/d uhat of: mode 0 lam.(K w - F) [+ penalty], 1 int u.u J, 2 mass, 3 elastic energy
 static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const double* lam, double scale, double* out) {
+    if (c->cr) return fail(c, "CG2CR1: shape derivatives are not provided for this element");
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int nthreads = c->nel * 3 * c->nvc;
@@ -3002,7 +3045,7 @@ int femo_set_strain_quadrature(femo_ctx* c, int32_t nred) {
     if (!c->quad) return fail(c, "reduced strain quadrature is implemented for quadrilaterals only");
     if (nred < 0 || nred > 5 || nred * nred + c->nquad * c->nquad > MAXQ) return fail(c, "unsupported reduced rule");
     Tables T;
-    build_tables(true, c->nquad, T, nred, c->cg1);
+    build_tables(true, c->nquad, T, nred, c->cg1, c->cr);
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
     c->tab_nq = T.nq;
     c->nred = nred; operator_changed(c);
@@ -3076,6 +3119,7 @@ int femo_grad_get(femo_ctx* c, double* out, int64_t n) {
 //   w_mid = (w_old + w)/2,  wdot = 2/dt (w - w_old) - wdot_old,  wddot = (wdot - wdot_old)/dt      (plate_sim.py:131-140)
 //   step:  (a M + K/2) w_i = F_i + M (a w_{i-1} + b wdot_{i-1}) - K/2 w_{i-1},   a = 2/dt^2, b = 2/dt
 int femo_newmark_setup(femo_ctx* c, int32_t time_levels, double dt) {
+    if (c->cr) return fail(c, "CG2CR1: the transient march is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     auto& nm = c->nm;
     if (time_levels < 2 || !(dt > 0)) return fail(c, "femo_newmark_setup: need at least two time levels and dt > 0");
@@ -3379,6 +3423,7 @@ int femo_newmark_tangent(femo_ctx* c, const double* dR, int32_t levels) {
 // perm[k]: index into the element-matrix buffer (element * ld*ld + i*ld + j) of the k-th contribution in
 // destination order; dest[k]: its position in the CSR value array (non-decreasing).
 int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* perm, const int32_t* dest) {
+    if (c->cr) return fail(c, "CG2CR1: the CSR export is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     if (ncontrib != (int64_t)c->nel * c->ld * c->ld) return fail(c, "ncontrib must be nel * ldof^2");
     for (int64_t k = 0; k < ncontrib; ++k) {
@@ -3400,6 +3445,7 @@ int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* 
 
 // pattern + destination-sorted contribution map on the device (csr_map.h); *nnz_out = number of stored entries
 int femo_build_csr_map(femo_ctx* c, int32_t* nnz_out) {
+    if (c->cr) return fail(c, "CG2CR1: the CSR export is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     const long long nc = (long long)c->nel * c->ld * c->ld;
     if (nc >= (1ll << 31)) return fail(c, "CSR export: more than 2^31 element contributions (the matrix-free solvers have no such limit)");

@@ -107,9 +107,9 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
         const QPoint<NPC, NVC>& p = sq[q];
         // strains of e_j without the 39-entry reduction: the reduced vectors are scalar multiples of one unit vector;
         // the lane reads its own node's table row (a per-lane index into d[][] would send the array to scratch)
-        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
+        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dNR[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dNR[q][aj][1];
         const double dk0 = r0 * p.g.Q[0][0] + r1 * p.g.Q[1][0], dk1 = r0 * p.g.Q[0][1] + r1 * p.g.Q[1][1];
-        const double Mj = is_u ? 0.0 : tab->N1[q][aj];
+        const double Mj = is_u ? 0.0 : tab->NR[q][aj];
         double G0[3], G1[3], th[3], T0[3], T1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -122,7 +122,7 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
         }
         const Gen s = strains_reduced(p.g, G0, G1, th, T0, T1);
         const Gen t = stress_of(s, p.mat);
-        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->N1[q], t, ye);
+        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->NR[q], t, ye);
     }
     if (MASS) {
         // The inertia term in a loop of its own (compiled out of the static operator): inside the stiffness loop its live values pushed
@@ -138,7 +138,7 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
             double rq = 0.0;
 #pragma unroll
             for (int b = 0; b < NVC; ++b) rq += tab->N1[q][b] * rhon[b];
-            const double cmj = aM * rq * p.hq * tab->w[q] * p.g.det * p.g.Ju * hk2 * (is_u ? tab->N2[q][aj] : tab->N1[q][aj]);
+            const double cmj = aM * rq * p.hq * tab->w[q] * p.g.det * p.g.Ju * hk2 * (is_u ? tab->N2[q][aj] : tab->NR[q][aj]);
 #pragma unroll
             for (int a = 0; a < NPC; ++a)
 #pragma unroll
@@ -146,7 +146,7 @@ k_front_assemble(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double 
 #pragma unroll
             for (int b = 0; b < NVC; ++b)
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) ye[3 * NPC + 3 * b + cc] += (!is_u && cc == cj) ? cmj * tab->N1[q][b] : 0.0;
+                for (int cc = 0; cc < 3; ++cc) ye[3 * NPC + 3 * b + cc] += (!is_u && cc == cj) ? cmj * tab->NR[q][b] : 0.0;
         }
     }
     const int t = elem_front[e];
@@ -186,6 +186,15 @@ __global__ void k_front_penalty(FacetDev pf, FrontDev fd, const int* __restrict_
                 if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]])))
                     atomicAdd(fv.col(pb) + pa, pf.M2[9 * i + 3 * a + b] * (eq ? eq[gd[pa]] * eq[gd[pb]] : 1.0));
             }
+        if (pf.MR) {
+            // CG2CR1: the 3 x 3 rotation block over the cell's three edge midpoints (element-local rotation slots 0, 1, 2)
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    const int pa = map[3 * npc + 3 * a + c], pb = map[3 * npc + 3 * b + c];
+                    if (pa >= pb && !(mask && (mask[gd[pa]] || mask[gd[pb]])))
+                        atomicAdd(fv.col(pb) + pa, pf.MR[9 * i + 3 * a + b] * (eq ? eq[gd[pa]] * eq[gd[pb]] : 1.0));
+                }
+        } else
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) {
                 const int pa = map[3 * npc + 3 * vn[a] + c], pb = map[3 * npc + 3 * vn[b] + c];

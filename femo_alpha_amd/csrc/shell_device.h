@@ -32,6 +32,11 @@ struct Tables {
     double dN2[MAXQ][9][2];
     double N1[MAXQ][4];
     double dN1[MAXQ][4][2];
+    // shape functions of the ROTATION: a copy of N1 / dN1 for CG2CG1 and CG1CG1 (rotation on the vertices); for CG2CR1 (triangles,
+    // linear_shell_model.py:68-73) the Crouzeix-Raviart functions of the edge midpoints, NR_k = 1 - 2 lambda_(k+2) for edge k (vertex
+    // k -> k + 1).  N1 / dN1 stay what the geometry and the nodal fields (thickness, E, nu, density, pressure) are interpolated with
+    double NR[MAXQ][4];
+    double dNR[MAXQ][4][2];
 };
 
 struct MeshDev {
@@ -42,6 +47,7 @@ struct MeshDev {
     const double* hK;     // nel, UFL CellDiameter
     const int* ctag;      // nel, sub-domain index of every cell (-1: none), or null
     int csel;             // sub-domain the stress aggregate integrates over; -1: the whole mesh
+    int cr;               // CG2CR1: the rotation lives on the edge midpoints -- rotation node k of a cell = its P2 node 3 + k, numbered from nn
 };
 
 // false for cells outside the selected sub-domain (the reference's dxx(i) measure, rm_shell_model.py:242-253)
@@ -186,6 +192,16 @@ __device__ __forceinline__ void load_elem(const MeshDev& m, const FieldsDev& f, 
 #pragma unroll
     for (int a = 0; a < NPC; ++a) el.pid[a] = m.cellp2[a * m.nel + e];
     el.hK = m.hK[e];
+}
+
+// node that carries the rotation DOFs of local slot b (theta entries of the state vector: ndof_u + 3 * node + c): the vertex for
+// CG2CG1 / CG1CG1; for CG2CR1 the midpoint of edge b, which is also P2 node NVC + b of the cell (mesh.py: cell_p2 = vertices, edges)
+template <int NPC, int NVC>
+__device__ __forceinline__ int rot_node(const MeshDev& m, const Elem<NPC, NVC>& el, int b) {
+    if constexpr (NPC == 6 && NVC == 3) {
+        if (m.cr) return el.pid[NVC + b] - m.nn;
+    }
+    return el.vid[b];
 }
 
 // geometry of one quadrature point
@@ -385,7 +401,7 @@ __device__ __forceinline__ void local_derivs(const Tables& t, int q, const doubl
     }
 #pragma unroll
     for (int b = 0; b < NVC; ++b) {
-        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double r0 = t.dNR[q][b][0], r1 = t.dNR[q][b][1];
         m[b][0] = r0 * Q[0][0] + r1 * Q[1][0];
         m[b][1] = r0 * Q[0][1] + r1 * Q[1][1];
     }
@@ -537,9 +553,9 @@ __device__ __forceinline__ Gen strains_q(const Tables& t, int q, const QPG& g, c
     double th[3] = {0, 0, 0}, T0[3] = {0, 0, 0}, T1[3] = {0, 0, 0};
 #pragma unroll
     for (int b = 0; b < NVC; ++b) {
-        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double r0 = t.dNR[q][b][0], r1 = t.dNR[q][b][1];
         const double m0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], m1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
-        const double Mb = t.N1[q][b];
+        const double Mb = t.NR[q][b];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double v = xe[3 * NPC + 3 * b + c];
@@ -598,9 +614,9 @@ __device__ __forceinline__ void strains_T_q(const Tables& t, int q, const QPG& g
     }
 #pragma unroll
     for (int b = 0; b < NVC; ++b) {
-        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double r0 = t.dNR[q][b][0], r1 = t.dNR[q][b][1];
         const double m0 = r0 * g.Q[0][0] + r1 * g.Q[1][0], m1 = r0 * g.Q[0][1] + r1 * g.Q[1][1];
-        const double Mb = t.N1[q][b];
+        const double Mb = t.NR[q][b];
 #pragma unroll
         for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += Mb * Tq[c] + m0 * C0[c] + m1 * C1[c];
     }
@@ -619,7 +635,7 @@ __device__ __forceinline__ void mass_qp(const Tables& t, int q, double cm, doubl
 #pragma unroll
     for (int b = 0; b < NVC; ++b)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tq[c] += t.N1[q][b] * xe[3 * NPC + 3 * b + c];
+        for (int c = 0; c < 3; ++c) tq[c] += t.NR[q][b] * xe[3 * NPC + 3 * b + c];
 #pragma unroll
     for (int a = 0; a < NPC; ++a)
 #pragma unroll
@@ -628,7 +644,7 @@ __device__ __forceinline__ void mass_qp(const Tables& t, int q, double cm, doubl
 #pragma unroll
     for (int b = 0; b < NVC; ++b)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += ct * t.N1[q][b] * tq[c];
+        for (int c = 0; c < 3; ++c) ye[3 * NPC + 3 * b + c] += ct * t.NR[q][b] * tq[c];
 }
 
 // ---- the production element operator: 4 lanes per element (each lane a quarter of the quadrature points),
@@ -652,7 +668,7 @@ constexpr int YSTRIDE = 40;     // doubles per element slot of the element-resul
 template <int NPC, int NVC>
 __global__ void __launch_bounds__(256)
 k_gather_sum(int nP2, int nV, int ndof_u, int ndof, const int* __restrict__ n2e_off, const int* __restrict__ n2e_ent,
-             const double* __restrict__ ybuf, double* __restrict__ y) {
+             const double* __restrict__ ybuf, double* __restrict__ y, int cr, int nrot) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < nP2) {
         double s0 = 0, s1 = 0, s2 = 0, t0 = 0, t1 = 0, t2 = 0;
@@ -662,16 +678,20 @@ k_gather_sum(int nP2, int nV, int ndof_u, int ndof, const int* __restrict__ n2e_
             const int slot = ent / NPC, a = ent - slot * NPC;
             const double* src = ybuf + (size_t)slot * YSTRIDE;
             s0 += src[3 * a]; s1 += src[3 * a + 1]; s2 += src[3 * a + 2];
-            if (a < NVC) {
-                t0 += src[3 * NPC + 3 * a]; t1 += src[3 * NPC + 3 * a + 1]; t2 += src[3 * NPC + 3 * a + 2];
+            // the rotation results of the slot sit behind its displacement results: with the vertices for CG2CG1 / CG1CG1 (local
+            // P2 node a < NVC), with the edge midpoints for CG2CR1 (local P2 node NVC + k carries rotation slot k)
+            const int rb = cr ? a - NVC : a;
+            if (rb >= 0 && rb < NVC) {
+                t0 += src[3 * NPC + 3 * rb]; t1 += src[3 * NPC + 3 * rb + 1]; t2 += src[3 * NPC + 3 * rb + 2];
             }
         }
         y[3 * p] = s0; y[3 * p + 1] = s1; y[3 * p + 2] = s2;
-        if (p < nV) {
-            y[ndof_u + 3 * p] = t0; y[ndof_u + 3 * p + 1] = t1; y[ndof_u + 3 * p + 2] = t2;
+        const int rn = cr ? p - nV : p;                 // rotation node of this P2 node, if it carries one
+        if (rn >= 0 && rn < nrot) {
+            y[ndof_u + 3 * rn] = t0; y[ndof_u + 3 * rn + 1] = t1; y[ndof_u + 3 * rn + 2] = t2;
         }
     } else {
-        const int g = ndof_u + 3 * nV + (p - nP2);      // ghost entries: no element touches them
+        const int g = ndof_u + 3 * nrot + (p - nP2);    // ghost entries: no element touches them
         if (g < ndof) y[g] = 0.0;
     }
 }
@@ -747,7 +767,9 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
         for (int i = 0; i < LD; ++i) {
             if ((i & 3) == sub) {
                 const int node = i / 3, c = i - 3 * node;
-                const int g = node < NPC ? 3 * pid[node < NPC ? node : 0] + c : m.ndof_u + 3 * vid[node >= NPC ? node - NPC : 0] + c;
+                const int rb = node >= NPC ? node - NPC : 0;
+                const int rnode = (NPC == 6 && NVC == 3 && m.cr) ? pid[(NVC + rb) % NPC] - m.nn : vid[rb];     // CG2CR1: the edge midpoint
+                const int g = node < NPC ? 3 * pid[node < NPC ? node : 0] + c : m.ndof_u + 3 * rnode + c;
                 sx[le][i] = x[g];
             }
         }
@@ -846,7 +868,7 @@ k_diag(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restric
         cross3(g.E1, g.w1, x11);
 #pragma unroll
         for (int b = 0; b < NVC; ++b) {
-            const double Mb = tab->N1[q][b];
+            const double Mb = tab->NR[q][b];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double k00 = -g.E1[c] * mm[b][0] + Mb * x00[c];
@@ -865,7 +887,7 @@ k_diag(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, double* __restric
 #pragma unroll
     for (int b = 0; b < NVC; ++b)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(&diag[m.ndof_u + 3 * el.vid[b] + c], de[3 * NPC + 3 * b + c]);
+        for (int c = 0; c < 3; ++c) atomicAdd(&diag[m.ndof_u + 3 * rot_node(m, el, b) + c], de[3 * NPC + 3 * b + c]);
 }
 
 // F += int N_a f J dx   (sign: the residual subtracts it)
@@ -1069,8 +1091,8 @@ k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doubl
     for (int b = 0; b < NVC; ++b)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            we[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
-            le[3 * NPC + 3 * b + c] = lam[m.ndof_u + 3 * el.vid[b] + c];
+            we[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * rot_node(m, el, b) + c];
+            le[3 * NPC + 3 * b + c] = lam[m.ndof_u + 3 * rot_node(m, el, b) + c];
         }
     double ge[NVC];
 #pragma unroll
@@ -1084,8 +1106,8 @@ k_dRdfield_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doubl
         Mat mat, ex;
         material<WHICH>(interp<NVC>(tab->N1[q], el.hn), interp<NVC>(tab->N1[q], el.En),
                         interp<NVC>(tab->N1[q], el.nun), el.hK, tab->wS[q] * g.det, tab->w[q] * g.det, g.Ju, mat, ex);
-        const Gen sw = strains<NPC, NVC>(g, d, mm, tab->N1[q], we);
-        const Gen sl = strains<NPC, NVC>(g, d, mm, tab->N1[q], le);
+        const Gen sw = strains<NPC, NVC>(g, d, mm, tab->NR[q], we);
+        const Gen sl = strains<NPC, NVC>(g, d, mm, tab->NR[q], le);
         Gen t = stress_of(sw, mat);
         if (WHICH == DERIV_NU) stress_add_dnu(sw, ex, t);
         const double dens = gen_dot(t, sl);
@@ -1120,7 +1142,7 @@ k_apply_dh(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double*
     for (int a = 0; a < NPC; ++a)
         for (int c = 0; c < 3; ++c) xe[3 * a + c] = x[3 * el.pid[a] + c];
     for (int b = 0; b < NVC; ++b) {
-        for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = x[m.ndof_u + 3 * el.vid[b] + c];
+        for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = x[m.ndof_u + 3 * rot_node(m, el, b) + c];
         dhn[b] = dh[f.ewm ? e : el.vid[b]];
     }
     for (int i = 0; i < LD; ++i) ye[i] = 0.0;
@@ -1148,7 +1170,7 @@ k_apply_dh(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double*
     for (int a = 0; a < NPC; ++a)
         for (int c = 0; c < 3; ++c) atomicAdd(&y[3 * el.pid[a] + c], ye[3 * a + c]);
     for (int b = 0; b < NVC; ++b)
-        for (int c = 0; c < 3; ++c) atomicAdd(&y[m.ndof_u + 3 * el.vid[b] + c], ye[3 * NPC + 3 * b + c]);
+        for (int c = 0; c < 3; ++c) atomicAdd(&y[m.ndof_u + 3 * rot_node(m, el, b) + c], ye[3 * NPC + 3 * b + c]);
 }
 
 // out += scale * y^T (dM/dh) x  per thickness DOF:  int rho M_b (x_u.y_u + h_K^2 x_theta.y_theta) J dx
@@ -1176,8 +1198,8 @@ k_dMdh_T(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const double* _
         for (int b = 0; b < NVC; ++b) {
             rq += tab->N1[q][b] * f.rho[f.ewm ? e : el.vid[b]];
             for (int c = 0; c < 3; ++c) {
-                xt[c] += tab->N1[q][b] * x[m.ndof_u + 3 * el.vid[b] + c];
-                yt[c] += tab->N1[q][b] * y[m.ndof_u + 3 * el.vid[b] + c];
+                xt[c] += tab->NR[q][b] * x[m.ndof_u + 3 * rot_node(m, el, b) + c];
+                yt[c] += tab->NR[q][b] * y[m.ndof_u + 3 * rot_node(m, el, b) + c];
             }
         }
         const double dens = tab->w[q] * g.det * g.Ju * rq * (dot3(xu, yu) + el.hK * el.hK * dot3(xt, yt));
@@ -1267,9 +1289,9 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
     const int nq = tab->nq;
     for (int q = 0; q < nq; ++q) {
         const QPoint<NPC, NVC>& p = sq[q];
-        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dN1[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dN1[q][aj][1];
+        const double r0 = is_u ? tab->dN2[q][aj][0] : tab->dNR[q][aj][0], r1 = is_u ? tab->dN2[q][aj][1] : tab->dNR[q][aj][1];
         const double dk0 = r0 * p.g.Q[0][0] + r1 * p.g.Q[1][0], dk1 = r0 * p.g.Q[0][1] + r1 * p.g.Q[1][1];
-        const double Mj = is_u ? 0.0 : tab->N1[q][aj];
+        const double Mj = is_u ? 0.0 : tab->NR[q][aj];
         double G0[3], G1[3], th[3], T0[3], T1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -1282,7 +1304,7 @@ k_element_matrices(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int f
         }
         const Gen s = strains_reduced(p.g, G0, G1, th, T0, T1);
         const Gen t = stress_of(s, p.mat);
-        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->N1[q], t, ye);
+        strains_T<NPC, NVC>(p.g, p.d, p.mm, tab->NR[q], t, ye);
     }
     double* out = Ke + (size_t)le * LD * LD;
 #pragma unroll
@@ -1366,6 +1388,10 @@ struct FacetDev {
     const int* vnode;    // nf*2  vertices (a, b)
     double* M2;          // nf*9  beta/h_K * int N2_i N2_j |J F^-T N| ds
     double* M1;          // nf*4
+    // CG2CR1 only (null otherwise): the rotation's trace on a facet involves ALL THREE Crouzeix-Raviart functions of the cell (on edge k:
+    // NR_k = 1, NR_(k+1) = s, NR_(k+2) = -s, s in [-1, 1] along the edge), so its block is 3 x 3 over the cell's three edge midpoints
+    const int* rnode;    // nf*3  rotation nodes of the facet's cell, in the cell's local order
+    double* MR;          // nf*9
 };
 
 __device__ __forceinline__ void edge_ref_point(bool quad, int k, double s, double& xi, double& eta) {
@@ -1429,7 +1455,7 @@ __global__ void k_penalty_setup(MeshDev m, FieldsDev f, FacetDev fd, double beta
     for (int c = 0; c < 3; ++c) tv[c] /= len;
     const double gs[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};
     const double gw[3] = {0.5555555555555556, 0.8888888888888888, 0.5555555555555556};
-    double M2[9] = {0}, M1[4] = {0};
+    double M2[9] = {0}, M1[4] = {0}, MR[9] = {0};
     for (int q = 0; q < 3; ++q) {
         const double s = gs[q];
         double nanson = 1.0;
@@ -1476,9 +1502,17 @@ __global__ void k_penalty_setup(MeshDev m, FieldsDev f, FacetDev fd, double beta
             for (int b = 0; b < 3; ++b) M2[3 * a + b] += wq * U3[a] * U3[b];
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b) M1[2 * a + b] += wq * L1[a] * L1[b];
+        if (fd.MR) {
+            double R[3];
+            R[k % 3] = 1.0; R[(k + 1) % 3] = s; R[(k + 2) % 3] = -s;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) MR[3 * a + b] += wq * R[a] * R[b];
+        }
     }
     for (int a = 0; a < 9; ++a) fd.M2[9 * i + a] = M2[a];
     for (int a = 0; a < 4; ++a) fd.M1[4 * i + a] = M1[a];
+    if (fd.MR)
+        for (int a = 0; a < 9; ++a) fd.MR[9 * i + a] = MR[a];
 }
 
 // y += P x (mode 0) or diag += diag(P) (mode 1); *dotslot += x.Px
@@ -1496,16 +1530,30 @@ __global__ void k_penalty_apply(FacetDev fd, int ndof_u, int mode, const double*
         for (int c = 0; c < 3; ++c) {
             if (mode == 1) {
                 for (int a = 0; a < 3; ++a) atomicAdd(&y[3 * un[a] + c], A[4 * a]);
-                for (int a = 0; a < 2; ++a) atomicAdd(&y[ndof_u + 3 * vn[a] + c], B[3 * a]);
+                if (fd.MR) {
+                    for (int a = 0; a < 3; ++a) atomicAdd(&y[ndof_u + 3 * fd.rnode[3 * i + a] + c], fd.MR[9 * i + 4 * a]);
+                } else {
+                    for (int a = 0; a < 2; ++a) atomicAdd(&y[ndof_u + 3 * vn[a] + c], B[3 * a]);
+                }
             } else {
                 double xu[3], xv[2];
                 for (int a = 0; a < 3; ++a) xu[a] = x[3 * un[a] + c];
-                for (int a = 0; a < 2; ++a) xv[a] = x[ndof_u + 3 * vn[a] + c];
+                for (int a = 0; a < 2; ++a) xv[a] = fd.MR ? 0.0 : x[ndof_u + 3 * vn[a] + c];
                 for (int a = 0; a < 3; ++a) {
                     const double r = A[3 * a] * xu[0] + A[3 * a + 1] * xu[1] + A[3 * a + 2] * xu[2];
                     local += r * xu[a];
                     atomicAdd(&y[3 * un[a] + c], r);
                 }
+                if (fd.MR) {
+                    const double* R = fd.MR + 9 * i;
+                    double xr[3];
+                    for (int a = 0; a < 3; ++a) xr[a] = x[ndof_u + 3 * fd.rnode[3 * i + a] + c];
+                    for (int a = 0; a < 3; ++a) {
+                        const double r = R[3 * a] * xr[0] + R[3 * a + 1] * xr[1] + R[3 * a + 2] * xr[2];
+                        local += r * xr[a];
+                        atomicAdd(&y[ndof_u + 3 * fd.rnode[3 * i + a] + c], r);
+                    }
+                } else
                 for (int a = 0; a < 2; ++a) {
                     const double r = B[2 * a] * xv[0] + B[2 * a + 1] * xv[1];
                     local += r * xv[a];

@@ -28,7 +28,7 @@ __device__ __forceinline__ TopStrain top_strain(const Tables& t, int q, const QP
     double th[3] = {0, 0, 0};
     double gh0 = 0.0, gh1 = 0.0;
     for (int b = 0; b < NVC; ++b) {
-        const double Mb = t.N1[q][b];
+        const double Mb = t.NR[q][b];           // the rotation's shape function (N1 itself except for CG2CR1)
         for (int c = 0; c < 3; ++c) th[c] += Mb * xe[3 * NPC + 3 * b + c];
         if (!ewm) {
             const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
@@ -82,7 +82,7 @@ k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double
         for (int a = 0; a < NPC; ++a)
             for (int c = 0; c < 3; ++c) xe[3 * a + c] = w[3 * el.pid[a] + c];
         for (int b = 0; b < NVC; ++b)
-            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
+            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * rot_node(m, el, b) + c];
         for (int i = 0; i < LD; ++i) ye[i] = 0.0;
         for (int b = 0; b < NVC; ++b) ge[b] = 0.0;
         const int nq = tab->nq;
@@ -162,7 +162,7 @@ k_pnorm(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mode, double
             for (int a = 0; a < NPC; ++a)
                 for (int c = 0; c < 3; ++c) atomicAdd(&out[3 * el.pid[a] + c], scale * ye[3 * a + c]);
             for (int b = 0; b < NVC; ++b)
-                for (int c = 0; c < 3; ++c) atomicAdd(&out[m.ndof_u + 3 * el.vid[b] + c], scale * ye[3 * NPC + 3 * b + c]);
+                for (int c = 0; c < 3; ++c) atomicAdd(&out[m.ndof_u + 3 * rot_node(m, el, b) + c], scale * ye[3 * NPC + 3 * b + c]);
         } else if (mode >= 2) {
             if (f.ewm) out[e] += scale * ge[0];
             else
@@ -189,7 +189,7 @@ k_stress_field(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const dou
     for (int a = 0; a < NPC; ++a)
         for (int c = 0; c < 3; ++c) xe[3 * a + c] = w[3 * el.pid[a] + c];
     for (int b = 0; b < NVC; ++b)
-        for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
+        for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * rot_node(m, el, b) + c];
     double A[NVC][NVC + 1];
     for (int i = 0; i < NVC; ++i)
         for (int j = 0; j <= NVC; ++j) A[i][j] = 0.0;
@@ -242,7 +242,7 @@ k_stress_sums(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const doub
         for (int a = 0; a < NPC; ++a)
             for (int c = 0; c < 3; ++c) xe[3 * a + c] = w[3 * el.pid[a] + c];
         for (int b = 0; b < NVC; ++b)
-            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
+            for (int c = 0; c < 3; ++c) xe[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * rot_node(m, el, b) + c];
         const int nq = tab->nq;
         for (int q = 0; q < nq; ++q) {
             QPG g;

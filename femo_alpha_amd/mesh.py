@@ -14,7 +14,7 @@ strong Dirichlet conditions need.
 State-vector layout (solver-internal, opaque to callers exactly as in the reference,
 SURVEY.md section 8a row N)::
 
-    w = [ u(P2 node 0) xyz, u(P2 node 1) xyz, ...,  theta(vertex 0) xyz, ... ]
+    w = [ u(P2 node 0) xyz, u(P2 node 1) xyz, ...,  theta(vertex 0) xyz, ... ]       (CG2CR1: theta(edge 0) xyz, ...)
     P2 node ids:  vertices 0..nV-1 | edge midpoints nV..nV+nE-1 | cell centres (quads)
 
 so ``ndof = 3*(nV+nE+nC) + 3*nV`` on quads (``3*(nV+nE) + 3*nV`` on triangles).
@@ -36,8 +36,9 @@ class ShellMesh:
         # element: the mixed space of the state (ShellElement.setUpFunctionSpace, linear_shell_model.py:47-86).  'CG2CG1' -- the
         # one RMShellPDE selects (rm_shell_pde.py:27): displacement on the P2 nodes, rotation on the vertices; 'CG1CG1'
         # (:74-79): both on the vertices -- the "P2 node" set then IS the vertex set and every table of the displacement is the
-        # bilinear / linear one.  ('CG2CR1', triangles only, :68-73, is not provided.)
-        if element not in ("CG2CG1", "CG1CG1"):
+        # bilinear / linear one; 'CG2CR1' (:68-73, triangles only as in the reference): displacement on the P2 nodes, rotation on the
+        # EDGE MIDPOINTS with the Crouzeix-Raviart functions -- the rotation nodes are the P2 nodes nV .. nV + nE - 1.
+        if element not in ("CG2CG1", "CG1CG1", "CG2CR1"):
             raise ValueError("Invalid element type.")
         self.element = element
         nodes = np.ascontiguousarray(np.asarray(nodes, dtype=np.float64))
@@ -50,6 +51,8 @@ class ShellMesh:
             raise ValueError("Invalid cell shape--should be either triangular or quadrilateral")
         if cells.size and (cells.min() < 0 or cells.max() >= nodes.shape[0]):
             raise ValueError("connectivity refers to a node that does not exist")
+        if element == "CG2CR1" and cells.shape[1] != 3:
+            raise ValueError("Invalid element type.")          # CR1 is a simplex element
         self.nodes = nodes
         self.cells = cells
         self.nn = nodes.shape[0]
@@ -120,7 +123,10 @@ class ShellMesh:
         self.cell_p2 = np.ascontiguousarray(np.hstack(cols).astype(np.int32))
         self.npc = self.cell_p2.shape[1]
         self.ndof_u = 3 * self.nP2
-        self.ndof_t = 3 * nV
+        # rotation nodes: the vertices, or (CG2CR1) the edge midpoints -- node k of that set is edge k = P2 node nV + k
+        self.nR = nE if self.element == "CG2CR1" else nV
+        self.cell_rot = self.cell_edges if self.element == "CG2CR1" else self.cells          # (nel, nvc) rotation node of every local slot
+        self.ndof_t = 3 * self.nR
         self.ndof = self.ndof_u + self.ndof_t
         self.ldof = 3 * self.npc + 3 * self.nvc      # 39 (quad) / 27 (triangle)
 
@@ -139,7 +145,7 @@ class ShellMesh:
         """(nel, ldof) global DOF numbers, element-local order [u_a xyz ..., theta_b xyz ...]."""
         npc, nvc = self.cell_p2.shape[1], self.cells.shape[1]
         out = np.empty((self.nel, 3 * npc + 3 * nvc), dtype=np.int32)
-        p3, v3 = 3 * self.cell_p2.astype(np.int32), np.int32(self.ndof_u) + 3 * self.cells.astype(np.int32)
+        p3, v3 = 3 * self.cell_p2.astype(np.int32), np.int32(self.ndof_u) + 3 * self.cell_rot.astype(np.int32)
         for c in range(3):
             out[:, c:3 * npc:3] = p3 + np.int32(c)
             out[:, 3 * npc + c::3] = v3 + np.int32(c)
@@ -249,7 +255,7 @@ class ShellMesh:
         (reference rm_shell_model.py:168-180): every P2 node (u) and every vertex
         (theta) whose coordinates satisfy ``func``."""
         m2 = self._eval_marker(func, self.p2_coords)
-        mv = m2[: self.nV]
+        mv = m2[self.nV: self.nV + self.nE] if self.element == "CG2CR1" else m2[: self.nV]       # rotation nodes: edge midpoints / vertices
         un = np.nonzero(m2)[0]
         tn = np.nonzero(mv)[0]
         ud = (3 * un[:, None] + np.arange(3)[None, :]).ravel()

@@ -94,6 +94,8 @@ def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=
     if impl == "native":
         from . import _native
         return _tree_from_native(_native.plan_arrays(mesh, leaf_size, min_depth, axis_rule, gap))
+    if getattr(mesh, "element", "") == "CG2CR1":
+        raise NotImplementedError("the numpy twin of the analysis knows the vertex-rotation layouts only; CG2CR1 goes through the native library")
     nel, nP2 = mesh.nel, mesh.nP2
     xc = mesh.nodes[mesh.cells]
     cent = xc.mean(axis=1)
@@ -321,6 +323,12 @@ def build_plan(mesh, leaf_size=12, impl="native", axis_rule=None, gap=None) -> F
 
 
 def rank_plan(mesh, T: Tree, rank, nranks):
+    if getattr(mesh, "element", "") == "CG2CR1":
+        raise NotImplementedError("CG2CR1: the element-partitioned driver is not provided for this element")
+    return _rank_plan(mesh, T, rank, nranks)
+
+
+def _rank_plan(mesh, T: Tree, rank, nranks):
     """Cut the plan of one rank out of the global tree ``T`` (``analyse(mesh, leaf, min_depth=log2 nranks)``).
 
     Returns ``(sub, plan, info)``: the rank's sub-mesh (its elements, own numbering), the plan in the

@@ -49,6 +49,16 @@ int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc
 int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                       const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                       int elementwise_material, int elementwise_pressure, int nquad, int32_t nghost);
+/* The same with the mixed element chosen explicitly (ShellElement.setUpFunctionSpace, linear_shell_model.py:47-86):
+ *   element 0   'CG2CG1' -- or 'CG1CG1' when nP2 == nn -- exactly femo_create_ghost;
+ *   element 1   'CG2CR1' (:68-73; triangles only, as in the reference): displacement on the P2 nodes, rotation on the EDGE MIDPOINTS with
+ *               the Crouzeix-Raviart functions.  The rotation nodes are the P2 nodes nn .. nP2 - 1 (cell_p2 lists the edge midpoints of a
+ *               cell behind its vertices): state vector [u(P2 nodes) xyz | theta(edge midpoints) xyz], femo_ndof = 3 nP2 + 3 (nP2 - nn).
+ *               Provided: operator, both Dirichlet treatments, solves, scalar outputs, stress outputs, the adjoint chain for thickness / E /
+ *               nu / F_solid.  Not provided (the call fails with a message): shape derivatives, the transient march, the CSR export, ghosts. */
+int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
+                        const double* xyz, const int32_t* cells, const int32_t* cell_p2,
+                        int elementwise_material, int elementwise_pressure, int nquad, int32_t nghost, int element);
 void femo_destroy(femo_ctx* ctx);
 
 int64_t femo_ndof(const femo_ctx* ctx);

@@ -190,6 +190,15 @@ class ShellOracle:
         if getattr(mesh, "element", "CG2CG1") == "CG1CG1":
             # ShellElement 'CG1CG1' (linear_shell_model.py:74-79): the displacement is interpolated on the vertices as well
             self.N2, self.dN2 = self.N1, self.dN1
+        # shape functions of the ROTATION: the vertex functions, or -- ShellElement 'CG2CR1' (linear_shell_model.py:68-73, triangles) --
+        # the Crouzeix-Raviart functions of the edge midpoints: with barycentric coordinates L, the function of edge k (vertex k -> k + 1,
+        # opposite vertex k + 2) is 1 - 2 L_(k+2): one at its own midpoint, zero at the other two, NOT continuous across edges
+        self.cr = getattr(mesh, "element", "CG2CG1") == "CG2CR1"
+        self.NR, self.dNR = self.N1, self.dN1
+        if self.cr:
+            opp = [2, 0, 1]
+            self.NR = 1.0 - 2.0 * self.N1[:, opp]
+            self.dNR = -2.0 * self.dN1[:, opp, :]
         self.nq = self.pts.shape[0]
         self.npc = mesh.cell_p2.shape[1]
         self.nvc = mesh.cells.shape[1]
@@ -259,7 +268,8 @@ class ShellOracle:
         E0, E1, E2, Finv = g["E0"], g["E1"], g["E2"], g["Finv"]
         gradN = np.einsum("eqki,qak->eqai", g["Kinv"], self.dN2)        # (ne,nq,npc,3)
         gxN = np.einsum("eqak,eqkj->eqaj", gradN, Finv)
-        gxM = np.einsum("eqbk,eqkj->eqbj", g["gradM"], Finv)
+        gradR = np.einsum("eqki,qbk->eqbi", g["Kinv"], self.dNR)        # surface gradient of the rotation's shape functions
+        gxM = np.einsum("eqbk,eqkj->eqbj", gradR, Finv)
         d = np.stack([np.einsum("eqj,eqaj->eqa", E0, gxN), np.einsum("eqj,eqaj->eqa", E1, gxN)], axis=-1)
         m = np.stack([np.einsum("eqj,eqbj->eqb", E0, gxM), np.einsum("eqj,eqbj->eqb", E1, gxM)], axis=-1)
         Wp = np.einsum("eqik,eqkj->eqij", g["W"], Finv)
@@ -275,7 +285,7 @@ class ShellOracle:
         Bu[:, :, 6] = e2 * d0
         Bu[:, :, 7] = e2 * d1
         Bu[:, :, 8] = 0.5 * (e0 * d1 - e1 * d0)
-        M = self.N1[None, :, :, None]                                   # (1,nq,nvc,1)
+        M = self.NR[None, :, :, None]                                   # (1,nq,nvc,1)
         m0, m1 = m[..., 0][..., None], m[..., 1][..., None]
         c00 = -e1 * m0 + M * _cross(E0, wl[0])[:, :, None, :]
         c01 = -e1 * m1 + M * _cross(E0, wl[1])[:, :, None, :]
@@ -371,7 +381,14 @@ class ShellOracle:
                     out.append((np.array([3 * pa + c, 3 * pb + c]), M1))
                 else:
                     out.append((np.array([3 * pa + c, 3 * pm + c, 3 * pb + c]), M2))
-                out.append((mesh.ndof_u + np.array([3 * va + c, 3 * vb + c]), M1))
+                if self.cr:
+                    # the trace of a Crouzeix-Raviart rotation on edge k involves all three functions of the cell: along the edge
+                    # (s in [-1, 1] from vertex k to k + 1) R_k = 1, R_(k+1) = 1 - 2 L_k = s, R_(k+2) = 1 - 2 L_(k+1) = -s
+                    R = np.zeros((x.size, 3))
+                    R[:, k % 3], R[:, (k + 1) % 3], R[:, (k + 2) % 3] = 1.0, x, -x
+                    out.append((mesh.ndof_u + 3 * mesh.cell_edges[cell].astype(np.int64) + c, np.einsum("q,qi,qj->ij", wq, R, R)))
+                else:
+                    out.append((mesh.ndof_u + np.array([3 * va + c, 3 * vb + c]), M1))
         return out
 
     def _nanson(self, cell, k, s):
@@ -418,7 +435,7 @@ class ShellOracle:
             g = self._geometry(sl, self.N1, self.dN1)
             c = self.wts[None, :] * g["det"] * g["Ju"] * self._at_qp(self.rho, sl) * self._at_qp(self.h, sl)
             Mu = np.einsum("eq,qa,qb->eab", c, self.N2, self.N2)
-            Mt = np.einsum("eq,qa,qb->eab", c * (self.hK[sl] ** 2)[:, None], self.N1, self.N1)
+            Mt = np.einsum("eq,qa,qb->eab", c * (self.hK[sl] ** 2)[:, None], self.NR, self.NR)
             d = self.dofs[sl]
             for comp in range(3):
                 du = d[:, comp:3 * self.npc:3]
@@ -603,7 +620,7 @@ class ShellOracle:
         we = w[self.dofs[sl]]
         s = np.einsum("eqij,ej->eqi", B, we)
         h, E, nu = self._at_qp(self.h, sl), self._at_qp(self.E, sl), self._at_qp(self.nu, sl)
-        th = np.einsum("qb,ebc->eqc", self.N1, we[:, 3 * self.npc:].reshape(-1, self.nvc, 3))
+        th = np.einsum("qb,ebc->eqc", self.NR, we[:, 3 * self.npc:].reshape(-1, self.nvc, 3))
         b0 = -np.einsum("eqc,eqc->eq", th, g["E1"]); b1 = np.einsum("eqc,eqc->eq", th, g["E0"])
         if self.ewm:
             gh0 = gh1 = np.zeros_like(h)

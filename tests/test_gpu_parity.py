@@ -877,3 +877,92 @@ def test_cg1cg1_stress_csr_and_shape_outputs(kind):
             d = (vals[0] - vals[1]) / (2 * step)
             assert abs(g_r[v, comp] - d) <= 5e-6 * np.abs(g_r).max() + 1e-7 * abs(d), ("penalty", v, comp, g_r[v, comp], d)
     c.close()
+
+
+@pytest.mark.parametrize("kind,uhat,bc,ewm", [("tri", False, "strong", False), ("tri", True, "penalty", False), ("delaunay", False, "penalty", False),
+                                              ("delaunay", True, "strong", True)])
+def test_cg2cr1_element(kind, uhat, bc, ewm):
+    """ShellElement 'CG2CR1' (linear_shell_model.py:68-73; triangles; the reference's RMShellPDE never selects it, rm_shell_pde.py:27):
+    displacement on the P2 nodes, rotation on the EDGE MIDPOINTS with the Crouzeix-Raviart functions.  In the library the rotation's
+    shape tables part from the tables of the geometry and the nodal fields (Tables::NR / dNR) and a rotation node is the cell's P2 node
+    3 + k; the penalty clamp gets a 3 x 3 rotation block per facet (a Crouzeix-Raviart trace involves all three functions of the cell).
+    Against the oracle's CG2CR1 branch -- which builds its B matrices from 1 - 2 L_(k+2) directly: operator, diagonal, load, functionals,
+    partial gradients, stress outputs at 1e-11; forward solve and adjoint gradient through the multifrontal Cholesky at 1e-8; what is not
+    provided for this element fails with a message."""
+    from femo_alpha_amd.backend import FemoHipError, ShellContext
+    from oracle.rm_shell_oracle import ShellOracle
+    base = _mesh(kind)
+    m = ShellMesh(base.nodes, base.cells, "CG2CR1")
+    assert m.nR == m.nE and m.ndof == 3 * (m.nV + m.nE) + 3 * m.nE and m.ldof == 27
+    with pytest.raises(ValueError, match="Invalid element type"):
+        ShellMesh(_mesh("warped").nodes, _mesh("warped").cells, "CG2CR1")          # a simplex element
+    rng = np.random.default_rng(6)
+    nT = m.nel if ewm else m.nn
+    fields = dict(thickness=0.05 * (1 + 0.3 * rng.uniform(-1, 1, nT)), E=3e7 * (1 + 0.2 * rng.uniform(-1, 1, nT)),
+                  nu=0.3 + 0.05 * rng.uniform(-1, 1, nT), density=10 * (1 + 0.1 * rng.uniform(-1, 1, nT)),
+                  F_solid=rng.uniform(-1, 1, (m.nn, 3)))
+    if uhat:
+        fields["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
+    marker = lambda x: np.less(x[1], 1e-12)
+    sd = m.locate_dofs_geometrical(marker) if bc == "strong" else None
+    pf = m.penalty_facets(marker) if bc == "penalty" else None
+    # (penalty 1e10, not the reference's 1e15: the oracle's float64 LU of a 1e15-penalised operator is itself only good to ~2e-7 on this
+    #  element -- its 3 x 3 rotation blocks have rank 2 -- and the forward solve below is compared with it at 1e-8; the blocks themselves
+    #  are checked entry by entry through apply_K and the diagonal, whatever beta is)
+    beta = 1e10
+    o = ShellOracle(m, element_wise_material=ewm, strong_dofs=sd, penalty_facets=pf, beta=beta)
+    o.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"], uhat=fields.get("uhat"))
+    c = ShellContext(m, element_wise_material=ewm)
+    assert c.ndof == m.ndof
+    for k, v in fields.items():
+        c.set_field(k, v)
+    if sd is not None:
+        c.set_strong_dofs(sd)
+    else:
+        c.set_penalty_facets(pf, beta)
+    tol = 1e-11
+    x = rng.uniform(-1, 1, m.ndof)
+    K = o.assemble_K()
+    assert rel(c.apply_K(x), K @ x) < tol
+    assert rel(c.diagonal(), K.diagonal()) < tol
+    assert rel(c.load_vector(), o.load_vector()) < tol
+    Ke = c.element_matrices(0, 3)
+    assert rel(Ke, o.element_matrices(slice(0, 3))) < tol
+    w = rng.uniform(-1, 1, m.ndof) * 1e-3
+    if sd is not None:
+        w[o.strong_dofs] = 0.0
+    c.set_state(w)
+    assert abs(c.functional("compliance") - o.compliance(w)) < tol * abs(o.compliance(w))
+    assert abs(c.functional("mass") - o.mass()) < tol * abs(o.mass())
+    assert abs(c.functional("elastic_energy") - o.elastic_energy(w)) < tol * abs(o.elastic_energy(w))
+    assert rel(c.dfunctional("compliance", "disp_solid"), o.dcompliance_du(w)) < tol
+    assert rel(c.dfunctional("compliance", "thickness"), o.dcompliance_dh(w)) < tol
+    assert rel(c.dfunctional("elastic_energy", "thickness"), 0.5 * o.dRdfield_T("h", w, w)) < tol
+    lam = rng.uniform(-1, 1, m.ndof)
+    for arg, name in (("thickness", "h"), ("E", "E"), ("nu", "nu")):
+        assert rel(c.dRdarg_T(arg, lam), o.dRdfield_T(name, w, lam)) < tol
+    assert rel(c.dRdarg_T("F_solid", lam), o.dRdf_T(lam)) < tol
+    # the stress outputs interpolate the rotation too: the p-norm aggregate of the top-surface von Mises stress
+    os_ = ShellOracle(m, element_wise_material=ewm, nquad=3)
+    os_.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], uhat=fields.get("uhat"))
+    c.set_stress_params(1e-6, 6.0)
+    assert abs(c.functional("pnorm_stress") - os_.pnorm_stress(w, 1e-6, 6.0)) < 1e-10 * abs(os_.pnorm_stress(w, 1e-6, 6.0))
+    # not provided for this element: a message, not a wrong number
+    with pytest.raises(FemoHipError, match="CG2CR1"):
+        c.dRdarg_T("uhat", lam)
+    with pytest.raises(FemoHipError, match="CG2CR1"):
+        c.enable_csr()
+    # forward + adjoint through the direct solver
+    w_ref, J_ref, dJ_ref = o.forward_adjoint()
+    c.use_direct_solver(leaf_size=4)
+    it, rr = c.solve_state(zero_guess=True)
+    assert it <= 4 and rr <= 1e-12
+    assert rel(c.get_state(), w_ref) < 1e-8
+    assert abs(c.functional("compliance") - J_ref) < 1e-8 * abs(J_ref)
+    dJ, it2, _ = c.total_gradient("compliance", "thickness")
+    assert it2 <= 4 and rel(dJ, dJ_ref) < 1e-8
+    # and the matrix-free Jacobi-PCG agrees with it (the Krylov path of the north star on this element)
+    c.set_solver(preconditioner=0, rtol=1e-12, maxit=200000, check_every=50)
+    it3, rr3 = c.solve_state(zero_guess=True)
+    assert rr3 <= 1e-12 and rel(c.get_state(), w_ref) < 1e-7
+    c.close()

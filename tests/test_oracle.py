@@ -368,3 +368,52 @@ def test_cg1cg1_branch_of_the_oracle():
         K = o.assemble_K(with_penalty=False, with_strong=False).toarray()
         ev = np.linalg.eigvalsh(K)
         assert np.sum(np.abs(ev) < 1e-9 * ev.max()) == 6, ev[:8] / ev.max()
+
+
+def test_cg2cr1_layout_oracle_branch_and_plan():
+    """ShellElement 'CG2CR1' (linear_shell_model.py:68-73, triangles): the DOF layout of the mesh container (rotation on the edge
+    midpoints = P2 nodes nV .. nV + nE - 1), the oracle's branch (Crouzeix-Raviart rotation: symmetric operator, exactly six zero-energy
+    rigid-body modes, a constant rotation field reproduced by the functions, softer in bending than the conforming CG2CG1), and the
+    analysis phase, which sees the mesh with its edge nodes relabelled as the six-DOF nodes and whose fronts must come back in the
+    mesh's own DOF numbers."""
+    from femo_alpha_amd.mesh import ShellMesh, plate_mesh, quads_to_triangles, wing_skin_mesh
+    from femo_alpha_amd.solver.symbolic import build_plan
+    from oracle.rm_shell_oracle import ShellOracle
+    base = quads_to_triangles(wing_skin_mesh(4, 8, shuffle=True))
+    m = ShellMesh(base.nodes, base.cells, "CG2CR1")
+    assert m.nR == m.nE and m.ndof_u == 3 * (m.nV + m.nE) and m.ndof == m.ndof_u + 3 * m.nE and m.ldof == 27
+    cd = m.cell_dofs()
+    assert np.array_equal(cd[:, 18::3], m.ndof_u + 3 * m.cell_edges)                       # theta x of the three edge midpoints
+    with pytest.raises(ValueError, match="Invalid element type"):
+        ShellMesh(plate_mesh().nodes, plate_mesh().cells, "CG2CR1")
+    # the Dirichlet set: P2 nodes for u, EDGE MIDPOINTS for theta
+    sd = m.locate_dofs_geometrical(lambda x: np.less(x[1], 1e-9))
+    mid = 0.5 * (m.nodes[m.edges[:, 0]] + m.nodes[m.edges[:, 1]])
+    on = np.nonzero(mid[:, 1] < 1e-9)[0]
+    assert np.array_equal(np.sort(sd[sd >= m.ndof_u]), np.sort((m.ndof_u + 3 * on[:, None] + np.arange(3)).ravel()))
+    o = ShellOracle(m)
+    rng = np.random.default_rng(0)
+    o.set_fields(h=0.02 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=[7e10], nu=[0.3], rho=[2700.0], f=rng.uniform(-1, 1, (m.nn, 3)))
+    assert np.allclose(o.NR.sum(axis=1), 1.0) and not np.allclose(o.NR, o.N1)              # a partition of unity, not the vertex functions
+    K = o.assemble_K(with_penalty=False, with_strong=False).toarray()
+    assert np.abs(K - K.T).max() < 1e-14 * np.abs(K).max()
+    ev = np.linalg.eigvalsh(K)
+    assert np.sum(ev < 1e-9 * ev.max()) == 6 and ev[6] > 1e-9 * ev.max()
+    # bending: the non-conforming rotation is softer than the conforming one on the same triangles
+    mb = quads_to_triangles(plate_mesh(2.0, 10.0, 2, 6))
+    Js = []
+    for mesh in (mb, ShellMesh(mb.nodes, mb.cells, "CG2CR1")):
+        ob = ShellOracle(mesh, penalty_facets=mesh.penalty_facets(lambda x: np.less(x[0], 3e-16)))
+        ob.set_fields(h=[0.1], E=[1e8], nu=[0.3], rho=[10.0], f=np.tile([0, 0, 5.0], (mesh.nn, 1)))
+        Js.append(ob.compliance(ob.solve()))
+    assert Js[0] < Js[1] < 1.1 * Js[0]
+    # analysis phase: every DOF eliminated exactly once, element maps consistent with the mesh's own numbering
+    plan = build_plan(m, 6)
+    piv = np.concatenate([plan.front_dofs[plan.dof_off[t]:plan.dof_off[t] + plan.npiv[t]] for t in range(plan.ntree)])
+    assert np.array_equal(np.sort(piv), np.arange(m.ndof))
+    for e in range(m.nel):
+        t = plan.elem_front[e]
+        fd = plan.front_dofs[plan.dof_off[t]:plan.dof_off[t + 1]]
+        assert np.array_equal(fd[plan.elem_map[e]], cd[e])
+    with pytest.raises(NotImplementedError):
+        build_plan(m, 6, impl="python")
