@@ -1,0 +1,21 @@
+# Final measurement pass of round 5 on the GPU box: the whole GPU suite (with the call audit of the C-ABI entry points), the bench
+# workloads as the driver runs them, the per-level tables, the schedule fuzz, then the rocprofv3 passes (scripts/r5_rocprof.sh).
+# Everything lands in gpurun_out/; what is judged is copied into profiles/ afterwards.
+set -eu
+cd "${GRAFT_REPO_ROOT:?not on a GPU box: GRAFT_REPO_ROOT is unset}"
+. scripts/r5_lib.sh
+mkdir -p gpurun_out
+FEMO_CALL_AUDIT=gpurun_out/r5_entry_point_calls.json run 900 gpurun_out/r5z_tests.log python -m pytest tests -q -m gpu --durations=5
+tail -3 gpurun_out/r5z_tests.log
+run 600 gpurun_out/r5z_bench_wing1m.json python bench.py
+run 300 gpurun_out/r5z_bench_plate250k.json python bench.py --workload plate250k
+run 400 gpurun_out/r5z_dynamic_500k.json python bench.py --workload plate500k_dynamic
+run 400 gpurun_out/r5z_bench_uquad1m.json python bench.py --workload uquad1m --steps 40
+run 400 gpurun_out/r5z_bench_uskin1m.json python bench.py --workload uskin1m --steps 40 --no-keep-numbering-leg
+run 300 gpurun_out/r5z_levels_wing1m.txt python scripts/r2_levels.py wing1m
+run 300 gpurun_out/r5z_sweeps_wing1m.txt python scripts/r3_sweeps.py wing1m
+run 300 gpurun_out/r5z_smoke.txt python -c "import __graft_entry__ as g; g.smoke()"
+run 600 gpurun_out/r5z_fuzz.txt python scripts/fuzz_schedules.py 5 60
+# a step of the profile pass that is killed at its limit stops this script as well: no further GPU step on that box
+bash scripts/r5_rocprof.sh > gpurun_out/r5z_rocprof.log 2>&1 || { echo 'rocprof pass stopped'; exit 1; }
+tail -c 400 gpurun_out/r5z_bench_wing1m.json; tail -3 gpurun_out/r5z_rocprof.log; tail -2 gpurun_out/r5z_smoke.txt; tail -1 gpurun_out/r5z_fuzz.txt
