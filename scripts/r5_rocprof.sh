@@ -23,4 +23,4 @@ python3 scripts/r4_pmc_levels.py "$(f gpurun_out/pmc_r5lf)" "$(f gpurun_out/pmc_
 python3 scripts/r4_pmc_sq_apply.py "$(f gpurun_out/pmc_r5s1)" "$(f gpurun_out/pmc_r5s2)" "$(f gpurun_out/pmc_r5s3)" > gpurun_out/r5_pmc_sq_apply.txt 2>&1
 cp profiles/pmc_wing1m.json gpurun_out/pmc_wing1m.json
 find gpurun_out/prof_r5 -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/r5_wing1m_kernel_stats.csv
-cat gpurun_out/r5_pmc_sq_apply.txt; tail -3 gpurun_out/pmc_r5s1/out.err gpurun_out/pmc_r5s2/out.err gpurun_out/pmc_r5s3/out.err
+cat gpurun_out/r5_pmc_sq_apply.txt; tail -n 3 gpurun_out/pmc_r5s1/out.err gpurun_out/pmc_r5s2/out.err gpurun_out/pmc_r5s3/out.err
