@@ -9,19 +9,22 @@
 
 namespace femo {
 
-__device__ __forceinline__ int csr_cell_dof(int e, int i, int nel, int npc, int ndof_u, const int* __restrict__ cellp2, const int* __restrict__ cells) {
+// cr_nn >= 0 (CG2CR1): the rotation of local slot k lives on the cell's edge midpoint k = P2 node nvc + k, numbered from cr_nn (= nn)
+__device__ __forceinline__ int csr_cell_dof(int e, int i, int nel, int npc, int ndof_u, const int* __restrict__ cellp2, const int* __restrict__ cells,
+                                            int cr_nn) {
     if (i < 3 * npc) return 3 * cellp2[(size_t)(i / 3) * nel + e] + i % 3;
     const int k = i - 3 * npc;
+    if (cr_nn >= 0) return ndof_u + 3 * (cellp2[(size_t)(3 + k / 3) * nel + e] - cr_nn) + k % 3;
     return ndof_u + 3 * cells[(size_t)(k / 3) * nel + e] + k % 3;
 }
 
 __global__ void k_csr_keys(long long ncontrib, int nel, int ld, int npc, int ndof_u, long long ndof, const int* __restrict__ cellp2,
-                           const int* __restrict__ cells, long long* __restrict__ keys, int* __restrict__ vals) {
+                           const int* __restrict__ cells, long long* __restrict__ keys, int* __restrict__ vals, int cr_nn) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncontrib) return;
     const int e = (int)(k / (ld * ld)), r = (int)(k % (ld * ld));
     const int i = r / ld, j = r % ld;
-    keys[k] = (long long)csr_cell_dof(e, i, nel, npc, ndof_u, cellp2, cells) * ndof + csr_cell_dof(e, j, nel, npc, ndof_u, cellp2, cells);
+    keys[k] = (long long)csr_cell_dof(e, i, nel, npc, ndof_u, cellp2, cells, cr_nn) * ndof + csr_cell_dof(e, j, nel, npc, ndof_u, cellp2, cells, cr_nn);
     vals[k] = (int)k;
 }
 

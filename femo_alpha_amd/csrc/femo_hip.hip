@@ -2264,7 +2264,6 @@ int femo_functional(femo_ctx* c, const char* name, double* value) {
 
 // out (3 nn) += scale * d/d uhat of: mode 0 lam.(K w - F) [+ penalty], 1 int u.u J, 2 mass, 3 elastic energy
 static int shape_gradient_dev(femo_ctx* c, int mode, const double* w, const double* lam, double scale, double* out) {
-    if (c->cr) return fail(c, "CG2CR1: shape derivatives are not provided for this element");
     const MeshDev m = mesh_dev(c);
     const FieldsDev f = fields_dev(c);
     const int nthreads = c->nel * 3 * c->nvc;
@@ -3119,7 +3118,6 @@ int femo_grad_get(femo_ctx* c, double* out, int64_t n) {
 //   w_mid = (w_old + w)/2,  wdot = 2/dt (w - w_old) - wdot_old,  wddot = (wdot - wdot_old)/dt      (plate_sim.py:131-140)
 //   step:  (a M + K/2) w_i = F_i + M (a w_{i-1} + b wdot_{i-1}) - K/2 w_{i-1},   a = 2/dt^2, b = 2/dt
 int femo_newmark_setup(femo_ctx* c, int32_t time_levels, double dt) {
-    if (c->cr) return fail(c, "CG2CR1: the transient march is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     auto& nm = c->nm;
     if (time_levels < 2 || !(dt > 0)) return fail(c, "femo_newmark_setup: need at least two time levels and dt > 0");
@@ -3423,7 +3421,6 @@ int femo_newmark_tangent(femo_ctx* c, const double* dR, int32_t levels) {
 // perm[k]: index into the element-matrix buffer (element * ld*ld + i*ld + j) of the k-th contribution in
 // destination order; dest[k]: its position in the CSR value array (non-decreasing).
 int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* perm, const int32_t* dest) {
-    if (c->cr) return fail(c, "CG2CR1: the CSR export is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     if (ncontrib != (int64_t)c->nel * c->ld * c->ld) return fail(c, "ncontrib must be nel * ldof^2");
     for (int64_t k = 0; k < ncontrib; ++k) {
@@ -3445,7 +3442,6 @@ int femo_set_csr_map(femo_ctx* c, int32_t nnz, int64_t ncontrib, const int32_t* 
 
 // pattern + destination-sorted contribution map on the device (csr_map.h); *nnz_out = number of stored entries
 int femo_build_csr_map(femo_ctx* c, int32_t* nnz_out) {
-    if (c->cr) return fail(c, "CG2CR1: the CSR export is not provided for this element");
     HIPCHK(c, hipSetDevice(c->device));
     const long long nc = (long long)c->nel * c->ld * c->ld;
     if (nc >= (1ll << 31)) return fail(c, "CSR export: more than 2^31 element contributions (the matrix-free solvers have no such limit)");
@@ -3464,7 +3460,7 @@ int femo_build_csr_map(femo_ctx* c, int32_t* nnz_out) {
     HIPCHK(c, hipMalloc((void**)&flags, nc * sizeof(int)));
     const unsigned gb = (unsigned)((nc + 255) / 256);
     hipLaunchKernelGGL(k_csr_keys, dim3(gb), dim3(256), 0, c->stream, nc, c->nel, c->ld, c->npc, c->ndof_u, (long long)c->ndof, (const int*)c->cellp2,
-                       (const int*)c->cells, k0, v0);
+                       (const int*)c->cells, k0, v0, c->cr ? c->nn : -1);
     int bits = 1;
     while (bits < 63 && (1ull << bits) <= (unsigned long long)c->ndof * (unsigned long long)c->ndof) ++bits;
     HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, c->csr_perm, (int)nc, 0, bits, c->stream));

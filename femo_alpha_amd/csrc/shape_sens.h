@@ -126,9 +126,9 @@ __device__ __forceinline__ GenD strains_dual(const Tables& t, int q, const QPG& 
         }
     }
     for (int b = 0; b < NVC; ++b) {
-        const double r0 = t.dN1[q][b][0], r1 = t.dN1[q][b][1];
+        const double r0 = t.dNR[q][b][0], r1 = t.dNR[q][b][1];          // the rotation's shape functions (N1 itself except for CG2CR1)
         const D1 m0 = r0 * s.Q[0][0] + r1 * s.Q[1][0], m1 = r0 * s.Q[0][1] + r1 * s.Q[1][1];
-        const double Mb = t.N1[q][b];
+        const double Mb = t.NR[q][b];
         for (int c = 0; c < 3; ++c) {
             const double v = xe[3 * NPC + 3 * b + c];
             th[c] = th[c] + mk(Mb * v);
@@ -196,8 +196,8 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
         }
     for (int b = 0; b < NVC; ++b)
         for (int c = 0; c < 3; ++c) {
-            we[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * el.vid[b] + c];
-            le[3 * NPC + 3 * b + c] = lam ? lam[m.ndof_u + 3 * el.vid[b] + c] : 0.0;
+            we[3 * NPC + 3 * b + c] = w[m.ndof_u + 3 * rot_node(m, el, b) + c];
+            le[3 * NPC + 3 * b + c] = lam ? lam[m.ndof_u + 3 * rot_node(m, el, b) + c] : 0.0;
         }
     double fn[NVC][3], rhon[NVC];
     for (int b = 0; b < NVC; ++b) {
@@ -235,7 +235,7 @@ k_shape_gradient(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, int mod
             double th[3] = {0, 0, 0};
             D1 gh0 = mk(0.0), gh1 = mk(0.0);
             for (int b = 0; b < NVC; ++b) {
-                for (int c = 0; c < 3; ++c) th[c] += tab->N1[q][b] * we[3 * NPC + 3 * b + c];
+                for (int c = 0; c < 3; ++c) th[c] += tab->NR[q][b] * we[3 * NPC + 3 * b + c];
                 if (!f.ewm) {
                     const double r0 = tab->dN1[q][b][0], r1 = tab->dN1[q][b][1];
                     gh0 = gh0 + el.hn[b] * (r0 * s.Q[0][0] + r1 * s.Q[1][0]);
@@ -324,6 +324,15 @@ __global__ void k_shape_gradient_penalty(MeshDev m, FieldsDev f, FacetDev fd, do
                 wu += L2[a] * w[3 * un[a] + c];
                 lu += L2[a] * lam[3 * un[a] + c];
             }
+            if (fd.MR) {
+                // CG2CR1: the rotation's trace on edge k through all three Crouzeix-Raviart functions of the cell (k_penalty_setup)
+                double R[3];
+                R[k % 3] = 1.0; R[(k + 1) % 3] = s; R[(k + 2) % 3] = -s;
+                for (int a = 0; a < 3; ++a) {
+                    wt += R[a] * w[m.ndof_u + 3 * fd.rnode[3 * i + a] + c];
+                    lt += R[a] * lam[m.ndof_u + 3 * fd.rnode[3 * i + a] + c];
+                }
+            } else
             for (int a = 0; a < 2; ++a) {
                 wt += L1[a] * w[m.ndof_u + 3 * vn[a] + c];
                 lt += L1[a] * lam[m.ndof_u + 3 * vn[a] + c];

@@ -55,7 +55,8 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
  *               the Crouzeix-Raviart functions.  The rotation nodes are the P2 nodes nn .. nP2 - 1 (cell_p2 lists the edge midpoints of a
  *               cell behind its vertices): state vector [u(P2 nodes) xyz | theta(edge midpoints) xyz], femo_ndof = 3 nP2 + 3 (nP2 - nn).
  *               Provided: operator, both Dirichlet treatments, solves, scalar outputs, stress outputs, the adjoint chain for thickness / E /
- *               nu / F_solid.  Not provided (the call fails with a message): shape derivatives, the transient march, the CSR export, ghosts. */
+ *               nu / F_solid / uhat (shape), the transient march with its adjoint, the CSR export.  Not provided (femo_create_element fails
+ *               with a message): ghosts, i.e. element partitions. */
 int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                         const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                         int elementwise_material, int elementwise_pressure, int nquad, int32_t nghost, int element);

@@ -18,13 +18,17 @@ def _gust(time_levels, nn, dt):
     return F.reshape(time_levels, -1)
 
 
-@pytest.mark.parametrize("ewt,element", [(False, "CG2CG1"), (True, "CG2CG1"), (False, "CG1CG1")])
+@pytest.mark.parametrize("ewt,element", [(False, "CG2CG1"), (True, "CG2CG1"), (False, "CG1CG1"), (False, "CG2CR1")])
 def test_march_and_adjoint(ewt, element):
     from femo_alpha_amd.dynamic_rm_shell.operations import StateOperation, TotalStrainEnergyOperation, VolumeOperation
     from femo_alpha_amd.dynamic_rm_shell.plate_sim import PlateSim
     from oracle.rm_shell_oracle import ShellOracle
     mesh = plate_mesh(2.0, 10.0, 4, 12)
-    if element != "CG2CG1":                 # the other quadrilateral element of ShellElement (linear_shell_model.py:74-79)
+    if element == "CG2CR1":                 # Crouzeix-Raviart rotations (linear_shell_model.py:68-73): a simplex element
+        from femo_alpha_amd.mesh import ShellMesh, quads_to_triangles
+        tri = quads_to_triangles(mesh)
+        mesh = ShellMesh(tri.nodes, tri.cells, element)
+    elif element != "CG2CG1":               # the other quadrilateral element of ShellElement (linear_shell_model.py:74-79)
         from femo_alpha_amd.mesh import ShellMesh
         mesh = ShellMesh(mesh.nodes, mesh.cells, element)
     E, nu, rho, dt, N = 1e8, 0.3, 10.0, 0.01, 12

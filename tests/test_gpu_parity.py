@@ -887,8 +887,9 @@ def test_cg2cr1_element(kind, uhat, bc, ewm):
     shape tables part from the tables of the geometry and the nodal fields (Tables::NR / dNR) and a rotation node is the cell's P2 node
     3 + k; the penalty clamp gets a 3 x 3 rotation block per facet (a Crouzeix-Raviart trace involves all three functions of the cell).
     Against the oracle's CG2CR1 branch -- which builds its B matrices from 1 - 2 L_(k+2) directly: operator, diagonal, load, functionals,
-    partial gradients, stress outputs at 1e-11; forward solve and adjoint gradient through the multifrontal Cholesky at 1e-8; what is not
-    provided for this element fails with a message."""
+    partial gradients, stress outputs, CSR export at 1e-11; forward solve and adjoint gradient through the multifrontal Cholesky at 1e-8
+    (the transient march: tests/test_gpu_dynamic.py); shape derivatives against finite differences of the oracle; element partitions are
+    refused with a message."""
     from femo_alpha_amd.backend import FemoHipError, ShellContext
     from oracle.rm_shell_oracle import ShellOracle
     base = _mesh(kind)
@@ -947,11 +948,29 @@ def test_cg2cr1_element(kind, uhat, bc, ewm):
     os_.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], uhat=fields.get("uhat"))
     c.set_stress_params(1e-6, 6.0)
     assert abs(c.functional("pnorm_stress") - os_.pnorm_stress(w, 1e-6, 6.0)) < 1e-10 * abs(os_.pnorm_stress(w, 1e-6, 6.0))
-    # not provided for this element: a message, not a wrong number
+    # shape derivatives (dual-number kernels; the penalty clamp's 3-node rotation trace included) against central finite differences of
+    # the oracle, where the mesh moves (uhat != 0)
+    if uhat:
+        u0 = o.uhat.copy()
+        g_e = c.dfunctional("elastic_energy", "uhat").reshape(-1, 3)
+        g_r = c.dRdarg_T("uhat", lam).reshape(-1, 3)
+        phis = lambda: (o.elastic_energy(w), lam @ (o.assemble_K(with_strong=False) @ w - o.load_vector()))
+        for v in rng.choice(m.nn, 2, replace=False):
+            for comp in range(3):
+                up = u0.copy(); up[v, comp] += 1e-6
+                um = u0.copy(); um[v, comp] -= 1e-6
+                o.set_fields(uhat=up); fp = phis()
+                o.set_fields(uhat=um); fm = phis()
+                o.set_fields(uhat=u0)
+                for name, g, d in (("energy", g_e, (fp[0] - fm[0]) / 2e-6), ("residual", g_r, (fp[1] - fm[1]) / 2e-6)):
+                    assert abs(g[v, comp] - d) <= 2e-6 * np.abs(g).max() + 1e-9 * abs(d), (name, v, comp, g[v, comp], d)
+    # element partitions are not provided for this element: a message at creation, not a wrong number
     with pytest.raises(FemoHipError, match="CG2CR1"):
-        c.dRdarg_T("uhat", lam)
-    with pytest.raises(FemoHipError, match="CG2CR1"):
-        c.enable_csr()
+        ShellContext(m, nghost=3)
+    # the CSR export (pattern built on the device from the edge-midpoint rotation nodes) against the oracle's assembly
+    info = c.enable_csr()
+    Kel = o.assemble_K(with_penalty=False, with_strong=False)
+    assert info["nnz"] == Kel.nnz and abs(c.assemble_csr() - Kel).max() < 1e-11 * abs(Kel).max()
     # forward + adjoint through the direct solver
     w_ref, J_ref, dJ_ref = o.forward_adjoint()
     c.use_direct_solver(leaf_size=4)
