@@ -2474,8 +2474,15 @@ __device__ __host__ inline int sweep_ltiles(int np, int nb) { return ((nb + 127)
 constexpr int BB_COLS_F = 16;                             // columns per workgroup of the fused L21^T x_B (== BB_COLS)
 __device__ __host__ inline int sweep_bblocks(int np, int nb) { return nb > 0 ? (np + BB_COLS_F - 1) / BB_COLS_F : 0; }
 
-__device__ __forceinline__ void sweep_wait(const int* cnt, int want) {
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+// Every wait has an exit: after ~4 million polls (seconds; a dependency is microseconds away) the workgroup gives up, poisons what it
+// was about to compute with a NaN -- the Krylov loop then stops with "NaN residual" -- and signals as if it had finished, so that the
+// grid drains whatever went wrong (a workgroup order this code did not expect) instead of hanging the device.
+__device__ __forceinline__ bool sweep_wait(const int* cnt, int want) {
+    for (int it = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++it) {
+        if (it > (1 << 22)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
 }
 // RM 0: a returning atomic (add of zero): the value as the memory side holds it; RM 1: an agent-scope load (global_load sc1: past
 // this CU's L1); RM 2: a plain load (an experiment: NOT safe across workgroups)
@@ -2532,6 +2539,7 @@ k_sweep_wide_fwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTa
 #pragma unroll
         for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + k, np - 1)];
         if (tid == 0) {
+            bool ok = true;
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd) {
                 const int c = fd.child[sd][t];
@@ -2539,11 +2547,14 @@ k_sweep_wide_fwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTa
                 const int cs = slot_of[c];
                 if (cs < slot_lo) continue;                    // finished by an earlier launch
                 const int cnp = fd.npiv[c];
-                sweep_wait(cnt + 2 * cs + 1, sweep_xtiles(cnp) + sweep_ltiles(cnp, fd.nf[c] - cnp));
+                ok = sweep_wait(cnt + 2 * cs + 1, sweep_xtiles(cnp) + sweep_ltiles(cnp, fd.nf[c] - cnp)) && ok;
             }
+            part[0] = ok ? 0.0 : __builtin_nan("");
         }
         __syncthreads();
-        if (tid < 128) xs[tid] = c0 + tid < np ? sweep_read<RM>(&v[gd[c0 + tid]]) : 0.0;
+        const double poison = part[0];                          // 0, or NaN after a wait that gave up
+        __syncthreads();
+        if (tid < 128) xs[tid] = (c0 + tid < np ? sweep_read<RM>(&v[gd[c0 + tid]]) : 0.0) + poison;
         __syncthreads();
         double s = 0.0;
 #pragma unroll
@@ -2569,9 +2580,11 @@ k_sweep_wide_fwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTa
         double a[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) a[k] = row[(size_t)ld * min(cb0 + k, np - 1)];
-        if (tid == 0) sweep_wait(xdone, sweep_xtiles(np));
+        if (tid == 0) part[0] = sweep_wait(xdone, sweep_xtiles(np)) ? 0.0 : __builtin_nan("");
         __syncthreads();
-        if (tid < 128) xs[tid] = (tid < cw && c0 + tid < np) ? sweep_read<RM>(&y[gd[c0 + tid]]) : 0.0;
+        const double poison = part[0];
+        __syncthreads();
+        if (tid < 128) xs[tid] = ((tid < cw && c0 + tid < np) ? sweep_read<RM>(&y[gd[c0 + tid]]) : 0.0) + poison;
         __syncthreads();
         double s = 0.0;
 #pragma unroll
@@ -2617,12 +2630,15 @@ k_sweep_wide_bwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTa
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int u = 0; u < 8; ++u) a[k][u] = col[k][min(lane + 64 * u, nb - 1)];
+        __shared__ double poison_s;
         if (tid == 0) {
             const int p = fd.parent[t];
-            if (p >= 0 && slot_of[p] < slot_hi) sweep_wait(cnt + 2 * slot_of[p] + 1, sweep_xtiles(fd.npiv[p]));
+            bool ok = true;
+            if (p >= 0 && slot_of[p] < slot_hi) ok = sweep_wait(cnt + 2 * slot_of[p] + 1, sweep_xtiles(fd.npiv[p]));
+            poison_s = ok ? 0.0 : __builtin_nan("");
         }
         __syncthreads();
-        for (int r = tid; r < nb; r += 256) xsd[r] = sweep_read<RM>(&xv[gd[np + r]]);
+        for (int r = tid; r < nb; r += 256) xsd[r] = sweep_read<RM>(&xv[gd[np + r]]) + poison_s;
         __syncthreads();
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int rb = 0; rb < nb; rb += 512) {
@@ -2661,9 +2677,10 @@ k_sweep_wide_bwd(FrontDev fd, const int* __restrict__ level_nodes, const SweepTa
             a0[k] = colp[min(ra, np - 1)];
             a1[k] = colp[min(rb, np - 1)];
         }
-        if (tid == 0) sweep_wait(bdone, sweep_bblocks(np, nb));
+        __shared__ double poison_x;
+        if (tid == 0) poison_x = sweep_wait(bdone, sweep_bblocks(np, nb)) ? 0.0 : __builtin_nan("");
         __syncthreads();
-        if (tid < 128) xsd[tid] = r0 + tid < np ? sweep_read<RM>(&sv[gd[r0 + tid]]) : 0.0;
+        if (tid < 128) xsd[tid] = (r0 + tid < np ? sweep_read<RM>(&sv[gd[r0 + tid]]) : 0.0) + poison_x;
         __syncthreads();
         const double x0 = xsd[lane], x1 = xsd[lane + 64];
         double p[32];
