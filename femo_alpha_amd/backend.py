@@ -57,6 +57,11 @@ class ShellContext:
         self.nghost = int(nghost)
         self.ndof = int(self.lib.femo_ndof(h))            # vector length: mesh DOFs + ghost entries
         assert self.ndof == mesh.ndof + self.nghost
+        # schedule experiments without touching the caller: FEMO_OPTIONS="sweep_w=0,strip_cnt=256" sets those options on every context
+        import os
+        for kv in filter(None, os.environ.get("FEMO_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), float(v))
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):

@@ -178,6 +178,13 @@ struct femo_ctx {
         // own atomics before it may signal, and a tile in flight holds one of 512 slots for ~17 us instead of ~9.  Off; kept as a validated
         // alternative schedule (schedule fuzz)
         int sweep_fuse = 0;
+        // wide levels: W = L21 X takes the place of L21 in the factor store (k_w_inplace, on stream3 behind the inversion of L11), and a
+        // wide level is ONE launch per sweep direction: both of its products read the same input (k_sweep_fwd_w / k_sweep_bwd_w).
+        // Measured at 1 M DOF (profiles/r5_sweep_w_ab.txt): an application of the preconditioner 1.459 ms against 1.520 -- inside the
+        // replayed graph the launch that goes away costs ~3 us, not the ~11 us the event-marked level tables show -- while the 28 GFLOP
+        // of W add 1.5 ms to the factorisation and 0.9 ms of waiting to the first sweep: forward 19.10 ms against 16.84.  Off; kept as a
+        // validated alternative schedule (schedule fuzz)
+        int sweep_w = 0;
         // Optimisation loops: when only FIELDS changed since the last factorisation (a new thickness), keep that factor as the PCG
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
@@ -202,6 +209,7 @@ struct femo_ctx {
         bool have_factor = false;             // a complete factorisation of SOME earlier operator sits in the panel store (option "stale_factor")
         double* snap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // thickness, E, nu, density, uhat as they were when that factor was made
         bool snap_valid = false;
+        bool w_mode = false;                  // the wide levels of the stored factor hold W = L21 X where L21 was (option "sweep_w" at the time of the factorisation)
         bool x_inflight = false;              // k_xinv launches on stream3 that the main stream has not waited for yet (event ev_x[1])
         int ntree = 0, nlevels = 0;
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
@@ -694,6 +702,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     if (assemble) for (int i = 0; i < 8; ++i) { fr.prof_ms[i] = 0; fr.prof_calls[i] = 0; fr.prof_flops[i] = 0; fr.prof_bytes[i] = 0; }
     bool x_pending = false;
     if (join_xinv(c)) return 1;             // a previous factorisation's inversion must be done before X is written again
+    if (l0 == 0) fr.w_mode = c->opt.sweep_w != 0;
     const FrontDev fd = front_dev(c);
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1112,7 +1121,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             HIPCHK(c, hipEventRecord(c->ev_g[1], c->stream_g));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_g[1], 0));
         }
-        if (wide && max_np_level > NBO) {
+        const bool w_level = wide && fr.w_mode && fr.h_level_maxnb[L] > 0;
+        if (wide && (max_np_level > NBO || w_level)) {
             const int max_np = max_np_level, cnt = cnt_level;
             const int* lev = lev_level;
             // L11^-1 of this level's fronts beyond the diagonal blocks, on its own stream: nothing in the factorisation of the
@@ -1134,6 +1144,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                         hipLaunchKernelGGL((k_xinv<1, 128, 64>), grid, dim3(256), 0, c->stream3, fd, lev, off, bs);
                     }
                 }
+            }
+            if (w_level) {
+                // W = L21 X over L21: nothing in the factorisation reads L21 of this level again (its Schur complements are complete)
+                const int nrt = (fr.h_level_maxnb[L] + WT_M - 1) / WT_M;
+                FOR_FRONT_CHUNKS(cnt, off, n) hipLaunchKernelGGL(k_w_inplace, dim3(nrt, n), dim3(256), 0, c->stream3, fd, lev, off);
             }
             x_pending = true;
             if (fr.profile) {                       // profiling: no overlap, so that every class is timed on an otherwise idle chip
@@ -1211,7 +1226,7 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
-        if (fr.h_level_wide[L] && c->opt.sweep_fuse) {
+        if (fr.h_level_wide[L] && c->opt.sweep_fuse && !fr.w_mode) {
             // the run of consecutive wide levels from here: one launch, tiles ordered by per-front counters
             if (join_xinv(c)) return 1;
             int Le = L;
@@ -1232,6 +1247,13 @@ static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         if (fr.h_level_wide[L]) {
             if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
+            if (fr.w_mode) {
+                const int nx = nct * (nct + 1) / 2;
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL(k_sweep_fwd_w, dim3(nx + nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, nx, v, y);
+                mark(); mark();
+                continue;
+            }
             FOR_FRONT_CHUNKS(cnt, off, n)
                 hipLaunchKernelGGL(k_sweep_gemv_n<true>, dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)v, y);
             mark();
@@ -1264,7 +1286,7 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         const int* lev = fr.level_nodes + b;
         const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
         if (maxnp == 0) continue;
-        if (fr.h_level_wide[L] && c->opt.sweep_fuse) {
+        if (fr.h_level_wide[L] && c->opt.sweep_fuse && !fr.w_mode) {
             if (join_xinv(c)) return 1;
             int Lb = L;                                            // the run of consecutive wide levels from L down to Lb
             while (Lb > l0 && fr.h_level_wide[Lb - 1]) --Lb;
@@ -1286,6 +1308,16 @@ static int frontal_bwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEv
         if (fr.h_level_wide[L]) {
             if (join_xinv(c)) return 1;
             const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
+            if (fr.w_mode) {
+                const int nx = nct * (nct + 1) / 2, nbb = maxnb > 0 ? (maxnp + BB_COLS - 1) / BB_COLS : 0;
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    if (c->opt.sweep_butterfly & 2)
+                        hipLaunchKernelGGL(k_sweep_bwd_w<true>, dim3(nx + nbb, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream, fd, lev, off, nx, (const double*)y, v);
+                    else
+                        hipLaunchKernelGGL(k_sweep_bwd_w<false>, dim3(nx + nbb, n), dim3(256), (size_t)maxnb * sizeof(double), c->stream, fd, lev, off, nx, (const double*)y, v);
+                mark(); mark();
+                continue;
+            }
             if (maxnb > 0) {
                 if (maxnb >= c->opt.bnd_tiled_nb) {
                     FOR_FRONT_CHUNKS(cnt, off, n)
@@ -1330,7 +1362,8 @@ static int frontal_solve_z(femo_ctx* c) {
     auto& fr = c->fr;
     if (!c->opt.sweep_graph) return frontal_solve(c, c->z);
     if (join_xinv(c)) return 1;                            // the cross-stream join stays outside the capture
-    if (!fr.sweep_graph || fr.sweep_graph_key != c->opt_version) {
+    const long long graph_key = 2 * c->opt_version + (fr.w_mode ? 1 : 0);
+    if (!fr.sweep_graph || fr.sweep_graph_key != graph_key) {
         if (fr.sweep_graph) { hipGraphExecDestroy(fr.sweep_graph); fr.sweep_graph = nullptr; }
         hipGraph_t g = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -1340,7 +1373,7 @@ static int frontal_solve_z(femo_ctx* c) {
         HIPCHK(c, e);
         HIPCHK(c, hipGraphInstantiate(&fr.sweep_graph, g, nullptr, nullptr, 0));
         hipGraphDestroy(g);
-        fr.sweep_graph_key = c->opt_version;
+        fr.sweep_graph_key = graph_key;
     }
     HIPCHK(c, hipGraphLaunch(fr.sweep_graph, c->stream));
     return 0;
@@ -2156,6 +2189,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
+    else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
     else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }
@@ -2638,6 +2672,8 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_bwd_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bnd_cols<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bwd_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_bwd_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

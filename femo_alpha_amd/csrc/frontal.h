@@ -2290,15 +2290,13 @@ k_front_bwd_small(FrontDev fd, const int* __restrict__ level_nodes, const double
 
 // 128 x 128 tile, 256 threads: thread (row lr, column half ch) keeps 32 loads in flight at a time
 template <bool TRI>
-__global__ void __launch_bounds__(256)
-k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
-    const int t = level_nodes[first + blockIdx.y];
+__device__ __forceinline__ void gemv_n_tile(const FrontDev& fd, int t, int bx, const double* __restrict__ in, double* __restrict__ out) {
     const int np = fd.npiv[t], nf = fd.nf[t];
     if (np == 0) return;
     const int nct = (np + 127) / 128;
     int ti, tj;                                              // row tile, column tile
     if (TRI) {
-        const int lin = blockIdx.x;
+        const int lin = bx;
         if (lin >= nct * (nct + 1) / 2) return;
         ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
@@ -2306,8 +2304,8 @@ k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
         tj = lin - ti * (ti + 1) / 2;
     } else {
         const int nrt = (nf - np + 127) / 128;
-        if ((int)blockIdx.x >= nrt * nct) return;
-        ti = blockIdx.x / nct; tj = blockIdx.x % nct;
+        if (bx >= nrt * nct) return;
+        ti = bx / nct; tj = bx % nct;
     }
     const int* gd = fd.dofs + fd.doff[t];
     const int ld = TRI ? ldx_of(np) : ldp_of(nf);
@@ -2344,19 +2342,22 @@ k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
         else atomicAdd(&out[gd[np + r]], -s);
     }
 }
+template <bool TRI>
+__global__ void __launch_bounds__(256)
+k_sweep_gemv_n(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
+    gemv_n_tile<TRI>(fd, level_nodes[first + blockIdx.y], (int)blockIdx.x, in, out);
+}
 
 // transposed products: tile of 128 rows x 128 columns, wave w owns columns 32 w .. 32 w + 31 with its lanes along the
 // (contiguous) rows, 64 loads in flight per lane; per column one wave reduction
 template <bool TRI>
-__global__ void __launch_bounds__(256)
-k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
-    const int t = level_nodes[first + blockIdx.y];
+__device__ __forceinline__ void gemv_t_tile(const FrontDev& fd, int t, int bx, const double* __restrict__ in, double* __restrict__ out) {
     const int np = fd.npiv[t], nf = fd.nf[t];
     if (np == 0) return;
     const int nct = (np + 127) / 128;
     int ti, tj;
     if (TRI) {
-        const int lin = blockIdx.x;
+        const int lin = bx;
         if (lin >= nct * (nct + 1) / 2) return;
         ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= lin) ++ti;
@@ -2364,8 +2365,8 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
         tj = lin - ti * (ti + 1) / 2;
     } else {
         const int nrt = (nf - np + 127) / 128;
-        if ((int)blockIdx.x >= nrt * nct) return;
-        ti = blockIdx.x / nct; tj = blockIdx.x % nct;
+        if (bx >= nrt * nct) return;
+        ti = bx / nct; tj = bx % nct;
     }
     const int* gd = fd.dofs + fd.doff[t];
     const int ld = TRI ? ldx_of(np) : ldp_of(nf);
@@ -2399,20 +2400,24 @@ k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, cons
     const int c = c0 + 32 * wv + col;
     if (!(lane & 1) && c < np) atomicAdd(&out[gd[c]], TRI ? sum : -sum);
 }
+template <bool TRI>
+__global__ void __launch_bounds__(256)
+k_sweep_gemv_t(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
+    gemv_t_tile<TRI>(fd, level_nodes[first + blockIdx.y], (int)blockIdx.x, in, out);
+}
 
 // s_p = y_p - L21^T x_B with one workgroup per 16 pivot columns and ALL boundary rows of the front (no atomics, fixed
 // summation order): the better shape for the many medium fronts of the middle levels, where a front's L21 is a few
 // hundred rows; the tiled kernel above takes over where one workgroup per 32 columns could not pull the block out of HBM.
 constexpr int BB_COLS = 16;
-template <bool BFLY>
-__global__ void __launch_bounds__(256)
-k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, double* __restrict__ sv, const double* __restrict__ xv) {
-    const int t = level_nodes[first + blockIdx.y];
+// ATOMIC: the sums are subtracted from sv with atomic adds (the W form of the sweeps, where other workgroups of the same launch add
+// to the same entries)
+template <bool BFLY, bool ATOMIC>
+__device__ __forceinline__ void bnd_cols_block(const FrontDev& fd, int t, int bx, double* __restrict__ sv, const double* __restrict__ xv, double* xs) {
     const int np = fd.npiv[t], nf = fd.nf[t];
     const int nb = nf - np;
-    const int c0 = blockIdx.x * BB_COLS;
+    const int c0 = bx * BB_COLS;
     if (c0 >= np || nb == 0) return;
-    extern __shared__ double xs[];                       // nb
     const int* gd = fd.dofs + fd.doff[t];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int r = tid; r < nb; r += 256) xs[r] = xv[gd[np + r]];
@@ -2442,14 +2447,40 @@ k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, do
     if (BFLY) {
         int k;
         const double tot = wave_sum_cols<4>(s, lane, k);
-        if (!(lane & 15) && cb + k < np) sv[gd[cb + k]] -= tot;
+        if (!(lane & 15) && cb + k < np) { if (ATOMIC) atomicAdd(&sv[gd[cb + k]], -tot); else sv[gd[cb + k]] -= tot; }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double tot = wave_sum(s[k]);
-            if (lane == 0 && cb + k < np) sv[gd[cb + k]] -= tot;
+            if (lane == 0 && cb + k < np) { if (ATOMIC) atomicAdd(&sv[gd[cb + k]], -tot); else sv[gd[cb + k]] -= tot; }
         }
     }
+}
+template <bool BFLY>
+__global__ void __launch_bounds__(256)
+k_sweep_bnd_cols(FrontDev fd, const int* __restrict__ level_nodes, int first, double* __restrict__ sv, const double* __restrict__ xv) {
+    extern __shared__ double xs_bnd[];                   // nb
+    bnd_cols_block<BFLY, false>(fd, level_nodes[first + blockIdx.y], (int)blockIdx.x, sv, xv, xs_bnd);
+}
+
+// ---- the W form of the wide levels (option "sweep_w"): with W = L21 X stored in the place of L21 (k_w_inplace, beside the
+// factorisation like X itself) both products of a level read the SAME input,
+//   forward    y_p = X b_p,  v_B -= W b_p            backward   x_p = X^T y_p - W^T x_B,
+// so a level is ONE launch per direction instead of two dependent ones: the product with X -- ~10 us whatever it moves, the chip
+// mostly idle -- runs beside the tiles of W instead of in front of them.  The bytes are the same (W has the shape of L21).
+__global__ void __launch_bounds__(256)
+k_sweep_fwd_w(FrontDev fd, const int* __restrict__ level_nodes, int first, int nx, double* __restrict__ v, double* __restrict__ y) {
+    const int t = level_nodes[first + blockIdx.y];
+    if ((int)blockIdx.x < nx) gemv_n_tile<true>(fd, t, (int)blockIdx.x, v, y);
+    else gemv_n_tile<false>(fd, t, (int)blockIdx.x - nx, v, v);          // reads the pivot entries of v, adds to the boundary entries
+}
+template <bool BFLY>
+__global__ void __launch_bounds__(256)
+k_sweep_bwd_w(FrontDev fd, const int* __restrict__ level_nodes, int first, int nx, const double* __restrict__ y, double* __restrict__ x) {
+    extern __shared__ double xs_bnd[];                   // nb
+    const int t = level_nodes[first + blockIdx.y];
+    if ((int)blockIdx.x < nx) gemv_t_tile<true>(fd, t, (int)blockIdx.x, y, x);
+    else bnd_cols_block<BFLY, true>(fd, t, (int)blockIdx.x - nx, x, x, xs_bnd);     // reads the boundary entries of x, adds to the pivot entries
 }
 
 // ---- the wide levels as ONE launch per sweep direction: tiles as tasks with per-front dependencies.
@@ -2801,6 +2832,95 @@ k_xinv(FrontDev fd, const int* __restrict__ level_nodes, int first, int bs) {
                 const int r = r0 + wr + 16 * ir + l15;
                 if (r < mB) dst[(b0 + r) + (size_t)ldx * (a0 + c)] = PHASE == 0 ? acc[jc][ir][reg] : -acc[jc][ir][reg];
             }
+}
+
+// W = L21 X, written over L21 (option "sweep_w": the one-launch form of the wide levels' sweeps, k_sweep_fwd_w / k_sweep_bwd_w).  Row r
+// of W depends on row r of L21 only, so a workgroup owns 64 boundary rows and walks the column blocks from the left:
+//   W[r][c0 .. c0 + 127] = sum_{k >= c0} L21[r][k] X[k][c0 .. c0 + 127]      (X lower triangular),
+// block c0 reads the entries of its rows in the columns >= c0 and then overwrites the columns c0 .. c0 + 127 -- which no later block
+// reads.  fp64 MFMA, both operands staged through LDS 16 columns of k at a time (the scheme of k_xinv); runs on stream3 behind the
+// level's k_xinv launches, beside the factorisation of the levels above.
+constexpr int WT_M = 64, WT_N = 128;
+__global__ void __launch_bounds__(256, 2)
+k_w_inplace(FrontDev fd, const int* __restrict__ level_nodes, int first) {
+    const int t = level_nodes[first + blockIdx.y];
+    const int np = fd.npiv[t], nf = fd.nf[t], nb = nf - np;
+    const int r0 = blockIdx.x * WT_M;
+    if (np == 0 || r0 >= nb) return;
+    const int ldp = ldp_of(nf), ldx = ldx_of(np);
+    double* L = fd.P + fd.poff[t] + np;                   // L21: rows np.. of the pivot columns
+    const double* X = fd.X + fd.xoff[t];
+    constexpr int KC = 16, SA = WT_M + 16, SB = WT_N + 16;
+    constexpr int QA = KC / 4, QB = WT_N / 16;
+    __shared__ double sA[2][KC][SA];                      // sA[.][k][r] = L21[r0 + r][k]
+    __shared__ double sB[2][KC][SB];                      // sB[.][k][c] = X[k][c0 + c]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int lr = tid & 63, kq = tid >> 6;
+    const int kb = tid & 15, cb = tid >> 4;
+    const bool rok = r0 + lr < nb;
+    const double* arow = L + min(r0 + lr, nb - 1);
+    const int wr = (wv & 1) * 32, wc = (wv >> 1) * 64;
+    for (int c0 = 0; c0 < np; c0 += WT_N) {
+        double pa[QA], pb[QB];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q) {
+                const int k = k0 + kq + 4 * q;
+                const double v = arow[(size_t)ldp * min(k, np - 1)];
+                pa[q] = (rok && k < np) ? v : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int k = k0 + kb, c = c0 + cb + 16 * q;
+                pb[q] = (k < np && c < np && k >= c) ? X[k + (size_t)ldx * c] : 0.0;
+            }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < QA; ++q) sA[buf][kq + 4 * q][lr] = pa[q];
+#pragma unroll
+            for (int q = 0; q < QB; ++q) sB[buf][kb][cb + 16 * q] = pb[q];
+        };
+        mfma_d4 acc[4][2];
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+            for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        fetch(c0);
+        stash(0);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = c0; k0 < np; k0 += KC) {
+            const bool more = k0 + KC < np;
+            if (more) fetch(k0 + KC);
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 4) {
+                double ac[4], br[2];
+#pragma unroll
+                for (int jc = 0; jc < 4; ++jc) ac[jc] = sB[cur][kk + l4][wc + 16 * jc + l15];
+#pragma unroll
+                for (int ir = 0; ir < 2; ++ir) br[ir] = sA[cur][kk + l4][wr + 16 * ir + l15];
+#pragma unroll
+                for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+                    for (int ir = 0; ir < 2; ++ir) acc[jc][ir] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[jc], br[ir], acc[jc][ir], 0, 0, 0);
+            }
+            if (more) stash(cur ^ 1);
+            __syncthreads();                              // after the last pass: every wave has read the block's own columns
+            cur ^= 1;
+        }
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+            for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = c0 + wc + 16 * jc + l4 + 4 * reg;     // D[i = l4 + 4 reg -> column][j = l15 -> row]
+                    const int r = r0 + wr + 16 * ir + l15;
+                    if (r < nb && c < np) L[r + (size_t)ldp * c] = acc[jc][ir][reg];
+                }
+    }
 }
 
 }  // namespace femo
