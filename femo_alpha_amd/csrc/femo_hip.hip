@@ -185,10 +185,6 @@ struct femo_ctx {
         // of W add 1.5 ms to the factorisation and 0.9 ms of waiting to the first sweep: forward 19.10 ms against 16.84.  Off; kept as a
         // validated alternative schedule (schedule fuzz)
         int sweep_w = 0;
-        // levels whose Schur complements are gathered by their first rank-k update (fused_schur): the FIRST outer panel is gathered from the
-        // children by the diagonal-block and row kernels themselves (ChildGather) instead of being written to the panel store by
-        // k_extend_gather and read back
-        int panel_gather = 512;               // levels of at least this many fronts (0: never)
         // Optimisation loops: when only FIELDS changed since the last factorisation (a new thickness), keep that factor as the PCG
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
@@ -791,17 +787,10 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
             const int nt = (max_nb + TS - 1) / TS;
             const dim3 grid(nt * (nt + 1) / 2, cnt);
-            // option "panel_gather": the first panel's columns are gathered where they are consumed; this launch is left with the fronts
-            // that have no pivots (none, on the trees nested dissection builds)
-            bool any_empty = false;
-            for (int i = b; i < e; ++i) any_empty = any_empty || fr.h_npiv[fr.h_level_nodes[i]] == 0;
-            const bool pg = fused_schur && c->opt.panel_gather > 0 && cnt >= c->opt.panel_gather;
-            if (!pg || any_empty) {
-              ProfScope ps(c, 3);
+            { ProfScope ps(c, 3);
               FOR_FRONT_CHUNKS(cnt, off, n)
-                  hipLaunchKernelGGL(k_extend_gather, dim3(grid.x, n), dim3(256), 0, c->stream, fd, lev, off, mask, pg ? 2 : fused_schur ? 1 : 0); }
+                  hipLaunchKernelGGL(k_extend_gather, dim3(grid.x, n), dim3(256), 0, c->stream, fd, lev, off, mask, fused_schur ? 1 : 0); }
         }
-        const bool panel_gather = fused_schur && c->opt.panel_gather > 0 && cnt >= c->opt.panel_gather;
         const bool wide = fr.h_level_wide[L];                      // these levels keep S (inside X) for the triangular solves
         const int cnt_level = cnt, max_np_level = max_np;
         const int* lev_level = lev;
@@ -925,13 +914,12 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // rows below a diagonal block: launches of few workgroups (what one workgroup takes is what the launch takes) use the
         // kernel that brings all of S into LDS at once (option "rows_preload_wg": up to that many workgroups per launch)
         auto launch_rows = [&](int ntiles, int off, int n, int C0_, const double* sw_, int tile_first, hipStream_t st) {
-            const bool g0 = panel_gather && C0_ == 0;            // the first panel comes from the children
-#define ROWS_LAUNCH(K_, GX_, SHM_) do { if (g0) hipLaunchKernelGGL(K_<true>, dim3(GX_, n), dim3(256), SHM_, st, fd, lev, off, C0_, sw_, tile_first, mask); \
-                                        else hipLaunchKernelGGL(K_<false>, dim3(GX_, n), dim3(256), SHM_, st, fd, lev, off, C0_, sw_, tile_first, mask); } while (0)
-            if ((long long)ntiles * n <= c->opt.rows_fine_wg) ROWS_LAUNCH(k_panel_rows_fine, 4 * ntiles, 0);
-            else if ((long long)ntiles * n <= c->opt.rows_preload_wg) ROWS_LAUNCH(k_panel_rows_preload, ntiles, PANEL_ROWS_PRELOAD_LDS);
-            else ROWS_LAUNCH(k_panel_rows, ntiles, 0);
-#undef ROWS_LAUNCH
+            if ((long long)ntiles * n <= c->opt.rows_fine_wg)
+                hipLaunchKernelGGL(k_panel_rows_fine, dim3(4 * ntiles, n), dim3(256), 0, st, fd, lev, off, C0_, sw_, tile_first);
+            else if ((long long)ntiles * n <= c->opt.rows_preload_wg)
+                hipLaunchKernelGGL(k_panel_rows_preload, dim3(ntiles, n), dim3(256), PANEL_ROWS_PRELOAD_LDS, st, fd, lev, off, C0_, sw_, tile_first);
+            else
+                hipLaunchKernelGGL(k_panel_rows, dim3(ntiles, n), dim3(256), 0, st, fd, lev, off, C0_, sw_, tile_first);
         };
         // k_diag_block: factor + inverse of the kw x kw block ~ 2/3 kw^3 + 1/3 kw^3; k_panel_rows: rows x triangular S
         auto count_panel = [&](int C0) {
@@ -1019,17 +1007,15 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                       // 261 / 242 / 178 us with the new kernel throughout against 517 / 164 / 192 / 156).  Option "diag_v1": 1 forces
                       // the old kernel everywhere, 2 the new one.
                       const bool v1 = fuse_rows || c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= c->opt.diag_v1_cnt) || (c->opt.diag_v1 == 3 && cnt >= 512 && nblk < NBO / NB);
-                      const bool g0 = panel_gather && C0 == 0;             // the first panel comes from the children
-#define DIAG2_LAUNCH(R_, G_) hipLaunchKernelGGL((k_diag_block2<R_, G_>), dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st, \
-                                                fd, lev, start, nblk, C0, sw, fr.info, mask)
-                      if (v1) {
-                          if (g0) hipLaunchKernelGGL(k_diag_block<true>, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
-                                                     fd, lev, start, nblk, C0, sw, fr.info, fuse_rows ? 1 : 0, mask);
-                          else hipLaunchKernelGGL(k_diag_block<false>, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
-                                                  fd, lev, start, nblk, C0, sw, fr.info, fuse_rows ? 1 : 0, mask);
-                      } else if (c->opt.allow_pivot_repair) { if (g0) DIAG2_LAUNCH(true, true); else DIAG2_LAUNCH(true, false); }
-                      else { if (g0) DIAG2_LAUNCH(false, true); else DIAG2_LAUNCH(false, false); }
-#undef DIAG2_LAUNCH
+                      if (v1)
+                          hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
+                                             fd, lev, start, nblk, C0, sw, fr.info, fuse_rows ? 1 : 0);
+                      else if (c->opt.allow_pivot_repair)
+                          hipLaunchKernelGGL(k_diag_block2<true>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st,
+                                             fd, lev, start, nblk, C0, sw, fr.info);
+                      else
+                          hipLaunchKernelGGL(k_diag_block2<false>, dim3(end - start), dim3(256), diag_block2_lds_blocks(nblk) * sizeof(blk32), st,
+                                             fd, lev, start, nblk, C0, sw, fr.info);
                   }
                   start = end;
               } }
@@ -2203,7 +2189,6 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
-    else if (k == "panel_gather") o.panel_gather = v;
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
@@ -2693,17 +2678,15 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIPCHK(c, hipFuncSetAttribute((const void*)k_sweep_wide_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
-    const int lds1 = (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32)), lds2 = (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_panel_rows_preload<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_ROWS_PRELOAD_LDS));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_panel_rows_preload<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_ROWS_PRELOAD_LDS));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_panel_rows_preload, hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_ROWS_PRELOAD_LDS));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_trailing_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * sizeof(double) * 16 * LSTRB)));
-    HIPCHK(c, hipFuncSetAttribute((const void*)(k_diag_block2<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    HIPCHK(c, hipFuncSetAttribute((const void*)(k_diag_block2<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    HIPCHK(c, hipFuncSetAttribute((const void*)(k_diag_block2<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    HIPCHK(c, hipFuncSetAttribute((const void*)(k_diag_block2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_diag_block2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(diag_block2_lds_blocks(NBO / NB) * sizeof(blk32))));
     fr.ready = true;
     if (fr.sweep_graph) { hipGraphExecDestroy(fr.sweep_graph); fr.sweep_graph = nullptr; }     // captured for another plan
     fr.factored = false;

@@ -72,47 +72,6 @@ __device__ __forceinline__ FrontView front_view(const FrontDev& fd, int t) {
     return v;
 }
 
-// The first outer panel of a front with children, BEFORE anything has been stored in it (option "panel_gather"): entry (r, c), r >= c, is
-// the sum of the entries of the children's Schur complements that land there -- what k_extend_gather would have written to the panel
-// store for the diagonal-block and row kernels to read back.  Those kernels gather it themselves instead: the pivot columns of the first
-// panel then move through HBM once (written as factor columns) instead of three times.
-struct ChildGather {
-    const double* S0; const double* S1;       // the children's Schur blocks, shifted so that [hi + nb * lo] takes child FRONT rows hi >= lo
-    const int* m0; const int* m1;             // front row of this front -> front row of the left / right child, or -1
-    int nb0, nb1, npp;
-    const unsigned char* mask; const int* gd;
-    bool any;
-    __device__ __forceinline__ double at(int r, int c) const {
-        double x = 0.0;
-        if (S0) { const int a = m0[r], b = m0[c]; if (a >= 0 && b >= 0) x += S0[max(a, b) + (size_t)nb0 * min(a, b)]; }
-        if (S1) { const int a = m1[r], b = m1[c]; if (a >= 0 && b >= 0) x += S1[max(a, b) + (size_t)nb1 * min(a, b)]; }
-        if (mask && r == c && r < npp && mask[gd[r]]) x = 1.0;      // strong-BC pivots: unit diagonal, as in the extend-add
-        return x;
-    }
-    // the same with the map entries already in registers (a thread's rows and columns repeat: the maps are read once, not per entry)
-    __device__ __forceinline__ int row0(int r) const { return S0 ? m0[r] : -1; }
-    __device__ __forceinline__ int row1(int r) const { return S1 ? m1[r] : -1; }
-    __device__ __forceinline__ double at_mapped(int a0, int a1, int b0, int b1) const {
-        double x = 0.0;
-        if (a0 >= 0 && b0 >= 0) x += S0[max(a0, b0) + (size_t)nb0 * min(a0, b0)];
-        if (a1 >= 0 && b1 >= 0) x += S1[max(a1, b1) + (size_t)nb1 * min(a1, b1)];
-        return x;
-    }
-    __device__ __forceinline__ bool masked_pivot(int r) const { return mask && r < npp && mask[gd[r]]; }
-};
-__device__ __forceinline__ ChildGather child_gather(const FrontDev& fd, int p, const unsigned char* mask) {
-    ChildGather g;
-    const int ch0 = fd.child[0][p], ch1 = fd.child[1][p];
-    const long long dp = fd.doff[p];
-    g.any = ch0 >= 0 || ch1 >= 0;
-    g.S0 = g.S1 = nullptr; g.nb0 = g.nb1 = 0;
-    if (ch0 >= 0) { const int np0 = fd.npiv[ch0]; g.nb0 = fd.nf[ch0] - np0; g.S0 = fd.S + fd.soff[ch0] - (size_t)g.nb0 * np0 - np0; }
-    if (ch1 >= 0) { const int np1 = fd.npiv[ch1]; g.nb1 = fd.nf[ch1] - np1; g.S1 = fd.S + fd.soff[ch1] - (size_t)g.nb1 * np1 - np1; }
-    g.m0 = fd.cinv[0] + dp; g.m1 = fd.cinv[1] + dp;
-    g.npp = fd.npiv[p]; g.mask = mask; g.gd = fd.dofs + dp;
-    return g;
-}
-
 // leading dimension of a front's X (a multiple of the 128-column outer panel, so that k_diag_block can write the
 // inverse of every diagonal block straight into place)
 __device__ __host__ inline int ldx_of(int np) { return (np + SPD - 1) / SPD * SPD; }
@@ -295,9 +254,6 @@ k_extend_gather(FrontDev fd, const int* __restrict__ level_nodes, int first, con
     // skip_schur: only the first outer panel's columns are filled here -- every other column of this level's fronts is
     // gathered from the children by the rank-k update that touches it first (k_trailing_mfma<true>); fronts without
     // pivots have no such update
-    // skip_schur 2 (option "panel_gather"): the first panel is gathered by the diagonal-block and row kernels as well -- only fronts
-    // without pivots are left to this kernel
-    if (skip_schur == 2 && npp > 0) return;
     const int c_end = (skip_schur && npp > 0) ? min(npp, NBO) : nfp;
     if (c0 >= c_end) return;
     __shared__ int rmap[2][TS], cmap[2][TS];
@@ -665,18 +621,14 @@ __device__ __host__ inline int diag_block_lds_blocks(int nblk) { return nblk * (
 // S read from LDS where the inverse phase leaves it -- S never goes to memory and k_panel_rows is not launched.  On the leaves
 // this kernel is HBM-bound (block in, factor sub-blocks, the 32 x 32 inverses and the 128 x 128 S out: 2.4 GB at 1 M DOF), and S is
 // the largest item; k_panel_rows then read it back.
-template <bool GATHER>                              // GATHER (first panel only, C0 == 0): the block and the rows come from the children (ChildGather)
 __global__ void __launch_bounds__(256)
 k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
-             int* __restrict__ info, int fuse_rows, const unsigned char* __restrict__ mask) {
+             int* __restrict__ info, int fuse_rows) {
     STAMP(31);
     const int slot = first + blockIdx.x;                       // position of the front in its level
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];
     if (C0 >= np) return;
-    ChildGather cg;
-    if (GATHER) cg = child_gather(fd, t, mask);
-    const bool gth = GATHER && cg.any;
     const int kw = min(NBO, np - C0);
     const int nkb = (kw + NB - 1) / NB;
     const int ldp = ldp_of(fd.nf[t]);
@@ -694,20 +646,6 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     // are issued before the first one is consumed -- a loop over the sub-blocks would pay the memory latency ten times
     {
         double v[10][4];
-        // GATHER: this thread's rows are 32 bi + tid % 32, its columns 32 bj + tid / 32 + 8 q: 4 + 16 map entries per child
-        int mr0[4], mr1[4], mc0[4][4], mc1[4][4];
-        if (gth) {
-#pragma unroll
-            for (int bi = 0; bi < 4; ++bi) {
-                const int gr = NB * bi + tid % NB;
-                mr0[bi] = gr < kw ? cg.row0(gr) : -1; mr1[bi] = gr < kw ? cg.row1(gr) : -1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gc = NB * bi + tid / NB + 8 * q;
-                    mc0[bi][q] = gc < kw ? cg.row0(gc) : -1; mc1[bi][q] = gc < kw ? cg.row1(gc) : -1;
-                }
-            }
-        }
 #pragma unroll
         for (int b = 0; b < 10; ++b) {
             const int bi = b < 1 ? 0 : b < 3 ? 1 : b < 6 ? 2 : 3;
@@ -718,10 +656,7 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
                 const int r = idx % NB, c = idx / NB;
                 const int gr = NB * bi + r, gc = NB * bj + c;
                 v[b][q] = (gr == gc) ? 1.0 : 0.0;
-                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) {
-                    if (gth) { v[b][q] = cg.at_mapped(mr0[bi], mr1[bi], mc0[bj][q], mc1[bj][q]); if (gr == gc && cg.masked_pivot(gr)) v[b][q] = 1.0; }
-                    else v[b][q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
-                }
+                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
             }
         }
 #pragma unroll
@@ -833,28 +768,14 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
         // at a time, their kw entries in registers as the MFMA B operand, S[c][k] from the sub-blocks in LDS as the A operand
         __syncthreads();
         const int nf = fd.nf[t];
-        int mk0[NBO / 4], mk1[NBO / 4];                   // GATHER: the child rows of this lane's 32 columns, read once for all row tiles
-        if (gth) {
-#pragma unroll
-            for (int kk = 0; kk < NBO / 4; ++kk) {
-                const int k = 4 * kk + l4;
-                mk0[kk] = k < kw ? cg.row0(k) : -1; mk1[kk] = k < kw ? cg.row1(k) : -1;
-            }
-        }
         for (int row0 = C0 + kw + 16 * wv; row0 < nf; row0 += 64) {
             const int row = row0 + l15;
             const bool rok = row < nf;
             double a[NBO / 4];
-            if (gth) {
-                const int ra0 = rok ? cg.row0(row) : -1, ra1 = rok ? cg.row1(row) : -1;
-#pragma unroll
-                for (int kk = 0; kk < NBO / 4; ++kk) a[kk] = cg.at_mapped(ra0, ra1, mk0[kk], mk1[kk]);
-            } else {
 #pragma unroll
             for (int kk = 0; kk < NBO / 4; ++kk) {
                 const int k = 4 * kk + l4;
                 a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
-            }
             }
 #pragma unroll
             for (int cb = 0; cb < NBO / 16; ++cb) {
@@ -923,18 +844,15 @@ __device__ __forceinline__ void wave_store(blk32& dst, const mfma_d4 (&acc)[2][2
             }
 }
 
-template <bool REPAIR, bool GATHER>
+template <bool REPAIR>
 __global__ void __launch_bounds__(256)
 k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int nblk, int C0, double* __restrict__ Swork,
-              int* __restrict__ info, const unsigned char* __restrict__ mask) {
+              int* __restrict__ info) {
     STAMP(31);
     const int slot = first + blockIdx.x;
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];
     if (C0 >= np) return;
-    ChildGather cg;
-    if (GATHER) cg = child_gather(fd, t, mask);
-    const bool gth = GATHER && cg.any;
     const int kw = min(NBO, np - C0);
     const int nkb = (kw + NB - 1) / NB;
     const int ldp = ldp_of(fd.nf[t]);
@@ -958,7 +876,7 @@ k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int n
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             a0[c] = (lane < NB) ? (lane == c ? 1.0 : 0.0) : (c == lane - NB ? 1.0 : 0.0);
-            if (lane < NB && c <= lane && lane < kw) a0[c] = gth ? cg.at(lane, c) : F[(C0 + lane) + (size_t)ldp * (C0 + c)];
+            if (lane < NB && c <= lane && lane < kw) a0[c] = F[(C0 + lane) + (size_t)ldp * (C0 + c)];
         }
     }
     if (wv > 0) {
@@ -975,7 +893,7 @@ k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int n
             const int r = idx % NB, c = idx / NB;
             const int gr = NB * bi + r, gc = NB * bj + c;
             v[q] = (gr == gc) ? 1.0 : 0.0;
-            if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[q] = gth ? cg.at(gr, gc) : F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
+            if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
         }
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
@@ -1132,10 +1050,8 @@ k_diag_block2(FrontDev fd, const int* __restrict__ level_nodes, int first, int n
 // kw <= 128 entries sit in registers as the MFMA B operand (read once, so the result can overwrite them in place),
 // S streams from L2 as the A operand, and the product is formed transposed so that the stores run along the
 // columns of the column-major front.
-template <bool GATHER>
 __global__ void __launch_bounds__(256, 4)      // four waves per SIMD (measured: -15 % against three, 20 B of scratch)
-k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first,
-        const unsigned char* __restrict__ mask) {
+k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
     const int slot = first + blockIdx.y;                       // position of the front in its level
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];
@@ -1148,9 +1064,6 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.P + fd.poff[t];                             // pivot columns only
-    ChildGather cg;
-    if (GATHER) cg = child_gather(fd, t, mask);
-    const bool gth = GATHER && cg.any;
     const int ldp = ldp_of(nf);
     const int lds_ = Swork ? SPD : ldx_of(np);
     const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
@@ -1159,15 +1072,11 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
     __shared__ double sb[2][NBO][16];
     const int row = row0 + l15;
     const bool rok = row < nf;
-    const int ra0 = (gth && rok) ? cg.row0(row) : -1, ra1 = (gth && rok) ? cg.row1(row) : -1;
     double a[NBO / 4];
 #pragma unroll
     for (int kk = 0; kk < NBO / 4; ++kk) {
         const int k = 4 * kk + l4;
-        if (gth) {
-            const int ck0 = k < kw ? cg.row0(k) : -1, ck1 = k < kw ? cg.row1(k) : -1;
-            a[kk] = cg.at_mapped(ra0, ra1, ck0, ck1);
-        } else a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
     }
     const int sc = tid & 15, sk0 = tid >> 4;              // staging: column sc of the block, rows sk0, sk0 + 16, ...
     double pre[NBO / 16];
@@ -1207,10 +1116,8 @@ k_panel_rows(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0
 // cover it).  Here all 36 lower-triangular 16 x 16 blocks of S travel to LDS in one burst (72 KB, two workgroups per CU),
 // and the 144 MFMAs of a wave follow without a barrier or a global load between them.
 constexpr int PANEL_ROWS_PRELOAD_LDS = (NBO / 16) * (NBO / 16 + 1) / 2 * 256 * (int)sizeof(double);
-template <bool GATHER>
 __global__ void __launch_bounds__(256, 2)
-k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first,
-        const unsigned char* __restrict__ mask) {
+k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
     extern __shared__ double sall[];                           // block (cb, kb <= cb) at cb (cb + 1) / 2 + kb: [k][c], 16 x 16
     const int slot = first + blockIdx.y;
     const int t = level_nodes[slot];
@@ -1224,9 +1131,6 @@ k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first
     if (tile0 >= nf) return;
     const int row0 = tile0 + 16 * wv;
     double* F = fd.P + fd.poff[t];
-    ChildGather cg;
-    if (GATHER) cg = child_gather(fd, t, mask);
-    const bool gth = GATHER && cg.any;
     const int ldp = ldp_of(nf);
     const int lds_ = Swork ? SPD : ldx_of(np);
     const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
@@ -1241,15 +1145,11 @@ k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first
             pre[cb * (cb + 1) / 2 + kb] = cb < ncb ? S[(16 * cb + sc) + (size_t)lds_ * (16 * kb + sk)] : 0.0;
     const int row = row0 + l15;
     const bool rok = row < nf;
-    const int ra0 = (gth && rok) ? cg.row0(row) : -1, ra1 = (gth && rok) ? cg.row1(row) : -1;
     double a[NBO / 4];
 #pragma unroll
     for (int kk = 0; kk < NBO / 4; ++kk) {
         const int k = 4 * kk + l4;
-        if (gth) {
-            const int ck0 = k < kw ? cg.row0(k) : -1, ck1 = k < kw ? cg.row1(k) : -1;
-            a[kk] = cg.at_mapped(ra0, ra1, ck0, ck1);
-        } else a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
     }
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) sall[b * 256 + sk * 16 + sc] = pre[b];
@@ -1276,10 +1176,8 @@ k_panel_rows_preload(FrontDev fd, const int* __restrict__ level_nodes, int first
 // LDS: the MFMA A operand S[c][k] (16 consecutive c per k: one 128-byte segment) and the rows travel straight to registers, all
 // loads of a wave in flight at once.  The product overwrites the rows in place and the four waves share them, so every wave
 // has ALL its loads back before any wave stores (the barrier).
-template <bool GATHER>
 __global__ void __launch_bounds__(256, 2)
-k_panel_rows_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first,
-        const unsigned char* __restrict__ mask) {
+k_panel_rows_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, const double* __restrict__ Swork, int tile_first) {
     const int slot = first + blockIdx.y;
     const int t = level_nodes[slot];
     const int np = fd.npiv[t];
@@ -1291,9 +1189,6 @@ k_panel_rows_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, i
     const int row0 = C0 + kw + (blockIdx.x + 4 * tile_first) * 16;     // tile_first counts 64-row tiles, as in k_panel_rows
     if (row0 >= nf) return;
     double* F = fd.P + fd.poff[t];
-    ChildGather cg;
-    if (GATHER) cg = child_gather(fd, t, mask);
-    const bool gth = GATHER && cg.any;
     const int ldp = ldp_of(nf);
     const int lds_ = Swork ? SPD : ldx_of(np);
     const double* S = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
@@ -1302,15 +1197,11 @@ k_panel_rows_fine(FrontDev fd, const int* __restrict__ level_nodes, int first, i
     const int cbs[2] = {wv, NCB - 1 - wv};                    // this wave's two column blocks
     const int row = row0 + l15;
     const bool rok = row < nf;
-    const int ra0 = (gth && rok) ? cg.row0(row) : -1, ra1 = (gth && rok) ? cg.row1(row) : -1;
     double a[NBO / 4];
 #pragma unroll
     for (int kk = 0; kk < NBO / 4; ++kk) {
         const int k = 4 * kk + l4;
-        if (gth) {
-            const int ck0 = k < kw ? cg.row0(k) : -1, ck1 = k < kw ? cg.row1(k) : -1;
-            a[kk] = cg.at_mapped(ra0, ra1, ck0, ck1);
-        } else a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+        a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
     }
     // S operands of both blocks: block cb needs k < 16 cb + 16; the second block (cb >= 4) the longer chain
     double s0[4 * (NCB / 2)], s1[4 * NCB];
