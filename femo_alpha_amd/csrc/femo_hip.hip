@@ -185,6 +185,9 @@ struct femo_ctx {
         // of W add 1.5 ms to the factorisation and 0.9 ms of waiting to the first sweep: forward 19.10 ms against 16.84.  Off; kept as a
         // validated alternative schedule (schedule fuzz)
         int sweep_w = 0;
+        // front assembly with one workgroup per leaf front (k_front_assemble_fc): the front is zeroed, filled and written once, no float
+        // atomics (which execute at the memory side on this chip and bound k_front_assemble).  0: one wave per element + k_zero_fronts
+        int assemble_fc = 1;
         // Optimisation loops: when only FIELDS changed since the last factorisation (a new thickness), keep that factor as the PCG
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
@@ -221,6 +224,8 @@ struct femo_ctx {
         double *P = nullptr, *S = nullptr, *Linv = nullptr, *X = nullptr, *Xtmp = nullptr, *Swork = nullptr;
         // fused sweeps of the wide levels (option "sweep_fuse"): tiles as tasks of one launch per run of consecutive wide levels
         int* slot_of = nullptr;               // position of every front in level_nodes
+        int *fel_off = nullptr, *fel = nullptr;      // elements of every level-0 front, by position in the level (front-centric assembly)
+        bool fc_ok = false;                   // every element belongs to a level-0 front
         int* sweep_cnt = nullptr;             // two counters per position (k_sweep_wide_fwd / _bwd)
         SweepTask *ftasks = nullptr, *btasks = nullptr;
         std::vector<long long> h_ft_off;      // forward table (levels ascending): tasks of level L at [h_ft_off[L], h_ft_off[L + 1])
@@ -707,6 +712,8 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (assemble) {
+        const bool fc = c->opt.assemble_fc != 0 && fr.fc_ok && fr.fel_off;
+        if (!fc)
         { ProfScope ps(c, 5);
           // only the leaf fronts start from zero (element matrices are added into them); every other front is written
           // entry by entry by the extend-add gather of its level
@@ -745,7 +752,18 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         }
         const size_t qlds = (size_t)anq * (c->cg1 ? (c->quad ? sizeof(QPoint<4, 4>) : sizeof(QPoint<3, 3>)) : (c->quad ? sizeof(QPoint<9, 4>) : sizeof(QPoint<6, 3>)));
         { ProfScope ps(c, 4);
-        if (c->op_aM != 0.0)
+        if (fc) {
+            // one workgroup per leaf front: zero fill, element columns and their sums without atomics (k_front_assemble_fc)
+            const int cnt0 = fr.h_level_off[1] - fr.h_level_off[0];
+            const int ablk = assemble_block(c->ld);
+            const size_t alds = assemble_lds(c->ld, qlds);
+            if (c->op_aM != 0.0)
+                ELEM_LAUNCH_S(c, k_front_assemble_fc, COMMA_TRUE, cnt0, ablk, alds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd,
+                              (const int*)fr.level_nodes, (const int*)fr.fel_off, (const int*)fr.fel, fr.elem_map, mask, eq);
+            else
+                ELEM_LAUNCH_S(c, k_front_assemble_fc, COMMA_FALSE, cnt0, ablk, alds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd,
+                              (const int*)fr.level_nodes, (const int*)fr.fel_off, (const int*)fr.fel, fr.elem_map, mask, eq);
+        } else if (c->op_aM != 0.0)
             ELEM_LAUNCH_S(c, k_front_assemble, COMMA_TRUE, c->nel, 64, qlds, mesh_dev(c), fields_dev(c), atab, c->op_aK, c->op_aM, fd, fr.elem_front,
                           fr.elem_map, mask, eq);
         else
@@ -1822,7 +1840,7 @@ void femo_destroy(femo_ctx* c) {
         if (p) hipFree(p);
     void* fptrs[] = {c->fr.nf, c->fr.npiv, c->fr.dofs, c->fr.upmap, c->fr.parent, c->fr.left, c->fr.right, c->fr.level_nodes,
                      c->fr.elem_front, c->fr.elem_map, c->fr.info, c->fr.poff, c->fr.soff, c->fr.doff, c->fr.linvoff, c->fr.P, c->fr.S, c->fr.Linv,
-                     c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1, c->fr.slot_of, c->fr.sweep_cnt, c->fr.ftasks,
+                     c->fr.xoff, c->fr.X, c->fr.Xtmp, c->fr.Swork, c->fr.cinv0, c->fr.cinv1, c->fr.slot_of, c->fr.fel_off, c->fr.fel, c->fr.sweep_cnt, c->fr.ftasks,
                      c->fr.btasks, c->fr.snap[0], c->fr.snap[1], c->fr.snap[2], c->fr.snap[3], c->fr.snap[4]};
     for (void* p : fptrs)
         if (p) hipFree(p);
@@ -2189,6 +2207,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
+    else if (k == "assemble_fc") o.assemble_fc = v != 0;
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
@@ -2650,6 +2669,20 @@ int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int
         }
         if (sweep_xtiles(fr.max_nf) >= (1 << 24)) return fail(c, "front too large for the fused sweep task table");
         UPI(fr.slot_of, slot_of.data(), ntree);
+        // front-centric assembly: the elements of every level-0 front
+        const int cnt0 = level_off[1] - level_off[0];
+        std::vector<int> fel_off(cnt0 + 1, 0), fel((size_t)std::max<long long>(c->nel, 1));
+        fr.fc_ok = true;
+        for (long long e = 0; e < c->nel && fr.fc_ok; ++e) {
+            const int sl = slot_of[elem_front[e]] - level_off[0];
+            if (sl < 0 || sl >= cnt0) fr.fc_ok = false; else ++fel_off[sl + 1];
+        }
+        if (fr.fc_ok) {
+            for (int i = 0; i < cnt0; ++i) fel_off[i + 1] += fel_off[i];
+            std::vector<int> fill(fel_off.begin(), fel_off.end() - 1);
+            for (long long e = 0; e < c->nel; ++e) fel[fill[slot_of[elem_front[e]] - level_off[0]]++] = (int)e;
+            UPI(fr.fel_off, fel_off.data(), cnt0 + 1); UPI(fr.fel, fel.data(), c->nel);
+        }
         UPI(fr.ftasks, ft.data(), ft.size()); UPI(fr.btasks, bt.data(), bt.size());
         HIPCHK(c, hipMalloc((void**)&fr.sweep_cnt, (size_t)std::max(ntree, 1) * 2 * sizeof(int)));
     }

@@ -161,6 +161,9 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   one workgroup per 64-row strip of a front (k_schur_strip) -- measured slower than the tile kernel, off (profiles/r5_strip_ab.txt);
  *   "sweep_fuse" (0): all consecutive wide levels of a triangular sweep as ONE launch, tiles ordered by per-front counters -- measured
  *   slower than the level-wise launches, off (profiles/r5_sweep_fuse_ab.txt); "sweep_read_mode" (its read of other workgroups' values);
+ *   "assemble_fc" (1): front assembly with one workgroup per leaf front -- zero fill, element columns and their sums without float
+ *   atomics, the front written once (k_front_assemble_fc); 0: one wave per element adding with atomics into zero-filled fronts
+ *   (profiles/r5_assemble_fc_ab.txt);
  *   "sweep_w" (0): W = L21 L11^-1 stored where L21 was, a wide level of a sweep as one launch instead of two -- an application 4 % shorter,
  *   the factorisation 1.5 ms longer, off (profiles/r5_sweep_w_ab.txt); changing it discards the factor;
  *   "equilibrate" (0), "precond_nquad" (0): measured experiments, off;
