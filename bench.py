@@ -112,7 +112,7 @@ def pmc_traffic(workload):
     pj = json.load(open(pmc))
     if pj.get("source_digest") != _build.source_digest():
         print(f"warning: {os.path.relpath(pmc, ROOT)} was measured on other kernel sources (digest mismatch): roofline.traffic = null; "
-              "re-run scripts/r4_rocprof.sh", file=sys.stderr)
+              "re-run scripts/r5_rocprof.sh", file=sys.stderr)
         return None, None, {}
     # per-class figures of the rank-k updates (scripts/r4_pmc_levels.py): launches above / below the ridge of the chip
     by_class = {"mfma": pj.get("trailing_mfma_bound_hbm_bytes_per_launch"), "hbm": pj.get("trailing_hbm_bound_hbm_bytes_per_launch")}
