@@ -149,7 +149,8 @@ def test_gradient_accumulator_and_field_gradient_on_vector_ids():
     c.close()
 
 
-def test_level_ranges_sweeps_and_schur_blocks():
+@pytest.mark.parametrize("assemble_fc", [1, 0])           # both front assemblies: one workgroup per leaf front | one wave per element + atomics
+def test_level_ranges_sweeps_and_schur_blocks(assemble_fc):
     """femo_factorize_range + femo_frontal_sweep compose to the preconditioner; the Schur block femo_front_schur_get hands out is the
     Schur complement of the subtree's own stiffness onto its boundary (dense algebra on the oracle's element matrices);
     femo_front_block_set refuses a front that has pivots; the instrumented factorisation and sweep profiles report every level."""
@@ -160,6 +161,7 @@ def test_level_ranges_sweeps_and_schur_blocks():
     m = wing_skin_mesh(8, 20, shuffle=True).renumbered()[0]
     sd = m.locate_dofs_geometrical(lambda x: np.less(x[1], 1e-9))
     c, f, rng = _context(m, strong=sd)
+    c.set_option("assemble_fc", assemble_fc)
     plan = c.enable_frontal(6)
     c.set_solver(preconditioner=2, rtol=1e-12, maxit=30, check_every=1)
     L = plan.nlevels
