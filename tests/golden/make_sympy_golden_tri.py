@@ -1,0 +1,133 @@
+"""Generate tests/golden/sympy_triangle.npz -- the independent symbolic derivation of tests/golden/make_sympy_golden.py
+for the TRIANGLE elements: 'CG2CG1' (P2 displacement, P1 rotation) and 'CG2CR1' (P2 displacement, Crouzeix-Raviart
+rotation on the edge midpoints; reference femo_alpha/rm_shell/linear_shell_fenicsx/linear_shell_model.py:68-73).
+It pins the triangle and the Crouzeix-Raviart branches of the CPU oracle (oracle/rm_shell_oracle.py), which until round 5
+were held by structural identities only.
+
+As in the quadrilateral script the reference's UFL text is followed operation by operation with sympy (surface gradient =
+d/dxi * pseudo-inverse Jacobian, CellNormal, cross products, gradx = grad . inv(F), local frame, Voigt strains, energy
+densities; kinematics.py:12-106, linear_shell_model.py:136-157, 199-306) -- no B matrix is formed by hand and no code is
+shared with the oracle.
+
+Case T: an affine triangle tilted in 3-D, nodal thickness (affine over the cell), uniform E / nu, uhat = 0: exact (rational)
+integration of the 27 x 27 element stiffness for both rotation spaces, and of the load vector.
+
+Local numbering (the oracle's and the library's): displacement nodes = vertices 0, 1, 2, then the midpoints of the edges
+0-1, 1-2, 2-0; rotation nodes = the vertices (CG1) or those three midpoints (CR).  DOF 3 a + c, then 18 + 3 b + c.
+
+Run:  python tests/golden/make_sympy_golden_tri.py   (about a minute)
+"""
+import itertools
+import os
+
+import numpy as np
+import sympy as sm
+
+xi, eta = sm.symbols("xi eta")
+K_SHEAR = sm.Rational(833, 1000)
+LAM = [1 - xi - eta, xi, eta]                                    # barycentric coordinates of the unit triangle
+EDGES = [(0, 1), (1, 2), (2, 0)]
+N2 = [l * (2 * l - 1) for l in LAM] + [4 * LAM[i] * LAM[j] for i, j in EDGES]
+N1 = list(LAM)
+NCR = [1 - 2 * LAM[(k + 2) % 3] for k in range(3)]               # one on its own edge midpoint, zero on the other two
+
+
+def vec(fn, coefs):
+    return sm.Matrix([sum(fn[b] * coefs[b][c] for b in range(len(fn))) for c in range(3)])
+
+
+def build(X, hn, E, nu, NRot):
+    x = vec(N1, X)
+    Jg = x.jacobian([xi, eta])
+    a = Jg[:, 0].cross(Jg[:, 1])
+    detg = sm.sqrt(a.dot(a))
+    n = a / detg                                                 # CellNormal
+    Kinv = (Jg.T * Jg).inv() * Jg.T                              # pseudo-inverse (2 x 3)
+
+    def grad(v):                                                 # UFL grad on the manifold; uhat = 0: gradx == grad
+        return v.jacobian([xi, eta]) * Kinv
+
+    A0 = Jg[:, 0]
+    E0 = A0 / sm.sqrt(A0.dot(A0))                                # kinematics.py:66-67
+    E1 = n.cross(E0)                                             # kinematics.py:68
+    T = sm.Matrix([E0.T, E1.T])                                  # kinematics.py:79-80
+    h = sum(N1[b] * hn[b] for b in range(3))
+    hK = max(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3))) for i, j in itertools.combinations(range(3), 2))
+
+    def strains(U, TH):
+        u = vec(N2, U)
+        th = vec(NRot, TH)
+        gradu = grad(u)                                          # linear_shell_model.py:220
+        t_gu = T * gradu * T.T                                   # :222, kinematics.py:90-91
+        eps = (t_gu + t_gu.T) / 2                                # :238
+        gb = T * grad(n.cross(th)) * T.T                         # :242
+        kap = (gb + gb.T) / 2
+        gam = T * (-(n.cross(th))) + T * (gradu.T * n)           # :252-257
+        om = (t_gu[0, 1] - t_gu[1, 0]) / 2 + th.dot(n)           # :288-289
+        return [eps[0, 0], eps[1, 1], 2 * eps[0, 1], kap[0, 0], kap[1, 1], 2 * kap[0, 1], gam[0], gam[1], om]
+
+    Cp = (E / (1 - nu * nu)) * sm.Matrix([[1, nu, 0], [nu, 1, 0], [0, 0, (1 - nu) / 2]])
+    G = E / 2 / (1 + nu)
+    C = sm.zeros(9, 9)
+    C[0:3, 0:3] = h * Cp                                         # linear_shell_model.py:136-157
+    C[3:6, 3:6] = h ** 3 / 12 * Cp
+    C[6, 6] = C[7, 7] = K_SHEAR * G * h
+    C[8, 8] = E * h ** 3 / hK ** 2                               # drilling, :284-296
+    return strains, sm.simplify(C), sm.simplify(detg)
+
+
+def tri_int(p):
+    """Exact integral over the unit triangle of a polynomial in xi, eta:  int xi^i eta^j = i! j! / (i + j + 2)!"""
+    P = sm.Poly(sm.expand(p), xi, eta)
+    return sum(c * sm.factorial(i) * sm.factorial(j) / sm.factorial(i + j + 2) for (i, j), c in P.terms())
+
+
+def unit_dofs():
+    for i in range(27):
+        U = [[0] * 3 for _ in range(6)]
+        TH = [[0] * 3 for _ in range(3)]
+        if i < 18:
+            U[i // 3][i % 3] = 1
+        else:
+            TH[(i - 18) // 3][(i - 18) % 3] = 1
+        yield U, TH
+
+
+def stiffness(X, hn, E, nu, NRot):
+    strains, C, detg = build(X, hn, E, nu, NRot)
+    Bs = [[sm.expand(sm.simplify(e)) for e in strains(U, TH)] for U, TH in unit_dofs()]
+    CB = [[sm.expand(sum(C[k, l] * Bs[j][l] for l in range(9))) for k in range(9)] for j in range(27)]
+    Ke = np.zeros((27, 27))
+    for i in range(27):
+        for j in range(i, 27):
+            Ke[i, j] = Ke[j, i] = float(tri_int(sum(Bs[i][k] * CB[j][k] for k in range(9)) * detg))
+    return Ke, detg
+
+
+def case_T():
+    R = sm.Rational
+    x0 = [R(1, 10), R(-1, 5), R(3, 10)]
+    d0 = [R(6, 5), 0, R(8, 5)]                                   # x1 - x0: length 2 (the cell diameter)
+    d1 = [R(3, 5), R(4, 5), R(4, 5)]                             # x2 - x0; |d0 x d1| = 8 / 5
+    X = [x0, [x0[c] + d0[c] for c in range(3)], [x0[c] + d1[c] for c in range(3)]]
+    hn = [R(1, 10), R(3, 25), R(2, 25)]
+    E, nu = R(7, 2), R(3, 10)
+    fn = [[R(1), R(-2), R(1, 2)], [R(1, 3), R(0), R(2)], [R(-1), R(1), R(1)]]
+    Ke_cg, detg = stiffness(X, hn, E, nu, N1)
+    print("CG2CG1 triangle done")
+    Ke_cr, _ = stiffness(X, hn, E, nu, NCR)
+    print("CG2CR1 triangle done")
+    f = vec(N1, fn)
+    Fe = np.zeros(18)
+    for a in range(6):
+        for c in range(3):
+            Fe[3 * a + c] = float(tri_int(N2[a] * f[c] * detg))
+    return dict(T_X=np.array(X, float), T_h=np.array(hn, float), T_E=np.array([float(E)]), T_nu=np.array([float(nu)]),
+                T_f=np.array(fn, float), T_Ke_cg2cg1=Ke_cg, T_Ke_cg2cr1=Ke_cr, T_Fe=Fe)
+
+
+if __name__ == "__main__":
+    out = case_T()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)

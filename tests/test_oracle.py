@@ -50,6 +50,22 @@ def test_golden_warped_pointwise(golden_dir):
         assert np.abs(Fq - g["B_Fq"][ip]).max() / np.abs(g["B_Fq"][ip]).max() < 1e-12
 
 
+@pytest.mark.parametrize("element", ["CG2CG1", "CG2CR1"])
+def test_golden_affine_triangle(golden_dir, element):
+    """The triangle branch of the oracle, and its Crouzeix-Raviart rotation, against the independent symbolic derivation
+    (tests/golden/make_sympy_golden_tri.py): exact element stiffness of an affine triangle tilted in space, nodal thickness."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = ShellMesh(g["T_X"], np.array([[0, 1, 2]]), element)
+    o = ShellOracle(m)
+    o.set_fields(h=g["T_h"], E=g["T_E"], nu=g["T_nu"], f=g["T_f"])
+    Ke = o.element_matrices()[0]
+    ref = g["T_Ke_" + element.lower()]
+    assert np.abs(Ke - ref).max() / np.abs(ref).max() < 1e-13
+    assert np.abs(g["T_Ke_cg2cg1"] - g["T_Ke_cg2cr1"]).max() > 1e-3 * np.abs(ref).max()      # the two spaces do differ
+    Fe = o.load_vector()[m.cell_dofs()[0][:18]]
+    assert np.abs(Fe - g["T_Fe"]).max() / np.abs(g["T_Fe"]).max() < 1e-13
+
+
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
     m = plate_mesh(2.0, 10.0, nw, nl)
     rng = np.random.default_rng(seed)
