@@ -1,8 +1,9 @@
 """Generate tests/golden/sympy_triangle.npz -- the independent symbolic derivation of tests/golden/make_sympy_golden.py
-for the TRIANGLE elements: 'CG2CG1' (P2 displacement, P1 rotation) and 'CG2CR1' (P2 displacement, Crouzeix-Raviart
-rotation on the edge midpoints; reference femo_alpha/rm_shell/linear_shell_fenicsx/linear_shell_model.py:68-73).
-It pins the triangle and the Crouzeix-Raviart branches of the CPU oracle (oracle/rm_shell_oracle.py), which until round 5
-were held by structural identities only.
+for the element variants it does not cover: the TRIANGLES with 'CG2CG1' (P2 displacement, P1 rotation), 'CG2CR1'
+(P2 displacement, Crouzeix-Raviart rotation on the edge midpoints) and 'CG1CG1' (P1 / P1), and the 'CG1CG1' QUADRILATERAL
+(reference femo_alpha/rm_shell/linear_shell_fenicsx/linear_shell_model.py:60-80).
+It pins those branches of the CPU oracle (oracle/rm_shell_oracle.py), which until round 5 were held by structural
+identities only.
 
 As in the quadrilateral script the reference's UFL text is followed operation by operation with sympy (surface gradient =
 d/dxi * pseudo-inverse Jacobian, CellNormal, cross products, gradx = grad . inv(F), local frame, Voigt strains, energy
@@ -10,7 +11,8 @@ densities; kinematics.py:12-106, linear_shell_model.py:136-157, 199-306) -- no B
 shared with the oracle.
 
 Case T: an affine triangle tilted in 3-D, nodal thickness (affine over the cell), uniform E / nu, uhat = 0: exact (rational)
-integration of the 27 x 27 element stiffness for both rotation spaces, and of the load vector.
+integration of the element stiffness for the three spaces (27 x 27, 27 x 27, 18 x 18), and of the load vector.
+Case Q: the affine quadrilateral of the other script's case A with the CG1CG1 space: 24 x 24.
 
 Local numbering (the oracle's and the library's): displacement nodes = vertices 0, 1, 2, then the midpoints of the edges
 0-1, 1-2, 2-0; rotation nodes = the vertices (CG1) or those three midpoints (CR).  DOF 3 a + c, then 18 + 3 b + c.
@@ -30,14 +32,16 @@ EDGES = [(0, 1), (1, 2), (2, 0)]
 N2 = [l * (2 * l - 1) for l in LAM] + [4 * LAM[i] * LAM[j] for i, j in EDGES]
 N1 = list(LAM)
 NCR = [1 - 2 * LAM[(k + 2) % 3] for k in range(3)]               # one on its own edge midpoint, zero on the other two
+Q1 = [(1 - xi) * (1 - eta) / 4, (1 + xi) * (1 - eta) / 4, (1 + xi) * (1 + eta) / 4, (1 - xi) * (1 + eta) / 4]   # on [-1, 1]^2
 
 
 def vec(fn, coefs):
     return sm.Matrix([sum(fn[b] * coefs[b][c] for b in range(len(fn))) for c in range(3)])
 
 
-def build(X, hn, E, nu, NRot):
-    x = vec(N1, X)
+def build(X, hn, E, nu, NGeo, NDisp, NRot):
+    """NGeo: vertex functions of the cell (geometry, thickness); NDisp / NRot: the displacement / rotation spaces."""
+    x = vec(NGeo, X)
     Jg = x.jacobian([xi, eta])
     a = Jg[:, 0].cross(Jg[:, 1])
     detg = sm.sqrt(a.dot(a))
@@ -51,11 +55,11 @@ def build(X, hn, E, nu, NRot):
     E0 = A0 / sm.sqrt(A0.dot(A0))                                # kinematics.py:66-67
     E1 = n.cross(E0)                                             # kinematics.py:68
     T = sm.Matrix([E0.T, E1.T])                                  # kinematics.py:79-80
-    h = sum(N1[b] * hn[b] for b in range(3))
-    hK = max(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3))) for i, j in itertools.combinations(range(3), 2))
+    h = sum(NGeo[b] * hn[b] for b in range(len(NGeo)))
+    hK = max(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3))) for i, j in itertools.combinations(range(len(NGeo)), 2))
 
     def strains(U, TH):
-        u = vec(N2, U)
+        u = vec(NDisp, U)
         th = vec(NRot, TH)
         gradu = grad(u)                                          # linear_shell_model.py:220
         t_gu = T * gradu * T.T                                   # :222, kinematics.py:90-91
@@ -82,25 +86,32 @@ def tri_int(p):
     return sum(c * sm.factorial(i) * sm.factorial(j) / sm.factorial(i + j + 2) for (i, j), c in P.terms())
 
 
-def unit_dofs():
-    for i in range(27):
-        U = [[0] * 3 for _ in range(6)]
-        TH = [[0] * 3 for _ in range(3)]
-        if i < 18:
+def quad_int(p):
+    """Exact integral over [-1, 1]^2 of a polynomial in xi, eta."""
+    P = sm.Poly(sm.expand(p), xi, eta)
+    return sum(c * sm.Rational(2, i + 1) * sm.Rational(2, j + 1) for (i, j), c in P.terms() if i % 2 == 0 and j % 2 == 0)
+
+
+def unit_dofs(nd, nr):
+    for i in range(3 * (nd + nr)):
+        U = [[0] * 3 for _ in range(nd)]
+        TH = [[0] * 3 for _ in range(nr)]
+        if i < 3 * nd:
             U[i // 3][i % 3] = 1
         else:
-            TH[(i - 18) // 3][(i - 18) % 3] = 1
+            TH[(i - 3 * nd) // 3][(i - 3 * nd) % 3] = 1
         yield U, TH
 
 
-def stiffness(X, hn, E, nu, NRot):
-    strains, C, detg = build(X, hn, E, nu, NRot)
-    Bs = [[sm.expand(sm.simplify(e)) for e in strains(U, TH)] for U, TH in unit_dofs()]
-    CB = [[sm.expand(sum(C[k, l] * Bs[j][l] for l in range(9))) for k in range(9)] for j in range(27)]
-    Ke = np.zeros((27, 27))
-    for i in range(27):
-        for j in range(i, 27):
-            Ke[i, j] = Ke[j, i] = float(tri_int(sum(Bs[i][k] * CB[j][k] for k in range(9)) * detg))
+def stiffness(X, hn, E, nu, NGeo, NDisp, NRot, integrate):
+    strains, C, detg = build(X, hn, E, nu, NGeo, NDisp, NRot)
+    n = 3 * (len(NDisp) + len(NRot))
+    Bs = [[sm.expand(sm.simplify(e)) for e in strains(U, TH)] for U, TH in unit_dofs(len(NDisp), len(NRot))]
+    CB = [[sm.expand(sum(C[k, l] * Bs[j][l] for l in range(9))) for k in range(9)] for j in range(n)]
+    Ke = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i, n):
+            Ke[i, j] = Ke[j, i] = float(integrate(sum(Bs[i][k] * CB[j][k] for k in range(9)) * detg))
     return Ke, detg
 
 
@@ -113,21 +124,37 @@ def case_T():
     hn = [R(1, 10), R(3, 25), R(2, 25)]
     E, nu = R(7, 2), R(3, 10)
     fn = [[R(1), R(-2), R(1, 2)], [R(1, 3), R(0), R(2)], [R(-1), R(1), R(1)]]
-    Ke_cg, detg = stiffness(X, hn, E, nu, N1)
+    Ke_cg, detg = stiffness(X, hn, E, nu, N1, N2, N1, tri_int)
     print("CG2CG1 triangle done")
-    Ke_cr, _ = stiffness(X, hn, E, nu, NCR)
+    Ke_cr, _ = stiffness(X, hn, E, nu, N1, N2, NCR, tri_int)
     print("CG2CR1 triangle done")
+    Ke_11, _ = stiffness(X, hn, E, nu, N1, N1, N1, tri_int)
+    print("CG1CG1 triangle done")
     f = vec(N1, fn)
     Fe = np.zeros(18)
     for a in range(6):
         for c in range(3):
             Fe[3 * a + c] = float(tri_int(N2[a] * f[c] * detg))
     return dict(T_X=np.array(X, float), T_h=np.array(hn, float), T_E=np.array([float(E)]), T_nu=np.array([float(nu)]),
-                T_f=np.array(fn, float), T_Ke_cg2cg1=Ke_cg, T_Ke_cg2cr1=Ke_cr, T_Fe=Fe)
+                T_f=np.array(fn, float), T_Ke_cg2cg1=Ke_cg, T_Ke_cg2cr1=Ke_cr, T_Ke_cg1cg1=Ke_11, T_Fe=Fe)
+
+
+def case_Q():
+    R = sm.Rational                                              # the parallelogram of make_sympy_golden.py, case A
+    x0 = [R(1, 10), R(-1, 5), R(3, 10)]
+    d0 = [R(6, 5), 0, R(8, 5)]
+    d1 = [R(3, 5), R(4, 5), R(4, 5)]
+    X = [x0, [x0[c] + d0[c] for c in range(3)], [x0[c] + d0[c] + d1[c] for c in range(3)], [x0[c] + d1[c] for c in range(3)]]
+    hn = [R(1, 10), R(3, 25), R(2, 25), R(11, 100)]
+    E, nu = R(7, 2), R(3, 10)
+    Ke, _ = stiffness(X, hn, E, nu, Q1, Q1, Q1, quad_int)
+    print("CG1CG1 quadrilateral done")
+    return dict(Q_X=np.array(X, float), Q_h=np.array(hn, float), Q_E=np.array([float(E)]), Q_nu=np.array([float(nu)]), Q_Ke_cg1cg1=Ke)
 
 
 if __name__ == "__main__":
     out = case_T()
+    out.update(case_Q())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

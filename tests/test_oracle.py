@@ -50,9 +50,9 @@ def test_golden_warped_pointwise(golden_dir):
         assert np.abs(Fq - g["B_Fq"][ip]).max() / np.abs(g["B_Fq"][ip]).max() < 1e-12
 
 
-@pytest.mark.parametrize("element", ["CG2CG1", "CG2CR1"])
+@pytest.mark.parametrize("element", ["CG2CG1", "CG2CR1", "CG1CG1"])
 def test_golden_affine_triangle(golden_dir, element):
-    """The triangle branch of the oracle, and its Crouzeix-Raviart rotation, against the independent symbolic derivation
+    """The triangle branches of the oracle (P2 / P1, the Crouzeix-Raviart rotation, P1 / P1) against the independent symbolic derivation
     (tests/golden/make_sympy_golden_tri.py): exact element stiffness of an affine triangle tilted in space, nodal thickness."""
     g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
     m = ShellMesh(g["T_X"], np.array([[0, 1, 2]]), element)
@@ -60,10 +60,21 @@ def test_golden_affine_triangle(golden_dir, element):
     o.set_fields(h=g["T_h"], E=g["T_E"], nu=g["T_nu"], f=g["T_f"])
     Ke = o.element_matrices()[0]
     ref = g["T_Ke_" + element.lower()]
-    assert np.abs(Ke - ref).max() / np.abs(ref).max() < 1e-13
-    assert np.abs(g["T_Ke_cg2cg1"] - g["T_Ke_cg2cr1"]).max() > 1e-3 * np.abs(ref).max()      # the two spaces do differ
-    Fe = o.load_vector()[m.cell_dofs()[0][:18]]
-    assert np.abs(Fe - g["T_Fe"]).max() / np.abs(g["T_Fe"]).max() < 1e-13
+    assert Ke.shape == ref.shape and np.abs(Ke - ref).max() / np.abs(ref).max() < 1e-13
+    assert np.abs(g["T_Ke_cg2cg1"] - g["T_Ke_cg2cr1"]).max() > 1e-3 * np.abs(ref).max()      # the two rotation spaces do differ
+    if element != "CG1CG1":
+        Fe = o.load_vector()[m.cell_dofs()[0][:18]]
+        assert np.abs(Fe - g["T_Fe"]).max() / np.abs(g["T_Fe"]).max() < 1e-13
+
+
+def test_golden_affine_cg1cg1_quadrilateral(golden_dir):
+    """ShellElement 'CG1CG1' (linear_shell_model.py:74-79) on the affine quadrilateral of the other golden: 24 x 24, exact."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = ShellMesh(g["Q_X"], np.array([[0, 1, 2, 3]]), "CG1CG1")
+    o = ShellOracle(m)
+    o.set_fields(h=g["Q_h"], E=g["Q_E"], nu=g["Q_nu"])
+    Ke = o.element_matrices()[0]
+    assert Ke.shape == (24, 24) and np.abs(Ke - g["Q_Ke_cg1cg1"]).max() / np.abs(g["Q_Ke_cg1cg1"]).max() < 1e-13
 
 
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
