@@ -13,6 +13,10 @@ shared with the oracle.
 Case T: an affine triangle tilted in 3-D, nodal thickness (affine over the cell), uniform E / nu, uhat = 0: exact (rational)
 integration of the element stiffness for the three spaces (27 x 27, 27 x 27, 18 x 18), and of the load vector.
 Case Q: the affine quadrilateral of the other script's case A with the CG1CG1 space: 24 x 24.
+Case S: the von Mises stress of ShellStressRM at the top, middle and bottom surface (thickness a field) on a warped quadrilateral
+        with uhat != 0, at three points, for a given state.
+Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0, at
+        three points of every facet of a warped quadrilateral and of a triangle.
 
 Local numbering (the oracle's and the library's): displacement nodes = vertices 0, 1, 2, then the midpoints of the edges
 0-1, 1-2, 2-0; rotation nodes = the vertices (CG1) or those three midpoints (CR).  DOF 3 a + c, then 18 + 3 b + c.
@@ -152,9 +156,116 @@ def case_Q():
     return dict(Q_X=np.array(X, float), Q_h=np.array(hn, float), Q_E=np.array([float(E)]), Q_nu=np.array([float(nu)]), Q_Ke_cg1cg1=Ke)
 
 
+def nanson(X, Uhat, NGeo, edges_ref, params):
+    """|| J(uhat) F(uhat)^-T N || on the facets (linear_shell_model.py:323-333: Nanson's formula for the facet measure), with
+    N = FacetNormal of a manifold cell: the reference facet normal pushed forward by the pseudo-inverse Jacobian and normalised.
+    ``edges_ref``: per local facet (point(s) -> (xi, eta), reference outward normal).  Returns values [facet][parameter]."""
+    x = vec(NGeo, X)
+    Jg = x.jacobian([xi, eta])
+    Kinv = (Jg.T * Jg).inv() * Jg.T
+
+    def grad(v):
+        return v.jacobian([xi, eta]) * Kinv
+
+    F = sm.eye(3) + grad(vec(NGeo, Uhat))                        # kinematics.py:42-44
+    out = []
+    for point, nref in edges_ref:
+        N = Kinv.T * sm.Matrix(nref)
+        row = []
+        for sv in params:
+            px, py = point(sv)
+            sub = {xi: px, eta: py}
+            Fn = F.subs(sub)
+            Nn = N.subs(sub)
+            Nn = Nn / sm.sqrt(Nn.dot(Nn))
+            v = Fn.det() * (Fn.inv().T * Nn)
+            row.append(float(sm.sqrt(v.dot(v)).evalf(30)))
+        out.append(row)
+    return np.array(out)
+
+
+def case_N():
+    R = sm.Rational
+    params = [R(-3, 5), R(1, 10), R(4, 5)]                       # edge parameter s in [-1, 1], from local vertex k to k + 1
+    Xq = [[R(0), R(0), R(0)], [R(1), R(1, 10), R(1, 5)], [R(6, 5), R(9, 10), R(-1, 10)], [R(-1, 10), R(1), R(3, 10)]]   # case B's warped quad
+    Uq = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)], [R(0), R(-3, 100), R(1, 100)]]
+    quad_edges = [(lambda s: (s, -1), (0, -1)), (lambda s: (1, s), (1, 0)), (lambda s: (-s, 1), (0, 1)), (lambda s: (-1, -s), (-1, 0))]
+    Xt = [[R(1, 10), R(-1, 5), R(3, 10)], [R(13, 10), R(-1, 5), R(19, 10)], [R(7, 10), R(3, 5), R(11, 10)]]              # case T's triangle
+    Ut = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)]]
+    half = lambda s: (s + 1) / 2
+    tri_edges = [(lambda s: (half(s), 0), (0, -1)), (lambda s: (1 - half(s), half(s)), (1, 1)), (lambda s: (0, 1 - half(s)), (-1, 0))]
+    out = dict(N_s=np.array(params, float), N_quad_X=np.array(Xq, float), N_quad_uhat=np.array(Uq, float),
+               N_quad=nanson(Xq, Uq, Q1, quad_edges, params),
+               N_tri_X=np.array(Xt, float), N_tri_uhat=np.array(Ut, float), N_tri=nanson(Xt, Ut, N1, tri_edges, params))
+    print("Nanson factors done")
+    return out
+
+
+Q2_IJ = [(0, 0), (2, 0), (2, 2), (0, 2), (1, 0), (2, 1), (1, 2), (0, 1), (1, 1)]   # local P2 nodes of a quadrilateral: vertices, edge midpoints, centre
+
+
+def _lag(nodes, t):
+    out = []
+    for i, a in enumerate(nodes):
+        p = sm.Integer(1)
+        for j, b in enumerate(nodes):
+            if i != j:
+                p *= (t - b) / (a - b)
+        out.append(sm.expand(p))
+    return out
+
+
+def case_S():
+    """von Mises stress of ShellStressRM (linear_shell_model.py:350-467) at xi2 = zf h(x) -- the through-thickness coordinate is a FIELD
+    (rm_shell_pde.py:117-119, 153-165), so gradx differentiates it too -- on the warped quadrilateral with uhat != 0, nodal h / E / nu and
+    a given state, at three points and zf = 1/2, 0, -1/2."""
+    R = sm.Rational
+    X = [[R(0), R(0), R(0)], [R(1), R(1, 10), R(1, 5)], [R(6, 5), R(9, 10), R(-1, 10)], [R(-1, 10), R(1), R(3, 10)]]
+    Uhat = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)], [R(0), R(-3, 100), R(1, 100)]]
+    hn = [R(1, 20), R(3, 50), R(1, 25), R(11, 200)]
+    En = [R(2), R(5, 2), R(9, 4), R(3)]
+    nun = [R(3, 10), R(1, 4), R(7, 20), R(1, 5)]
+    rs = np.random.default_rng(7)
+    U = [[R(int(v), 1000) for v in row] for row in rs.integers(-40, 40, (9, 3))]
+    TH = [[R(int(v), 1000) for v in row] for row in rs.integers(-60, 60, (4, 3))]
+    pts = [(R(-3, 5), R(1, 4)), (R(1, 3), R(-7, 10)), (R(4, 5), R(9, 10))]
+    L2x, L2y = _lag([-1, 0, 1], xi), _lag([-1, 0, 1], eta)
+    NQ2 = [L2x[i] * L2y[j] for i, j in Q2_IJ]
+    x = vec(Q1, X)
+    Jg = x.jacobian([xi, eta])
+    a = Jg[:, 0].cross(Jg[:, 1])
+    E2 = a / sm.sqrt(a.dot(a))                                   # CellNormal
+    Kinv = (Jg.T * Jg).inv() * Jg.T
+    grad = lambda v: v.jacobian([xi, eta]) * Kinv
+    Finv = (sm.eye(3) + grad(vec(Q1, Uhat))).inv()
+    gradx = lambda v: grad(v) * Finv                             # kinematics.py:21
+    A0 = Jg[:, 0]
+    E0 = A0 / sm.sqrt(A0.dot(A0))
+    E1 = E2.cross(E0)
+    E01 = sm.Matrix([E0.T, E1.T])
+    h = sum(Q1[b] * hn[b] for b in range(4)); E = sum(Q1[b] * En[b] for b in range(4)); nu = sum(Q1[b] * nun[b] for b in range(4))
+    u_mid, theta = vec(NQ2, U), vec(Q1, TH)
+    out = np.zeros((3, len(pts)))
+    for iz, zf in enumerate((R(1, 2), R(0), R(-1, 2))):
+        u = u_mid - (zf * h) * E2.cross(theta)                   # ShellStressRM.u, :393-398, with xi2 = zf h
+        gl = E01 * gradx(u) * E01.T                              # gradu_local, :401-409
+        em = (gl + gl.T) / 2
+        eps = sm.Matrix([em[0, 0], em[1, 1], 2 * em[0, 1]])      # :412-420
+        D = (E / (1 - nu * nu)) * sm.Matrix([[1, nu, 0], [nu, 1, 0], [0, 0, (1 - nu) / 2]])
+        sg = D * eps                                             # cauchyStresses, :433-442
+        vm = sm.sqrt(sg[0] ** 2 - sg[0] * sg[1] + sg[1] ** 2 + 3 * sg[2] ** 2)      # :459-467
+        for ip, (px, py) in enumerate(pts):
+            out[iz, ip] = float(vm.subs({xi: px, eta: py}).evalf(30))
+    print("von Mises stresses done")
+    return dict(S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
+                S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
+
+
 if __name__ == "__main__":
     out = case_T()
     out.update(case_Q())
+    out.update(case_N())
+    out.update(case_S())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

@@ -77,6 +77,39 @@ def test_golden_affine_cg1cg1_quadrilateral(golden_dir):
     assert Ke.shape == (24, 24) and np.abs(Ke - g["Q_Ke_cg1cg1"]).max() / np.abs(g["Q_Ke_cg1cg1"]).max() < 1e-13
 
 
+def test_golden_facet_factor_of_the_penalty_term(golden_dir):
+    """|| J(uhat) F(uhat)^-T N || of the penalty measure (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0: the oracle's
+    edge factor against the symbolic one (FacetNormal = the reference facet normal pushed forward by the pseudo-inverse Jacobian) at
+    three points of every facet of a warped, non-planar quadrilateral and of a triangle."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    for X, U, ref in ((g["N_quad_X"], g["N_quad_uhat"], g["N_quad"]), (g["N_tri_X"], g["N_tri_uhat"], g["N_tri"])):
+        m = ShellMesh(X, np.arange(X.shape[0])[None, :])
+        o = ShellOracle(m)
+        o.set_fields(h=[0.05], E=[2.0], nu=[0.3], uhat=U)
+        got = np.array([o._nanson(0, k, g["N_s"]) for k in range(X.shape[0])])
+        assert np.abs(got - ref).max() < 1e-13 and np.abs(ref - 1).max() > 1e-3           # ... and the factor is not trivially one
+    o.set_fields(h=[0.05], E=[2.0], nu=[0.3], uhat=0 * U)
+    assert np.array_equal(o._nanson(0, 0, g["N_s"]), np.ones(3))
+
+
+def test_golden_von_mises_stress_pointwise(golden_dir):
+    """ShellStressRM.vonMisesStress (linear_shell_model.py:350-467) at xi2 = +h/2, 0, -h/2 with the thickness a FIELD
+    (rm_shell_pde.py:117-119, 153-165): the oracle's restatement (strains minus zf h kappa minus the grad(h) term) against the symbolic
+    derivation that differentiates u_mid - xi2 E2 x theta as written, on the warped quadrilateral with uhat != 0 and nodal h / E / nu."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = _single_quad(g["S_X"])
+    d = m.cell_dofs()[0]
+    w = np.zeros(m.ndof)
+    w[d] = np.concatenate([g["S_U"].ravel(), g["S_TH"].ravel()])
+    for ip in range(g["S_pts"].shape[0]):
+        o = ShellOracle(m, rule=(g["S_pts"][ip:ip + 1], np.ones(1)))
+        o.set_fields(h=g["S_h"], E=g["S_E"], nu=g["S_nu"], uhat=g["S_uhat"])
+        for iz, zf in enumerate((0.5, 0.0, -0.5)):
+            vm = o.von_mises_top(w, zf=zf)[0][0, 0]
+            assert abs(vm - g["S_vm"][iz, ip]) < 1e-12 * g["S_vm"][iz, ip], (ip, zf)
+    assert np.abs(g["S_vm"][0] - g["S_vm"][2]).min() > 1e-4 * g["S_vm"].max()          # the three surfaces do differ
+
+
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
     m = plate_mesh(2.0, 10.0, nw, nl)
     rng = np.random.default_rng(seed)
