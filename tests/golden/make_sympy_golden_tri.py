@@ -256,8 +256,17 @@ def case_S():
         vm = sm.sqrt(sg[0] ** 2 - sg[0] * sg[1] + sg[1] ** 2 + 3 * sg[2] ** 2)      # :459-467
         for ip, (px, py) in enumerate(pts):
             out[iz, ip] = float(vm.subs({xi: px, eta: py}).evalf(30))
-    print("von Mises stresses done")
-    return dict(S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
+    # compliance density u_mid . u_mid J(uhat) + 1/2 1e-2 grad(h) . grad(h)  (rm_shell_pde.py:64-89, nodal thickness: 'H1'), and the mass
+    # density rho h J(uhat) (:101-102), per unit of the reference measure (x detg)
+    detg = sm.sqrt(a.dot(a))
+    Ju = (sm.eye(3) + grad(vec(Q1, Uhat))).det()
+    gh = sm.Matrix([[h]]).jacobian([xi, eta]) * Kinv
+    comp = (u_mid.dot(u_mid) * Ju + sm.Rational(1, 2) * sm.Rational(1, 100) * (gh * gh.T)[0, 0]) * detg
+    rho = R(27, 10)
+    mdens = rho * h * Ju * detg
+    fun = np.array([[float(comp.subs({xi: px, eta: py}).evalf(30)), float(mdens.subs({xi: px, eta: py}).evalf(30))] for px, py in pts])
+    print("von Mises stresses and functional densities done")
+    return dict(S_fun=fun, S_rho=np.array([float(rho)]), S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
                 S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
 
 

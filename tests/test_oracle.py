@@ -2,7 +2,8 @@
 
 The reference's own tests pin nothing on this path (reference tests/test_pytest.py:5-86 is
 a project template), so the oracle is pinned by: the independent sympy derivation in
-tests/golden/sympy_element.npz, structural identities, the Euler-Bernoulli limit the
+tests/golden/sympy_element.npz and sympy_triangle.npz (every element variant, the facet factor of the
+penalty term, the von Mises stress, the functionals' densities), structural identities, the Euler-Bernoulli limit the
 reference example prints (ex_simple_shell_opt.py:100-105; ex_simple_shell.py:38-44,61), and
 the reference's own adjoint-vs-finite-difference method (ex_simple_shell_opt.py:109-111).
 """
@@ -108,6 +109,13 @@ def test_golden_von_mises_stress_pointwise(golden_dir):
             vm = o.von_mises_top(w, zf=zf)[0][0, 0]
             assert abs(vm - g["S_vm"][iz, ip]) < 1e-12 * g["S_vm"][iz, ip], (ip, zf)
     assert np.abs(g["S_vm"][0] - g["S_vm"][2]).min() > 1e-4 * g["S_vm"].max()          # the three surfaces do differ
+    # the functionals' densities at the same points: compliance (u.u J + the H1 regularisation of a nodal thickness,
+    # rm_shell_pde.py:64-89) and mass (rho h J, :101-102)
+    for ip in range(g["S_pts"].shape[0]):
+        o = ShellOracle(m, rule=(g["S_pts"][ip:ip + 1], np.ones(1)))
+        o.set_fields(h=g["S_h"], E=g["S_E"], nu=g["S_nu"], rho=g["S_rho"], uhat=g["S_uhat"])
+        assert abs(o.compliance(w) - g["S_fun"][ip, 0]) < 1e-12 * abs(g["S_fun"][ip, 0])
+        assert abs(o.mass() - g["S_fun"][ip, 1]) < 1e-13 * g["S_fun"][ip, 1]
 
 
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
