@@ -15,6 +15,8 @@ integration of the element stiffness for the three spaces (27 x 27, 27 x 27, 18 
 Case Q: the affine quadrilateral of the other script's case A with the CG1CG1 space: 24 x 24.
 Case S: the von Mises stress of ShellStressRM at the top, middle and bottom surface (thickness a field) on a warped quadrilateral
         with uhat != 0, at three points, for a given state.
+Case W: the warped quadrilateral with uhat != 0 and nodal h / E / nu integrated with the 5 x 5 Gauss rule from the symbolic point values
+        (element matrix and load vector): what a kernel using that rule must reproduce.
 Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0, at
         three points of every facet of a warped quadrilateral and of a triangle.
 
@@ -270,11 +272,53 @@ def case_S():
                 S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
 
 
+def case_W(n=5):
+    """The warped, non-planar quadrilateral of make_sympy_golden.py's case B (uhat != 0, nodal h / E / nu) INTEGRATED with the n x n
+    Gauss-Legendre rule: K_e = sum_q w_q B(q)^T C(q) B(q) detg(q) and the load vector, every point evaluated from the symbolic
+    expressions at 40 digits.  What a kernel that uses the same rule must reproduce -- no oracle in between."""
+    import importlib.util
+    import mpmath as mp
+    spec = importlib.util.spec_from_file_location("make_sympy_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "make_sympy_golden.py"))
+    q = importlib.util.module_from_spec(spec); spec.loader.exec_module(q)
+    R = sm.Rational
+    X = [[R(0), R(0), R(0)], [R(1), R(1, 10), R(1, 5)], [R(6, 5), R(9, 10), R(-1, 10)], [R(-1, 10), R(1), R(3, 10)]]
+    hn = [R(1, 20), R(3, 50), R(1, 25), R(11, 200)]
+    En = [R(2), R(5, 2), R(9, 4), R(3)]
+    nun = [R(3, 10), R(1, 4), R(7, 20), R(1, 5)]
+    Uhat = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)], [R(0), R(-3, 100), R(1, 100)]]
+    fn = [[R(1), R(-2), R(1, 2)], [R(1, 3), R(0), R(2)], [R(-1), R(1), R(1)], [R(1, 4), R(1, 5), R(-3)]]
+    mp.mp.dps = 40
+    strains, geo = q.build(X, Uhat, hn, En, nun)
+    C = q.cmat(geo)
+    Bsym = sm.Matrix([strains(U, TH)[0] for _, U, TH in q.unit_dofs()]).T                # 9 x 39
+    fB = sm.lambdify((xi, eta), Bsym, "mpmath")
+    fC = sm.lambdify((xi, eta), C, "mpmath")
+    fd = sm.lambdify((xi, eta), sm.Matrix([geo["detg"], geo["Ju"]]), "mpmath")
+    f = q.vec(q.N1, fn)
+    fF = sm.lambdify((xi, eta), sm.Matrix([q.N2[a] * f[c] for a in range(9) for c in range(3)]), "mpmath")
+    xs = sorted(sm.Poly(sm.legendre(n, xi), xi).nroots(n=40))
+    dP = sm.diff(sm.legendre(n, xi), xi)
+    ws = [2 / ((1 - x * x) * dP.subs(xi, x) ** 2) for x in xs]
+    Ke = mp.zeros(39, 39); Fe = mp.zeros(27, 1)
+    for x1, w1 in zip(xs, ws):
+        for x2, w2 in zip(xs, ws):
+            a, b = mp.mpf(str(x1)), mp.mpf(str(x2))
+            B = fB(a, b); Cn = fC(a, b); dj = fd(a, b)
+            wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
+            Ke += wq * (B.T * Cn * B)
+            Fe += wq * dj[1] * fF(a, b)
+    print("warped quadrilateral, integrated: done")
+    return dict(W_n=np.array([n]), W_X=np.array(X, float), W_h=np.array(hn, float), W_E=np.array(En, float), W_nu=np.array(nun, float),
+                W_uhat=np.array(Uhat, float), W_f=np.array(fn, float),
+                W_Ke=np.array(Ke.tolist(), dtype=float), W_Fe=np.array(Fe.tolist(), dtype=float).ravel())
+
+
 if __name__ == "__main__":
     out = case_T()
     out.update(case_Q())
     out.update(case_N())
     out.update(case_S())
+    out.update(case_W())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

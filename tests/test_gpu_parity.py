@@ -526,6 +526,27 @@ def test_element_matrices_against_the_symbolic_derivation(case):
     c.close()
 
 
+def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
+    """... and the general case: a warped, non-planar quadrilateral with uhat != 0 and nodal h / E / nu.  The golden integrates the
+    symbolic point values with the 5 x 5 Gauss rule (make_sympy_golden_tri.py, case W); the HIP kernels with that rule reproduce the
+    element matrix (CSR of the one-cell mesh) and the load vector -- frame, differentiated normal, gradx = grad F^-1, J(uhat) and the
+    interpolated material without the oracle in between."""
+    import os
+    from femo_alpha_amd.backend import ShellContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_triangle.npz"))
+    m = ShellMesh(g["W_X"], np.array([[0, 1, 2, 3]]))
+    c = ShellContext(m, nquad=int(g["W_n"][0]))
+    c.set_field("thickness", g["W_h"]); c.set_field("E", g["W_E"]); c.set_field("nu", g["W_nu"]); c.set_field("density", [1.0])
+    c.set_field("uhat", g["W_uhat"]); c.set_field("F_solid", g["W_f"])
+    c.enable_csr()
+    d = m.cell_dofs()[0]
+    Ke = c.assemble_csr().toarray()[np.ix_(d, d)]
+    assert np.abs(Ke - g["W_Ke"]).max() < 1e-11 * np.abs(g["W_Ke"]).max()
+    Fe = c.load_vector()[d[:27]]
+    assert np.abs(Fe - g["W_Fe"]).max() < 1e-12 * np.abs(g["W_Fe"]).max()
+    c.close()
+
+
 def test_non_convergence_and_indefinite_operators_raise():
     """The reference solves with a direct LU; here an iteration that stops short of rtol, or a Cholesky that meets a
     non-positive pivot, must not hand back numbers silently."""

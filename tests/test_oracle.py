@@ -118,6 +118,19 @@ def test_golden_von_mises_stress_pointwise(golden_dir):
         assert abs(o.mass() - g["S_fun"][ip, 1]) < 1e-13 * g["S_fun"][ip, 1]
 
 
+def test_golden_warped_element_integrated(golden_dir):
+    """The warped quadrilateral with uhat != 0 and nodal h / E / nu, integrated with the 5 x 5 Gauss rule from the symbolic point values
+    (tests/golden/make_sympy_golden_tri.py, case W): the oracle with the same rule reproduces the element matrix and the load vector."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = _single_quad(g["W_X"])
+    o = ShellOracle(m, nquad=int(g["W_n"][0]))
+    o.set_fields(h=g["W_h"], E=g["W_E"], nu=g["W_nu"], f=g["W_f"], uhat=g["W_uhat"])
+    Ke = o.element_matrices()[0]
+    assert np.abs(Ke - g["W_Ke"]).max() < 1e-12 * np.abs(g["W_Ke"]).max()
+    Fe = o.load_vector()[m.cell_dofs()[0][:27]]
+    assert np.abs(Fe - g["W_Fe"]).max() < 1e-13 * np.abs(g["W_Fe"]).max()
+
+
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
     m = plate_mesh(2.0, 10.0, nw, nl)
     rng = np.random.default_rng(seed)
