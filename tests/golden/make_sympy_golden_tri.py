@@ -17,6 +17,7 @@ Case S: the von Mises stress of ShellStressRM at the top, middle and bottom surf
         with uhat != 0, at three points, for a given state.
 Case W: the warped quadrilateral with uhat != 0 and nodal h / E / nu integrated with the 5 x 5 Gauss rule from the symbolic point values
         (element matrix and load vector): what a kernel using that rule must reproduce.
+Case P: the penalty blocks of that quadrilateral's four facets with uhat != 0 (three-point facet rule).
 Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0, at
         three points of every facet of a warped quadrilateral and of a triangle.
 
@@ -272,6 +273,32 @@ def case_S():
                 S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
 
 
+def case_P():
+    """The penalty blocks of every facet of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333, per unit of beta):
+    1 / h_K  int_facet || J F^-T N ||  L_i L_j ds  with the three-point Gauss rule of the reference's degree-4 facet measure
+    (utils_dolfinx.py:556), for the P2 trace (vertex a, midpoint, vertex b) and the P1 trace (a, b)."""
+    R = sm.Rational
+    X = [[R(0), R(0), R(0)], [R(1), R(1, 10), R(1, 5)], [R(6, 5), R(9, 10), R(-1, 10)], [R(-1, 10), R(1), R(3, 10)]]
+    Uq = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)], [R(0), R(-3, 100), R(1, 100)]]
+    quad_edges = [(lambda s: (s, -1), (0, -1)), (lambda s: (1, s), (1, 0)), (lambda s: (-s, 1), (0, 1)), (lambda s: (-1, -s), (-1, 0))]
+    g3 = [-sm.sqrt(R(3, 5)), R(0), sm.sqrt(R(3, 5))]
+    w3 = [R(5, 9), R(8, 9), R(5, 9)]
+    nf = nanson(X, Uq, Q1, quad_edges, g3)                      # [facet][point]
+    hK = max(float(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3)))) for i, j in itertools.combinations(range(4), 2))
+    M2 = np.zeros((4, 3, 3)); M1 = np.zeros((4, 2, 2))
+    for k in range(4):
+        a, b = X[k], X[(k + 1) % 4]
+        length = float(sm.sqrt(sum((a[c] - b[c]) ** 2 for c in range(3))))
+        for iq in range(3):
+            sq = float(g3[iq])
+            L2 = np.array([sq * (sq - 1) / 2, 1 - sq * sq, sq * (sq + 1) / 2])
+            L1 = np.array([(1 - sq) / 2, (1 + sq) / 2])
+            wq = float(w3[iq]) * 0.5 * length * nf[k, iq] / hK
+            M2[k] += wq * np.outer(L2, L2); M1[k] += wq * np.outer(L1, L1)
+    print("penalty blocks done")
+    return dict(P_X=np.array(X, float), P_uhat=np.array(Uq, float), P_M2=M2, P_M1=M1)
+
+
 def case_W(n=5):
     """The warped, non-planar quadrilateral of make_sympy_golden.py's case B (uhat != 0, nodal h / E / nu) INTEGRATED with the n x n
     Gauss-Legendre rule: K_e = sum_q w_q B(q)^T C(q) B(q) detg(q) and the load vector, every point evaluated from the symbolic
@@ -307,8 +334,30 @@ def case_W(n=5):
             wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
             Ke += wq * (B.T * Cn * B)
             Fe += wq * dj[1] * fF(a, b)
+    # the functionals on a given state with the same rule: compliance = int u.u J dx + 1/2 1e-2 int grad(h).grad(h) dx, mass = int rho h J dx
+    # (rm_shell_pde.py:64-102); the elastic energy is 1/2 w^T K_e w
+    rs = np.random.default_rng(11)
+    U = [[R(int(v), 1000) for v in row] for row in rs.integers(-40, 40, (9, 3))]
+    TH = [[R(int(v), 1000) for v in row] for row in rs.integers(-60, 60, (4, 3))]
+    u_mid = q.vec(q.N2, U)
+    x = q.vec(q.N1, X)
+    Jg = x.jacobian([xi, eta])
+    Kinv = (Jg.T * Jg).inv() * Jg.T
+    hf = sum(q.N1[b] * hn[b] for b in range(4))
+    gh = sm.Matrix([[hf]]).jacobian([xi, eta]) * Kinv
+    rho = R(27, 10)
+    ffun = sm.lambdify((xi, eta), sm.Matrix([u_mid.dot(u_mid), (gh * gh.T)[0, 0], hf]), "mpmath")
+    comp = mp.mpf(0); mass = mp.mpf(0)
+    for x1, w1 in zip(xs, ws):
+        for x2, w2 in zip(xs, ws):
+            a, b = mp.mpf(str(x1)), mp.mpf(str(x2))
+            dj = fd(a, b); v = ffun(a, b)
+            wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
+            comp += wq * (v[0] * dj[1] + mp.mpf(1) / 200 * v[1])
+            mass += wq * mp.mpf(27) / 10 * v[2] * dj[1]
     print("warped quadrilateral, integrated: done")
-    return dict(W_n=np.array([n]), W_X=np.array(X, float), W_h=np.array(hn, float), W_E=np.array(En, float), W_nu=np.array(nun, float),
+    return dict(W_U=np.array(U, float), W_TH=np.array(TH, float), W_rho=np.array([float(rho)]), W_compliance=np.array([float(comp)]),
+                W_mass=np.array([float(mass)]), W_n=np.array([n]), W_X=np.array(X, float), W_h=np.array(hn, float), W_E=np.array(En, float), W_nu=np.array(nun, float),
                 W_uhat=np.array(Uhat, float), W_f=np.array(fn, float),
                 W_Ke=np.array(Ke.tolist(), dtype=float), W_Fe=np.array(Fe.tolist(), dtype=float).ravel())
 
@@ -318,6 +367,7 @@ if __name__ == "__main__":
     out.update(case_Q())
     out.update(case_N())
     out.update(case_S())
+    out.update(case_P())
     out.update(case_W())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)

@@ -544,7 +544,41 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
     assert np.abs(Ke - g["W_Ke"]).max() < 1e-11 * np.abs(g["W_Ke"]).max()
     Fe = c.load_vector()[d[:27]]
     assert np.abs(Fe - g["W_Fe"]).max() < 1e-12 * np.abs(g["W_Fe"]).max()
+    # the functionals of a given state, integrated with the same rule from the symbolic densities
+    w = np.zeros(m.ndof); w[d] = np.concatenate([g["W_U"].ravel(), g["W_TH"].ravel()])
+    c.set_field("density", g["W_rho"])
+    c.set_state(w)
+    assert abs(c.functional("compliance") - g["W_compliance"][0]) < 1e-11 * g["W_compliance"][0]
+    assert abs(c.functional("mass") - g["W_mass"][0]) < 1e-12 * g["W_mass"][0]
+    e_ref = 0.5 * w[d] @ g["W_Ke"] @ w[d]
+    assert abs(c.functional("elastic_energy") - e_ref) < 1e-11 * abs(e_ref)
     c.close()
+
+
+def test_penalty_term_against_the_symbolic_facet_blocks():
+    """The penalty term of all four facets of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333): the HIP operator with
+    the facets minus the one without (unit vectors through femo_apply_K) against the symbolic blocks -- Nanson factor || J F^-T N ||,
+    three-point facet rule, 1 / h_K (make_sympy_golden_tri.py, case P)."""
+    import os
+    from femo_alpha_amd.backend import ShellContext
+    from test_oracle import _penalty_reference
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_triangle.npz"))
+    m = ShellMesh(g["P_X"], np.array([[0, 1, 2, 3]]))
+    beta = 1e3
+    d = m.cell_dofs()[0]
+
+    def operator(with_facets):
+        c = ShellContext(m)
+        c.set_field("thickness", [0.05]); c.set_field("E", [2.0]); c.set_field("nu", [0.3]); c.set_field("density", [1.0])
+        c.set_field("uhat", g["P_uhat"])
+        if with_facets:
+            c.set_penalty_facets(np.array([[0, k] for k in range(4)]), beta=beta)
+        K = np.stack([c.apply_K(np.eye(m.ndof)[j]) for j in range(m.ndof)], axis=1)
+        c.close()
+        return K[np.ix_(d, d)]
+    P = operator(True) - operator(False)
+    ref = _penalty_reference(g, beta)
+    assert np.abs(P - ref).max() < 1e-11 * np.abs(ref).max()
 
 
 def test_non_convergence_and_indefinite_operators_raise():

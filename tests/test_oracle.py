@@ -129,6 +129,40 @@ def test_golden_warped_element_integrated(golden_dir):
     assert np.abs(Ke - g["W_Ke"]).max() < 1e-12 * np.abs(g["W_Ke"]).max()
     Fe = o.load_vector()[m.cell_dofs()[0][:27]]
     assert np.abs(Fe - g["W_Fe"]).max() < 1e-13 * np.abs(g["W_Fe"]).max()
+    # the functionals of a given state with the same rule
+    d = m.cell_dofs()[0]
+    w = np.zeros(m.ndof); w[d] = np.concatenate([g["W_U"].ravel(), g["W_TH"].ravel()])
+    o.set_fields(h=g["W_h"], E=g["W_E"], nu=g["W_nu"], rho=g["W_rho"], f=g["W_f"], uhat=g["W_uhat"])
+    assert abs(o.compliance(w) - g["W_compliance"][0]) < 1e-12 * g["W_compliance"][0]
+    assert abs(o.mass() - g["W_mass"][0]) < 1e-13 * g["W_mass"][0]
+    assert abs(o.elastic_energy(w) - 0.5 * w[d] @ g["W_Ke"] @ w[d]) < 1e-12 * abs(o.elastic_energy(w))
+
+
+def _penalty_reference(g, beta):
+    """39 x 39 penalty matrix of the one-cell mesh in element-local numbering from the symbolic facet blocks (case P)."""
+    P = np.zeros((39, 39))
+    for k in range(4):
+        un = [k, 4 + k, (k + 1) % 4]                     # P2 nodes of facet k: vertex a, midpoint, vertex b
+        vn = [k, (k + 1) % 4]
+        for c in range(3):
+            iu = [3 * a + c for a in un]; it = [27 + 3 * b + c for b in vn]
+            P[np.ix_(iu, iu)] += beta * g["P_M2"][k]
+            P[np.ix_(it, it)] += beta * g["P_M1"][k]
+    return P
+
+
+def test_golden_penalty_blocks(golden_dir):
+    """The penalty term on all four facets of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333): the oracle's
+    operator with and without it against the symbolic facet blocks (Nanson factor, three-point facet rule, 1 / h_K)."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = _single_quad(g["P_X"])
+    beta = 1e3
+    o = ShellOracle(m, penalty_facets=np.array([[0, k] for k in range(4)]), beta=beta)
+    o.set_fields(h=[0.05], E=[2.0], nu=[0.3], uhat=g["P_uhat"])
+    d = m.cell_dofs()[0]
+    P = (o.assemble_K(with_penalty=True, with_strong=False) - o.assemble_K(with_penalty=False, with_strong=False)).toarray()[np.ix_(d, d)]
+    ref = _penalty_reference(g, beta)
+    assert np.abs(P - ref).max() < 1e-12 * np.abs(ref).max()
 
 
 def _jittered_plate(nw, nl, seed=0, amp=0.25, tilt=True):
