@@ -259,6 +259,16 @@ def case_S():
         vm = sm.sqrt(sg[0] ** 2 - sg[0] * sg[1] + sg[1] ** 2 + 3 * sg[2] ** 2)      # :459-467
         for ip, (px, py) in enumerate(pts):
             out[iz, ip] = float(vm.subs({xi: px, eta: py}).evalf(30))
+        if iz == 0:
+            # the p-norm aggregate of the top surface, 1 / alpha int (m vm)^rho J dx (rm_shell_pde.py:112-128), with the 3 x 3 Gauss rule of
+            # the reference's degree-4 measure (rm_shell_model.py:200-201), m = 2, rho = 4 and alpha = 1 given by the caller
+            detg_ = sm.sqrt(a.dot(a))
+            Ju_ = (sm.eye(3) + grad(vec(Q1, Uhat))).det()
+            import mpmath as mp
+            mp.mp.dps = 40
+            g3 = [-mp.sqrt(mp.mpf(3) / 5), mp.mpf(0), mp.sqrt(mp.mpf(3) / 5)]; w3 = [mp.mpf(5) / 9, mp.mpf(8) / 9, mp.mpf(5) / 9]
+            fdens = sm.lambdify((xi, eta), (2 * vm) ** 4 * Ju_ * detg_, "mpmath")       # (numeric points: substituting sqrt(3/5) symbolically does not end)
+            pnorm = float(sum(w3[i] * w3[j] * fdens(g3[i], g3[j]) for i in range(3) for j in range(3)))
     # compliance density u_mid . u_mid J(uhat) + 1/2 1e-2 grad(h) . grad(h)  (rm_shell_pde.py:64-89, nodal thickness: 'H1'), and the mass
     # density rho h J(uhat) (:101-102), per unit of the reference measure (x detg)
     detg = sm.sqrt(a.dot(a))
@@ -269,7 +279,7 @@ def case_S():
     mdens = rho * h * Ju * detg
     fun = np.array([[float(comp.subs({xi: px, eta: py}).evalf(30)), float(mdens.subs({xi: px, eta: py}).evalf(30))] for px, py in pts])
     print("von Mises stresses and functional densities done")
-    return dict(S_fun=fun, S_rho=np.array([float(rho)]), S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
+    return dict(S_fun=fun, S_rho=np.array([float(rho)]), S_pnorm=np.array([pnorm]), S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
                 S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
 
 
@@ -368,7 +378,13 @@ if __name__ == "__main__":
     out.update(case_N())
     out.update(case_S())
     out.update(case_P())
-    out.update(case_W())
+    import sys
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
+    if "--keep-W" in sys.argv and os.path.exists(path):          # case W takes two minutes: keep the committed values
+        old = np.load(path)
+        out.update({k: old[k] for k in old.files if k.startswith("W_")})
+    else:
+        out.update(case_W())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

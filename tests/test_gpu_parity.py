@@ -555,6 +555,26 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
     c.close()
 
 
+def test_stress_aggregate_against_the_symbolic_derivation():
+    """1 / alpha int (m vm)^rho J dx of the top surface (rm_shell_pde.py:112-128, ShellStressRM with the thickness a field) on the warped
+    quadrilateral with uhat != 0, nodal h / E / nu and a given state: the HIP aggregate against the symbolic von Mises stress integrated
+    with the 3 x 3 rule of the degree-4 measure (make_sympy_golden_tri.py, case S; m = 2, rho = 4, alpha = 1)."""
+    import os
+    from femo_alpha_amd.backend import ShellContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_triangle.npz"))
+    m = ShellMesh(g["S_X"], np.array([[0, 1, 2, 3]]))
+    c = ShellContext(m)
+    c.set_field("thickness", g["S_h"]); c.set_field("E", g["S_E"]); c.set_field("nu", g["S_nu"]); c.set_field("density", [1.0])
+    c.set_field("uhat", g["S_uhat"])
+    d = m.cell_dofs()[0]
+    w = np.zeros(m.ndof); w[d] = np.concatenate([g["S_U"].ravel(), g["S_TH"].ravel()])
+    c.set_state(w)
+    c.set_stress_params(m=2.0, rho=4.0)
+    c.set_stress_alpha(1.0)
+    assert abs(c.functional("pnorm_stress") - g["S_pnorm"][0]) < 1e-11 * g["S_pnorm"][0]
+    c.close()
+
+
 def test_penalty_term_against_the_symbolic_facet_blocks():
     """The penalty term of all four facets of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333): the HIP operator with
     the facets minus the one without (unit vectors through femo_apply_K) against the symbolic blocks -- Nanson factor || J F^-T N ||,

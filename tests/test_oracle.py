@@ -109,6 +109,10 @@ def test_golden_von_mises_stress_pointwise(golden_dir):
             vm = o.von_mises_top(w, zf=zf)[0][0, 0]
             assert abs(vm - g["S_vm"][iz, ip]) < 1e-12 * g["S_vm"][iz, ip], (ip, zf)
     assert np.abs(g["S_vm"][0] - g["S_vm"][2]).min() > 1e-4 * g["S_vm"].max()          # the three surfaces do differ
+    # the p-norm aggregate of the top surface with the 3 x 3 rule of the reference's degree-4 measure, m = 2, rho = 4, alpha = 1
+    o3 = ShellOracle(m, nquad=3)
+    o3.set_fields(h=g["S_h"], E=g["S_E"], nu=g["S_nu"], uhat=g["S_uhat"])
+    assert abs(o3.pnorm_stress(w, m=2.0, rho=4, alpha=1.0) - g["S_pnorm"][0]) < 1e-12 * g["S_pnorm"][0]
     # the functionals' densities at the same points: compliance (u.u J + the H1 regularisation of a nodal thickness,
     # rm_shell_pde.py:64-89) and mass (rho h J, :101-102)
     for ip in range(g["S_pts"].shape[0]):
