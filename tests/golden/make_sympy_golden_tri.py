@@ -365,8 +365,25 @@ def case_W(n=5):
             wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
             comp += wq * (v[0] * dj[1] + mp.mpf(1) / 200 * v[1])
             mass += wq * mp.mpf(27) / 10 * v[2] * dj[1]
+    # the inertia operator of the dynamic shell, rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348), with the same rule:
+    # per component a 9 x 9 block on the displacement nodes and a 4 x 4 block on the rotation nodes
+    hK = max(float(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3)))) for i, j in itertools.combinations(range(4), 2))
+    fN = sm.lambdify((xi, eta), sm.Matrix(list(q.N2) + list(q.N1) + [hf]), "mpmath")
+    Mu = mp.zeros(9, 9); Mt = mp.zeros(4, 4)
+    for x1, w1 in zip(xs, ws):
+        for x2, w2 in zip(xs, ws):
+            a, b = mp.mpf(str(x1)), mp.mpf(str(x2))
+            dj = fd(a, b); v = fN(a, b)
+            wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0] * dj[1] * mp.mpf(27) / 10 * v[13]
+            n2 = mp.matrix([v[i] for i in range(9)]); n1 = mp.matrix([v[9 + i] for i in range(4)])
+            Mu += wq * (n2 * n2.T); Mt += wq * (n1 * n1.T)
+    Me = np.zeros((39, 39))
+    Mu_, Mt_ = np.array(Mu.tolist(), dtype=float), np.array(Mt.tolist(), dtype=float) * hK ** 2
+    for c in range(3):
+        Me[np.ix_(range(c, 27, 3), range(c, 27, 3))] = Mu_
+        Me[np.ix_(range(27 + c, 39, 3), range(27 + c, 39, 3))] = Mt_
     print("warped quadrilateral, integrated: done")
-    return dict(W_U=np.array(U, float), W_TH=np.array(TH, float), W_rho=np.array([float(rho)]), W_compliance=np.array([float(comp)]),
+    return dict(W_Me=Me, W_U=np.array(U, float), W_TH=np.array(TH, float), W_rho=np.array([float(rho)]), W_compliance=np.array([float(comp)]),
                 W_mass=np.array([float(mass)]), W_n=np.array([n]), W_X=np.array(X, float), W_h=np.array(hn, float), W_E=np.array(En, float), W_nu=np.array(nun, float),
                 W_uhat=np.array(Uhat, float), W_f=np.array(fn, float),
                 W_Ke=np.array(Ke.tolist(), dtype=float), W_Fe=np.array(Fe.tolist(), dtype=float).ravel())

@@ -552,6 +552,15 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
     assert abs(c.functional("mass") - g["W_mass"][0]) < 1e-12 * g["W_mass"][0]
     e_ref = 0.5 * w[d] @ g["W_Ke"] @ w[d]
     assert abs(c.functional("elastic_energy") - e_ref) < 1e-11 * abs(e_ref)
+    # the inertia operator rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348): femo_op_apply_vec2 with aK = 0, aM = 1
+    import torch
+    Me = np.zeros((m.ndof, m.ndof))
+    for j in range(m.ndof):
+        c.vec_tensor("p").copy_(torch.from_numpy(np.eye(m.ndof)[j])); c.sync()
+        c.op_apply_vec2("p", "Ap", 0.0, 1.0, with_penalty=False); c.sync()
+        Me[:, j] = c.vec_tensor("Ap").cpu().numpy()
+    Me = Me[np.ix_(d, d)]
+    assert np.abs(Me - g["W_Me"]).max() < 1e-12 * np.abs(g["W_Me"]).max()
     c.close()
 
 
