@@ -365,6 +365,32 @@ def case_W(n=5):
             wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
             comp += wq * (v[0] * dj[1] + mp.mpf(1) / 200 * v[1])
             mass += wq * mp.mpf(27) / 10 * v[2] * dj[1]
+    # the thickness sensitivities on that state and a given multiplier lam (rm_shell_model.py:216-232, state_operation.py:242-258):
+    #   ((dR/dh)^T lam)_b = int lam^T B^T (dC/dh) B w  N_b dx      (the load does not depend on h),
+    #   (d compliance / dh)_b = 1e-2 int grad(h) . grad(N_b) dx      (the H1 regularisation; u.u J does not depend on h)
+    Hs = sm.Symbol("Hs")
+    geoH = dict(geo); geoH["h"] = Hs
+    dC = sm.diff(q.cmat(geoH), Hs).subs(Hs, geo["h"])
+    fdC = sm.lambdify((xi, eta), dC, "mpmath")
+    LU = [[R(int(v), 1000) for v in row] for row in rs.integers(-50, 50, (9, 3))]
+    LT = [[R(int(v), 1000) for v in row] for row in rs.integers(-50, 50, (4, 3))]
+    wv = mp.matrix([mp.mpf(int(v.p)) / int(v.q) for row in U for v in row] + [mp.mpf(int(v.p)) / int(v.q) for row in TH for v in row])
+    lv = mp.matrix([mp.mpf(int(v.p)) / int(v.q) for row in LU for v in row] + [mp.mpf(int(v.p)) / int(v.q) for row in LT for v in row])
+    fgh = sm.lambdify((xi, eta), sm.Matrix([[(gh * (sm.Matrix([[q.N1[b_]]]).jacobian([xi, eta]) * Kinv).T)[0, 0] for b_ in range(4)]]), "mpmath")
+    fN1 = sm.lambdify((xi, eta), sm.Matrix(list(q.N1)), "mpmath")
+    dRdh = [mp.mpf(0)] * 4; dJdh = [mp.mpf(0)] * 4
+    for x1, w1 in zip(xs, ws):
+        for x2, w2 in zip(xs, ws):
+            a, b = mp.mpf(str(x1)), mp.mpf(str(x2))
+            dj = fd(a, b); B = fB(a, b)
+            wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
+            val = ((B * lv).T * fdC(a, b) * (B * wv))[0, 0]
+            n1 = fN1(a, b); gg = fgh(a, b)
+            for b_ in range(4):
+                dRdh[b_] += wq * val * n1[b_]
+                dJdh[b_] += wq * mp.mpf(1) / 100 * gg[b_]
+    sens = dict(W_LU=np.array(LU, float), W_LT=np.array(LT, float), W_dRdh_T_lam=np.array([float(v) for v in dRdh]),
+                W_dcompliance_dh=np.array([float(v) for v in dJdh]))
     # the inertia operator of the dynamic shell, rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348), with the same rule:
     # per component a 9 x 9 block on the displacement nodes and a 4 x 4 block on the rotation nodes
     hK = max(float(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3)))) for i, j in itertools.combinations(range(4), 2))
@@ -383,7 +409,7 @@ def case_W(n=5):
         Me[np.ix_(range(c, 27, 3), range(c, 27, 3))] = Mu_
         Me[np.ix_(range(27 + c, 39, 3), range(27 + c, 39, 3))] = Mt_
     print("warped quadrilateral, integrated: done")
-    return dict(W_Me=Me, W_U=np.array(U, float), W_TH=np.array(TH, float), W_rho=np.array([float(rho)]), W_compliance=np.array([float(comp)]),
+    return dict(**sens, W_Me=Me, W_U=np.array(U, float), W_TH=np.array(TH, float), W_rho=np.array([float(rho)]), W_compliance=np.array([float(comp)]),
                 W_mass=np.array([float(mass)]), W_n=np.array([n]), W_X=np.array(X, float), W_h=np.array(hn, float), W_E=np.array(En, float), W_nu=np.array(nun, float),
                 W_uhat=np.array(Uhat, float), W_f=np.array(fn, float),
                 W_Ke=np.array(Ke.tolist(), dtype=float), W_Fe=np.array(Fe.tolist(), dtype=float).ravel())

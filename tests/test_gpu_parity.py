@@ -552,6 +552,13 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
     assert abs(c.functional("mass") - g["W_mass"][0]) < 1e-12 * g["W_mass"][0]
     e_ref = 0.5 * w[d] @ g["W_Ke"] @ w[d]
     assert abs(c.functional("elastic_energy") - e_ref) < 1e-11 * abs(e_ref)
+    # the two halves of the north star's adjoint gradient on that state, for a given multiplier: (dR/dthickness)^T lam and
+    # d compliance / d thickness (state_operation.py:174-184, output_operation.py:58-69)
+    lam = np.zeros(m.ndof); lam[d] = np.concatenate([g["W_LU"].ravel(), g["W_LT"].ravel()])
+    gR = c.dRdarg_T("thickness", lam)
+    assert np.abs(gR - g["W_dRdh_T_lam"]).max() < 1e-11 * np.abs(g["W_dRdh_T_lam"]).max()
+    gJ = c.dfunctional("compliance", "thickness")
+    assert np.abs(gJ - g["W_dcompliance_dh"]).max() < 1e-11 * np.abs(g["W_dcompliance_dh"]).max()
     # the inertia operator rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348): femo_op_apply_vec2 with aK = 0, aM = 1
     import torch
     Me = np.zeros((m.ndof, m.ndof))

@@ -140,6 +140,12 @@ def test_golden_warped_element_integrated(golden_dir):
     assert abs(o.compliance(w) - g["W_compliance"][0]) < 1e-12 * g["W_compliance"][0]
     assert abs(o.mass() - g["W_mass"][0]) < 1e-13 * g["W_mass"][0]
     assert abs(o.elastic_energy(w) - 0.5 * w[d] @ g["W_Ke"] @ w[d]) < 1e-12 * abs(o.elastic_energy(w))
+    # thickness sensitivities on that state and a given multiplier: (dR/dh)^T lam and d compliance / dh (the regularisation's part)
+    lam = np.zeros(m.ndof); lam[d] = np.concatenate([g["W_LU"].ravel(), g["W_LT"].ravel()])
+    gR = o.dRdfield_T("h", w, lam)
+    assert np.abs(gR - g["W_dRdh_T_lam"]).max() < 1e-12 * np.abs(g["W_dRdh_T_lam"]).max()
+    gJ = o.dcompliance_dh(w)
+    assert np.abs(gJ - g["W_dcompliance_dh"]).max() < 1e-12 * np.abs(g["W_dcompliance_dh"]).max()
     # the inertia operator of the dynamic shell (linear_shell_model.py:335-348) with the same rule
     Me = o.assemble_M().toarray()[np.ix_(d, d)]
     assert np.abs(Me - g["W_Me"]).max() < 1e-13 * np.abs(g["W_Me"]).max()
