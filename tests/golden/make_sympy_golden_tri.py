@@ -18,6 +18,7 @@ Case S: the von Mises stress of ShellStressRM at the top, middle and bottom surf
 Case W: the warped quadrilateral with uhat != 0 and nodal h / E / nu integrated with the 5 x 5 Gauss rule from the symbolic point values
         (element matrix and load vector): what a kernel using that rule must reproduce.
 Case P: the penalty blocks of that quadrilateral's four facets with uhat != 0 (three-point facet rule).
+Case PC: the penalty blocks of the affine triangle for CG2CR1 (the rotation's trace involves all three Crouzeix-Raviart functions).
 Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0, at
         three points of every facet of a warped quadrilateral and of a triangle.
 
@@ -309,6 +310,34 @@ def case_P():
     return dict(P_X=np.array(X, float), P_uhat=np.array(Uq, float), P_M2=M2, P_M1=M1)
 
 
+def case_PC():
+    """Penalty blocks of the three facets of the affine triangle T for the CG2CR1 element (uhat = 0; per unit of beta, with 1 / h_K):
+    the P2 trace of the displacement (vertex a, midpoint, vertex b) and the trace of the Crouzeix-Raviart rotation, in which ALL THREE
+    functions of the cell take part (they are not zero on the other edges).  Exact integrals along the facet."""
+    R = sm.Rational
+    s_ = sm.Symbol("s")
+    x0 = [R(1, 10), R(-1, 5), R(3, 10)]
+    d0 = [R(6, 5), 0, R(8, 5)]
+    d1 = [R(3, 5), R(4, 5), R(4, 5)]
+    X = [x0, [x0[c] + d0[c] for c in range(3)], [x0[c] + d1[c] for c in range(3)]]
+    hK = max(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3))) for i, j in itertools.combinations(range(3), 2))
+    t = (s_ + 1) / 2
+    pts = [(t, 0), (1 - t, t), (0, 1 - t)]                      # facet k from vertex k to k + 1, s in [-1, 1]
+    M2 = np.zeros((3, 3, 3)); MR = np.zeros((3, 3, 3))
+    for k in range(3):
+        a, b = X[k], X[(k + 1) % 3]
+        length = sm.sqrt(sum((a[c] - b[c]) ** 2 for c in range(3)))
+        sub = {xi: pts[k][0], eta: pts[k][1]}
+        tr2 = [N2[k].subs(sub), N2[3 + k].subs(sub), N2[(k + 1) % 3].subs(sub)]
+        trR = [NCR[i].subs(sub) for i in range(3)]
+        for i in range(3):
+            for j in range(3):
+                M2[k, i, j] = float(sm.integrate(sm.expand(tr2[i] * tr2[j]), (s_, -1, 1)) * length / 2 / hK)
+                MR[k, i, j] = float(sm.integrate(sm.expand(trR[i] * trR[j]), (s_, -1, 1)) * length / 2 / hK)
+    print("CG2CR1 penalty blocks done")
+    return dict(PC_X=np.array(X, float), PC_M2=M2, PC_MR=MR)
+
+
 def case_W(n=5):
     """The warped, non-planar quadrilateral of make_sympy_golden.py's case B (uhat != 0, nodal h / E / nu) INTEGRATED with the n x n
     Gauss-Legendre rule: K_e = sum_q w_q B(q)^T C(q) B(q) detg(q) and the load vector, every point evaluated from the symbolic
@@ -421,6 +450,7 @@ if __name__ == "__main__":
     out.update(case_N())
     out.update(case_S())
     out.update(case_P())
+    out.update(case_PC())
     import sys
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     if "--keep-W" in sys.argv and os.path.exists(path):          # case W takes two minutes: keep the committed values

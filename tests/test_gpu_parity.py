@@ -591,6 +591,30 @@ def test_stress_aggregate_against_the_symbolic_derivation():
     c.close()
 
 
+def test_penalty_term_of_cg2cr1_against_the_symbolic_facet_blocks():
+    """CG2CR1: the penalty operator of the three facets of the affine triangle (3 x 3 rotation blocks: all three Crouzeix-Raviart functions
+    have a trace on every facet) -- the HIP operator with the facets minus the one without, against the symbolic blocks (case PC)."""
+    import os
+    from femo_alpha_amd.backend import ShellContext
+    from test_oracle import _penalty_reference_cr
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_triangle.npz"))
+    m = ShellMesh(g["PC_X"], np.array([[0, 1, 2]]), "CG2CR1")
+    beta = 1e3
+    d = m.cell_dofs()[0]
+
+    def operator(with_facets):
+        c = ShellContext(m)
+        c.set_field("thickness", [0.05]); c.set_field("E", [2.0]); c.set_field("nu", [0.3]); c.set_field("density", [1.0])
+        if with_facets:
+            c.set_penalty_facets(np.array([[0, k] for k in range(3)]), beta=beta)
+        K = np.stack([c.apply_K(np.eye(m.ndof)[j]) for j in range(m.ndof)], axis=1)
+        c.close()
+        return K[np.ix_(d, d)]
+    P = operator(True) - operator(False)
+    ref = _penalty_reference_cr(g, beta)
+    assert np.abs(P - ref).max() < 1e-11 * np.abs(ref).max()
+
+
 def test_penalty_term_against_the_symbolic_facet_blocks():
     """The penalty term of all four facets of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333): the HIP operator with
     the facets minus the one without (unit vectors through femo_apply_K) against the symbolic blocks -- Nanson factor || J F^-T N ||,

@@ -164,6 +164,32 @@ def _penalty_reference(g, beta):
     return P
 
 
+def _penalty_reference_cr(g, beta):
+    """27 x 27 penalty matrix of the one-triangle CG2CR1 mesh in element-local numbering from the symbolic facet blocks (case PC)."""
+    P = np.zeros((27, 27))
+    for k in range(3):
+        un = [k, 3 + k, (k + 1) % 3]
+        for c in range(3):
+            iu = [3 * a + c for a in un]; it = [18 + 3 * b + c for b in range(3)]
+            P[np.ix_(iu, iu)] += beta * g["PC_M2"][k]
+            P[np.ix_(it, it)] += beta * g["PC_MR"][k]
+    return P
+
+
+def test_golden_penalty_blocks_of_the_crouzeix_raviart_rotation(golden_dir):
+    """CG2CR1: the trace of the rotation on a facet involves all three functions of the cell; the oracle's penalty operator on the three
+    facets of the affine triangle against the symbolic blocks."""
+    g = np.load(os.path.join(golden_dir, "sympy_triangle.npz"))
+    m = ShellMesh(g["PC_X"], np.array([[0, 1, 2]]), "CG2CR1")
+    beta = 1e3
+    o = ShellOracle(m, penalty_facets=np.array([[0, k] for k in range(3)]), beta=beta)
+    o.set_fields(h=[0.05], E=[2.0], nu=[0.3])
+    d = m.cell_dofs()[0]
+    P = (o.assemble_K(with_penalty=True, with_strong=False) - o.assemble_K(with_penalty=False, with_strong=False)).toarray()[np.ix_(d, d)]
+    ref = _penalty_reference_cr(g, beta)
+    assert np.abs(P - ref).max() < 1e-12 * np.abs(ref).max()
+
+
 def test_golden_penalty_blocks(golden_dir):
     """The penalty term on all four facets of the warped quadrilateral with uhat != 0 (linear_shell_model.py:323-333): the oracle's
     operator with and without it against the symbolic facet blocks (Nanson factor, three-point facet rule, 1 / h_K)."""
