@@ -270,6 +270,22 @@ def case_S():
             g3 = [-mp.sqrt(mp.mpf(3) / 5), mp.mpf(0), mp.sqrt(mp.mpf(3) / 5)]; w3 = [mp.mpf(5) / 9, mp.mpf(8) / 9, mp.mpf(5) / 9]
             fdens = sm.lambdify((xi, eta), (2 * vm) ** 4 * Ju_ * detg_, "mpmath")       # (numeric points: substituting sqrt(3/5) symbolically does not end)
             pnorm = float(sum(w3[i] * w3[j] * fdens(g3[i], g3[j]) for i in range(3) for j in range(3)))
+            # int sigma_ij J dx of the top-surface in-plane stress in GLOBAL coordinates (ShellStressRM.inplaneStress, :444-457;
+            # sum_stress_subdomain, rm_shell_pde.py:130-150), components xx, yy, zz, xy, xz, yz, with the 5 x 5 Gauss rule
+            E012 = sm.Matrix([E0.T, E1.T, E2.T])
+            s3 = sm.Matrix([[sg[0], sg[2], 0], [sg[2], sg[1], 0], [0, 0, 0]])
+            sglob = E012 * s3 * E012.T                            # as written: sigma[i, j] = E012[i, k] sigma_hat_3d[k, l] E012[j, l]
+            comps = sm.Matrix([sglob[0, 0], sglob[1, 1], sglob[2, 2], sglob[0, 1], sglob[0, 2], sglob[1, 2]]) * Ju_ * detg_
+            fs = sm.lambdify((xi, eta), comps, "mpmath")
+            x5 = sorted(sm.Poly(sm.legendre(5, xi), xi).nroots(n=40))
+            dP5 = sm.diff(sm.legendre(5, xi), xi)
+            w5 = [mp.mpf(str(2 / ((1 - xv * xv) * dP5.subs(xi, xv) ** 2))) for xv in x5]
+            x5 = [mp.mpf(str(xv)) for xv in x5]
+            acc = mp.zeros(6, 1)
+            for i in range(5):
+                for j in range(5):
+                    acc += w5[i] * w5[j] * fs(x5[i], x5[j])
+            sum_stress = np.array([float(v) for v in acc])
     # compliance density u_mid . u_mid J(uhat) + 1/2 1e-2 grad(h) . grad(h)  (rm_shell_pde.py:64-89, nodal thickness: 'H1'), and the mass
     # density rho h J(uhat) (:101-102), per unit of the reference measure (x detg)
     detg = sm.sqrt(a.dot(a))
@@ -280,7 +296,7 @@ def case_S():
     mdens = rho * h * Ju * detg
     fun = np.array([[float(comp.subs({xi: px, eta: py}).evalf(30)), float(mdens.subs({xi: px, eta: py}).evalf(30))] for px, py in pts])
     print("von Mises stresses and functional densities done")
-    return dict(S_fun=fun, S_rho=np.array([float(rho)]), S_pnorm=np.array([pnorm]), S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
+    return dict(S_fun=fun, S_rho=np.array([float(rho)]), S_pnorm=np.array([pnorm]), S_sum_stress=sum_stress, S_X=np.array(X, float), S_uhat=np.array(Uhat, float), S_h=np.array(hn, float), S_E=np.array(En, float),
                 S_nu=np.array(nun, float), S_U=np.array(U, float), S_TH=np.array(TH, float), S_pts=np.array(pts, float), S_vm=out)
 
 

@@ -589,6 +589,14 @@ def test_stress_aggregate_against_the_symbolic_derivation():
     c.set_stress_alpha(1.0)
     assert abs(c.functional("pnorm_stress") - g["S_pnorm"][0]) < 1e-11 * g["S_pnorm"][0]
     c.close()
+    # the six sums int sigma_ij J dx of the top-surface in-plane stress (sum_stress_subdomain, rm_shell_pde.py:130-150), 5 x 5 rule
+    c = ShellContext(m, nquad=5)
+    c.set_field("thickness", g["S_h"]); c.set_field("E", g["S_E"]); c.set_field("nu", g["S_nu"]); c.set_field("density", [1.0])
+    c.set_field("uhat", g["S_uhat"])
+    c.set_state(w)
+    got = np.array([c.functional("sum_stress_" + k) for k in ("x", "y", "z", "xy", "xz", "yz")])
+    assert np.abs(got - g["S_sum_stress"]).max() < 1e-11 * np.abs(g["S_sum_stress"]).max()
+    c.close()
 
 
 def test_penalty_term_of_cg2cr1_against_the_symbolic_facet_blocks():

@@ -113,6 +113,11 @@ def test_golden_von_mises_stress_pointwise(golden_dir):
     o3 = ShellOracle(m, nquad=3)
     o3.set_fields(h=g["S_h"], E=g["S_E"], nu=g["S_nu"], uhat=g["S_uhat"])
     assert abs(o3.pnorm_stress(w, m=2.0, rho=4, alpha=1.0) - g["S_pnorm"][0]) < 1e-12 * g["S_pnorm"][0]
+    # int sigma_ij J dx of the top-surface in-plane stress, "global" components as ShellStressRM.inplaneStress writes them
+    # (linear_shell_model.py:444-457; sum_stress_subdomain, rm_shell_pde.py:130-150), 5 x 5 rule
+    o5 = ShellOracle(m, nquad=5)
+    o5.set_fields(h=g["S_h"], E=g["S_E"], nu=g["S_nu"], uhat=g["S_uhat"])
+    assert np.abs(o5.sum_stress_subdomain(w) - g["S_sum_stress"]).max() < 1e-12 * np.abs(g["S_sum_stress"]).max()
     # the functionals' densities at the same points: compliance (u.u J + the H1 regularisation of a nodal thickness,
     # rm_shell_pde.py:64-89) and mass (rho h J, :101-102)
     for ip in range(g["S_pts"].shape[0]):
