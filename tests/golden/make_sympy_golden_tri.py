@@ -25,7 +25,7 @@ Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, l
 Local numbering (the oracle's and the library's): displacement nodes = vertices 0, 1, 2, then the midpoints of the edges
 0-1, 1-2, 2-0; rotation nodes = the vertices (CG1) or those three midpoints (CR).  DOF 3 a + c, then 18 + 3 b + c.
 
-Run:  python tests/golden/make_sympy_golden_tri.py   (about a minute)
+Run:  python tests/golden/make_sympy_golden_tri.py   (about ten minutes; --keep-W keeps the committed values of case W, the longest)
 """
 import itertools
 import os
