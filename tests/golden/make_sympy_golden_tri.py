@@ -434,8 +434,31 @@ def case_W(n=5):
             for b_ in range(4):
                 dRdh[b_] += wq * val * n1[b_]
                 dJdh[b_] += wq * mp.mpf(1) / 100 * gg[b_]
+    # ... and the same for the nodal E and nu fields (derivatives of the constitutive matrix), and for the load:
+    #   ((dR/df)^T lam)_(b, c) = - int N_b lam_u[c] J dx     (rm_shell_model.py:216-232)
+    Es, Ns = sm.Symbol("Es"), sm.Symbol("Ns")
+    geoE = dict(geo); geoE["E"] = Es
+    geoN = dict(geo); geoN["nu"] = Ns
+    fdCE = sm.lambdify((xi, eta), sm.diff(q.cmat(geoE), Es).subs(Es, geo["E"]), "mpmath")
+    fdCN = sm.lambdify((xi, eta), sm.diff(q.cmat(geoN), Ns).subs(Ns, geo["nu"]), "mpmath")
+    lam_u = q.vec(q.N2, LU)
+    flu = sm.lambdify((xi, eta), lam_u, "mpmath")
+    dRdE = [mp.mpf(0)] * 4; dRdnu = [mp.mpf(0)] * 4; dRdf = [[mp.mpf(0)] * 3 for _ in range(4)]
+    for x1, w1 in zip(xs, ws):
+        for x2, w2 in zip(xs, ws):
+            a, b = mp.mpf(str(x1)), mp.mpf(str(x2))
+            dj = fd(a, b); B = fB(a, b)
+            wq = mp.mpf(str(w1)) * mp.mpf(str(w2)) * dj[0]
+            Bl, Bw = B * lv, B * wv
+            vE = (Bl.T * fdCE(a, b) * Bw)[0, 0]; vN = (Bl.T * fdCN(a, b) * Bw)[0, 0]
+            n1 = fN1(a, b); lu = flu(a, b)
+            for b_ in range(4):
+                dRdE[b_] += wq * vE * n1[b_]; dRdnu[b_] += wq * vN * n1[b_]
+                for c_ in range(3):
+                    dRdf[b_][c_] -= wq * dj[1] * n1[b_] * lu[c_]
     sens = dict(W_LU=np.array(LU, float), W_LT=np.array(LT, float), W_dRdh_T_lam=np.array([float(v) for v in dRdh]),
-                W_dcompliance_dh=np.array([float(v) for v in dJdh]))
+                W_dcompliance_dh=np.array([float(v) for v in dJdh]), W_dRdE_T_lam=np.array([float(v) for v in dRdE]),
+                W_dRdnu_T_lam=np.array([float(v) for v in dRdnu]), W_dRdf_T_lam=np.array([[float(v) for v in row] for row in dRdf]))
     # the inertia operator of the dynamic shell, rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348), with the same rule:
     # per component a 9 x 9 block on the displacement nodes and a 4 x 4 block on the rotation nodes
     hK = max(float(sm.sqrt(sum((X[i][c] - X[j][c]) ** 2 for c in range(3)))) for i, j in itertools.combinations(range(4), 2))

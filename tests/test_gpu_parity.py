@@ -559,6 +559,11 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
     assert np.abs(gR - g["W_dRdh_T_lam"]).max() < 1e-11 * np.abs(g["W_dRdh_T_lam"]).max()
     gJ = c.dfunctional("compliance", "thickness")
     assert np.abs(gJ - g["W_dcompliance_dh"]).max() < 1e-11 * np.abs(g["W_dcompliance_dh"]).max()
+    # ... and the other inputs' (rm_shell_model.py:216-232): E, nu, F_solid
+    for name, key in (("E", "W_dRdE_T_lam"), ("nu", "W_dRdnu_T_lam")):
+        assert np.abs(c.dRdarg_T(name, lam) - g[key]).max() < 1e-11 * np.abs(g[key]).max(), name
+    gF = c.dRdarg_T("F_solid", lam).reshape(-1, 3)
+    assert np.abs(gF - g["W_dRdf_T_lam"]).max() < 1e-12 * np.abs(g["W_dRdf_T_lam"]).max()
     # the inertia operator rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348): femo_op_apply_vec2 with aK = 0, aM = 1
     import torch
     Me = np.zeros((m.ndof, m.ndof))

@@ -151,6 +151,9 @@ def test_golden_warped_element_integrated(golden_dir):
     assert np.abs(gR - g["W_dRdh_T_lam"]).max() < 1e-12 * np.abs(g["W_dRdh_T_lam"]).max()
     gJ = o.dcompliance_dh(w)
     assert np.abs(gJ - g["W_dcompliance_dh"]).max() < 1e-12 * np.abs(g["W_dcompliance_dh"]).max()
+    for name, key in (("E", "W_dRdE_T_lam"), ("nu", "W_dRdnu_T_lam")):
+        assert np.abs(o.dRdfield_T(name, w, lam) - g[key]).max() < 1e-12 * np.abs(g[key]).max(), name
+    assert np.abs(o.dRdf_T(lam).reshape(-1, 3) - g["W_dRdf_T_lam"]).max() < 1e-13 * np.abs(g["W_dRdf_T_lam"]).max()
     # the inertia operator of the dynamic shell (linear_shell_model.py:335-348) with the same rule
     Me = o.assemble_M().toarray()[np.ix_(d, d)]
     assert np.abs(Me - g["W_Me"]).max() < 1e-13 * np.abs(g["W_Me"]).max()
