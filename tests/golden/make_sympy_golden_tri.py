@@ -19,6 +19,8 @@ Case W: the warped quadrilateral with uhat != 0 and nodal h / E / nu integrated 
         (element matrix and load vector): what a kernel using that rule must reproduce.
 Case P: the penalty blocks of that quadrilateral's four facets with uhat != 0 (three-point facet rule).
 Case PC: the penalty blocks of the affine triangle for CG2CR1 (the rotation's trace involves all three Crouzeix-Raviart functions).
+Case W2: the shape sensitivity D . (dR/duhat)^T lam on that cell for three directions D, as a 50-digit central difference of the symbolic
+        point values (nothing differentiated by hand).
 Case N: the facet factor || J F^-T N || of the penalty term (Nanson's formula, linear_shell_model.py:323-333) with uhat != 0, at
         three points of every facet of a warped quadrilateral and of a triangle.
 
@@ -483,6 +485,64 @@ def case_W(n=5):
                 W_Ke=np.array(Ke.tolist(), dtype=float), W_Fe=np.array(Fe.tolist(), dtype=float).ravel())
 
 
+def case_W2(n=5):
+    """The shape sensitivity of the residual on the warped quadrilateral of case W, without differentiating anything by hand: with
+    uhat = uhat0 + ep D the scalar lam^T R(w; uhat) = lam^T (K_e(uhat) w - F_e(uhat)) is evaluated from the symbolic point values (n x n
+    Gauss rule) at ep = +-1e-20 in 50-digit arithmetic; the central difference is D . (dR/duhat)^T lam to ~40 digits.  Three directions D."""
+    import importlib.util
+    import mpmath as mp
+    spec = importlib.util.spec_from_file_location("make_sympy_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "make_sympy_golden.py"))
+    q = importlib.util.module_from_spec(spec); spec.loader.exec_module(q)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
+    R = sm.Rational
+    X = [[R(0), R(0), R(0)], [R(1), R(1, 10), R(1, 5)], [R(6, 5), R(9, 10), R(-1, 10)], [R(-1, 10), R(1), R(3, 10)]]
+    hn = [R(1, 20), R(3, 50), R(1, 25), R(11, 200)]
+    En = [R(2), R(5, 2), R(9, 4), R(3)]
+    nun = [R(3, 10), R(1, 4), R(7, 20), R(1, 5)]
+    U0 = [[R(1, 50), R(-1, 100), R(3, 100)], [R(-1, 50), R(1, 40), R(0)], [R(1, 100), R(1, 100), R(-1, 50)], [R(0), R(-3, 100), R(1, 100)]]
+    fn = [[R(1), R(-2), R(1, 2)], [R(1, 3), R(0), R(2)], [R(-1), R(1), R(1)], [R(1, 4), R(1, 5), R(-3)]]
+    rs = np.random.default_rng(11)                                # the state and the multiplier of case W
+    U = [[R(int(v), 1000) for v in row] for row in rs.integers(-40, 40, (9, 3))]
+    TH = [[R(int(v), 1000) for v in row] for row in rs.integers(-60, 60, (4, 3))]
+    LU = [[R(int(v), 1000) for v in row] for row in rs.integers(-50, 50, (9, 3))]
+    LT = [[R(int(v), 1000) for v in row] for row in rs.integers(-50, 50, (4, 3))]
+    mp.mp.dps = 50
+    tomp = lambda rows: [mp.mpf(int(v.p)) / int(v.q) for row in rows for v in row]
+    wv, lv = mp.matrix(tomp(U) + tomp(TH)), mp.matrix(tomp(LU) + tomp(LT))
+    xs = sorted(sm.Poly(sm.legendre(n, xi), xi).nroots(n=50))
+    dP = sm.diff(sm.legendre(n, xi), xi)
+    ws = [mp.mpf(str(2 / ((1 - x * x) * dP.subs(xi, x) ** 2))) for x in xs]
+    xs = [mp.mpf(str(x)) for x in xs]
+    f = q.vec(q.N1, fn)
+    fF = sm.lambdify((xi, eta), sm.Matrix([q.N2[a] * f[c] for a in range(9) for c in range(3)]), "mpmath")
+    ep = sm.Symbol("ep")
+    rd = np.random.default_rng(5)
+    dirs, vals = [], []
+    for _ in range(3):
+        D = [[R(int(v), 100) for v in row] for row in rd.integers(-9, 10, (4, 3))]
+        Uh = [[U0[b][c] + ep * D[b][c] for c in range(3)] for b in range(4)]
+        strains, geo = q.build(X, Uh, hn, En, nun)
+        fB = sm.lambdify((xi, eta, ep), sm.Matrix([strains(Uu, Tt)[0] for _, Uu, Tt in q.unit_dofs()]).T, "mpmath")
+        fC = sm.lambdify((xi, eta, ep), q.cmat(geo), "mpmath")
+        fdj = sm.lambdify((xi, eta, ep), sm.Matrix([geo["detg"], geo["Ju"]]), "mpmath")
+
+        def r(e):
+            tot = mp.mpf(0)
+            for i in range(n):
+                for j in range(n):
+                    a, b = xs[i], xs[j]
+                    B = fB(a, b, e); dj = fdj(a, b, e)
+                    wq = ws[i] * ws[j] * dj[0]
+                    Fv = fF(a, b)
+                    tot += wq * ((B * lv).T * fC(a, b, e) * (B * wv))[0, 0] - wq * dj[1] * sum(lv[k] * Fv[k] for k in range(27))
+            return tot
+        h = mp.mpf(10) ** -20
+        vals.append(float((r(h) - r(-h)) / (2 * h)))
+        dirs.append(np.array(D, float))
+        print("shape direction done", vals[-1])
+    return dict(W2_D=np.array(dirs), W2_val=np.array(vals))
+
+
 if __name__ == "__main__":
     out = case_T()
     out.update(case_Q())
@@ -492,11 +552,14 @@ if __name__ == "__main__":
     out.update(case_PC())
     import sys
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
-    if "--keep-W" in sys.argv and os.path.exists(path):          # case W takes two minutes: keep the committed values
+    if "--keep-W" in sys.argv and os.path.exists(path):          # cases W and W2 take minutes each: keep the committed values
         old = np.load(path)
-        out.update({k: old[k] for k in old.files if k.startswith("W_")})
+        out.update({k: old[k] for k in old.files if k.startswith("W_") or k.startswith("W2_")})
+        if not any(k.startswith("W2_") for k in old.files):
+            out.update(case_W2())
     else:
         out.update(case_W())
+        out.update(case_W2())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sympy_triangle.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)

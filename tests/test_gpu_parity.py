@@ -564,6 +564,11 @@ def test_warped_element_with_mesh_motion_against_the_symbolic_derivation():
         assert np.abs(c.dRdarg_T(name, lam) - g[key]).max() < 1e-11 * np.abs(g[key]).max(), name
     gF = c.dRdarg_T("F_solid", lam).reshape(-1, 3)
     assert np.abs(gF - g["W_dRdf_T_lam"]).max() < 1e-12 * np.abs(g["W_dRdf_T_lam"]).max()
+    # ... and the shape sensitivity (dR/duhat)^T lam through F(uhat), J(uhat), gradx (kinematics.py:12-44): the analytic HIP kernels
+    # against three directional derivatives taken from the symbolic point values in 50-digit arithmetic (case W2)
+    gU = c.dRdarg_T("uhat", lam).reshape(-1, 3)
+    for D, ref in zip(g["W2_D"], g["W2_val"]):
+        assert abs(np.sum(D * gU) - ref) < 1e-10 * abs(ref)
     # the inertia operator rho h (u.v + h_K^2 theta.eta) J dx (linear_shell_model.py:335-348): femo_op_apply_vec2 with aK = 0, aM = 1
     import torch
     Me = np.zeros((m.ndof, m.ndof))

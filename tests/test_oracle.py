@@ -154,6 +154,15 @@ def test_golden_warped_element_integrated(golden_dir):
     for name, key in (("E", "W_dRdE_T_lam"), ("nu", "W_dRdnu_T_lam")):
         assert np.abs(o.dRdfield_T(name, w, lam) - g[key]).max() < 1e-12 * np.abs(g[key]).max(), name
     assert np.abs(o.dRdf_T(lam).reshape(-1, 3) - g["W_dRdf_T_lam"]).max() < 1e-13 * np.abs(g["W_dRdf_T_lam"]).max()
+    # shape sensitivity D . (dR/duhat)^T lam (case W2: 50-digit central difference of the symbolic point values) against the oracle's
+    # own central difference of lam^T R(w; uhat +- eps D) -- the oracle has no analytic shape derivative
+    for D, ref in zip(g["W2_D"], g["W2_val"]):
+        vals = []
+        for sgn in (1.0, -1.0):
+            o.set_fields(uhat=g["W_uhat"] + sgn * 1e-6 * D)
+            vals.append(lam @ (o.apply_K(w, with_penalty=False) - o.load_vector()))
+        assert abs((vals[0] - vals[1]) / 2e-6 - ref) < 1e-7 * abs(ref)
+    o.set_fields(uhat=g["W_uhat"])
     # the inertia operator of the dynamic shell (linear_shell_model.py:335-348) with the same rule
     Me = o.assemble_M().toarray()[np.ix_(d, d)]
     assert np.abs(Me - g["W_Me"]).max() < 1e-13 * np.abs(g["W_Me"]).max()
