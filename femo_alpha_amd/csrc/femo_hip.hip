@@ -712,7 +712,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     const unsigned char* mask = c->has_mask ? c->mask : nullptr;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (assemble) {
-        const bool fc = c->opt.assemble_fc != 0 && fr.fc_ok && fr.fel_off;
+        // option "assemble_fc": 1 = where it was measured to pay (same box, profiles/r5_assemble_fc_ab.txt): elements whose columns and
+        // quadrature parts fit ONE wave (triangles, CG1CG1: no barrier between waves), or at least 20 quadrature points per cell (5 x 5 and
+        // 6 x 6 rules: +1.8 % at 1 M DOF; with 16 or 9 points the one-wave-per-element kernel is 1 % ahead); 2 = always; 0 = never
+        const bool fc_pays = assemble_block(c->ld) == 64 || c->tab_nq >= 20;
+        const bool fc = (c->opt.assemble_fc == 2 || (c->opt.assemble_fc == 1 && fc_pays)) && fr.fc_ok && fr.fel_off;
         if (!fc)
         { ProfScope ps(c, 5);
           // only the leaf fronts start from zero (element matrices are added into them); every other front is written
@@ -2207,7 +2211,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "bnd_tiled_nb") o.bnd_tiled_nb = v;
     else if (k == "sweep_butterfly") o.sweep_butterfly = v;
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
-    else if (k == "assemble_fc") o.assemble_fc = v != 0;
+    else if (k == "assemble_fc") { if (v < 0 || v > 2) return fail(c, "assemble_fc: 0 never, 1 where it pays, 2 always"); o.assemble_fc = v; }
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }

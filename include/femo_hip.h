@@ -162,7 +162,8 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "sweep_fuse" (0): all consecutive wide levels of a triangular sweep as ONE launch, tiles ordered by per-front counters -- measured
  *   slower than the level-wise launches, off (profiles/r5_sweep_fuse_ab.txt); "sweep_read_mode" (its read of other workgroups' values);
  *   "assemble_fc" (1): front assembly with one workgroup per leaf front -- zero fill, element columns and their sums without float
- *   atomics, the front written once (k_front_assemble_fc); 0: one wave per element adding with atomics into zero-filled fronts
+ *   atomics, the front written once (k_front_assemble_fc).  1: where it was measured to pay (triangles and CG1CG1, or at least 20
+ *   quadrature points per cell), 2: always, 0: never = one wave per element adding with atomics into zero-filled fronts
  *   (profiles/r5_assemble_fc_ab.txt);
  *   "sweep_w" (0): W = L21 L11^-1 stored where L21 was, a wide level of a sweep as one launch instead of two -- an application 4 % shorter,
  *   the factorisation 1.5 ms longer, off (profiles/r5_sweep_w_ab.txt); changing it discards the factor;

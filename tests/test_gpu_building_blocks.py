@@ -149,7 +149,7 @@ def test_gradient_accumulator_and_field_gradient_on_vector_ids():
     c.close()
 
 
-@pytest.mark.parametrize("assemble_fc", [1, 0])           # both front assemblies: one workgroup per leaf front | one wave per element + atomics
+@pytest.mark.parametrize("assemble_fc", [2, 0])           # both front assemblies: one workgroup per leaf front | one wave per element + atomics
 def test_level_ranges_sweeps_and_schur_blocks(assemble_fc):
     """femo_factorize_range + femo_frontal_sweep compose to the preconditioner; the Schur block femo_front_schur_get hands out is the
     Schur complement of the subtree's own stiffness onto its boundary (dense algebra on the oracle's element matrices);
