@@ -239,15 +239,51 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m", nqua
 
     def leg(cores, budget):
         t_leg = time.perf_counter()
+        thr0 = cb.cpu_throttled_periods()
         forward(cores)                                                          # warm-up (page faults of the fronts)
         runs = []
-        while len(runs) < 3 and (not runs or time.perf_counter() - t_leg + runs[-1][0] < budget):
+        # a leg the scheduler throttled (the control group's counter moved) gets two more runs, and the fastest run is reported beside the
+        # median: a throttled CPU leg flatters the GPU / CPU ratio
+        while len(runs) < 3 or (len(runs) < 5 and (cb.cpu_throttled_periods() or 0) > (thr0 or 0)):
+            if runs and time.perf_counter() - t_leg + runs[-1][0] >= budget:
+                break
             runs.append(forward(cores))
         runs.sort(key=lambda r: r[0])
         tot, asm, fac, w = runs[len(runs) // 2]
         adjoint(w, cores)
         adj = float(np.median([adjoint(w, cores)[0] for _ in range(3)]))
-        return dict(value=m.ndof / tot, cores=cores, forward_s=tot, assemble_s=asm, factor_s=fac, adjoint_ms=adj * 1e3, runs=len(runs))
+        thr1 = cb.cpu_throttled_periods()
+        return dict(value=m.ndof / tot, cores=cores, forward_s=tot, forward_s_fastest_run=runs[0][0], value_fastest_run=m.ndof / runs[0][0],
+                    assemble_s=asm, factor_s=fac, adjoint_ms=adj * 1e3, runs=len(runs),
+                    throttled_periods=None if thr0 is None or thr1 is None else thr1 - thr0)
+
+    def as_the_reference_runs_it(cores):
+        """EXECUTED, once, in this run: the reference's Newton loop never meets its tolerances and runs 3 iterations
+        = 3 x (Jacobian assembly into CSR + direct factorisation + solve) + 4 residual evaluations (utils_dolfinx.py:438-468), and on the
+        first evaluation assembles 7 derivative matrices and factorises once more for the adjoint (state_operation.py:260-296).  The direct
+        solver is the multifrontal Cholesky (half the flops of the reference's LU: this favours the CPU)."""
+        mf.nthreads = cores
+        t0 = time.perf_counter()
+        w = np.zeros(m.ndof)
+        r = -b
+        for _ in range(3):
+            K = cs.assemble_K(cores)
+            mf.factorize()
+            w = w - mf.solve(r)
+            r = K @ w - b
+        r = K @ w - b                                                           # the 4th residual (convergence check of the last iteration)
+        t_fwd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(3):                                                      # dR/du, A (two Jacobian assemblies) + dR/df and dR/duhat counted as one
+            K = cs.assemble_K(cores)
+        for name in ("h", "E", "nu"):
+            cs.assemble_drdfield(name, w, cores)
+        mf.factorize()
+        t_adj = time.perf_counter() - t0
+        del K
+        return dict(value=m.ndof / t_fwd, cores=cores, forward_s=t_fwd, adjoint_setup_s=t_adj, executed=True, runs=1,
+                    what="3 x (CSR assembly + front assembly + multifrontal Cholesky + solve) + 4 residuals; adjoint set-up: 7 matrix assemblies "
+                         "(3 Jacobian-sized, dR/dh, dR/dE, dR/dnu) + 1 factorisation")
 
     legs = [leg(share, budget_s)]
     if every > share:
@@ -262,6 +298,9 @@ def cpu_baseline(m, fields, marker, leaf, budget_s=25.0, workload="wing1m", nqua
                forward_s=best["forward_s"], adjoint_ms=best["adjoint_ms"], **cpu_allowance(cb, throttled0))
     for l in legs:
         out["gpu_share_16_threads" if l["cores"] == share else "all_cores"] = l
+    out["value_fastest_run"] = max(l["value_fastest_run"] for l in legs)
+    if time.perf_counter() - t_begin < 2 * budget_s + 20.0:
+        out["as_the_reference_runs_it"] = as_the_reference_runs_it(best["cores"])
     if time.perf_counter() - t_begin + 1.2 * share * legs[0]["forward_s"] < 2 * budget_s + 30.0:    # one single-core run, if it fits (same, already touched, fronts)
         t1, a1, f1, _ = forward(1)
         out["single_core"] = dict(value=m.ndof / t1, forward_s=t1, assemble_s=a1, factor_s=f1, cores=1)
@@ -332,6 +371,9 @@ def cpu_baseline_dynamic(mesh, dt, F, leaf, nsteps):
                time_steps_per_s_factor_once=1.0 / best["s_per_time_step_factor_once"], **cpu_allowance(cb, throttled0))
     for l in legs:
         out["gpu_share_16_threads" if l["cores"] == share else "all_cores"] = l
+    out["value_fastest_run"] = max(l["value_fastest_run"] for l in legs)
+    if time.perf_counter() - t_begin < 2 * budget_s + 20.0:
+        out["as_the_reference_runs_it"] = as_the_reference_runs_it(best["cores"])
     return out
 
 
@@ -858,9 +900,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel, "gauss_points_per_direction": nquad,
+            "config": {"workload": f"{args.workload}: {desc}", "ndof": m.ndof, "cells": m.nel,
+                       **({"gauss_points_per_direction": nquad} if m.is_quad else
+                          {"triangle_rule_degree": nquad, "quadrature_points_per_cell": ctx.quadrature()[1]}),
                        "gauss_points_rule": ("--nquad" if args.nquad is not None else
-                                             "ShellMesh.recommended_nquad: 4 on affine cells (exact), 5 when a cell is warped"),
+                                             "ShellMesh.recommended_nquad: quadrilaterals 4 points per direction on affine cells (exact), 5 / 6 when "
+                                             "cells are warped; triangles the symmetric rule of degree 6 (exact for cell-wise polynomial data), 9 "
+                                             "when a nodal Poisson ratio varies"),
+                       # schedule options taken from the environment (FEMO_OPTIONS): a line from a non-default schedule says so
+                       "femo_options_env": dict(ctx.env_options),
                        "true_relres_forward": true_relres,
                        "solver": ("PCG, matrix-free element-by-element operator, multifrontal Cholesky preconditioner "
                                   f"(nested dissection, leaves of about {args.leaf} cells)" if args.solver == "frontal"

@@ -52,6 +52,9 @@ SIGNATURES = {
     "femo_force_to_pressure": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_double, C.c_int32, _c_int32_p, _c_double_p]),
     "femo_set_operator": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "femo_set_strain_quadrature": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_set_quadrature": (C.c_int, [C.c_void_p, C.c_int32]),
+    "femo_get_quadrature": (C.c_int, [C.c_void_p, _c_int32_p, _c_int32_p]),
+    "femo_quadrature_tables": (C.c_int, [C.c_int32] * 5 + [_c_int32_p] + [_c_double_p] * 8),
     "femo_op_apply_vec2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int]),
     "femo_solve_vec": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, _c_int32_p, _c_double_p]),
     "femo_vec_mask_zero": (C.c_int, [C.c_void_p, C.c_int32]),

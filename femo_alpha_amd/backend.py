@@ -29,8 +29,12 @@ class ShellContext:
                  nquad=None, device=0, nghost=0):
         self.lib = _lib.load()
         self.mesh = mesh
-        # Gauss points per direction: by default what the mesh asks for (4 on affine cells, where that is exact; 5 on warped
-        # quadrilaterals, where the reference's near-exact integration is only met to 1e-9 by 5 -- ShellMesh.recommended_nquad)
+        # The rule of the static forms: by default what the mesh asks for (ShellMesh.recommended_nquad) -- quadrilaterals: Gauss points
+        # per direction, 4 on affine cells, where that is exact, 5 / 6 on warped ones, where the reference's near-exact integration is
+        # only met to 1e-9 by more points; triangles: the DEGREE of the symmetric rule, 6 where that is exact, and 9 (UFL's estimate for
+        # these forms) from the moment a nodal Poisson ratio that varies over the cells arrives (set_field) -- unless the caller named
+        # the rule.
+        self._rule_auto = nquad is None
         nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
         self.nquad = nquad
         self.element_wise_material = bool(element_wise_material)
@@ -59,9 +63,19 @@ class ShellContext:
         assert self.ndof == mesh.ndof + self.nghost
         # schedule experiments without touching the caller: FEMO_OPTIONS="sweep_w=0,strip_cnt=256" sets those options on every context
         import os
-        for kv in filter(None, os.environ.get("FEMO_OPTIONS", "").split(",")):
-            k, v = kv.split("=")
-            self.set_option(k.strip(), float(v))
+        self.env_options = {}
+        for kv in filter(None, (t.strip() for t in os.environ.get("FEMO_OPTIONS", "").split(","))):
+            k, sep, v = kv.partition("=")
+            try:
+                if not sep:
+                    raise ValueError
+                self.env_options[k.strip()] = float(v)
+            except ValueError:
+                raise FemoHipError(f"FEMO_OPTIONS: '{kv}' is not of the form option=number (e.g. FEMO_OPTIONS=\"sweep_w=0,strip_cnt=256\")") from None
+            self.set_option(k.strip(), self.env_options[k.strip()])
+        if self.env_options:
+            import sys
+            print(f"femo_alpha_amd: FEMO_OPTIONS sets {self.env_options} on this context", file=sys.stderr)
 
     # ------------------------------------------------------------------ plumbing
     def _chk(self, rc):
@@ -104,6 +118,24 @@ class ShellContext:
     def set_field(self, name, values):
         v = self._vec(values)
         self._chk(self.lib.femo_set_field(self._h, name.encode(), dptr(v), v.size))
+        if name == "nu" and self._rule_auto and not self.mesh.is_quad:
+            # a nodal Poisson ratio that varies over a cell makes the integrand rational: the reference's answer is then that of the
+            # degree-9 rule UFL selects; everywhere else degree 6 integrates the same polynomial exactly (ShellMesh.recommended_nquad)
+            varies = (not self.element_wise_material) and v.size > 1 and bool(np.any(v != v[0]))
+            self.set_quadrature(self.mesh.recommended_nquad(nodal_nu_varies=varies))
+
+    def set_quadrature(self, nquad):
+        """The rule of the static forms (femo_set_quadrature): Gauss points per direction on quadrilaterals, the degree of the symmetric
+        rule (4, 6, 9, 12) on triangles."""
+        if int(nquad) != self.nquad:
+            self._chk(self.lib.femo_set_quadrature(self._h, int(nquad)))
+            self.nquad = int(nquad)
+
+    def quadrature(self):
+        """(rule, points per cell) in use."""
+        n, q = C.c_int32(), C.c_int32()
+        self._chk(self.lib.femo_get_quadrature(self._h, C.byref(n), C.byref(q)))
+        return int(n.value), int(q.value)
 
     def get_field(self, name):
         out = np.empty(self.field_size(name))

@@ -36,6 +36,7 @@ struct femo_ctx {
     int krylov = 0;                          // 0: conjugate gradients, 1: BiCGStab (femo_set_krylov)
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     int tab_nq = 0;                          // quadrature points of the operator's tables (c->tab)
+    double hK_mean = 0;                      // mean cell diameter (the yardstick of a change of uhat, option "stale_factor")
     long long opt_version = 0;               // bumped by every femo_set_option
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
@@ -270,6 +271,7 @@ static int fail(femo_ctx* c, const std::string& msg) {
 
 // whatever the operator A = aK K + aM M (+ Dirichlet treatment) depends on has changed: both preconditioners are stale
 static void operator_changed(femo_ctx* c, bool fields_only = false);
+static int snapshot_fields(femo_ctx* c);
 
 // ------------------------------------------------------------------------------------------ tables
 static void gauss_legendre(int n, double* x, double* w) {
@@ -333,6 +335,63 @@ static void lag1(double t, double* v, double* d) {
     d[0] = -0.5; d[1] = 0.5;
 }
 
+// Fully symmetric rules on the unit triangle, orbit by orbit (scripts/derive_triangle_rules.py: Newton's iteration on the moment
+// equations in 60-digit arithmetic; every coordinate is its own correctly rounded literal, and oracle/rm_shell_oracle.py::_TRI holds
+// the same numbers -- the table is part of the discrete problem).  S21 rows {a, b = 1 - 2a, w} give the points
+// (a,a) (b,a) (a,b); S111 rows {a, b, c = 1 - a - b, w} give (a,b) (b,a) (a,c) (c,a) (b,c) (c,b); the weights sum to one.
+//   degree  4,  6 points: the reference's p-norm stress measure (quadrature_degree 4, rm_shell_model.py:200-205; basix 0.5.0 takes the
+//                         Xiao-Gimbutas table of that degree on a simplex, the same six points)
+//   degree  6, 12 points: exact for the static forms on affine cells with uniform E, nu and uhat = 0 (integrand of degree <= 5)
+//   degree  9, 19 points: what UFL estimates for the static forms on triangles (plain dx, linear_shell_model.py:88-103;
+//                         scripts/ufl_degree_estimate.py) -- the rule when E / nu vary over a cell or the mesh moves (uhat != 0)
+//   degree 12, 33 points: the convergence check beyond it
+// Returns the number of points (0: no such rule); P[q] = {x, y, weight}.
+static int triangle_rule(int degree, double (*P)[3]) {
+    static const double S21_4[2][3] = {{0.4459484909159648863183293, 0.1081030181680702273633415, 0.2233815896780114656950070},
+                                       {0.09157621350977074345957146, 0.8168475729804585130808571, 0.1099517436553218676383263}};
+    static const double S21_6[2][3] = {{0.06308901449150222834033160, 0.8738219710169955433193368, 0.05084490637020681692093681},
+                                       {0.2492867451709104212916386, 0.5014265096581791574167229, 0.1167862757263793660252896}};
+    static const double S111_6[1][4] = {{0.05314504984481694735324967, 0.3103524510337844054166077, 0.6365024991213986472301426,
+                                         0.08285107561837357519355346}};
+    static const double S3_9 = 0.09713579628279883381924198;
+    static const double S21_9[4][3] = {{0.4896825191987376277837069, 0.02063496160252474443258615, 0.03133470022713907053685483},
+                                       {0.4370895914929366372699304, 0.1258208170141267254601393, 0.07782754100477427931673936},
+                                       {0.1882035356190327302409613, 0.6235929287619345395180774, 0.07964773892721025303289177},
+                                       {0.04472951339445270986510659, 0.9105409732110945802697868, 0.02557767565869803126167880}};
+    static const double S111_9[1][4] = {{0.03683841205473628363481760, 0.2219629891607656956751025, 0.7411985987844980206900799,
+                                         0.04328353937728937728937729}};
+    static const double S21_12[5][3] = {{0.4882173897738048825646621, 0.02356522045239023487067587, 0.02573106644045533541779092},
+                                        {0.4397243922944602729797366, 0.1205512154110794540405268, 0.04369254453803840213545726},
+                                        {0.2712103850121159223459513, 0.4575792299757681553080973, 0.06285822421788510035427051},
+                                        {0.1275761455415859246738963, 0.7448477089168281506522073, 0.03479611293070894298932840},
+                                        {0.02131735045321037024685698, 0.9573652990935792595062860, 0.006166261051559017233866484}};
+    static const double S111_12[3][4] = {
+        {0.1153434945346979991690112, 0.2757132696855141939747963, 0.6089432357797878068561924, 0.04037155776638092951782870},
+        {0.02283833222225702961023378, 0.2813255809899395482481307, 0.6958360867878034221416355, 0.02235677320230344571183908},
+        {0.02573405054833022816810924, 0.1162519159075971412413541, 0.8580140335440726305905366, 0.01731623110865889237164210}};
+    const double(*s21)[3] = nullptr;
+    const double(*s111)[4] = nullptr;
+    int n21 = 0, n111 = 0, n = 0;
+    switch (degree) {
+    case 4: s21 = S21_4; n21 = 2; break;
+    case 6: s21 = S21_6; n21 = 2; s111 = S111_6; n111 = 1; break;
+    case 9: s21 = S21_9; n21 = 4; s111 = S111_9; n111 = 1; break;
+    case 12: s21 = S21_12; n21 = 5; s111 = S111_12; n111 = 3; break;
+    default: return 0;
+    }
+    auto put = [&](double x, double y, double w) { P[n][0] = x; P[n][1] = y; P[n][2] = w; ++n; };
+    if (degree == 9) put(1.0 / 3.0, 1.0 / 3.0, S3_9);
+    for (int i = 0; i < n21; ++i) {
+        const double a = s21[i][0], b = s21[i][1], w = s21[i][2];
+        put(a, a, w); put(b, a, w); put(a, b, w);
+    }
+    for (int i = 0; i < n111; ++i) {
+        const double a = s111[i][0], b = s111[i][1], cc = s111[i][2], w = s111[i][3];
+        put(a, b, w); put(b, a, w); put(a, cc, w); put(cc, a, w); put(b, cc, w); put(cc, b, w);
+    }
+    return n;
+}
+
 // nred > 0 (quads): the membrane / bending / shear energies are integrated with nred x nred Gauss points, everything
 // else with nquad x nquad: the table then lists both point sets, each with a zero weight for the terms of the other
 static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1 = false, bool cr = false) {
@@ -370,16 +429,13 @@ static void build_tables(bool quad, int nquad, Tables& T, int nred = 0, bool cg1
         }
         T.nq = q0;
     } else {
-        // degree-6, 12-point symmetric rule on the unit triangle
-        const double a1 = 0.063089014491502, b1 = 0.873821971016996, w1 = 0.050844906370207;
-        const double a2 = 0.249286745170910, b2 = 0.501426509658179, w2 = 0.116786275726379;
-        const double a3 = 0.053145049844817, b3 = 0.310352451033784, c3 = 0.636502499121399, w3 = 0.082851075618374;
-        const double P[12][3] = {{a1, a1, w1}, {b1, a1, w1}, {a1, b1, w1}, {a2, a2, w2}, {b2, a2, w2}, {a2, b2, w2},
-                                 {a3, b3, w3}, {b3, a3, w3}, {a3, c3, w3}, {c3, a3, w3}, {b3, c3, w3}, {c3, b3, w3}};
+        // nquad is the DEGREE of the symmetric rule on triangles: 4 / 6 / 9 / 12 (triangle_rule)
+        double P[MAXQ][3];
+        const int npts = triangle_rule(nquad, P);
         const double dL[3][2] = {{-1, -1}, {1, 0}, {0, 1}};
         static const int ED[3][2] = {{0, 1}, {1, 2}, {2, 0}};
-        T.nq = 12;
-        for (int q = 0; q < 12; ++q) {
+        T.nq = npts;
+        for (int q = 0; q < npts; ++q) {
             const double x = P[q][0], y = P[q][1];
             T.w[q] = 0.5 * P[q][2];
             T.wS[q] = T.w[q];
@@ -653,7 +709,7 @@ static int pcg(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t* iter
     float t_setup = 0, t_loop = 0;
     hipEventElapsedTime(&t_setup, c->ev[0], c->ev[1]);
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
-    c->timing[0] = t_setup; c->timing[1] = t_loop; c->timing[2] = t_setup + t_loop; c->timing[4] = napply;
+    c->timing[0] = t_setup; c->timing[1] = t_loop; c->timing[2] = t_setup + t_loop; c->timing[3] = 0; c->timing[4] = napply;
     return finish_solve(c, "Jacobi-PCG", k, rr, bb, c->rtol * c->rtol * bb, iters, relres);
 }
 
@@ -715,7 +771,9 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // option "assemble_fc": 1 = where it was measured to pay (same box, profiles/r5_assemble_fc_ab.txt): elements whose columns and
         // quadrature parts fit ONE wave (triangles, CG1CG1: no barrier between waves), or at least 20 quadrature points per cell (5 x 5 and
         // 6 x 6 rules: +1.8 % at 1 M DOF; with 16 or 9 points the one-wave-per-element kernel is 1 % ahead); 2 = always; 0 = never
-        const bool fc_pays = assemble_block(c->ld) == 64 || c->tab_nq >= 20;
+        // (the points of the rule the ASSEMBLY runs with: option "precond_nquad" may name a lighter one than the operator's, below)
+        const bool lighter = c->quad && c->nred == 0 && c->opt.precond_nquad > 0 && c->opt.precond_nquad < c->nquad;
+        const bool fc_pays = assemble_block(c->ld) == 64 || (lighter ? c->opt.precond_nquad * c->opt.precond_nquad : c->tab_nq) >= 20;
         const bool fc = (c->opt.assemble_fc == 2 || (c->opt.assemble_fc == 1 && fc_pays)) && fr.fc_ok && fr.fel_off;
         if (!fc)
         { ProfScope ps(c, 5);
@@ -743,7 +801,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         // (un-split) quadrature -- the transient path's reduced strain rule keeps the operator's tables
         const Tables* atab = c->tab;
         int anq = c->tab_nq;
-        if (c->quad && c->nred == 0 && c->opt.precond_nquad > 0 && c->opt.precond_nquad < c->nquad) {
+        if (lighter) {
             if (!c->tab_pre || c->tab_pre_nq != c->opt.precond_nquad * c->opt.precond_nquad) {
                 Tables TP;                                           // 8 KB on this thread's stack (contexts of several threads factorise at once)
                 build_tables(true, c->opt.precond_nquad, TP, 0, c->cg1, c->cr);
@@ -1196,6 +1254,11 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
     fr.t_factor_ms += tf; fr.pivots_fixed = info;
     fr.factored = (l1 == fr.nlevels);
     fr.have_factor = fr.factored;
+    // option "stale_factor": the design this factor belongs to is remembered HERE, on every path that completes a factorisation
+    // (pcg_frontal, femo_factorize, femo_factorize_profile, a femo_factorize_range that reaches the root) -- a partial range leaves
+    // the panel store a mixture and the snapshot invalid
+    if (fr.factored) { if (snapshot_fields(c)) return 1; }
+    else fr.snap_valid = false;
     int pivot_rc = 0;
     if (info > 0 && !c->opt.allow_pivot_repair) {
         // the reference's LU would factorise an indefinite matrix; a Cholesky factor of one does not exist, and a silently
@@ -1204,7 +1267,7 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
         snprintf(buf, sizeof buf, "multifrontal Cholesky: %d non-positive pivot(s) -- the operator is not positive definite "
                  "(negative thickness / modulus, or no Dirichlet data?)", info);
         c->err = buf;
-        fr.factored = false; fr.have_factor = false;
+        fr.factored = false; fr.have_factor = false; fr.snap_valid = false;
         pivot_rc = 5;
     }
     for (size_t i = 0; i + 2 < fr.pev.size() + 0 && fr.profile; i += 3) {
@@ -1429,12 +1492,15 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
         double* cur[5] = {c->h, c->E, c->nu, c->rho, c->has_uhat ? c->uhat : nullptr};
         const int64_t len[5] = {c->nT, c->nT, c->nT, c->nT, 3 * (int64_t)c->nn};
         for (int i = 0; i < 5 && stale; ++i) {
-            if (!cur[i] || !c->fr.snap[i]) continue;
+            if (!cur[i] && !c->fr.snap[i]) continue;                                  // mesh motion absent then and now
+            if (!cur[i] || !c->fr.snap[i]) { stale = false; break; }                  // switched on or off since: a different operator
             HIPCHK(c, hipMemsetAsync(c->scal + 5, 0, 2 * sizeof(double), c->stream));
             hipLaunchKernelGGL(k_sq_change, dim3(red_grid(len[i])), dim3(256), 0, c->stream, (const double*)cur[i], (const double*)c->fr.snap[i], len[i], c->scal + 5);
             HIPCHK(c, hipMemcpyAsync(c->scal_host + 5, c->scal + 5, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            const double d2 = c->scal_host[5], r2 = c->scal_host[6];
+            // a field is measured against itself; the mesh motion against the cell size (what changes the operator is grad uhat ~
+            // |delta uhat| / h_K, and a relative change of a displacement field says nothing): sum |delta|^2 <= rel^2 nn mean(h_K)^2
+            const double d2 = c->scal_host[5], r2 = i == 4 ? (double)c->nn * c->hK_mean * c->hK_mean : c->scal_host[6];
             if (!(d2 <= c->opt.stale_rel * c->opt.stale_rel * r2)) stale = false;
         }
     }
@@ -1442,7 +1508,6 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     if (stale) { c->fr.t_assemble_ms = 0; c->fr.t_factor_ms = 0; }
     if (!c->fr.factored && !stale) {
         if (int rc = frontal_factorize(c)) return rc;
-        if (snapshot_fields(c)) return 1;
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     auto dot = [&](const double* a, const double* bb, double* out) -> int {
@@ -1475,10 +1540,10 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     // device scalars: [0] r.z of the previous iteration, [1] r.z, [2] p.Ap, [3] r.r -- one host synchronisation per iteration
     int k_restart = 0;                             // iteration at which the search directions start afresh
     while (bb > 0 && rr > target && k < c->maxit) {
-        if (stale && k >= c->opt.stale_factor) {
+        // (never end a solve unconverged on a kept factor: a fresh one needs two iterations, so the refresh comes no later than maxit - 2)
+        if (stale && k >= std::min(c->opt.stale_factor, std::max(c->maxit - 2, 0))) {
             // the kept factor is too far from this operator: factorise the current one and restart from the iterate reached so far
             if (int rc = frontal_factorize(c)) return rc;
-            if (snapshot_fields(c)) return 1;
             stale = false; factor_state = 2; k_restart = k;
             hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
             if (op_apply(c, x, c->Ap, nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
@@ -1611,7 +1676,7 @@ static int bicgstab(femo_ctx* c, double* b, double* x, bool zero_guess, int32_t*
     float t_loop = 0;
     hipEventElapsedTime(&t_loop, c->ev[1], c->ev[2]);
     c->timing[0] = c->precond == 2 ? c->fr.t_assemble_ms + c->fr.t_factor_ms : 0.0; c->timing[1] = t_loop;
-    c->timing[2] = c->timing[0] + t_loop; c->timing[4] = napply;
+    c->timing[2] = c->timing[0] + t_loop; c->timing[3] = 0; c->timing[4] = napply;
     return finish_solve(c, "BiCGStab", k, rr, bb, target, iters, relres);
 }
 
@@ -1733,6 +1798,7 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     }
     HIPCHK(c, hipMalloc((void**)&c->hK, (size_t)nel * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->hK, hK.data(), (size_t)nel * sizeof(double), hipMemcpyHostToDevice));
+    { double sum = 0; for (double v : hK) sum += v; c->hK_mean = sum / nel; }
     Tables T;
     c->nquad = nquad;
     build_tables(c->quad, nquad, T, 0, c->cg1, c->cr);
@@ -1740,7 +1806,8 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
     c->tab_nq = T.nq;
     Tables TS_;
-    build_tables(c->quad, 3, TS_, 0, c->cg1, c->cr);    // quadrature_degree 4 (rm_shell_model.py:200-201)
+    // quadrature_degree 4 (rm_shell_model.py:200-205): 3 x 3 Gauss on quadrilaterals, the 6-point rule of degree 4 on triangles
+    build_tables(c->quad, c->quad ? 3 : 4, TS_, 0, c->cg1, c->cr);
     HIPCHK(c, hipMalloc((void**)&c->tab_s, sizeof(Tables)));
     HIPCHK(c, hipMemcpy(c->tab_s, &TS_, sizeof(Tables), hipMemcpyHostToDevice));
     c->nT = c->ewm ? nel : c->nn;
@@ -1788,6 +1855,12 @@ int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int
     if (nvc != 3 && nvc != 4) { g_create_error = "nvc must be 3 (triangles) or 4 (quads)"; return 2; }
     if (nn <= 0 || nel <= 0 || !xyz || !cells || !cell_p2) { g_create_error = "empty mesh or null pointer"; return 2; }
     if (nvc == 4 && (nquad < 2 || nquad > 6)) { g_create_error = "nquad must be in 2..6"; return 2; }
+    // triangles: nquad is the degree of the symmetric rule (triangle_rule); 0 = the default, degree 6
+    if (nvc == 3 && nquad == 0) nquad = 6;
+    if (nvc == 3 && nquad != 4 && nquad != 6 && nquad != 9 && nquad != 12) {
+        g_create_error = "triangles: nquad is the degree of the symmetric rule -- 4 (6 points), 6 (12, the default 0), 9 (19) or 12 (33)";
+        return 2;
+    }
     // CG1CG1 (linear_shell_model.py:74-79): the caller's "P2 node" set is the vertex set itself and cell_p2 holds nvc entries per
     // cell -- told apart by nP2 == nn (a CG2CG1 mesh always has nP2 = nn + edges [+ cells] > nn)
     const bool cg1 = nP2 == nn;
@@ -3109,6 +3182,53 @@ int femo_factorize_profile_get(femo_ctx* c, double* out32) {
 // ---- dynamic shell: operator A = aK K + aM M, device-vector building blocks (femo_alpha_amd/dynamic_rm_shell) ----
 int femo_set_operator(femo_ctx* c, double aK, double aM) {
     if (aK != c->op_aK || aM != c->op_aM) { c->op_aK = aK; c->op_aM = aM; operator_changed(c); }
+    return 0;
+}
+
+// The rule of the operator after creation (same meaning as femo_create's nquad): the host mirror raises the triangles' rule from
+// degree 6 to 9 when a field makes the integrand non-polynomial (ShellContext.set_field); everything assembled or factorised with
+// the old tables is stale
+int femo_set_quadrature(femo_ctx* c, int32_t nquad) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->quad && (nquad < 2 || nquad > 6)) return fail(c, "nquad must be in 2..6");
+    if (!c->quad && nquad != 4 && nquad != 6 && nquad != 9 && nquad != 12)
+        return fail(c, "triangles: nquad is the degree of the symmetric rule -- 4, 6, 9 or 12");
+    if (c->quad && c->nred * c->nred + nquad * nquad > MAXQ) return fail(c, "the rule does not fit beside the reduced strain rule");
+    if (nquad == c->nquad) return 0;
+    Tables T;
+    build_tables(c->quad, nquad, T, c->nred, c->cg1, c->cr);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->tab, &T, sizeof(Tables), hipMemcpyHostToDevice));
+    c->tab_nq = T.nq;
+    c->nquad = nquad;
+    operator_changed(c);
+    return 0;
+}
+
+// Host only (no device needed): the tables build_tables makes for a rule, so that a test can hold them bit for bit against the
+// oracle's (tests/test_cabi.py).  Arrays are sized for MAXQ = 36 points: w, wS [36]; N2 [36][9]; dN2 [36][9][2]; N1, NR [36][4]; dN1, dNR [36][4][2].
+int femo_quadrature_tables(int32_t nvc, int32_t nquad, int32_t nred, int32_t cg1, int32_t cr, int32_t* npoints, double* w, double* wS,
+                           double* N2, double* dN2, double* N1, double* dN1, double* NR, double* dNR) {
+    if (nvc != 3 && nvc != 4) return 2;
+    if (nvc == 4 && (nquad < 2 || nquad > 6 || nred < 0 || nred * nred + nquad * nquad > MAXQ)) return 2;
+    if (nvc == 3 && (nred != 0 || (nquad != 4 && nquad != 6 && nquad != 9 && nquad != 12))) return 2;
+    static Tables T;
+    build_tables(nvc == 4, nquad, T, nred, cg1 != 0, cr != 0);
+    if (npoints) *npoints = T.nq;
+    if (w) memcpy(w, T.w, sizeof T.w);
+    if (wS) memcpy(wS, T.wS, sizeof T.wS);
+    if (N2) memcpy(N2, T.N2, sizeof T.N2);
+    if (dN2) memcpy(dN2, T.dN2, sizeof T.dN2);
+    if (N1) memcpy(N1, T.N1, sizeof T.N1);
+    if (dN1) memcpy(dN1, T.dN1, sizeof T.dN1);
+    if (NR) memcpy(NR, T.NR, sizeof T.NR);
+    if (dNR) memcpy(dNR, T.dNR, sizeof T.dNR);
+    return 0;
+}
+
+int femo_get_quadrature(femo_ctx* c, int32_t* nquad, int32_t* npoints) {
+    if (nquad) *nquad = c->nquad;
+    if (npoints) *npoints = c->tab_nq;
     return 0;
 }
 

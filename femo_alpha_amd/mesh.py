@@ -188,8 +188,9 @@ class ShellMesh:
         (1 M-DOF triangle skin: forward 20.8 ms with 12, 20.3 with 24, scripts/r4_tri.py)."""
         return 12 if self.is_quad else 24
 
-    def recommended_nquad(self):
-        """Gauss points per direction that reproduce the reference's integration of the static forms.  The reference leaves
+    def recommended_nquad(self, nodal_nu_varies=False):
+        """The rule that reproduces the reference's integration of the static forms: Gauss points per direction on quadrilaterals, the
+        DEGREE of the symmetric rule on triangles (femo_create's ``nquad``).  The reference leaves
         the degree to UFL (plain ``dx``, linear_shell_model.py:88-103), whose estimate is 43-53 on quadrilaterals
         (scripts/ufl_degree_estimate.py): (nearly) exact integration.  On affine cells (parallelograms) the integrand is a
         polynomial of degree <= 7 per direction and 4 points are exact; on any other quadrilateral the frame, the
@@ -202,9 +203,14 @@ class ShellMesh:
             (profiles/r5_quadrature_uquad1m.txt: exact discrete solutions at n = 5, 6, 7) -> 6.
         The measure is the MEDIAN over the cells of max / min of the Jacobian at the four corners (wing1m 1.43, uquad1m 3.00; the
         worst cells of the jittered grid reach 4.9, but what moves the solution is the typical cell); 6 from 2.0 on.
-        Triangles are affine: one rule."""
+        Triangles are affine, the surface gradient, the frame and (uhat being piecewise linear) F, J are constant on a cell, so with
+        nodal thickness and E the integrand is a polynomial of degree <= 6 (drilling: E h^3 omega^2) and the 12-point rule of degree 6 is
+        exact -- the same number as the degree-9 rule UFL's estimate selects (scripts/ufl_degree_estimate.py), up to rounding.  Only a
+        NODAL Poisson ratio that varies over a cell makes the integrand rational (E / (1 - nu^2), E / (2 (1 + nu))): then the reference's
+        answer is that of its degree-9 rule, 19 points (``nodal_nu_varies``; ShellContext switches by itself when such a field arrives).
+        The p-norm stress measure is degree 4 on either cell type whatever this returns (rm_shell_model.py:200-205)."""
         if not self.is_quad:
-            return 4
+            return 9 if nodal_nu_varies else 6
         x = self.nodes[self.cells]
         defect = np.linalg.norm(x[:, 0] - x[:, 1] + x[:, 2] - x[:, 3], axis=1)       # zero for a parallelogram
         if np.all(defect <= 1e-10 * self.cell_diameters()):

@@ -114,6 +114,9 @@ class HipEngine:
     def set_field(self, name, values):
         self.ctx.set_field(name, values)
 
+    def set_quadrature(self, nquad):
+        self.ctx.set_quadrature(nquad)
+
     def set_penalty_facets(self, pairs, beta):
         self.ctx.set_penalty_facets(pairs, beta)
 
@@ -177,6 +180,7 @@ class DistributedShell:
         leaf_size = mesh.recommended_leaf_size() if leaf_size is None else int(leaf_size)
         self.tree = analyse(mesh, leaf_size, min_depth=d) if tree is None else tree
         self.sub, self.plan, self.info = rank_plan(mesh, self.tree, comm.rank, comm.size)
+        self._rule_auto = nquad is None
         self.nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
         factory = engine_factory or (lambda sub, plan, info: HipEngine(sub, plan, info, device=device,
                                                                        element_wise_material=element_wise_material, nquad=self.nquad))
@@ -202,6 +206,13 @@ class DistributedShell:
         for name, v in (("thickness", thickness), ("E", E), ("nu", nu), ("density", density)):
             if v is not None:
                 v = np.asarray(v, dtype=np.float64).ravel()
+                if name == "nu" and self._rule_auto and not self.mesh.is_quad:
+                    # the rule of the WHOLE mesh, decided on the global field so that every rank takes the same one (ShellContext.set_field)
+                    varies = (not self.ewm) and v.size > 1 and bool(np.any(v != v[0]))
+                    nq = self.mesh.recommended_nquad(nodal_nu_varies=varies)
+                    if nq != self.nquad:
+                        self.eng.set_quadrature(nq)
+                        self.nquad = nq
                 self.eng.set_field(name, v if v.size == 1 else v[sel])
         if F_solid is not None:
             f = np.asarray(F_solid, dtype=np.float64).reshape(-1, 3)

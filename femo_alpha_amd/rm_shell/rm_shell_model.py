@@ -102,13 +102,20 @@ class RMShellModel:
         # estimate, which on quadrilaterals comes out near 47 (scripts/ufl_degree_estimate.py): exact integration.  Default:
         # what the mesh asks for -- 4 on affine cells (exact there), 5 as soon as one cell is warped (within 1e-9 of the
         # limit at BASELINE config 3; ShellMesh.recommended_nquad).
-        self.nquad = mesh.recommended_nquad() if nquad is None else int(nquad)
+        # On triangles nquad is the degree of the symmetric rule: 6 (exact for cell-wise polynomial data), and the context raises it to
+        # UFL's 9 by itself when a nodal Poisson ratio that varies over the cells arrives -- unless the caller names the rule here.
+        self._nquad_arg = None if nquad is None else int(nquad)
         self.association_table = None
         if shell_bc_func is None:
             raise ValueError("Please provide the shell bc location function.\n"
                              " Example:\n def ClampedBoundary(x):\n    return np.less(x[1], 0.0)")
         self.set_up_bcs(shell_bc_func, PENALTY_BC)
         self.set_up_fea()
+
+    @property
+    def nquad(self):
+        """The rule in use (ShellContext.nquad)."""
+        return self.shell_pde.ctx.nquad
 
     def set_up_subdomains(self, mesh_tags):
         """mesh_tags: {tag: [cell indices]} without duplicates (rm_shell_model.py:101-133).  Builds
@@ -135,7 +142,7 @@ class RMShellModel:
         mesh = self.mesh
         shell_pde = self.shell_pde = RMShellPDE(mesh, element_wise_material=self.element_wise_material,
                                                 elementwise_pressure=self.elementwise_pressure, device=self.device,
-                                                nquad=self.nquad)
+                                                nquad=self._nquad_arg)
         fea = FEA(mesh)
         fea.PDE_SOLVER = "Newton"
         fea.REPORT = False

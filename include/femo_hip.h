@@ -39,7 +39,11 @@ const char* femo_last_error(const femo_ctx* ctx);
  *   cells          nel*nvc vertex ids
  *   cell_p2        nel*npc P2 node ids (npc = 9 quads / 6 triangles: vertices, edge midpoints, centre)
  *   elementwise_material / elementwise_pressure   DG0 instead of CG1 for VT / VF (rm_shell_pde.py:37-44)
- *   nquad          Gauss points per direction on quads (2..6); ignored on triangles (12-point rule) */
+ *   nquad          the rule of the static forms (the reference leaves it to UFL's estimate: plain dx, linear_shell_model.py:88-103).
+ *                  Quadrilaterals: Gauss points per direction, 2..6.  Triangles: the DEGREE of the fully symmetric rule --
+ *                  4 (6 points), 6 (12 points; also what 0 selects), 9 (19 points: UFL's estimate for these forms) or 12 (33 points);
+ *                  exact literals of every rule: scripts/derive_triangle_rules.py.  The p-norm stress measure is the reference's
+ *                  quadrature_degree 4 whatever nquad says (rm_shell_model.py:200-205): 3 x 3 Gauss / the 6-point rule. */
 int femo_create(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                 const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                 int elementwise_material, int elementwise_pressure, int nquad);
@@ -206,6 +210,16 @@ int femo_force_to_pressure(femo_ctx* ctx, const double* force, double* pressure,
  * factorisation and solves, the reduced strain quadrature, and the thickness-gradient pieces. */
 int femo_set_operator(femo_ctx* ctx, double aK, double aM);          /* operator used by solves and femo_factorize */
 int femo_set_strain_quadrature(femo_ctx* ctx, int32_t nred);         /* nred x nred Gauss for membrane/bending/shear; 0 = full rule */
+/* The rule of the static forms after creation -- same meaning as femo_create's nquad (ShellElement.getQuadratureRule with given
+ * degrees, linear_shell_model.py:88-103).  Factor and Jacobi diagonal of the old rule are dropped.  femo_get_quadrature: the rule in
+ * use and its number of points per cell. */
+int femo_set_quadrature(femo_ctx* ctx, int32_t nquad);
+int femo_get_quadrature(femo_ctx* ctx, int32_t* nquad, int32_t* npoints);
+/* Host only, no device needed: the quadrature and shape tables of a rule exactly as the kernels receive them (what basix tabulates for
+ * the reference, linear_shell_model.py:47-103), so that a caller or a test can compare them bit for bit with its own.  Arrays hold 36
+ * points: w, wS [36]; N2 [36][9]; dN2 [36][9][2]; N1, NR [36][4]; dN1, dNR [36][4][2]; any pointer may be NULL. */
+int femo_quadrature_tables(int32_t nvc, int32_t nquad, int32_t nred, int32_t cg1, int32_t cr, int32_t* npoints, double* w, double* wS,
+                           double* N2, double* dN2, double* N1, double* dN1, double* NR, double* dNR);
 int femo_op_apply_vec2(femo_ctx* ctx, int32_t src, int32_t dst, double aK, double aM, int with_penalty);
 int femo_solve_vec(femo_ctx* ctx, int32_t b, int32_t x, int zero_guess, int32_t* iters, double* relres);
 int femo_vec_mask_zero(femo_ctx* ctx, int32_t id);

@@ -115,17 +115,60 @@ def quad_rule(n):
     return np.stack([X.ravel(), Y.ravel()], axis=1), W.ravel()
 
 
-# Dunavant-type symmetric rule, degree 6, 12 points, on the unit triangle (area 1/2)
-def tri_rule():
-    a1, b1, w1 = 0.063089014491502, 0.873821971016996, 0.050844906370207
-    a2, b2, w2 = 0.249286745170910, 0.501426509658179, 0.116786275726379
-    a3, b3, c3, w3 = 0.053145049844817, 0.310352451033784, 0.636502499121399, 0.082851075618374
+# Fully symmetric rules on the unit triangle (area 1/2), orbit by orbit -- the same literals as femo_hip.hip::triangle_rule, derived
+# in 60-digit arithmetic by scripts/derive_triangle_rules.py (the table is part of the discrete problem: DESIGN.md section 2).
+# S21 rows (a, b = 1 - 2a, w) give the points (a,a) (b,a) (a,b); S111 rows (a, b, c = 1 - a - b, w) give (a,b) (b,a) (a,c) (c,a) (b,c) (c,b);
+# the weights of a rule sum to one.
+#   degree  4 ( 6 points): the reference's p-norm stress measure, quadrature_degree 4 (rm_shell_model.py:200-205)
+#   degree  6 (12 points): exact for the static forms on affine cells with cell-wise polynomial data (integrand of degree <= 6)
+#   degree  9 (19 points): what UFL estimates for the static forms on triangles (plain dx, linear_shell_model.py:88-103)
+#   degree 12 (33 points): the convergence check beyond it
+_TRI = {
+    4: (None,
+        [(0.4459484909159648863183293, 0.1081030181680702273633415, 0.2233815896780114656950070),
+         (0.09157621350977074345957146, 0.8168475729804585130808571, 0.1099517436553218676383263)], []),
+    6: (None,
+        [(0.06308901449150222834033160, 0.8738219710169955433193368, 0.05084490637020681692093681),
+         (0.2492867451709104212916386, 0.5014265096581791574167229, 0.1167862757263793660252896)],
+        [(0.05314504984481694735324967, 0.3103524510337844054166077, 0.6365024991213986472301426, 0.08285107561837357519355346)]),
+    9: (0.09713579628279883381924198,
+        [(0.4896825191987376277837069, 0.02063496160252474443258615, 0.03133470022713907053685483),
+         (0.4370895914929366372699304, 0.1258208170141267254601393, 0.07782754100477427931673936),
+         (0.1882035356190327302409613, 0.6235929287619345395180774, 0.07964773892721025303289177),
+         (0.04472951339445270986510659, 0.9105409732110945802697868, 0.02557767565869803126167880)],
+        [(0.03683841205473628363481760, 0.2219629891607656956751025, 0.7411985987844980206900799, 0.04328353937728937728937729)]),
+    12: (None,
+         [(0.4882173897738048825646621, 0.02356522045239023487067587, 0.02573106644045533541779092),
+          (0.4397243922944602729797366, 0.1205512154110794540405268, 0.04369254453803840213545726),
+          (0.2712103850121159223459513, 0.4575792299757681553080973, 0.06285822421788510035427051),
+          (0.1275761455415859246738963, 0.7448477089168281506522073, 0.03479611293070894298932840),
+          (0.02131735045321037024685698, 0.9573652990935792595062860, 0.006166261051559017233866484)],
+         [(0.1153434945346979991690112, 0.2757132696855141939747963, 0.6089432357797878068561924, 0.04037155776638092951782870),
+          (0.02283833222225702961023378, 0.2813255809899395482481307, 0.6958360867878034221416355, 0.02235677320230344571183908),
+          (0.02573405054833022816810924, 0.1162519159075971412413541, 0.8580140335440726305905366, 0.01731623110865889237164210)]),
+}
+TRI_DEGREES = tuple(sorted(_TRI))
+
+
+def tri_rule(degree=6):
+    """Points (npts, 2) and weights (summing to the area 1/2) of the symmetric rule of that degree: 4, 6, 9 or 12."""
+    if degree not in _TRI:
+        raise ValueError(f"triangles: the rule is named by its degree, one of {TRI_DEGREES} (got {degree})")
+    s3, s21, s111 = _TRI[degree]
     pts, wts = [], []
-    for a, b, w in ((a1, b1, w1), (a2, b2, w2)):
+    if s3 is not None:
+        pts.append((1.0 / 3.0, 1.0 / 3.0)); wts.append(s3)
+    for a, b, w in s21:
         pts += [(a, a), (b, a), (a, b)]; wts += [w] * 3
-    for p in ((a3, b3), (b3, a3), (a3, c3), (c3, a3), (b3, c3), (c3, b3)):
-        pts.append(p); wts.append(w3)
+    for a, b, c, w in s111:
+        pts += [(a, b), (b, a), (a, c), (c, a), (b, c), (c, b)]; wts += [w] * 6
     return np.array(pts), 0.5 * np.array(wts)
+
+
+def degree4_rule(mesh):
+    """``nquad`` of the reference's degree-4 measures (p-norm stress: rm_shell_model.py:200-205) on this mesh: 3 x 3 Gauss points on
+    quadrilaterals, the 6-point rule of degree 4 on triangles."""
+    return 3 if mesh.is_quad else 4
 
 
 def tri_tables(pts):
@@ -160,10 +203,13 @@ class ShellOracle:
     def __init__(self, mesh, element_wise_material=False, elementwise_pressure=False,
                  nquad=None, penalty_facets=None, strong_dofs=None, beta=PENALTY_BETA, rule=None, nred=0):
         self.mesh = mesh
+        auto_rule = nquad is None
         if nquad is None:
             # the rule the mesh asks for: 4 x 4 Gauss on affine cells (exact there), 5 x 5 on warped quadrilaterals -- the
-            # reference integrates its static forms (nearly) exactly (plain dx, linear_shell_model.py:88-103)
-            nquad = mesh.recommended_nquad() if hasattr(mesh, "recommended_nquad") else 4
+            # reference integrates its static forms (nearly) exactly (plain dx, linear_shell_model.py:88-103); on triangles the
+            # DEGREE of the symmetric rule: 6 (exact for cell-wise polynomial data), raised to UFL's 9 by set_fields when a nodal
+            # Poisson ratio that varies over the cells arrives (the same policy as ShellContext.set_field)
+            nquad = mesh.recommended_nquad() if hasattr(mesh, "recommended_nquad") else (4 if mesh.is_quad else 6)
         self.nquad = int(nquad)
         self.ewm = bool(element_wise_material)
         self.ewp = bool(elementwise_pressure)
@@ -172,6 +218,24 @@ class ShellOracle:
                                else np.asarray(penalty_facets, np.int32).reshape(-1, 2))
         self.strong_dofs = (np.zeros(0, np.int32) if strong_dofs is None
                             else np.unique(np.asarray(strong_dofs, np.int32)))
+        self._rule_auto = auto_rule and rule is None
+        self._set_rule(self.nquad, rule, nred)
+        self.npc = mesh.cell_p2.shape[1]
+        self.nvc = mesh.cells.shape[1]
+        self.ldof = 3 * self.npc + 3 * self.nvc
+        self.hK = mesh.cell_diameters()
+        self.dofs = mesh.cell_dofs()
+        nT = mesh.nel if self.ewm else mesh.nn
+        nF = mesh.nel if self.ewp else mesh.nn
+        # defaults follow FEA.add_input init values, rm_shell_model.py:209-214
+        self.h = np.full(nT, 1e-3); self.E = np.ones(nT); self.nu = np.ones(nT) * 0.3
+        self.rho = np.ones(nT); self.f = np.ones((nF, 3)); self.uhat = np.zeros((mesh.nn, 3))
+
+    def _set_rule(self, nquad, rule=None, nred=0):
+        """Quadrature rule and shape tables: ``nquad`` x ``nquad`` Gauss points on quadrilaterals, the symmetric rule of DEGREE ``nquad``
+        (4, 6, 9, 12) on triangles, or an explicit ``rule`` = (points, weights)."""
+        mesh = self.mesh
+        self.nquad, self.nred = int(nquad), int(nred)
         if mesh.is_quad:
             self.pts, self.wts = quad_rule(nquad) if rule is None else rule
             self.wts_strain = self.wts
@@ -184,7 +248,7 @@ class ShellOracle:
                 self.pts = np.vstack([pr, self.pts])
             self.N2, self.dN2, self.N1, self.dN1 = quad_tables(self.pts)
         else:
-            self.pts, self.wts = tri_rule() if rule is None else rule
+            self.pts, self.wts = tri_rule(self.nquad) if rule is None else rule
             self.wts_strain = self.wts
             self.N2, self.dN2, self.N1, self.dN1 = tri_tables(self.pts)
         if getattr(mesh, "element", "CG2CG1") == "CG1CG1":
@@ -200,16 +264,6 @@ class ShellOracle:
             self.NR = 1.0 - 2.0 * self.N1[:, opp]
             self.dNR = -2.0 * self.dN1[:, opp, :]
         self.nq = self.pts.shape[0]
-        self.npc = mesh.cell_p2.shape[1]
-        self.nvc = mesh.cells.shape[1]
-        self.ldof = 3 * self.npc + 3 * self.nvc
-        self.hK = mesh.cell_diameters()
-        self.dofs = mesh.cell_dofs()
-        nT = mesh.nel if self.ewm else mesh.nn
-        nF = mesh.nel if self.ewp else mesh.nn
-        # defaults follow FEA.add_input init values, rm_shell_model.py:209-214
-        self.h = np.full(nT, 1e-3); self.E = np.ones(nT); self.nu = np.ones(nT) * 0.3
-        self.rho = np.ones(nT); self.f = np.ones((nF, 3)); self.uhat = np.zeros((mesh.nn, 3))
 
     # ------------------------------------------------------------------ fields
     def set_fields(self, h=None, E=None, nu=None, rho=None, f=None, uhat=None):
@@ -219,7 +273,12 @@ class ShellOracle:
         nT = self.h.size
         if h is not None: self.h = bc(h, nT)
         if E is not None: self.E = bc(E, nT)
-        if nu is not None: self.nu = bc(nu, nT)
+        if nu is not None:
+            self.nu = bc(nu, nT)
+            if self._rule_auto and not self.mesh.is_quad:
+                varies = (not self.ewm) and bool(np.any(self.nu != self.nu[0]))
+                if (9 if varies else 6) != self.nquad:
+                    self._set_rule(9 if varies else 6)
         if rho is not None: self.rho = bc(rho, nT)
         if f is not None: self.f = np.asarray(f, np.float64).reshape(-1, 3).copy()
         if uhat is not None: self.uhat = np.asarray(uhat, np.float64).reshape(-1, 3).copy()

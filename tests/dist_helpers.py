@@ -116,6 +116,14 @@ class NumpyEngine:
         self.oracle = ShellOracle(self.sub, element_wise_material=self.ewm, penalty_facets=pairs, beta=beta, nquad=self.nquad)
         self.oracle.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f)
 
+    def set_quadrature(self, nquad):
+        from oracle.rm_shell_oracle import ShellOracle
+        o = self.oracle
+        self.nquad = int(nquad)
+        self.oracle = ShellOracle(self.sub, element_wise_material=self.ewm, penalty_facets=o.penalty_facets, beta=o.beta, nquad=self.nquad)
+        self.oracle.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f)
+        self.F = self.L = None
+
     # ------------------------------------------------------------------ operator
     def apply(self, src, dst):
         y = np.zeros(self.nvec)

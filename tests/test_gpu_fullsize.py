@@ -220,13 +220,73 @@ def test_quadrature_rule_sensitivity_at_config3(workload):
     assert all(d[(rule - 1, rule)][k] < 1e-7 for k in range(3))
 
 
+@pytest.mark.parametrize("fields_kind", ["baseline", "nodal_material_and_mesh_motion", "nodal_material_and_mesh_motion_30"])
+def test_triangle_rule_sensitivity_on_the_unstructured_skin(fields_kind):
+    """The triangle counterpart of the test above: the unstructured 1 M-DOF triangle skin (uskin1m) solved with the
+    symmetric rules of degree 6, 9 and 12 (12, 19, 33 points; exact literals, scripts/derive_triangle_rules.py).
+      baseline                         BASELINE config 3's fields (uniform E, nu; uhat = 0): the integrand is a polynomial of degree <= 6 on
+                                       every cell, all three rules integrate it exactly and the solutions agree to the rounding of three
+                                       different summations -- degree 6 IS the reference's degree-9 answer there;
+      nodal_material_and_mesh_motion   nodal E and nu with +-10 % of seeded noise and a smooth uhat: the nodal Poisson ratio makes the
+                                       integrand rational (E and uhat alone do not: tests/test_oracle.py), the context picks degree 9 --
+                                       UFL's estimate -- by itself, and the steps 6 -> 9 -> 12 show how far each rule is from the limit
+                                       (measured: degree 6 is 3e-12 away in the gradient, 1e-13 elsewhere -- the error of a degree-6 rule
+                                       on E / (1 - nu^2) starts at the seventh power of the variation of nu over a cell);
+      ..._30                           the same with +-30 % (nu between 0.23 and 0.43 inside single cells): where the rules begin to part.
+    Printed numbers: profiles/r6_quadrature_uskin1m.txt, DESIGN.md section 2."""
+    from bench import make_workload
+    from femo_alpha_amd.backend import ShellContext
+    m, fields, marker, _ = make_workload("uskin1m")
+    assert not m.is_quad and m.recommended_nquad() == 6 and m.recommended_nquad(nodal_nu_varies=True) == 9
+    fields = dict(fields)
+    if fields_kind != "baseline":
+        rng = np.random.default_rng(17)
+        amp = 0.3 if fields_kind.endswith("_30") else 0.1
+        fields["E"] = float(np.ravel(fields["E"])[0]) * (1 + amp * rng.uniform(-1, 1, m.nn))
+        fields["nu"] = float(np.ravel(fields["nu"])[0]) * (1 + amp * rng.uniform(-1, 1, m.nn))
+        x = m.nodes
+        L = x.max(axis=0) - x.min(axis=0)
+        s = (x - x.min(axis=0)) / L
+        fields["uhat"] = 0.01 * L.max() * np.stack([0.2 * np.sin(2 * np.pi * s[:, 1]), 0.1 * np.cos(3 * s[:, 0]), np.sin(np.pi * s[:, 0]) * s[:, 1] ** 2], axis=1)
+    c = ShellContext(m)                                  # left to itself
+    for k, v in fields.items():
+        c.set_field(k, v)
+    assert c.nquad == (6 if fields_kind == "baseline" else 9)
+    c.close()
+    res = {}
+    for deg in (6, 9, 12):
+        c = ShellContext(m, nquad=deg)
+        for k, v in fields.items():
+            c.set_field(k, v)
+        c.set_penalty_facets(m.penalty_facets(marker))
+        c.use_direct_solver()
+        it, rr = c.solve_state(zero_guess=True)
+        assert it <= 4
+        g, _, _ = c.total_gradient("compliance", "thickness")
+        res[deg] = (c.get_state(), c.functional("compliance"), g)
+        c.close()
+    d = {}
+    for a, b in ((6, 9), (9, 12), (6, 12)):
+        wa, Ja, ga = res[a]; wb, Jb, gb = res[b]
+        d[(a, b)] = (np.abs(wa - wb).max() / np.abs(wb).max(), abs(Ja - Jb) / abs(Jb), np.abs(ga - gb).max() / np.abs(gb).max())
+        print(f"uskin1m [{fields_kind}]: degree {a} -> {b}: displacement {d[(a, b)][0]:.3e}, compliance {d[(a, b)][1]:.3e}, "
+              f"d compliance / d thickness {d[(a, b)][2]:.3e}")
+    if fields_kind == "baseline":
+        assert all(v < 1e-8 for key in d for v in d[key])                # one polynomial, three exact rules
+    else:
+        floor = 1e-12                                                    # three summation orders differ by this much on one polynomial
+        assert all(d[(9, 12)][k] < max(d[(6, 9)][k], floor) for k in range(3))       # convergence in the degree (where a step is above the floor)
+        assert all(d[(9, 12)][k] < 1e-8 for k in range(3))               # degree 9 -- the reference's rule -- is within the bar of the limit
+        assert all(d[(6, 12)][k] < 1e-8 for k in range(3))               # ... and so is degree 6 for material noise of this size
+
+
 def test_stress_outputs_at_config3_size():
     """The stress outputs of RMShellPDE (p-norm aggregate with the reference's defaults m = 1e-6, rho = 100 and with rho = 6, DG1 von
     Mises field on the top surface, rm_shell_pde.py:112-166) on the solved 1 015 470-DOF skin, against the oracle's quadrature evaluated
     at the SAME state on the host: the accumulation over 67 280 cells, the sub-domain selection and the reference area at full size."""
     from bench import make_workload
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m, fields, marker, _ = make_workload("wing1m")
     c = ShellContext(m)
     for k, v in fields.items():
@@ -235,7 +295,7 @@ def test_stress_outputs_at_config3_size():
     c.use_direct_solver()
     c.solve_state(zero_guess=True)
     w = c.get_state()
-    o3 = ShellOracle(m, nquad=3)                                     # the degree-4 measure of the aggregate (rm_shell_model.py:200-205)
+    o3 = ShellOracle(m, nquad=degree4_rule(m))                                     # the degree-4 measure of the aggregate (rm_shell_model.py:200-205)
     o3.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"])
     for mval, rho in ((1e-6, 100.0), (1e-6, 6.0)):
         c.set_stress_params(mval, rho)

@@ -21,7 +21,7 @@ def ClampedBoundary(x):
 @pytest.mark.parametrize("element_wise_material,penalty", [(False, True), (True, True), (False, False)])
 def test_rm_shell_model_protocol(element_wise_material, penalty):
     from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     mesh = plate_mesh(2.0, 10.0, 4, 20)
     nn, nel = mesh.nn, mesh.nel
     E_val, nu_val, h_val, rho_val, f_d = 1e8, 0.3, 0.1, 10.0, 5.0
@@ -74,8 +74,8 @@ def test_rm_shell_model_protocol(element_wise_material, penalty):
     assert out.F_solid.shape == (3 * nn,)
 
     # stress outputs (rm_shell_model.py:200-208, 230-239, 452-455)
-    from oracle.rm_shell_oracle import ShellOracle as _SO
-    o3 = _SO(mesh, element_wise_material=element_wise_material, nquad=3)
+    from oracle.rm_shell_oracle import ShellOracle as _SO, degree4_rule
+    o3 = _SO(mesh, element_wise_material=element_wise_material, nquad=degree4_rule(mesh))
     o3.set_fields(h=h0, E=E_val, nu=nu_val)
     pn = o3.pnorm_stress(w_ref, 1e-6, 100)
     assert abs(out.pnorm_stress.value[0] - pn) < 1e-6 * pn
@@ -182,7 +182,7 @@ def test_force_to_pressure_solve_on_the_device(kind):
 def test_mesh_tags_give_per_tag_stress_aggregates():
     """RMShellModel(mesh_tags=...) registers pnorm_stress_<tag> per sub-domain (rm_shell_model.py:101-133, 242-253)."""
     from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     mesh = plate_mesh(2.0, 10.0, 4, 20)
     nn, nel = mesh.nn, mesh.nel
     cx = mesh.nodes[mesh.cells].mean(axis=1)[:, 0]
@@ -202,7 +202,7 @@ def test_mesh_tags_give_per_tag_stress_aggregates():
     o = ShellOracle(mesh, penalty_facets=mesh.penalty_facets(ClampedBoundary))
     o.set_fields(h=0.1, E=1e8, nu=0.3, rho=10.0, f=pressure.value)
     w_ref = o.solve()
-    o3 = ShellOracle(mesh, nquad=3)
+    o3 = ShellOracle(mesh, nquad=degree4_rule(mesh))
     o3.set_fields(h=0.1, E=1e8, nu=0.3)
     for tag, cells in mesh_tags.items():
         ref = o3.pnorm_stress(w_ref, 1e-6, 100, cells=cells)
@@ -221,7 +221,7 @@ def test_renumbered_model_answers_in_caller_order():
     inputs, nodal displacements and gradients keep the caller's numbering (rm_shell_model.py:396-438, 505-527)."""
     from femo_alpha_amd.mesh import wing_skin_mesh
     from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     mesh = wing_skin_mesh(8, 24, shuffle=True)
     nn, nel = mesh.nn, mesh.nel
     root = lambda x: np.less(x[1], 1e-12)
@@ -251,7 +251,7 @@ def test_renumbered_model_answers_in_caller_order():
     assert np.abs(out.disp_extracted.value - u_ref).max() < 1e-7 * np.abs(u_ref).max()
     dJ = recorder.compute_totals(out.compliance, thickness)
     assert np.abs(np.ravel(dJ) - dJ_ref).max() < 1e-7 * np.abs(dJ_ref).max()
-    o3 = ShellOracle(mesh, nquad=3)
+    o3 = ShellOracle(mesh, nquad=degree4_rule(mesh))
     o3.set_fields(h=h0, E=7e9, nu=0.3)
     ref = o3.pnorm_stress(w_ref, 1e-6, 100, cells=tags["outboard"])
     assert abs(out.pnorm_stress_outboard.value[0] - ref) < 1e-6 * ref
@@ -347,3 +347,57 @@ def test_stale_factor_policy_gives_the_same_answers():
     gate_off, gated = run(6, rel=10.0), run(6)
     assert gate_off[-1][1] == 2 and gate_off[-1][3] == 0 and gate_off[-1][2] <= 3     # 50 % change: refreshed INSIDE the solve, the adjoint finds the fresh factor
     assert gated[-1][1] == 0 and gated[-1][0] <= 3                                    # with the gate: refreshed at once, no wasted iterations
+
+
+def test_stale_factor_gate_compares_with_the_design_of_the_stored_factor():
+    """every path that completes a factorisation records the design it belongs to -- not only the solver's own.  A public
+    ``factorize()`` at a DISTANT design followed by a small change of the fields must find the kept factor near (factor_state 1, a few
+    iterations), and a ``factorize()`` followed by a return to the first design must find it far (refreshed at once, factor_state 0);
+    switching the mesh motion on or off is a change whatever its size; and a kept factor never ends a solve unconverged at a small maxit."""
+    from femo_alpha_amd.backend import ShellContext
+    m = plate_mesh(2.0, 10.0, 16, 80)
+    rng = np.random.default_rng(4)
+    h0 = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn))
+    h_far = h0 * (1 + 0.5 * rng.uniform(-1, 1, m.nn))
+    c = ShellContext(m)
+    for k, v in dict(thickness=h0, E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1))).items():
+        c.set_field(k, v)
+    c.set_penalty_facets(m.penalty_facets(ClampedBoundary))
+    c.enable_frontal()
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=60, check_every=1)
+    c.set_option("stale_factor", 6)
+    c.solve_state(zero_guess=True)                                   # snapshot: h0
+    c.set_field("thickness", h_far)
+    c.factorize()                                                    # the stored factor now belongs to h_far ...
+    c.set_field("thickness", h_far * (1 + 1e-4 * rng.uniform(-1, 1, m.nn)))
+    it, _ = c.solve_state(zero_guess=True)
+    assert c.last_timing()["factor_state"] == 1 and it <= 6          # ... and a design next to h_far is near it
+    w_near = c.get_state()
+    c.set_field("thickness", h0)
+    it, _ = c.solve_state(zero_guess=True)
+    assert c.last_timing()["factor_state"] == 0 and it <= 3          # h0 is far from the factor's design: refreshed at once
+    w0 = c.get_state()
+    # mesh motion switched on: a different operator however small uhat is
+    c.set_field("uhat", 1e-9 * rng.uniform(-1, 1, (m.nn, 3)))
+    c.solve_state(zero_guess=True)
+    assert c.last_timing()["factor_state"] == 0
+    c.set_field("uhat", np.zeros((m.nn, 3)))
+    c.solve_state(zero_guess=True)
+    assert c.last_timing()["factor_state"] == 0
+    assert np.abs(c.get_state() - w0).max() < 1e-8 * np.abs(w0).max()
+    # maxit below stale_factor: the refresh comes in time for the solve to converge
+    c.set_solver(preconditioner=2, rtol=1e-12, maxit=4, check_every=1)
+    c.set_option("stale_rel", 10.0)
+    c.set_field("thickness", h_far)
+    it, rr = c.solve_state(zero_guess=True)
+    assert rr <= 1e-12 and c.last_timing()["factor_state"] in (1, 2)
+    # the answers are those of a context that always factorises
+    c2 = ShellContext(m)
+    for k, v in dict(thickness=h_far, E=[1e8], nu=[0.3], density=[10.0], F_solid=np.tile([0.0, 0.0, 5.0], (m.nn, 1))).items():
+        c2.set_field(k, v)
+    c2.set_penalty_facets(m.penalty_facets(ClampedBoundary))
+    c2.use_direct_solver()
+    c2.solve_state(zero_guess=True)
+    assert np.abs(c.get_state() - c2.get_state()).max() < 1e-8 * np.abs(c2.get_state()).max()
+    assert np.abs(w_near - c2.get_state()).max() < 1e-3 * np.abs(c2.get_state()).max()      # (a design 1e-4 away)
+    c.close(); c2.close()

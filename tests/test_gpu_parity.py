@@ -39,7 +39,7 @@ def _mesh(kind):
 
 def _pair(kind, ewm=False, ewp=False, uhat=False, bc="penalty", beta=1e15, seed=0):
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m = _mesh(kind)
     rng = np.random.default_rng(seed)
     nT = m.nel if ewm else m.nn
@@ -195,7 +195,7 @@ def test_super_panel_schedule_gives_the_same_factor(sp, force_right, ahead):
     solution as the panel-by-panel schedule, same parity with the oracle.  The root front has 582 pivots: three
     super-panels of 256, so the second-stream dependencies (two bulk updates in flight) are exercised."""
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m = plate_mesh(2.0, 5.0, 64, 64)
     rng = np.random.default_rng(5)
     fields = dict(thickness=0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)), E=np.full(m.nn, 3e7), nu=np.full(m.nn, 0.3),
@@ -236,7 +236,7 @@ def test_tiny_meshes_single_front(shape, tri):
     """One to nine cells: the elimination tree is a single front (no extend-add, no Schur complement); forward and
     adjoint solves against the oracle."""
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m = plate_mesh(1.0, float(shape[1]), shape[0], shape[1])
     if tri:
         m = quads_to_triangles(m)
@@ -341,11 +341,11 @@ def test_shape_sensitivities_vs_oracle_finite_differences(kind, bc):
 def test_stress_outputs(kind, ewm, uhat):
     """p-norm aggregate and DG1 field of the top-surface von Mises stress, and the partial gradients of the
     aggregate, against the oracle (value) and finite differences of the oracle (gradients)."""
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m, o, c, rng = _pair(kind, ewm=ewm, uhat=uhat, beta=1e6)
     w = rng.uniform(-1, 1, m.ndof) * 1e-4
     c.set_state(w)
-    o3 = ShellOracle(m, element_wise_material=ewm, nquad=3)            # the degree-4 measure
+    o3 = ShellOracle(m, element_wise_material=ewm, nquad=degree4_rule(m))            # the degree-4 measure
     o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
     mval, rho = 1e-6, 6.0
     c.set_stress_params(mval, rho)
@@ -358,7 +358,7 @@ def test_stress_outputs(kind, ewm, uhat):
     assert abs(c.functional("pnorm_stress") - v100) < 1e-9 * v100
     c.set_stress_params(mval, rho)
     area = o3.pnorm_stress(w * 0, mval, 0.0, alpha=1.0)                # int J dx with rho = 0 -> area (uhat included)
-    o0 = ShellOracle(m, element_wise_material=ewm, nquad=3); alpha = o0.pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
+    o0 = ShellOracle(m, element_wise_material=ewm, nquad=degree4_rule(m)); alpha = o0.pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
     P = lambda ww=w: o3.pnorm_stress(ww, mval, rho, alpha=alpha)
     g_w = c.dfunctional("pnorm_stress", "disp_solid")
     for i in rng.choice(m.ndof, 6, replace=False):
@@ -411,13 +411,13 @@ def test_regularization_and_volume_outputs(kind, ewm):
 def test_stress_aggregate_on_subdomains(kind, uhat):
     """Per-tag stress aggregates (the reference's dxx(i) measure, rm_shell_model.py:242-253): value and partial
     gradients restricted to a sub-domain, each normalised by its own reference area; selecting -1 restores the mesh."""
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m, o, c, rng = _pair(kind, uhat=uhat, beta=1e6)
     w = rng.uniform(-1, 1, m.ndof) * 1e-4
     c.set_state(w)
-    o3 = ShellOracle(m, nquad=3)
+    o3 = ShellOracle(m, nquad=degree4_rule(m))
     o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
-    o0 = ShellOracle(m, nquad=3)                                        # reference configuration: the frozen areas
+    o0 = ShellOracle(m, nquad=degree4_rule(m))                                        # reference configuration: the frozen areas
     mval, rho = 1e-6, 6.0
     c.set_stress_params(mval, rho)
     perm = rng.permutation(m.nel)
@@ -609,6 +609,70 @@ def test_stress_aggregate_against_the_symbolic_derivation():
     c.close()
 
 
+def test_triangle_rules_against_the_symbolic_derivation():
+    """The triangle rules (round 6): a tilted triangle with uhat != 0 and nodal h / E / nu -- a nodal Poisson ratio makes the integrand
+    rational, so the rule decides the number -- integrated from the symbolic point values with the symmetric rules of degree 6 / 9 / 12
+    (make_sympy_golden_tri_rules.py).  The HIP kernels with the rule of that degree reproduce element matrix (CSR of the one-cell mesh),
+    load vector, functionals and sensitivities; a context left to itself takes degree 9 (UFL's estimate for these forms) the moment such
+    a field arrives; and the p-norm stress measure is the 6-point rule of the reference's quadrature_degree 4 (rm_shell_model.py:200-205)
+    whatever the operator's rule -- with rho = 100 the 12-point rule of rounds 1-5 gives 447 times that number on this cell."""
+    import os
+    from femo_alpha_amd.backend import FemoHipError, ShellContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sympy_triangle_rules.npz"))
+    m = ShellMesh(g["TR_X"], np.array([[0, 1, 2]]))
+    d = m.cell_dofs()[0]
+    w = np.zeros(m.ndof); w[d] = np.concatenate([g["TR_U"].ravel(), g["TR_TH"].ravel()])
+    lam = np.zeros(m.ndof); lam[d] = np.concatenate([g["TR_LU"].ravel(), g["TR_LT"].ravel()])
+
+    def fill(c):
+        c.set_field("thickness", g["TR_h"]); c.set_field("E", g["TR_E"]); c.set_field("nu", g["TR_nu"]); c.set_field("density", g["TR_rho"])
+        c.set_field("uhat", g["TR_uhat"]); c.set_field("F_solid", g["TR_f"])
+
+    for deg in (6, 9, 12):
+        c = ShellContext(m, nquad=deg)
+        fill(c)
+        assert c.nquad == deg and c.quadrature() == (deg, {6: 12, 9: 19, 12: 33}[deg])
+        c.enable_csr()
+        Ke = c.assemble_csr().toarray()[np.ix_(d, d)]
+        ref = g[f"TR_Ke_d{deg}"]
+        assert np.abs(Ke - ref).max() < 1e-11 * np.abs(ref).max(), deg
+        Fe = c.load_vector()[d[:18]]
+        assert np.abs(Fe - g[f"TR_Fe_d{deg}"]).max() < 1e-12 * np.abs(g[f"TR_Fe_d{deg}"]).max()
+        c.set_state(w)
+        assert abs(c.functional("compliance") - g[f"TR_compliance_d{deg}"][0]) < 1e-11 * g[f"TR_compliance_d{deg}"][0]
+        assert abs(c.functional("mass") - g[f"TR_mass_d{deg}"][0]) < 1e-12 * g[f"TR_mass_d{deg}"][0]
+        e_ref = 0.5 * w[d] @ ref @ w[d]
+        assert abs(c.functional("elastic_energy") - e_ref) < 1e-11 * abs(e_ref)
+        if deg == 9:
+            for name, key in (("nu", "TR_dRdnu_d9"), ("thickness", "TR_dRdh_d9")):
+                assert np.abs(c.dRdarg_T(name, lam) - g[key]).max() < 1e-11 * np.abs(g[key]).max(), name
+        # the stress measure does not follow the operator's rule
+        c.set_stress_params(m=2.0, rho=4.0); c.set_stress_alpha(1.0)
+        assert abs(c.functional("pnorm_stress") - g["TR_pnorm4_d4"][0]) < 1e-11 * g["TR_pnorm4_d4"][0]
+        c.set_stress_params(m=float(g["TR_m100"][0]), rho=100.0); c.set_stress_alpha(1.0)
+        assert abs(c.functional("pnorm_stress") - g["TR_pnorm100_d4"][0]) < 1e-9 * g["TR_pnorm100_d4"][0]
+        c.close()
+    # left to itself: degree 6, and 9 from the moment the nodal Poisson ratio varies; back when it is uniform again; the rule can be
+    # named after creation as well (femo_set_quadrature), and a degree without a rule is refused
+    c = ShellContext(m)
+    assert c.nquad == 6
+    fill(c)
+    assert c.nquad == 9 and c.quadrature() == (9, 19)
+    c.enable_csr()
+    Ke = c.assemble_csr().toarray()[np.ix_(d, d)]
+    assert np.abs(Ke - g["TR_Ke_d9"]).max() < 1e-11 * np.abs(g["TR_Ke_d9"]).max()
+    c.set_quadrature(12)
+    Ke = c.assemble_csr().toarray()[np.ix_(d, d)]
+    assert np.abs(Ke - g["TR_Ke_d12"]).max() < 1e-11 * np.abs(g["TR_Ke_d12"]).max()
+    c.set_field("nu", [0.3])
+    assert c.nquad == 6
+    with pytest.raises(FemoHipError, match="degree"):
+        c.set_quadrature(5)
+    c.close()
+    with pytest.raises(FemoHipError, match="degree"):
+        ShellContext(m, nquad=5)
+
+
 def test_penalty_term_of_cg2cr1_against_the_symbolic_facet_blocks():
     """CG2CR1: the penalty operator of the three facets of the affine triangle (3 x 3 rotation blocks: all three Crouzeix-Raviart functions
     have a trace on every facet) -- the HIP operator with the facets minus the one without, against the symbolic blocks (case PC)."""
@@ -754,7 +818,7 @@ def test_csr_assembly_at_config2():
     assembly of the same matrix -- the matrix the full-size goldens were solved with."""
     from femo_alpha_amd.backend import ShellContext
     from femo_alpha_amd.mesh import plate_mesh
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m = plate_mesh(2.0, 10.0, 58, 290)
     rng = np.random.default_rng(0)
     h = 0.1 * (1 + 0.2 * rng.uniform(-1, 1, m.nn))
@@ -774,11 +838,11 @@ def test_csr_assembly_at_config2():
 
 def test_pnorm_stress_with_a_given_alpha():
     """pnorm_stress(alpha=...) (rm_shell_pde.py:112-128): the caller's normalisation replaces the reference area."""
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m, o, c, rng = _pair("warped", beta=1e6)
     w = rng.uniform(-1, 1, m.ndof) * 1e-4
     c.set_state(w)
-    o3 = ShellOracle(m, nquad=3)
+    o3 = ShellOracle(m, nquad=degree4_rule(m))
     o3.set_fields(h=o.h, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
     c.set_stress_params(1e-6, 6.0)
     c.set_stress_alpha(2.5)
@@ -838,18 +902,18 @@ def test_penalty_with_prescribed_values():
 def test_pnorm_stress_with_the_thickness_regularisation(ewm, uhat):
     """pnorm_stress(regularization=True) (rm_shell_pde.py:120-122): value and the thickness / shape gradients of the added
     0.5e3 int h^rho J dx term against the oracle (finite differences for the gradients)."""
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     m, o, c, rng = _pair("warped", ewm=ewm, uhat=uhat, beta=1e6)
     w = rng.uniform(-1, 1, m.ndof) * 1e-4
     c.set_state(w)
-    o3 = ShellOracle(m, element_wise_material=ewm, nquad=3)
+    o3 = ShellOracle(m, element_wise_material=ewm, nquad=degree4_rule(m))
     hh = 1.0 + 0.3 * rng.uniform(-1, 1, o.h.size)                       # thickness ~ 1 so that h^rho is neither 0 nor inf
     o3.set_fields(h=hh, E=o.E, nu=o.nu, rho=o.rho, f=o.f, uhat=o.uhat)
     c.set_field("thickness", hh)
     mval, rho = 1e-6, 6.0
     c.set_stress_params(mval, rho)
     c.set_option("stress_regularization", 0.5e3)
-    alpha = ShellOracle(m, element_wise_material=ewm, nquad=3).pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
+    alpha = ShellOracle(m, element_wise_material=ewm, nquad=degree4_rule(m)).pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)
     P = lambda: o3.pnorm_stress(w, mval, rho, alpha=alpha, regularization=True)
     ref = P()
     assert abs(c.functional("pnorm_stress") - ref) < 1e-10 * ref
@@ -879,7 +943,7 @@ def test_cg1cg1_element(kind, uhat, bc):
     oracle's CG1CG1 branch -- operator, load, functionals, partial gradients at 1e-11; forward solve and adjoint gradient through the
     multifrontal Cholesky; strong Dirichlet conditions and the penalty clamp (the linear edge block for the displacement too)."""
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     base = _mesh(kind)
     m = ShellMesh(base.nodes, base.cells, "CG1CG1")
     assert m.ndof == 6 * m.nn and m.ldof == 6 * m.nvc
@@ -939,7 +1003,7 @@ def test_cg1cg1_stress_csr_and_shape_outputs(kind):
     field, the CSR export and the shape derivatives (d/d uhat of the outputs and (dR/d uhat)^T lambda), each against the oracle's
     CG1CG1 branch (values) or its central finite differences (shape, stress gradients), the penalty clamp's shape term included."""
     from femo_alpha_amd.backend import ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     base = _mesh(kind)
     m = ShellMesh(base.nodes, base.cells, "CG1CG1")
     rng = np.random.default_rng(9)
@@ -952,7 +1016,7 @@ def test_cg1cg1_stress_csr_and_shape_outputs(kind):
         o_ = ShellOracle(m, strong_dofs=sd, nquad=nquad)
         o_.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], f=fields["F_solid"], uhat=fields["uhat"])
         return o_
-    o, o3 = oracle(), oracle(3)                                      # o3: the degree-4 measure of the stress aggregate
+    o, o3 = oracle(), oracle(degree4_rule(m))                        # o3: the degree-4 measure of the stress aggregate
     c = ShellContext(m)
     for k, v in fields.items():
         c.set_field(k, v)
@@ -973,7 +1037,7 @@ def test_cg1cg1_stress_csr_and_shape_outputs(kind):
     assert abs(c.functional("pnorm_stress") - o3.pnorm_stress(w, mval, rho)) < 1e-10 * o3.pnorm_stress(w, mval, rho)
     if kind != "tri":
         assert rel(c.field_output("stress").reshape(m.nel, -1), o.stress_dg1(w)) < 1e-10
-    o0 = ShellOracle(m, nquad=3)
+    o0 = ShellOracle(m, nquad=degree4_rule(m))
     alpha = o0.pnorm_stress(w * 0, 1.0, 0.0, alpha=1.0)              # reference area (uhat = 0)
     P = lambda ww=w: o3.pnorm_stress(ww, mval, rho, alpha=alpha)
     g_w = c.dfunctional("pnorm_stress", "disp_solid")
@@ -1053,7 +1117,7 @@ def test_cg2cr1_element(kind, uhat, bc, ewm):
     (the transient march: tests/test_gpu_dynamic.py); shape derivatives against finite differences of the oracle; element partitions are
     refused with a message."""
     from femo_alpha_amd.backend import FemoHipError, ShellContext
-    from oracle.rm_shell_oracle import ShellOracle
+    from oracle.rm_shell_oracle import ShellOracle, degree4_rule
     base = _mesh(kind)
     m = ShellMesh(base.nodes, base.cells, "CG2CR1")
     assert m.nR == m.nE and m.ndof == 3 * (m.nV + m.nE) + 3 * m.nE and m.ldof == 27
@@ -1106,7 +1170,7 @@ def test_cg2cr1_element(kind, uhat, bc, ewm):
         assert rel(c.dRdarg_T(arg, lam), o.dRdfield_T(name, w, lam)) < tol
     assert rel(c.dRdarg_T("F_solid", lam), o.dRdf_T(lam)) < tol
     # the stress outputs interpolate the rotation too: the p-norm aggregate of the top-surface von Mises stress
-    os_ = ShellOracle(m, element_wise_material=ewm, nquad=3)
+    os_ = ShellOracle(m, element_wise_material=ewm, nquad=degree4_rule(m))
     os_.set_fields(h=fields["thickness"], E=fields["E"], nu=fields["nu"], rho=fields["density"], uhat=fields.get("uhat"))
     c.set_stress_params(1e-6, 6.0)
     assert abs(c.functional("pnorm_stress") - os_.pnorm_stress(w, 1e-6, 6.0)) < 1e-10 * abs(os_.pnorm_stress(w, 1e-6, 6.0))

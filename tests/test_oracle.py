@@ -168,6 +168,84 @@ def test_golden_warped_element_integrated(golden_dir):
     assert np.abs(Me - g["W_Me"]).max() < 1e-13 * np.abs(g["W_Me"]).max()
 
 
+def test_golden_triangle_rules(golden_dir):
+    """The triangle with uhat != 0 and nodal h / E / nu -- a nodal Poisson ratio makes the integrand rational -- integrated from the
+    symbolic point values with the symmetric rules of degree 6, 9 and 12 and, for the p-norm stress measure, of degree 4
+    (tests/golden/make_sympy_golden_tri_rules.py; the script derives the rules itself from the moment equations): the oracle with the
+    rule of the same degree reproduces every number, and picks degree 9 -- UFL's estimate for these forms -- by itself for such a field."""
+    from oracle.rm_shell_oracle import degree4_rule
+    g = np.load(os.path.join(golden_dir, "sympy_triangle_rules.npz"))
+    m = ShellMesh(g["TR_X"], np.array([[0, 1, 2]]))
+    d = m.cell_dofs()[0]
+    w = np.zeros(m.ndof); w[d] = np.concatenate([g["TR_U"].ravel(), g["TR_TH"].ravel()])
+    lam = np.zeros(m.ndof); lam[d] = np.concatenate([g["TR_LU"].ravel(), g["TR_LT"].ravel()])
+    fields = dict(h=g["TR_h"], E=g["TR_E"], nu=g["TR_nu"], rho=g["TR_rho"], f=g["TR_f"], uhat=g["TR_uhat"])
+    for deg in (6, 9, 12):
+        o = ShellOracle(m, nquad=deg)
+        o.set_fields(**fields)
+        assert o.nquad == deg and o.nq == {6: 12, 9: 19, 12: 33}[deg]
+        Ke = o.element_matrices()[0]
+        ref = g[f"TR_Ke_d{deg}"]
+        assert np.abs(Ke - ref).max() < 1e-12 * np.abs(ref).max(), deg
+        Fe = o.load_vector()[d[:18]]
+        assert np.abs(Fe - g[f"TR_Fe_d{deg}"]).max() < 1e-13 * np.abs(g[f"TR_Fe_d{deg}"]).max()
+        assert abs(o.compliance(w) - g[f"TR_compliance_d{deg}"][0]) < 1e-12 * g[f"TR_compliance_d{deg}"][0]
+        assert abs(o.mass() - g[f"TR_mass_d{deg}"][0]) < 1e-13 * g[f"TR_mass_d{deg}"][0]
+        if deg == 9:
+            for name, key in (("nu", "TR_dRdnu_d9"), ("h", "TR_dRdh_d9")):
+                assert np.abs(o.dRdfield_T(name, w, lam) - g[key]).max() < 1e-12 * np.abs(g[key]).max(), name
+    # the rules differ on this integrand by far more than the tests' tolerance: the right one is being checked
+    assert g["TR_Ke_rule_distance"][0] > 1e-9 > 1e-10 > g["TR_Ke_rule_distance"][1]
+    # default rule: 6, and 9 from the moment the nodal Poisson ratio varies (ShellContext does the same); an explicit rule stays
+    o = ShellOracle(m)
+    assert o.nquad == 6
+    o.set_fields(**fields)
+    assert o.nquad == 9 and np.abs(o.element_matrices()[0] - g["TR_Ke_d9"]).max() < 1e-12 * np.abs(g["TR_Ke_d9"]).max()
+    o.set_fields(nu=0.3)
+    assert o.nquad == 6
+    o = ShellOracle(m, element_wise_material=True)
+    o.set_fields(nu=[0.25])
+    assert o.nquad == 6
+    # the p-norm stress measure, quadrature_degree 4 (rm_shell_model.py:200-205): the 6-point rule; rho = 100 as in the reference
+    o4 = ShellOracle(m, nquad=degree4_rule(m))
+    o4.set_fields(**fields)
+    assert o4.nq == 6
+    assert abs(o4.pnorm_stress(w, 2.0, 4.0, alpha=1.0) - g["TR_pnorm4_d4"][0]) < 1e-12 * g["TR_pnorm4_d4"][0]
+    assert abs(o4.pnorm_stress(w, g["TR_m100"][0], 100.0, alpha=1.0) - g["TR_pnorm100_d4"][0]) < 1e-10 * g["TR_pnorm100_d4"][0]
+    o6 = ShellOracle(m, nquad=6)
+    o6.set_fields(**fields)
+    assert abs(o6.pnorm_stress(w, g["TR_m100"][0], 100.0, alpha=1.0) - g["TR_pnorm100_d6"][0]) < 1e-10 * g["TR_pnorm100_d6"][0]
+    assert g["TR_pnorm100_d6"][0] > 100 * g["TR_pnorm100_d4"][0]          # with rho = 100 the rule is the value (rounds 1-5 used this one)
+
+
+def test_degree_six_is_exact_on_triangles_unless_the_poisson_ratio_varies():
+    """ShellMesh.recommended_nquad's claim: on (affine) triangles the surface gradient, the frame and -- uhat being piecewise linear -- F
+    and J are constant on a cell, so with nodal thickness and nodal E the integrand is a polynomial of degree <= 6 and the rules of degree
+    6, 9 and 12 give the same operator, load vector and functionals (to rounding) even with mesh motion; a nodal Poisson ratio that
+    varies makes it rational and they part."""
+    from femo_alpha_amd.mesh import quads_to_triangles, wing_skin_mesh
+    m = quads_to_triangles(wing_skin_mesh(4, 8))                     # cambered, twisted, jittered: every triangle tilted differently
+    rng = np.random.default_rng(5)
+    assert not m.is_quad
+    h = 0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)); E = 2.0 * (1 + 0.3 * rng.uniform(-1, 1, m.nn))
+    uhat = 0.02 * rng.uniform(-1, 1, (m.nn, 3)); f = rng.uniform(-1, 1, (m.nn, 3))
+    w = rng.uniform(-1, 1, m.ndof)
+
+    def numbers(deg, nu):
+        o = ShellOracle(m, nquad=deg)
+        o.set_fields(h=h, E=E, nu=nu, rho=2.0, f=f, uhat=uhat)
+        return o.apply_K(w, with_penalty=False), o.load_vector(), o.compliance(w), o.mass(), o.elastic_energy(w)
+
+    rel = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max()
+    a6, a9, a12 = numbers(6, 0.3), numbers(9, 0.3), numbers(12, 0.3)
+    for x6, x9, x12 in zip(a6, a9, a12):
+        assert rel(x6, x12) < 1e-13 and rel(x9, x12) < 1e-13
+    nu = 0.3 * (1 + 0.3 * rng.uniform(-1, 1, m.nn))
+    b6, b9, b12 = numbers(6, nu), numbers(9, nu), numbers(12, nu)
+    assert rel(b6[0], b12[0]) > 1e-11 and rel(b9[0], b12[0]) < 0.05 * rel(b6[0], b12[0])
+    assert rel(b6[1], b12[1]) < 1e-13                                   # the load does not see the material
+
+
 def _penalty_reference(g, beta):
     """39 x 39 penalty matrix of the one-cell mesh in element-local numbering from the symbolic facet blocks (case P)."""
     P = np.zeros((39, 39))
