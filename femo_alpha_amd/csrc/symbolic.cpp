@@ -52,7 +52,13 @@ void femo_plan_free(femo_plan* p) { delete p; }
 int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
                        const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
                        int32_t axis_rule, double gap_coeff) {
-    if (!out || nel < 1 || nP2 < 1 || nV < 1 || npc < 1 || ndpc < 1 || !cell_p2 || !cent || !cell_dofs || leaf_size < 1 || min_depth < 0 ||
+    return femo_plan_build_ex2(out, nel, nP2, nV, npc, ndpc, cell_p2, cent, cext, cell_dofs, leaf_size, min_depth, axis_rule, gap_coeff, 0);
+}
+
+int femo_plan_build_ex2(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                        const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
+                        int32_t axis_rule, double gap_coeff, int32_t node_order) {
+    if (!out || node_order < 0 || node_order > 1 || nel < 1 || nP2 < 1 || nV < 1 || npc < 1 || ndpc < 1 || !cell_p2 || !cent || !cell_dofs || leaf_size < 1 || min_depth < 0 ||
         axis_rule < 0 || axis_rule > 2 || (axis_rule >= 1 && !cext) || !(gap_coeff >= 0.0)) {
         g_error = "femo_plan_build: bad arguments";
         return 1;
@@ -247,6 +253,42 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
         std::vector<int64_t> fill(piv_off.begin(), piv_off.end() - 1);
         for (int32_t n = 0; n < nP2; ++n) piv_nodes[fill[owner[n]]++] = n;
     }
+    // node_order 1: the nodes of a separator in the order in which they lie ALONG it, and every boundary list grouped by owner
+    // (nearest ancestor first) in the owner's order.  A subtree touches a connected stretch of an ancestor's separator, so the rows a
+    // child's Schur block contributes to are then a few long RUNS of consecutive rows of the parent front (one per owner group) instead
+    // of node-sized snippets interleaved with the sibling's -- the gathering rank-k updates and the extend-add read their child entries
+    // as contiguous segments (scripts/r6_cinv_runs.py: median run 6-12 entries on levels 1-5 with the ascending-id order).  Position
+    // along a separator: the coordinate, along the axis of the largest extent of the separator's nodes, of the mean centroid of the
+    // cells that touch the node (no node coordinates are handed to this library); ties by node id.
+    std::vector<int32_t> rank;
+    if (node_order == 1) {
+        std::vector<double> nc(3 * (size_t)nP2, 0.0);
+        std::vector<int32_t> cnt(nP2, 0);
+        for (int32_t e = 0; e < nel; ++e)                                  // sequential sums in (cell, local node) order: the numpy twin adds in the same order
+            for (int a = 0; a < npc; ++a) {
+                const int32_t n = cell_p2[(int64_t)e * npc + a];
+                for (int c = 0; c < 3; ++c) nc[3 * (size_t)n + c] += cent[3 * (int64_t)e + c];
+                ++cnt[n];
+            }
+        for (int32_t n = 0; n < nP2; ++n)
+            for (int c = 0; c < 3; ++c) nc[3 * (size_t)n + c] /= (double)std::max(cnt[n], 1);
+        rank.assign(nP2, 0);
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+        for (int32_t t = 0; t < ntree; ++t) {
+            int32_t* b = piv_nodes.data() + piv_off[t];
+            const int64_t n = piv_off[t + 1] - piv_off[t];
+            if (n > 1) {
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int64_t i = 0; i < n; ++i)
+                    for (int c = 0; c < 3; ++c) { const double v = nc[3 * (size_t)b[i] + c]; mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); }
+                int ax = 0;
+                for (int c = 1; c < 3; ++c)
+                    if (mx[c] - mn[c] > mx[ax] - mn[ax]) ax = c;                 // first of equal extents, as numpy's argmax
+                std::stable_sort(b, b + n, [&](int32_t x, int32_t y) { return nc[3 * (size_t)x + ax] < nc[3 * (size_t)y + ax]; });
+            }
+            for (int64_t i = 0; i < n; ++i) rank[b[i]] = (int32_t)i;
+        }
+    }
     // ---- 3. boundary nodes, bottom-up (sorted ascending; union of the children's lists minus the node's own)
     std::vector<std::vector<int32_t>> bnd(ntree);
     {
@@ -274,6 +316,15 @@ int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, in
                     if (owner[n] != t) b.push_back(n);
             }
         }
+    }
+    if (node_order == 1) {
+        // (the unions above need the lists in ascending id; the order of the rows is settled here, once every list is complete)
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+        for (int32_t t = 0; t < ntree; ++t)
+            std::sort(bnd[t].begin(), bnd[t].end(), [&](int32_t x, int32_t y) {
+                const int32_t dx = depth[owner[x]], dy = depth[owner[y]];       // owners are ancestors of t: one per depth
+                return dx != dy ? dx > dy : rank[x] < rank[y];
+            });
     }
     std::vector<int64_t> bnd_off(ntree + 1, 0);
     for (int32_t t = 0; t < ntree; ++t) bnd_off[t + 1] = bnd_off[t] + (int64_t)bnd[t].size();

@@ -15,6 +15,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32]),
     "femo_plan_build_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+    "femo_plan_build_ex2": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double), _i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32]),
     "femo_plan_size": (C.c_int64, [C.c_void_p, C.c_char_p]),
     "femo_plan_itemsize": (C.c_int, [C.c_void_p, C.c_char_p]),
     "femo_plan_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
@@ -39,7 +41,7 @@ def load():
     return _lib
 
 
-def plan_arrays(mesh, leaf_size, min_depth=0, axis_rule=0, gap=0.0):
+def plan_arrays(mesh, leaf_size, min_depth=0, axis_rule=0, gap=0.0, node_order=0):
     """All arrays of include/femo_symbolic.h for ``mesh`` as a dict of numpy arrays.
 
     The library assumes that the P2 nodes below ``nV`` carry six DOFs (u and theta) and the others three.  For CG2CR1 the rotation
@@ -64,9 +66,9 @@ def plan_arrays(mesh, leaf_size, min_depth=0, axis_rule=0, gap=0.0):
     cext = np.ascontiguousarray(xc.max(axis=1) - xc.min(axis=1), dtype=np.float64)
     h = C.c_void_p()
     dp = C.POINTER(C.c_double)
-    rc = lib.femo_plan_build_ex(C.byref(h), mesh.nel, mesh.nP2, nV_lib, cell_p2.shape[1], cell_dofs.shape[1],
-                                cell_p2.ctypes.data_as(_i32p), cent.ctypes.data_as(dp), cext.ctypes.data_as(dp),
-                                cell_dofs.ctypes.data_as(_i32p), int(leaf_size), int(min_depth), int(axis_rule), float(gap))
+    rc = lib.femo_plan_build_ex2(C.byref(h), mesh.nel, mesh.nP2, nV_lib, cell_p2.shape[1], cell_dofs.shape[1],
+                                 cell_p2.ctypes.data_as(_i32p), cent.ctypes.data_as(dp), cext.ctypes.data_as(dp),
+                                 cell_dofs.ctypes.data_as(_i32p), int(leaf_size), int(min_depth), int(axis_rule), float(gap), int(node_order))
     if rc:
         msg = lib.femo_plan_last_error().decode()
         raise ValueError(msg) if rc == 2 else RuntimeError(msg)

@@ -82,18 +82,23 @@ def _tree_from_native(A) -> Tree:
 # 210 GFLOP, the Schur traffic from 9.3 to 7.2 GB and the panel steps of levels >= 6 from 60 to 49.
 AXIS_RULE = 2
 GAP = 0.75
+# Order of the rows inside a front (femo_plan_build_ex2): 1 = the nodes of a separator in the order in which they lie along it, boundary
+# lists grouped by owner (nearest ancestor first) in the owner's order -- a child's Schur block then lands in a few long runs of consecutive
+# parent rows (scripts/r6_cinv_runs.py); 0 = ascending node id (rounds 1-5).
+NODE_ORDER = 1
 GAP_NMIN = 128
 AXIS_NMIN = 16         # rule 2 measures the separators of pieces of at least this many cells
 
 
-def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=None) -> Tree:
+def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=None, node_order=None) -> Tree:
     """Bisection tree, node ownership and boundary lists.  ``min_depth`` forces every branch to be
     split at least that deep (the multi-GPU driver needs 2^d subtrees)."""
     axis_rule = AXIS_RULE if axis_rule is None else int(axis_rule)
     gap = GAP if gap is None else float(gap)
+    node_order = NODE_ORDER if node_order is None else int(node_order)
     if impl == "native":
         from . import _native
-        return _tree_from_native(_native.plan_arrays(mesh, leaf_size, min_depth, axis_rule, gap))
+        return _tree_from_native(_native.plan_arrays(mesh, leaf_size, min_depth, axis_rule, gap, node_order))
     if getattr(mesh, "element", "") == "CG2CR1":
         raise NotImplementedError("the numpy twin of the analysis knows the vertex-rotation layouts only; CG2CR1 goes through the native library")
     nel, nP2 = mesh.nel, mesh.nP2
@@ -227,6 +232,24 @@ def analyse(mesh, leaf_size=12, min_depth=0, impl="native", axis_rule=None, gap=
         else:
             u = np.union1d(bnd[T.left[t]], bnd[T.right[t]])
             bnd[t] = u[owner[u] != t]
+    if node_order == 1:
+        # the nodes of a separator in the order in which they lie along it (coordinate, along the axis of the separator's largest extent,
+        # of the mean centroid of the touching cells; ties by node id), boundary lists grouped by owner -- nearest ancestor first -- in
+        # the owner's order (csrc/symbolic.cpp, node_order 1)
+        nc = np.zeros((nP2, 3))
+        np.add.at(nc, mesh.cell_p2.ravel(), np.repeat(cent, mesh.cell_p2.shape[1], axis=0))      # sequential, (cell, local node) order
+        nc /= np.maximum(np.bincount(mesh.cell_p2.ravel(), minlength=nP2), 1)[:, None]
+        rank = np.zeros(nP2, dtype=np.int64)
+        for t in range(T.ntree):
+            p = T.piv_nodes[t]
+            if p.size > 1:
+                ax = int(np.argmax(nc[p].max(axis=0) - nc[p].min(axis=0)))
+                p = p[np.argsort(nc[p, ax], kind="stable")]
+                T.piv_nodes[t] = p
+            rank[p] = np.arange(p.size)
+        for t in range(T.ntree):
+            b = bnd[t]
+            bnd[t] = b[np.lexsort((rank[b], -T.depth[owner[b]]))]
     T.bnd_nodes = bnd
     return T
 
@@ -294,14 +317,15 @@ def _plan_from_native(A) -> FrontalPlan:
     return plan
 
 
-def build_plan(mesh, leaf_size=12, impl="native", axis_rule=None, gap=None) -> FrontalPlan:
+def build_plan(mesh, leaf_size=12, impl="native", axis_rule=None, gap=None, node_order=None) -> FrontalPlan:
     """Single-GPU plan: every tree node is a front, levels by height."""
     axis_rule = AXIS_RULE if axis_rule is None else int(axis_rule)
     gap = GAP if gap is None else float(gap)
+    node_order = NODE_ORDER if node_order is None else int(node_order)
     if impl == "native":
         from . import _native
-        return _plan_from_native(_native.plan_arrays(mesh, leaf_size, 0, axis_rule, gap))
-    T = analyse(mesh, leaf_size, impl="python", axis_rule=axis_rule, gap=gap)
+        return _plan_from_native(_native.plan_arrays(mesh, leaf_size, 0, axis_rule, gap, node_order))
+    T = analyse(mesh, leaf_size, impl="python", axis_rule=axis_rule, gap=gap, node_order=node_order)
     nV, ndof_u = mesh.nV, mesh.ndof_u
     # DOF lists of all fronts from ONE expansion of the concatenated node lists (pivots first, then the boundary)
     seq = [a for t in range(T.ntree) for a in (T.piv_nodes[t], T.bnd_nodes[t])]

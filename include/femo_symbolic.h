@@ -13,7 +13,7 @@
  *              "elem_front" (cell -> leaf front), "elem_map" (nel x ndpc: row of every element DOF in its leaf front)
  *   nodes:     "owner" (P2 node -> tree node that eliminates it)                  int32
  *              "piv_nodes" / "piv_off", "bnd_nodes" / "bnd_off": per tree node its own nodes and the ancestor-owned
- *              nodes its subtree touches, ascending (CSR; offsets int64)
+ *              nodes its subtree touches, in the order of their rows in the front (node_order; CSR; offsets int64)
  *   fronts:    "npiv", "nf" (pivot DOFs, all DOFs), "dof_off" (int64), "front_dofs" (pivots first),
  *              "up_map" (row of every boundary DOF in the parent front, -1 on pivots)
  *   schedule:  "level_nodes" / "level_off": fronts by height, largest first inside a level
@@ -50,6 +50,17 @@ int femo_plan_build(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32
 int femo_plan_build_ex(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
                        const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
                        int32_t axis_rule, double gap_coeff);
+/* The same with the order of the rows inside a front exposed (femo_plan_build_ex = node_order 0):
+ *   node_order 0: pivot nodes and boundary nodes of a front in ascending node id (rounds 1-5);
+ *   node_order 1 (the package's default): the nodes of a separator in the order in which they lie ALONG it (coordinate, along the axis of
+ *     the separator's largest extent, of the mean centroid of the cells that touch the node), and the boundary nodes of a front grouped
+ *     by owner -- nearest ancestor first -- in the owner's order.  A subtree touches a connected stretch of an ancestor's separator, so a
+ *     child's Schur block lands in a few long runs of consecutive parent rows ("up_map" is increasing, piecewise contiguous) and the
+ *     extend-add gathers of the numeric phase read contiguous segments.  Any order of the pivots inside a front is a valid elimination
+ *     order: the factor differs by rounding only. */
+int femo_plan_build_ex2(femo_plan** out, int32_t nel, int32_t nP2, int32_t nV, int32_t npc, int32_t ndpc, const int32_t* cell_p2,
+                        const double* cent, const double* cext, const int32_t* cell_dofs, int32_t leaf_size, int32_t min_depth,
+                        int32_t axis_rule, double gap_coeff, int32_t node_order);
 /* number of entries of a named array (-1: no such array); 4 or 8 bytes per entry (0: no such array) */
 int64_t femo_plan_size(const femo_plan* p, const char* name);
 int femo_plan_itemsize(const femo_plan* p, const char* name);

@@ -9,6 +9,10 @@ from femo_alpha_amd.backend import ShellContext
 
 which = sys.argv[1] if len(sys.argv) > 1 else "wing1m"
 opts = {a.split("=")[0]: float(a.split("=")[1]) for a in sys.argv[2:]}
+if "node_order" in opts:                     # rows of a front by ascending node id (0, rounds 1-5) or along the separators (1): a plan option
+    from femo_alpha_amd.solver import symbolic as _sym
+    _sym.NODE_ORDER = int(opts.pop("node_order"))
+    print("node_order", _sym.NODE_ORDER)
 m, fields, marker, desc = make_workload(which)
 c = ShellContext(m)
 for k, v in fields.items():
@@ -51,3 +55,8 @@ ts = []
 for _ in range(5):
     ts.append(c.factorize()["factor_ms"])
 print("factor_ms (unprofiled):", " ".join(f"{t:.2f}" for t in ts))
+ts = []
+for _ in range(5):
+    it, rr = c.solve_state(zero_guess=True)
+    ts.append(c.last_timing())
+print("forward solve (assemble + factorise + PCG, ms):", " ".join(f"{t['setup_ms'] + t['krylov_ms']:.2f}" for t in ts), " PCG:", " ".join(f"{t['krylov_ms']:.2f}" for t in ts), f" iterations {it}")

@@ -34,7 +34,7 @@ def test_symbolic_library_builds_and_exports_every_declared_symbol():
     text = open(os.path.join(ROOT, "include", "femo_symbolic.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     syms = sorted(set(re.findall(r"\b(femo_plan_[a-z_A-Z0-9]+)\s*\(", text)))
-    assert len(syms) == 7
+    assert len(syms) == 8
     for s in syms:
         assert hasattr(lib, s), f"libfemo_symbolic.so does not export {s}"
     assert sorted(_native.SIGNATURES) == syms, "ctypes SIGNATURES and include/femo_symbolic.h disagree"
