@@ -831,6 +831,28 @@ def main():
                             "tflops": prof[fk + "_flops"] / (ms * 1e-3) / 1e12 if ms > 0 else None,
                             "compulsory_GB": prof[fk + "_bytes"] / 1e9}
 
+    # the adjoint gradient of FOUR outputs of the state in one grouped solve (femo_total_gradients: compliance, elastic energy and two
+    # stress aggregates -- the reference registers these on disp_solid, rm_shell_model.py:221-253, and solves one adjoint per output):
+    # the four right-hand sides share the triangular sweeps (csrc/sweeps_multi.h); beside it the sweeps alone for 1 / 2 / 4 vectors
+    multi = None
+    if args.solver == "frontal" and world == 1:
+        ctx.solve_state(zero_guess=True)
+        ctx.set_stress_params(m=1e-6, rho=6.0)
+        names = ["compliance", "elastic_energy", "pnorm_stress", "tip_disp"]
+        def timed(fn, reps=7):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); out_ = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            return float(np.median(ts[1:]) * 1e3), out_
+        t4, (_, its4, _) = timed(lambda: ctx.total_gradients(names, "thickness"))
+        t1, _ = timed(lambda: ctx.total_gradient("compliance", "thickness"))
+        t4s, _ = timed(lambda: [ctx.total_gradient(nm, "thickness") for nm in names], reps=4)
+        sw = {f"vectors_{nr}": ctx.bench_kernel(f"sweeps{nr}", 20) for nr in (1, 2, 4)}
+        multi = {"adjoint_ms_4_outputs": t4, "adjoint_ms_1_output_same_clock": t1, "adjoint_ms_4_outputs_one_at_a_time": t4s,
+                 "ratio_4_outputs_to_1": t4 / t1, "outputs": names, "pcg_iterations": [int(v) for v in its4],
+                 "preconditioner_application_ms": sw,
+                 "what": "host wall-clock around the C-ABI call (device-to-host copy of the gradients inside), median of 6"}
+
     # true residual of the last forward solve, || F - K w || / || F || evaluated by the matrix-free operator (the
     # relres_* figures of the Krylov loop are recurrence residuals)
     ctx.solve_state(zero_guess=True)
@@ -922,6 +944,9 @@ def main():
             # once per mesh, outside the timed region (first solve of a new mesh = these + one step)
             "setup_s": setup,
         }
+        if multi is not None:
+            out["adjoint_ms_4_outputs"] = multi["adjoint_ms_4_outputs"]
+            out["adjoint_of_several_outputs"] = multi
         if keep is not None:
             out["keep_numbering"] = keep
         if rule4 is not None:

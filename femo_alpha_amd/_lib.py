@@ -44,11 +44,15 @@ SIGNATURES = {
     "femo_factorize_profile": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_frontal_info": (C.c_int, [C.c_void_p, _c_double_p]),
     "femo_sweep_profile": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64]),
+    "femo_sweep_profile_multi": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, C.c_int64]),
     "femo_set_solver": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int32, C.c_int32]),
     "femo_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "femo_set_krylov": (C.c_int, [C.c_void_p, C.c_int]),
     "femo_solve_state": (C.c_int, [C.c_void_p, C.c_int, _c_int32_p, _c_double_p]),
     "femo_solve_linear": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_solve_linear_multi": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p, _c_int32_p, _c_double_p]),
+    "femo_total_gradients": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _c_int32_p, C.c_char_p, _c_double_p, C.c_int64,
+                                       _c_int32_p, _c_double_p]),
     "femo_force_to_pressure": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_double, C.c_int32, _c_int32_p, _c_double_p]),
     "femo_set_operator": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "femo_set_strain_quadrature": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -246,6 +246,12 @@ class ShellContext:
         t = t.reshape(-1, 4)
         return t if detail else np.stack([t[:, 0] + t[:, 1], t[:, 2] + t[:, 3]], axis=1)
 
+    def sweep_profile_multi(self, nrhs):
+        """(nlevels, 2): ms of the forward / backward sweep per level with ``nrhs`` (2 or 4) interleaved vectors."""
+        t = np.zeros(2 * self.plan.nlevels)
+        self._chk(self.lib.femo_sweep_profile_multi(self._h, int(nrhs), dptr(t), t.size))
+        return t.reshape(-1, 2)
+
     def frontal_info(self):
         t = np.zeros(6)
         self._chk(self.lib.femo_frontal_info(self._h, dptr(t)))
@@ -277,6 +283,16 @@ class ShellContext:
         it = C.c_int32(); rr = C.c_double()
         self._chk(self.lib.femo_solve_linear(self._h, dptr(rhs), dptr(x), C.byref(it), C.byref(rr)))
         return x, it.value, rr.value
+
+    def solve_linear_multi(self, rhs):
+        """x_i = K^-1 rhs_i for the rows of ``rhs`` (nrhs, ndof): with the multifrontal preconditioner the right-hand sides share the
+        triangular sweeps in groups of up to four (femo_solve_linear_multi).  Returns (x (nrhs, ndof), iterations, relative residuals)."""
+        rhs = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).reshape(-1, self.ndof))
+        nr = rhs.shape[0]
+        x = np.empty_like(rhs)
+        it = np.zeros(nr, dtype=np.int32); rr = np.zeros(nr)
+        self._chk(self.lib.femo_solve_linear_multi(self._h, nr, dptr(rhs), dptr(x), iptr(it), dptr(rr)))
+        return x, it, rr
 
     def force_to_pressure(self, force, rtol=1e-13, maxit=500):
         """pressure = A^-1 force, A the consistent mass matrix of [CG1]^3 (rm_shell_model.py:414-421): Jacobi-PCG on the device."""
@@ -449,6 +465,20 @@ class ShellContext:
         self._chk(self.lib.femo_total_gradient(self._h, functional.encode(), arg.encode(), dptr(out), out.size,
                                                C.byref(it), C.byref(rr)))
         return out, it.value, rr.value
+
+    def total_gradients(self, functionals, arg, subdomains=None):
+        """d J_i / d arg for several functionals of the state with ONE grouped adjoint solve (femo_total_gradients); ``subdomains``:
+        per functional the tagged sub-domain it is restricted to (-1: the whole mesh).  Returns (gradients (nfun, n), iterations,
+        relative residuals)."""
+        names = [f.encode() for f in functionals]
+        nf = len(names)
+        arr = (C.c_char_p * nf)(*names)
+        out = np.empty((nf, self.field_size(arg)))
+        it = np.zeros(nf, dtype=np.int32); rr = np.zeros(nf)
+        sub = None if subdomains is None else np.ascontiguousarray(np.asarray(subdomains, dtype=np.int32))
+        self._chk(self.lib.femo_total_gradients(self._h, nf, arr, None if sub is None else iptr(sub), arg.encode(), dptr(out), out.shape[1],
+                                                iptr(it), dptr(rr)))
+        return out, it, rr
 
     # ------------------------------------------------------------------ building blocks of the multi-GPU driver
     def vec_tensor(self, name):

@@ -3,6 +3,7 @@
 #include "../../include/femo_hip.h"
 #include "shell_device.h"
 #include "frontal.h"
+#include "sweeps_multi.h"
 #include "shape_sens.h"
 #include "stress.h"
 #include "csr_map.h"
@@ -37,6 +38,11 @@ struct femo_ctx {
     double* bi[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // BiCGStab work vectors (allocated on first use)
     int tab_nq = 0;                          // quadrature points of the operator's tables (c->tab)
     double hK_mean = 0;                      // mean cell diameter (the yardstick of a change of uhat, option "stale_factor")
+    // multi-right-hand-side solves (femo_solve_linear_multi): two interleaved buffers of 4 ndof doubles for the sweeps, 5 work vectors
+    // per right-hand side (x, r, z, p, Ap), 8 device scalars per right-hand side; allocated on first use
+    double *mr_v = nullptr, *mr_y = nullptr, *mr_work = nullptr, *mr_scal = nullptr, *mr_scal_host = nullptr;
+    double* mr_io = nullptr;                 // right-hand sides, solutions and gradients of the multi entry points (grown on demand, kept)
+    size_t mr_io_cap = 0;
     long long opt_version = 0;               // bumped by every femo_set_option
     hipStream_t stream2 = nullptr;           // look-ahead: the bulk of a trailing update runs beside the next panel
     hipEvent_t ev_la[2] = {nullptr, nullptr};
@@ -193,6 +199,7 @@ struct femo_ctx {
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
         // reference never refreshes its derivative matrices at all (quirk Q2, csdl_alpha_opt/state_operation.py:130-131)
+        int multi_rhs = 1;        // femo_solve_linear_multi / femo_total_gradients: 1 = right-hand sides share the sweeps in groups of up to 4; 0 = one at a time
         int stale_factor = 0;
         // ... and only while no field has moved further than this from the factor's design (relative L2 norm).  Measured at 1 M DOF
         // (profiles/r5_stale_factor.txt): forward + adjoint with the kept factor 12.8 / 15.7 / 18.7 / 24.7 ms at a relative nodal change of
@@ -1441,6 +1448,185 @@ static int frontal_solve(femo_ctx* c, double* v) {
     return 0;
 }
 
+// ---- several right-hand sides through ONE pair of sweeps (sweeps_multi.h): V and Y hold NR interleaved vectors.  Same schedule as
+// frontal_fwd / frontal_bwd in its default form (level by level; the fused and the W forms are single-vector experiments).
+template <int NR>
+static int frontal_solve_multi(femo_ctx* c, double* V, double* Y, std::vector<hipEvent_t>* marks = nullptr) {
+    auto mark = [&]() { if (marks) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); marks->push_back(e); } };
+    auto& fr = c->fr;
+    const FrontDev fd = front_dev(c);
+    const size_t bytes = (size_t)c->ndof * NR * sizeof(double);
+    HIPCHK(c, hipMemsetAsync(Y, 0, bytes, c->stream));
+    mark();
+    for (int L = 0; L < fr.nlevels; ++L) {
+        const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
+        const int* lev = fr.level_nodes + b;
+        const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnp == 0) { mark(); continue; }
+        if (fr.h_level_wide[L]) {
+            if (join_xinv(c)) return 1;
+            const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
+            FOR_FRONT_CHUNKS(cnt, off, n)
+                hipLaunchKernelGGL((k_sweep_gemv_n_m<true, NR>), dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)V, Y);
+            if (maxnb > 0)
+                FOR_FRONT_CHUNKS(cnt, off, n)
+                    hipLaunchKernelGGL((k_sweep_gemv_n_m<false, NR>), dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)Y, V);
+        } else {
+            const size_t shm = (size_t)(maxnp + SMALL_PART) * NR * sizeof(double);
+            hipLaunchKernelGGL(k_front_fwd_small_m<NR>, dim3(cnt), dim3(256), shm, c->stream, fd, lev, V, Y);
+        }
+        mark();
+    }
+    HIPCHK(c, hipMemsetAsync(V, 0, bytes, c->stream));
+    mark();
+    for (int L = fr.nlevels - 1; L >= 0; --L) {
+        const int b = fr.h_level_off[L], cnt = fr.h_level_off[L + 1] - b;
+        const int* lev = fr.level_nodes + b;
+        const int maxnp = fr.h_level_maxnp[L], maxnb = fr.h_level_maxnb[L];
+        if (maxnp == 0) { mark(); continue; }
+        if (fr.h_level_wide[L]) {
+            if (join_xinv(c)) return 1;
+            const int nct = (maxnp + 127) / 128, nrt = (maxnb + 127) / 128;
+            if (maxnb > 0) {
+                if (maxnb >= c->opt.bnd_tiled_nb || (size_t)maxnb * NR * sizeof(double) > 60 * 1024) {
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        hipLaunchKernelGGL((k_sweep_gemv_t_m<false, NR>), dim3(nrt * nct, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)V, Y);
+                } else {
+                    FOR_FRONT_CHUNKS(cnt, off, n)
+                        hipLaunchKernelGGL(k_sweep_bnd_cols_m<NR>, dim3((maxnp + BB_COLS - 1) / BB_COLS, n), dim3(256), (size_t)maxnb * NR * sizeof(double),
+                                           c->stream, fd, lev, off, Y, (const double*)V);
+                }
+            }
+            FOR_FRONT_CHUNKS(cnt, off, n)
+                hipLaunchKernelGGL((k_sweep_gemv_t_m<true, NR>), dim3(nct * (nct + 1) / 2, n), dim3(256), 0, c->stream, fd, lev, off, (const double*)Y, V);
+        } else {
+            const size_t shm = (size_t)(maxnp + maxnb + SMALL_PART) * NR * sizeof(double);
+            hipLaunchKernelGGL(k_front_bwd_small_m<NR>, dim3(cnt), dim3(256), shm, c->stream, fd, lev, (const double*)Y, V);
+        }
+        mark();
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static double* mr_io_buffer(femo_ctx* c, size_t doubles) {
+    if (doubles > c->mr_io_cap) {
+        if (c->mr_io) { hipStreamSynchronize(c->stream); hipFree(c->mr_io); c->mr_io = nullptr; c->mr_io_cap = 0; }
+        if (hipMalloc((void**)&c->mr_io, doubles * sizeof(double)) != hipSuccess) { c->err = "out of device memory"; return nullptr; }
+        c->mr_io_cap = doubles;
+    }
+    return c->mr_io;
+}
+
+static int mr_alloc(femo_ctx* c) {
+    if (c->mr_v) return 0;
+    const size_t n = (size_t)c->ndof;
+    HIPCHK(c, hipMalloc((void**)&c->mr_v, 4 * n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->mr_y, 4 * n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->mr_work, 20 * n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->mr_scal, 32 * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void**)&c->mr_scal_host, 32 * sizeof(double)));
+    return 0;
+}
+
+// z_r = (L L^T)^-1 r_r for g = 1 .. 4 vectors at once: 3 vectors ride as 4 (the fourth lane carries zeros)
+static int frontal_apply_group(femo_ctx* c, int g, double* const* rin, double* const* zout) {
+    const int64_t n = c->ndof;
+    if (g == 1) {
+        HIPCHK(c, hipMemcpyAsync(zout[0], rin[0], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return frontal_solve(c, zout[0]);
+    }
+    const int NRk = g == 2 ? 2 : 4;
+    VecPtrs src, dst;
+    for (int r = 0; r < 4; ++r) { src.p[r] = rin[std::min(r, g - 1)]; dst.p[r] = zout[std::min(r, g - 1)]; }
+    const int vg = vec_grid(n);
+    if (NRk == 2) {
+        hipLaunchKernelGGL(k_interleave<2>, dim3(vg), dim3(256), 0, c->stream, src, c->mr_v, n);
+        if (int rc = frontal_solve_multi<2>(c, c->mr_v, c->mr_y)) return rc;
+        hipLaunchKernelGGL(k_deinterleave<2>, dim3(vg), dim3(256), 0, c->stream, (const double*)c->mr_v, dst, n);
+    } else {
+        // (g == 3: lane 3 repeats vector 2 and is written back to the same place with the same values)
+        hipLaunchKernelGGL(k_interleave<4>, dim3(vg), dim3(256), 0, c->stream, src, c->mr_v, n);
+        if (int rc = frontal_solve_multi<4>(c, c->mr_v, c->mr_y)) return rc;
+        hipLaunchKernelGGL(k_deinterleave<4>, dim3(vg), dim3(256), 0, c->stream, (const double*)c->mr_v, dst, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// PCG with the multifrontal preconditioner for g <= 4 right-hand sides: independent recurrences (own alpha, beta and stopping test
+// per right-hand side -- the iterates are those of g separate solves), the preconditioner applied to all residuals in ONE pair of
+// sweeps, one host synchronisation per iteration.  B[r] is overwritten (masked), X[r] receives the solution (zero initial guess).
+static int pcg_frontal_group(femo_ctx* c, int g, double* const* B, double* const* X, int32_t* iters, double* relres) {
+    const int64_t n = c->ndof;
+    const int vg = vec_grid(n);
+    const unsigned char* mask = c->has_mask ? c->mask : nullptr;
+    if (mr_alloc(c)) return 1;
+    if (!c->fr.factored)
+        if (int rc = frontal_factorize(c)) return rc;
+    double *R[4], *Z[4], *P[4], *AP[4];
+    for (int r = 0; r < g; ++r) {
+        double* base = c->mr_work + (size_t)r * 5 * n;
+        R[r] = base; Z[r] = base + n; P[r] = base + 2 * n; AP[r] = base + 3 * n;
+    }
+    double bb[4] = {0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemsetAsync(c->mr_scal, 0, 32 * sizeof(double), c->stream));
+    for (int r = 0; r < g; ++r) {
+        if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, B[r], mask, n);
+        hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)B[r], (const double*)B[r], n, c->mr_scal + 8 * r + 3);
+        hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, X[r], 0.0, n);
+        HIPCHK(c, hipMemcpyAsync(R[r], B[r], (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->mr_scal_host, c->mr_scal, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool active[4] = {false, false, false, false};
+    int its[4] = {0, 0, 0, 0};
+    for (int r = 0; r < g; ++r) { bb[r] = rr[r] = c->mr_scal_host[8 * r + 3]; active[r] = bb[r] > 0; }
+    int k = 0;
+    auto any_active = [&]() { for (int r = 0; r < g; ++r) if (active[r]) return true; return false; };
+    while (any_active() && k < c->maxit) {
+        // one application of the factor for every residual (those of converged right-hand sides ride along: the bytes are the factor's)
+        if (int rc = frontal_apply_group(c, g, R, Z)) return rc;
+        for (int r = 0; r < g; ++r) {
+            if (!active[r]) continue;
+            double* sc = c->mr_scal + 8 * r;
+            HIPCHK(c, hipMemsetAsync(sc + 1, 0, 3 * sizeof(double), c->stream));
+            hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)R[r], (const double*)Z[r], n, sc + 1);
+            hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, P[r], (const double*)Z[r], (const double*)sc, k == 0 ? 1 : 0, n);
+            hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, AP[r], 0.0, n);
+            if (op_apply(c, P[r], AP[r], nullptr, nullptr, nullptr, true, c->op_aK, c->op_aM)) return 1;
+            if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, AP[r], mask, n);
+            hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, (const double*)P[r], (const double*)AP[r], n, sc + 2);
+            hipLaunchKernelGGL(k_pcgf_update, dim3(red_grid(n)), dim3(256), 0, c->stream, X[r], R[r], (const double*)P[r], (const double*)AP[r], sc, n);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->mr_scal_host, c->mr_scal, 32 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ++k;
+        for (int r = 0; r < g; ++r) {
+            if (!active[r]) continue;
+            const double pAp = c->mr_scal_host[8 * r + 2];
+            rr[r] = c->mr_scal_host[8 * r + 3];
+            its[r] = k;
+            if (!(pAp > 0)) return fail(c, "PCG broke down: p.Ap <= 0 (preconditioner or operator not positive definite)");
+            if (!(rr[r] > c->rtol * c->rtol * bb[r])) active[r] = false;
+        }
+    }
+    int rc = 0;
+    for (int r = 0; r < g; ++r) {
+        if (iters) iters[r] = its[r];
+        const double rel = bb[r] > 0 ? sqrt(rr[r] / bb[r]) : 0.0;
+        if (relres) relres[r] = rel;
+        if (active[r] && c->opt.strict) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "PCG (multifrontal preconditioner, %d right-hand sides) did not converge: relative residual %.3e after %d iterations "
+                     "(rtol %.1e, maxit %d)", g, rel, k, c->rtol, c->maxit);
+            c->err = buf;
+            rc = 4;
+        }
+    }
+    return rc;
+}
+
 // The preconditioner application of the PCG loop (always on c->z: ~56 dependent launches whose arguments depend on the plan and the
 // options only) captured once as a HIP graph and replayed (option "sweep_graph").
 static int frontal_solve_z(femo_ctx* c) {
@@ -1871,7 +2057,6 @@ int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int
     if (element != 0 && element != 1) { g_create_error = "element: 0 (CG2CG1 / CG1CG1 by the node count) or 1 (CG2CR1)"; return 2; }
     const bool cr = element == 1;
     if (cr && (nvc != 3 || cg1)) { g_create_error = "Invalid element type: CG2CR1 is defined on triangles with P2 displacement"; return 2; }
-    if (cr && nghost != 0) { g_create_error = "CG2CR1: the element-partitioned driver is not provided for this element"; return 2; }
     for (int64_t i = 0; i < (int64_t)nel * nvc; ++i)
         if (cells[i] < 0 || cells[i] >= nn) { g_create_error = "cells refers to a vertex outside 0..nn-1"; return 2; }
     for (int64_t i = 0; i < (int64_t)nel * npc; ++i)
@@ -1904,6 +2089,10 @@ void femo_destroy(femo_ctx* c) {
     void* nptrs[] = {c->nm.W, c->nm.Fh, c->nm.wdot, c->nm.Fsw, c->nm.mu0, c->nm.mu1, c->nm.Lam, c->nm.Gh};
     for (void* p : nptrs)
         if (p) hipFree(p);
+    void* mptrs[] = {c->mr_v, c->mr_y, c->mr_work, c->mr_scal, c->mr_io};
+    for (void* p : mptrs)
+        if (p) hipFree(p);
+    if (c->mr_scal_host) hipHostFree(c->mr_scal_host);
     void* dptrs[] = {c->di.top_idx, c->di.sel, c->di.wdot, c->di.topbuf, c->di.topsave, c->di.gloc};
     for (void* p : dptrs)
         if (p) hipFree(p);
@@ -2286,6 +2475,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "sweep_fuse") o.sweep_fuse = v != 0;
     else if (k == "assemble_fc") { if (v < 0 || v > 2) return fail(c, "assemble_fc: 0 never, 1 where it pays, 2 always"); o.assemble_fc = v; }
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
+    else if (k == "multi_rhs") { o.multi_rhs = v != 0; }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
     else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }
@@ -2540,6 +2730,90 @@ int femo_total_gradient(femo_ctx* c, const char* functional, const char* arg, do
     return rc;
 }
 
+
+// Several linear solves with the state operator at once.  With the multifrontal preconditioner the right-hand sides travel through the
+// triangular sweeps in groups of up to four (sweeps_multi.h: the factor bytes are read once per group); any other solver setting, and
+// the experimental sweep forms that rewrite the factor, take them one after the other.
+static bool multi_sweeps_apply(const femo_ctx* c) {
+    return c->precond == 2 && c->krylov == 0 && c->fr.ready && c->opt.sweep_w == 0 && !c->opt.equilibrate && c->opt.multi_rhs != 0;
+}
+
+// B: nrhs device vectors (overwritten), X: nrhs device vectors
+static int solve_multi_dev(femo_ctx* c, int nrhs, double* const* B, double* const* X, int32_t* iters, double* relres) {
+    int rc_all = 0;
+    float t_fac = 0;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    for (int r0 = 0; r0 < nrhs;) {
+        const int g = multi_sweeps_apply(c) ? std::min(4, nrhs - r0) : 1;
+        int rc;
+        if (g == 1) rc = solve_dispatch(c, B[r0], X[r0], true, iters ? iters + r0 : nullptr, relres ? relres + r0 : nullptr);
+        else rc = pcg_frontal_group(c, g, B + r0, X + r0, iters ? iters + r0 : nullptr, relres ? relres + r0 : nullptr);
+        if (rc && rc != 4) return rc;
+        if (rc) rc_all = rc;
+        r0 += g;
+    }
+    (void)t_fac;
+    return rc_all;
+}
+
+int femo_solve_linear_multi(femo_ctx* c, int32_t nrhs, const double* rhs, double* x, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nrhs < 1 || !rhs || !x) return fail(c, "femo_solve_linear_multi: nrhs >= 1 right-hand sides, one vector after the other");
+    const size_t n = (size_t)c->ndof;
+    double* Bd = mr_io_buffer(c, 2 * (size_t)nrhs * n);
+    if (!Bd) return 1;
+    double* Xd = Bd + (size_t)nrhs * n;
+    std::vector<double*> B(nrhs), X(nrhs);
+    for (int r = 0; r < nrhs; ++r) { B[r] = Bd + r * n; X[r] = Xd + r * n; }
+    int rc = 0;
+    if (hipMemcpy(Bd, rhs, (size_t)nrhs * n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, "copy of the right-hand sides failed");
+    if (!rc) rc = solve_multi_dev(c, nrhs, B.data(), X.data(), iters, relres);
+    if (!rc || rc == 4) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(x, Xd, (size_t)nrhs * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    return rc;
+}
+
+// Total derivatives of SEVERAL functionals of the state with respect to one argument: the adjoint right-hand sides dJ_i/dw are known
+// together, so their solves share the sweeps (the reference solves one adjoint per output: state_operation.py:188-220 called once per
+// registered output of `disp_solid`, rm_shell_model.py:221-253).  subdomains[i] restricts functional i to a tagged sub-domain
+// (femo_set_cell_tags; -1 or a NULL array: the whole mesh) -- the reference's pnorm_stress_<tag>.  out: nfun x n, row i = d J_i / d arg.
+int femo_total_gradients(femo_ctx* c, int32_t nfun, const char* const* functionals, const int32_t* subdomains, const char* arg, double* out,
+                         int64_t n, int32_t* iters, double* relres) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nfun < 1 || !functionals || !out) return fail(c, "femo_total_gradients: nfun >= 1 functional names");
+    const std::string a(arg ? arg : "");
+    const size_t nd = (size_t)c->ndof;
+    const int keep_sel = c->csel;
+    for (int i = 0; i < nfun; ++i)
+        if (subdomains && (subdomains[i] < -1 || subdomains[i] >= c->ntags)) return fail(c, "unknown sub-domain");
+    double* Bd = mr_io_buffer(c, (size_t)nfun * (2 * nd + (size_t)std::max<int64_t>(n, 1)));
+    if (!Bd) return 1;
+    double *Xd = Bd + (size_t)nfun * nd, *Gd = Xd + (size_t)nfun * nd;
+    std::vector<double*> B(nfun), X(nfun);
+    for (int i = 0; i < nfun; ++i) { B[i] = Bd + i * nd; X[i] = Xd + i * nd; }
+    int rc = 0;
+    for (int i = 0; i < nfun && !rc; ++i) {
+        c->csel = subdomains ? subdomains[i] : -1;
+        rc = dfunctional_dev(c, functionals[i] ? functionals[i] : "", "disp_solid", B[i], c->ndof);      // dJ_i/dw
+    }
+    if (!rc) { rc = solve_multi_dev(c, nfun, B.data(), X.data(), iters, relres); }                       // lambda_i = K^-1 dJ_i/dw
+    for (int i = 0; i < nfun && !rc; ++i) {
+        c->csel = subdomains ? subdomains[i] : -1;
+        double* g = Gd + (size_t)i * n;
+        rc = dfunctional_dev(c, functionals[i], a, g, n);                                                // dJ_i/d arg (zero-fills g)
+        if (!rc) rc = dRdarg_T_dev(c, a, X[i], -1.0, g, n);                                              // - (dR/d arg)^T lambda_i
+    }
+    c->csel = keep_sel;
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, Gd, (size_t)nfun * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = 1; }
+    }
+    return rc;
+}
 
 int femo_set_frontal_plan(femo_ctx* c, int32_t ntree, int32_t nlevels, const int32_t* nf, const int32_t* npiv,
                           const int64_t* front_off, const int64_t* dof_off, const int32_t* front_dofs, const int32_t* up_map,
@@ -2858,6 +3132,37 @@ int femo_sweep_profile(femo_ctx* c, double* out, int64_t n) {
     }
     for (auto e : mf) hipEventDestroy(e);
     for (auto e : mb) hipEventDestroy(e);
+    return rc;
+}
+
+// the same for the sweeps with nrhs = 2 or 4 interleaved vectors (sweeps_multi.h): out[2 L] = forward sweep of level L, out[2 L + 1] =
+// backward sweep (ms); n >= 2 nlevels
+int femo_sweep_profile_multi(femo_ctx* c, int32_t nrhs, double* out, int64_t n) {
+    HIPCHK(c, hipSetDevice(c->device));
+    auto& fr = c->fr;
+    if (!fr.ready) return fail(c, "no frontal plan");
+    if (nrhs != 2 && nrhs != 4) return fail(c, "nrhs: 2 or 4");
+    if (n < 2 * (int64_t)fr.nlevels) return fail(c, "output too small: 2 * nlevels doubles");
+    if (!fr.factored)
+        if (int rc = frontal_factorize(c)) return rc;
+    if (mr_alloc(c)) return 1;
+    hipLaunchKernelGGL(k_fill, dim3(vec_grid((int64_t)c->ndof * nrhs)), dim3(256), 0, c->stream, c->mr_v, 1.0, (int64_t)c->ndof * nrhs);
+    if (join_xinv(c)) return 1;
+    std::vector<hipEvent_t> mk;
+    int rc = nrhs == 2 ? frontal_solve_multi<2>(c, c->mr_v, c->mr_y, &mk) : frontal_solve_multi<4>(c, c->mr_v, c->mr_y, &mk);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "synchronisation failed");
+    if (!rc && (int)mk.size() == 2 * fr.nlevels + 2) {
+        for (int L = 0; L < fr.nlevels; ++L) {
+            float a = 0, b = 0;
+            hipEventElapsedTime(&a, mk[L], mk[L + 1]);
+            const int k = fr.nlevels + 1 + (fr.nlevels - 1 - L);          // the backward sweep visits the levels in reverse
+            hipEventElapsedTime(&b, mk[k], mk[k + 1]);
+            out[2 * L] = a; out[2 * L + 1] = b;
+        }
+    } else if (!rc) {
+        rc = fail(c, "internal: unexpected number of sweep marks");
+    }
+    for (auto e : mk) hipEventDestroy(e);
     return rc;
 }
 
@@ -3783,6 +4088,15 @@ int femo_bench_kernel(femo_ctx* c, const char* name, int32_t reps, double* avg_m
         if (s == "pcg_update") { hipLaunchKernelGGL(k_pcg_update, dim3(vg), dim3(256), 0, c->stream, c->tmp, c->r, c->z, c->p, c->Ap, c->dinv, (const unsigned char*)nullptr, n, c->scal, 0); return 0; }
         if (s == "pcg_direction") { hipLaunchKernelGGL(k_pcg_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->Ap, n, c->scal, 0); return 0; }
         if (s == "diag") { ELEM_LAUNCH(c, k_diag, NOEXTRA, nblk(c->nel, EB), EB, mesh_dev(c), fields_dev(c), c->tab, c->tmp); return 0; }
+        // one application of the factor to 1 / 2 / 4 vectors (the sweeps alone: no interleaving copies); needs a factorisation
+        if (s == "sweeps1" || s == "sweeps2" || s == "sweeps4") {
+            if (!c->fr.factored) return fail(c, "no factorisation to sweep with");
+            if (mr_alloc(c)) return 1;
+            if (s == "sweeps1") { hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->z, 1.0, n); return frontal_solve(c, c->z); }
+            const int nr = s == "sweeps2" ? 2 : 4;
+            hipLaunchKernelGGL(k_fill, dim3(vec_grid(n * nr)), dim3(256), 0, c->stream, c->mr_v, 1.0, n * nr);
+            return nr == 2 ? frontal_solve_multi<2>(c, c->mr_v, c->mr_y) : frontal_solve_multi<4>(c, c->mr_v, c->mr_y);
+        }
         return fail(c, "unknown kernel '" + s + "'");
     };
     for (int i = 0; i < 3; ++i)

@@ -8,6 +8,8 @@
 // doubles, and the atomics of a tile go to adjacent addresses.  The plain kernels stay what they are (NR = 1 is not routed here).
 #pragma once
 
+namespace femo {
+
 // forward, one workgroup per front (levels of many small fronts): y_p = L11^-1 v_p -> yv ; v_B -= L21 y_p
 template <int NR>
 __global__ void __launch_bounds__(256, NR > 2 ? 2 : 3)
@@ -416,3 +418,5 @@ __global__ void k_deinterleave(const double* __restrict__ src, VecPtrs dst, int6
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) dst.p[rr][i] = src[i * NR + rr];
 }
+
+}  // namespace femo

@@ -46,9 +46,24 @@ class Tree:
     (``piv_nodes``) and the ancestor-owned P2 nodes its subtree touches (``bnd_nodes``)."""
 
 
-def _node_dofs(nodes, nV, ndof_u):
-    """DOF ids of P2 nodes (vertices carry u and theta: 6 DOFs, the others 3), concatenated in order."""
+def _node_dofs(nodes, nV, ndof_u, rot=None):
+    """DOF ids of P2 nodes (the nodes that carry the rotation have u and theta: 6 DOFs, the others 3), concatenated in order.
+    The rotation lives on the vertices (nodes < nV, theta of vertex v at ndof_u + 3 v + c) -- or, ``rot = (first, count)``: CG2CR1,
+    on the edge midpoints, the P2 nodes first .. first + count - 1 (theta of edge k at ndof_u + 3 k + c)."""
     nodes = np.asarray(nodes, dtype=np.int64)
+    if rot is not None:
+        r0, nr = rot
+        is_r = (nodes >= r0) & (nodes < r0 + nr)
+        cnt = np.where(is_r, 6, 3)
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        out = np.empty(off[-1], dtype=np.int64)
+        base = off[:-1]
+        for c in range(3):
+            out[base + c] = 3 * nodes + c
+        rb, rn = base[is_r], nodes[is_r] - r0
+        for c in range(3):
+            out[rb + 3 + c] = ndof_u + 3 * rn + c
+        return out
     is_v = nodes < nV
     cnt = np.where(is_v, 6, 3)
     off = np.concatenate([[0], np.cumsum(cnt)])
@@ -347,8 +362,6 @@ def build_plan(mesh, leaf_size=12, impl="native", axis_rule=None, gap=None, node
 
 
 def rank_plan(mesh, T: Tree, rank, nranks):
-    if getattr(mesh, "element", "") == "CG2CR1":
-        raise NotImplementedError("CG2CR1: the element-partitioned driver is not provided for this element")
     return _rank_plan(mesh, T, rank, nranks)
 
 
@@ -377,6 +390,9 @@ def _rank_plan(mesh, T: Tree, rank, nranks):
         raise ValueError("tree is not deep enough for this many ranks")
     root = int(roots[rank])
     nVg, ndof_ug = mesh.nV, mesh.ndof_u
+    # CG2CR1 (linear_shell_model.py:68-73): the rotation lives on the edge midpoints, P2 nodes nV .. nV + nE - 1
+    cr = getattr(mesh, "element", "") == "CG2CR1"
+    rot_g = (mesh.nV, mesh.nE) if cr else None
     # ---- sub-mesh
     cells_g = np.sort(T.eorder[T.lo[root]:T.hi[root]])
     verts_g = np.unique(mesh.cells[cells_g])
@@ -388,7 +404,10 @@ def _rank_plan(mesh, T: Tree, rank, nranks):
     l2g_dof = np.empty(sub.ndof, dtype=np.int64)
     for c in range(3):
         l2g_dof[3 * np.arange(sub.nP2) + c] = 3 * l2g_p2 + c
-        l2g_dof[sub.ndof_u + 3 * np.arange(sub.nV) + c] = ndof_ug + 3 * verts_g + c
+        if cr:
+            l2g_dof[sub.ndof_u + 3 * np.arange(sub.nE) + c] = ndof_ug + 3 * (l2g_p2[sub.nV:sub.nV + sub.nE] - nVg) + c
+        else:
+            l2g_dof[sub.ndof_u + 3 * np.arange(sub.nV) + c] = ndof_ug + 3 * verts_g + c
     # ---- which tree nodes become fronts here
     top = np.nonzero(T.depth < d)[0]
     in_sub = np.zeros(T.ntree, dtype=bool)
@@ -404,7 +423,7 @@ def _rank_plan(mesh, T: Tree, rank, nranks):
     new_id = -np.ones(T.ntree, dtype=np.int64)
     new_id[order] = np.arange(order.size)
     # ---- replicated DOFs and ghosts
-    top_dofs_g = np.sort(np.concatenate([_node_dofs(T.piv_nodes[t], nVg, ndof_ug) for t in top])) if top.size else np.zeros(0, np.int64)
+    top_dofs_g = np.sort(np.concatenate([_node_dofs(T.piv_nodes[t], nVg, ndof_ug, rot_g) for t in top])) if top.size else np.zeros(0, np.int64)
     srt = np.argsort(l2g_dof, kind="stable")
     lg_sorted = l2g_dof[srt]
     k = np.searchsorted(lg_sorted, top_dofs_g)
@@ -427,8 +446,8 @@ def _rank_plan(mesh, T: Tree, rank, nranks):
     dof_lists, npiv, level_of = [], [], []
     h_root = int(T.height[root])
     for t in order:
-        pd = _node_dofs(T.piv_nodes[t], nVg, ndof_ug)
-        bd = _node_dofs(T.bnd_nodes[t], nVg, ndof_ug)
+        pd = _node_dofs(T.piv_nodes[t], nVg, ndof_ug, rot_g)
+        bd = _node_dofs(T.bnd_nodes[t], nVg, ndof_ug, rot_g)
         if in_sub[t]:
             dof_lists.append(g2l(np.concatenate([pd, bd]))); npiv.append(pd.size)
             level_of.append(int(T.height[t]))
@@ -450,6 +469,6 @@ def _rank_plan(mesh, T: Tree, rank, nranks):
     info = dict(cells=cells_g, vertices=verts_g, nghost=nghost, top_local=top_local.astype(np.int64),
                 n_local_levels=h_root + 1, root_front=int(new_id[root]),
                 stub_fronts=[int(new_id[r]) for r in roots],
-                schur_sizes=[int(_node_dofs(T.bnd_nodes[r], nVg, ndof_ug).size) for r in roots],
+                schur_sizes=[int(_node_dofs(T.bnd_nodes[r], nVg, ndof_ug, rot_g).size) for r in roots],
                 l2g_dof=l2g_full, l2g_p2=l2g_p2, n_top=int(top_dofs_g.size))
     return sub, plan, info

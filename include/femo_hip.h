@@ -59,8 +59,8 @@ int femo_create_ghost(femo_ctx** out, int device, int32_t nn, int32_t nel, int32
  *               the Crouzeix-Raviart functions.  The rotation nodes are the P2 nodes nn .. nP2 - 1 (cell_p2 lists the edge midpoints of a
  *               cell behind its vertices): state vector [u(P2 nodes) xyz | theta(edge midpoints) xyz], femo_ndof = 3 nP2 + 3 (nP2 - nn).
  *               Provided: operator, both Dirichlet treatments, solves, scalar outputs, stress outputs, the adjoint chain for thickness / E /
- *               nu / F_solid / uhat (shape), the transient march with its adjoint, the CSR export.  Not provided (femo_create_element fails
- *               with a message): ghosts, i.e. element partitions. */
+ *               nu / F_solid / uhat (shape), the transient march with its adjoint, the CSR export, ghost entries (element partitions: the
+ *               rotation DOFs of a replicated separator belong to its edge midpoints). */
 int femo_create_element(femo_ctx** out, int device, int32_t nn, int32_t nel, int32_t nvc, int32_t nP2,
                         const double* xyz, const int32_t* cells, const int32_t* cell_p2,
                         int elementwise_material, int elementwise_pressure, int nquad, int32_t nghost, int element);
@@ -130,6 +130,9 @@ int femo_factorize_profile(femo_ctx* ctx, double* out32);
 /* One application of the factor (forward + backward sweep) with HIP events between the launches, per tree level L:
  * out[4 L + 0 / 1] forward sweep, first / second launch; out[4 L + 2 / 3] backward sweep (ms); n >= 4 * levels. */
 int femo_sweep_profile(femo_ctx* ctx, double* out, int64_t n);
+/* ... and of the sweeps with nrhs = 2 or 4 interleaved vectors (femo_solve_linear_multi): out[2 L] forward, out[2 L + 1] backward sweep of
+ * level L in ms; n >= 2 nlevels. */
+int femo_sweep_profile_multi(femo_ctx* ctx, int32_t nrhs, double* out, int64_t n);
 /* out6: [0] front assembly ms, [1] factorisation ms, [2] front storage GB, [3] factor GFLOP,
  *       [4] non-positive pivots repaired, [5] number of fronts. */
 int femo_frontal_info(const femo_ctx* ctx, double* out6);
@@ -196,6 +199,13 @@ int femo_solve_state(femo_ctx* ctx, int zero_guess, int32_t* iters, double* relr
  * (fea/fea_dolfinx.py:173-203) and the BC zeroing of state_operation.py:216-218.  K is symmetric, so
  * the same call serves both modes (reference quirk Q3). */
 int femo_solve_linear(femo_ctx* ctx, const double* rhs, double* x, int32_t* iters, double* relres);
+/* Several right-hand sides at once: rhs and x hold nrhs vectors of femo_ndof entries, one after the other; iters / relres: nrhs entries
+ * (or NULL).  With the multifrontal preconditioner (femo_set_solver preconditioner 2) the right-hand sides go through the triangular
+ * sweeps in groups of up to four with the vectors interleaved, so that the factor is read once per group instead of once per vector
+ * (option "multi_rhs" 0: one at a time); every right-hand side keeps its own PCG recurrence and stopping test, so the iterates are those
+ * of nrhs separate femo_solve_linear calls.  Replaces repeated StateOperation.apply_inverse_jacobian calls (state_operation.py:188-220),
+ * forward or reverse (K is symmetric).  Status 4 if any right-hand side stops at maxit short of rtol (option "strict"). */
+int femo_solve_linear_multi(femo_ctx* ctx, int32_t nrhs, const double* rhs, double* x, int32_t* iters, double* relres);
 
 /* pressure = A^-1 force with A the consistent mass matrix of the pressure space [CG1]^3 (node-major xyz, 3 nn entries) -- replaces
  * csdl.solve_linear(A, force) on the matrix of RMShellPDE.construct_force_to_pressure_map (rm_shell/rm_shell_model.py:414-421,
@@ -280,6 +290,13 @@ int femo_dRdarg_T(femo_ctx* ctx, const char* arg, const double* lambda, double* 
  * (SURVEY.md section 3.3). */
 int femo_total_gradient(femo_ctx* ctx, const char* functional, const char* arg, double* out, int64_t n,
                         int32_t* iters, double* relres);
+/* The same for SEVERAL functionals of the state and one argument: the reference registers compliance, elastic_energy, pnorm_stress and
+ * one pnorm_stress_<tag> per sub-domain on `disp_solid` (rm_shell_model.py:221-253) and the simulator solves one adjoint per output
+ * (state_operation.py:188-220); here the adjoint right-hand sides dJ_i/dw are formed together and solved by femo_solve_linear_multi's
+ * grouped sweeps.  subdomains[i]: the tagged sub-domain functional i is restricted to (femo_set_cell_tags; -1, or subdomains == NULL:
+ * the whole mesh).  out: nfun x n, row i = d J_i / d arg; iters, relres: nfun entries or NULL. */
+int femo_total_gradients(femo_ctx* ctx, int32_t nfun, const char* const* functionals, const int32_t* subdomains, const char* arg, double* out,
+                         int64_t n, int32_t* iters, double* relres);
 
 /* Timing of the most recent solve, measured with HIP events on the context's stream (ms):
  * [0] setup (diagonal / preconditioner), [1] Krylov loop (with option "stale_factor": a factorisation inside the loop included),

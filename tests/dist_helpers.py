@@ -233,6 +233,11 @@ def make_case(kind="wing"):
     if kind == "wing":
         m = wing_skin_mesh(8, 24, shuffle=True)
         marker = lambda x: np.less(x[1], 1e-12)
+    elif kind == "wing_cr":        # ShellElement 'CG2CR1' (linear_shell_model.py:68-73): triangles, rotation on the edge midpoints
+        from femo_alpha_amd.mesh import ShellMesh, quads_to_triangles
+        t = quads_to_triangles(wing_skin_mesh(8, 24, shuffle=True))
+        m = ShellMesh(t.nodes, t.cells, "CG2CR1")
+        marker = lambda x: np.less(x[1], 1e-12)
     else:
         m = plate_mesh(2.0, 10.0, 6, 24)
         marker = lambda x: np.less(x[0], 3e-16)

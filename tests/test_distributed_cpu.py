@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (8, "wing"), (2, "plate")])
+@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (8, "wing"), (2, "plate"), (2, "wing_cr"), (4, "wing_cr")])
 def test_partitioned_solve_matches_single_domain(world, kind):
     m, marker, fields = H.make_case(kind)
     w0, J0, dJ0, M0 = H.reference_solution(m, marker, fields)
@@ -37,9 +37,10 @@ def test_partitioned_solve_matches_single_domain(world, kind):
         assert int(r["ntop"]) > 0
 
 
-def test_rank_plans_partition_the_mesh():
+@pytest.mark.parametrize("kind", ["wing", "wing_cr"])
+def test_rank_plans_partition_the_mesh(kind):
     from femo_alpha_amd.solver.symbolic import analyse, rank_plan
-    m, _, _ = H.make_case("wing")
+    m, _, _ = H.make_case(kind)
     T = analyse(m, 4, min_depth=2)
     seen = np.zeros(m.nel, int)
     owned = np.zeros(m.ndof, int)

@@ -1190,9 +1190,18 @@ def test_cg2cr1_element(kind, uhat, bc, ewm):
                 o.set_fields(uhat=u0)
                 for name, g, d in (("energy", g_e, (fp[0] - fm[0]) / 2e-6), ("residual", g_r, (fp[1] - fm[1]) / 2e-6)):
                     assert abs(g[v, comp] - d) <= 2e-6 * np.abs(g).max() + 1e-9 * abs(d), (name, v, comp, g[v, comp], d)
-    # element partitions are not provided for this element: a message at creation, not a wrong number
-    with pytest.raises(FemoHipError, match="CG2CR1"):
-        ShellContext(m, nghost=3)
+    # ghost entries (element partitions, round 6): three extra entries behind [u | theta(edges)], untouched by the element kernels
+    cg = ShellContext(m, element_wise_material=ewm, nghost=3)
+    assert cg.ndof == m.ndof + 3
+    for k, v in fields.items():
+        cg.set_field(k, v)
+    if sd is not None:
+        cg.set_strong_dofs(sd)
+    else:
+        cg.set_penalty_facets(pf, beta)
+    xg = np.concatenate([w, [1.0, 2.0, 3.0]])
+    assert np.abs(cg.apply_K(xg)[:m.ndof] - c.apply_K(w)).max() < 1e-13 * np.abs(c.apply_K(w)).max()
+    cg.close()
     # the CSR export (pattern built on the device from the edge-midpoint rotation nodes) against the oracle's assembly
     info = c.enable_csr()
     Kel = o.assemble_K(with_penalty=False, with_strong=False)
