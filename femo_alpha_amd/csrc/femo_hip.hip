@@ -199,6 +199,7 @@ struct femo_ctx {
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
         // reference never refreshes its derivative matrices at all (quirk Q2, csdl_alpha_opt/state_operation.py:130-131)
+        int diag_t = 0;           // 1 / 2: classes of fewer than four sub-blocks take k_diag_block_t (LDL / Cholesky elimination): measured slower / equal (profiles/r6_diag_ab.txt)
         int multi_rhs = 1;        // femo_solve_linear_multi / femo_total_gradients: 1 = right-hand sides share the sweeps in groups of up to 4; 0 = one at a time
         int stale_factor = 0;
         // ... and only while no field has moved further than this from the factor's design (relative L2 norm).  Measured at 1 M DOF
@@ -1094,7 +1095,18 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
                       // 261 / 242 / 178 us with the new kernel throughout against 517 / 164 / 192 / 156).  Option "diag_v1": 1 forces
                       // the old kernel everywhere, 2 the new one.
                       const bool v1 = fuse_rows || c->opt.diag_v1 == 1 || (c->opt.diag_v1 == 0 && cnt >= c->opt.diag_v1_cnt) || (c->opt.diag_v1 == 3 && cnt >= 512 && nblk < NBO / NB);
-                      if (v1)
+                      if (v1 && c->opt.diag_t && nblk < NBO / NB) {
+                          // classes of at most 1 / 2 / 3 sub-blocks: the compile-time-bounded kernel (3-4 workgroups per CU, LDL elimination)
+#define DIAG_T(NBLK_, REP_) do { if (c->opt.diag_t == 2) hipLaunchKernelGGL((k_diag_block_t<NBLK_, REP_, false>), dim3(end - start), dim3(256), diag_block_lds_blocks(NBLK_) * sizeof(blk32), st, \
+                                               fd, lev, start, C0, sw, fr.info, fuse_rows ? 1 : 0); \
+                            else hipLaunchKernelGGL((k_diag_block_t<NBLK_, REP_, true>), dim3(end - start), dim3(256), diag_block_lds_blocks(NBLK_) * sizeof(blk32), st, \
+                                               fd, lev, start, C0, sw, fr.info, fuse_rows ? 1 : 0); } while (0)
+                          const bool rep = c->opt.allow_pivot_repair != 0;
+                          if (nblk == 1) { if (rep) DIAG_T(1, true); else DIAG_T(1, false); }
+                          else if (nblk == 2) { if (rep) DIAG_T(2, true); else DIAG_T(2, false); }
+                          else { if (rep) DIAG_T(3, true); else DIAG_T(3, false); }
+#undef DIAG_T
+                      } else if (v1)
                           hipLaunchKernelGGL(k_diag_block, dim3(end - start), dim3(256), diag_block_lds_blocks(nblk) * sizeof(blk32), st,
                                              fd, lev, start, nblk, C0, sw, fr.info, fuse_rows ? 1 : 0);
                       else if (c->opt.allow_pivot_repair)
@@ -2476,6 +2488,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "assemble_fc") { if (v < 0 || v > 2) return fail(c, "assemble_fc: 0 never, 1 where it pays, 2 always"); o.assemble_fc = v; }
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "multi_rhs") { o.multi_rhs = v != 0; }
+    else if (k == "diag_t") { o.diag_t = v; }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
     else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }

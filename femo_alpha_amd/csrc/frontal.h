@@ -930,6 +930,199 @@ k_diag_block(FrontDev fd, const int* __restrict__ level_nodes, int first, int nb
     }
 }
 
+// k_diag_block for the classes of at most NBLK = 1, 2 or 3 sub-blocks (round 6): the same phases with every loop bounded at compile
+// time, so that a front of 72 pivots does not carry the registers of a 128-column block (188 VGPRs: two workgroups per CU whatever
+// the LDS footprint) -- 168 registers, three workgroups per CU for one or two sub-blocks (capped at 128 the elimination spills
+// 370 bytes) -- and with the LDL^T elimination of k_diag_block2 on
+// wave 0.  The levels of many small fronts are bound by workgroups per CU times the latency of one (8192 leaf fronts / (256 CUs x 2)
+// rounds of ~45 us), not by bytes or flops.
+template <int NBLK, bool REPAIR, bool LDL>
+__global__ void __launch_bounds__(256, NBLK <= 2 ? 3 : 2)
+k_diag_block_t(FrontDev fd, const int* __restrict__ level_nodes, int first, int C0, double* __restrict__ Swork,
+               int* __restrict__ info, int fuse_rows) {
+    constexpr int nblk = NBLK, ND = NBLK * (NBLK + 1) / 2;
+    STAMP(31);
+    const int slot = first + blockIdx.x;                       // position of the front in its level
+    const int t = level_nodes[slot];
+    const int np = fd.npiv[t];
+    if (C0 >= np) return;
+    const int kw = min(NBO, np - C0);
+    const int nkb = (kw + NB - 1) / NB;
+    const int ldp = ldp_of(fd.nf[t]);
+    double* F = fd.P + fd.poff[t];                             // pivot columns only
+    // the inverse of this diagonal block: scratch (levels solved with the one-workgroup-per-front kernels) or the diagonal
+    // block of the front's X (wide levels)
+    const int lds_ = Swork ? SPD : ldx_of(np);
+    double* Sout = Swork ? Swork + (size_t)slot * SPD * SPD : fd.X + fd.xoff[t] + C0 + (size_t)lds_ * C0;
+    extern __shared__ double lds_raw[];
+    blk32* D = reinterpret_cast<blk32*>(lds_raw);              // sub-block (i, j), i >= j, at i (i + 1) / 2 + j
+    constexpr int nD = ND;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int si = wv & 1, sj = wv >> 1, l15 = lane & 15, l4 = lane >> 4;
+    // load (identity padding beyond kw; only the lower triangle of the front is maintained): all 40 loads of a thread
+    // are issued before the first one is consumed -- a loop over the sub-blocks would pay the memory latency ten times
+    {
+        double v[ND][4];
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+            const int bi = b < 1 ? 0 : b < 3 ? 1 : b < 6 ? 2 : 3;
+            const int bj = b - bi * (bi + 1) / 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                const int r = idx % NB, c = idx / NB;
+                const int gr = NB * bi + r, gc = NB * bj + c;
+                v[b][q] = (gr == gc) ? 1.0 : 0.0;
+                if (b < nD && bi < nkb && gr < kw && gc < kw && gc <= gr) v[b][q] = F[(C0 + gr) + (size_t)ldp * (C0 + gc)];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < ND; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = tid + 256 * q;
+                if (b < nD) D[b][idx % NB][idx / NB] = v[b][q];
+            }
+    }
+    // (no zero fill of S: every sub-block on or below the block diagonal is written in full below, and nothing above it
+    //  or beyond the kw columns is ever read)
+    STAMP(0);
+    __syncthreads();
+    STAMP(1);
+    for (int j = 0; j < nkb; ++j) {
+        blk32& Djj = D[j * (j + 1) / 2 + j];
+        const int wb = min(NB, kw - NB * j);
+        STAMP(2 + 4 * j);
+        if (wv == 0) {
+            double a[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a[c] = (lane < NB) ? Djj[lane][c] : (c == lane - NB ? 1.0 : 0.0);
+            // LDL^T elimination: no square root on the pivot chain (4.9 against ~6.5 us per block, scripts/micro/lat_micro.hip); the rows of
+            // the inverse take 1 / sqrt(d_row) afterwards (the broadcast reads lanes < 32 and stays outside the divergent store)
+            int bad;
+            if (LDL) {
+                double rs;
+                bad = ldl32_inverse<REPAIR>(a, wb, lane, &rs);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) a[r] *= rl(rs, r);
+            } else {
+                bad = chol32_inverse(a, wb, lane);
+            }
+            if (lane >= NB) {
+                const int cl = lane - NB;               // this lane holds column cl of the inverse
+                double* Li = fd.Linv + fd.linvoff[t] + (size_t)(C0 / NB + j) * NB * NB;
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const double v = (cl < wb && r < wb && cl <= r) ? a[r] : 0.0;
+                    Djj[r][cl] = v;                     // the diagonal sub-block now holds Linv_j
+                    Li[r + NB * cl] = v;
+                }
+                if (cl == 0 && bad) atomicAdd(info, bad);
+            }
+        }
+        __syncthreads();
+        STAMP(3 + 4 * j);
+        if (j + 1 < nkb) {
+            // L_ij = D_ij Linv_j^T for the sub-blocks below
+            mfma_d4 acc[NBLK > 1 ? NBLK - 1 : 1];
+#pragma unroll
+            for (int i = 1; i < NBLK; ++i) {
+                acc[i - 1] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+                if (j + i < nkb) mfma_blk<false, true>(acc[i - 1], D[(j + i) * (j + i + 1) / 2 + j], Djj, si, sj, l15, l4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 1; i < NBLK; ++i) {
+                if (j + i >= nkb) continue;
+                blk32& Dij = D[(j + i) * (j + i + 1) / 2 + j];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+                    Dij[r][c] = acc[i - 1][reg];
+                    const int gr = NB * (j + i) + r, gc = NB * j + c;
+                    if (gr < kw && gc < kw) F[(C0 + gr) + (size_t)ldp * (C0 + gc)] = acc[i - 1][reg];
+                }
+            }
+            __syncthreads();
+            STAMP(4 + 4 * j);
+            // D_ik -= L_ij L_kj^T, i >= k > j (each wave updates its own sub-block of every D_ik)
+            for (int i = j + 1; i < nkb; ++i)
+                for (int k = j + 1; k <= i; ++k) {
+                    mfma_d4 u = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+                    mfma_blk<false, true>(u, D[i * (i + 1) / 2 + j], D[k * (k + 1) / 2 + j], si, sj, l15, l4);
+                    blk32& Dik = D[i * (i + 1) / 2 + k];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) Dik[16 * si + l4 + 4 * reg][16 * sj + l15] -= u[reg];
+                }
+            __syncthreads();
+        }
+    }
+    // inverse of the kw x kw factor, block column by block column
+    STAMP(20);
+    for (int j = 0; j < nkb; ++j) {
+        const blk32& Sjj = D[j * (j + 1) / 2 + j];
+        if (!fuse_rows)
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx % NB, c = idx / NB;
+            Sout[(NB * j + r) + (size_t)lds_ * (NB * j + c)] = Sjj[r][c];
+        }
+        for (int i = j + 1; i < nkb; ++i) {
+            // W = sum_{k=j}^{i-1} L_ik S_kj: S_kj (j < k < i) already sits where L_kj was; L_ij is read here for the last time
+            blk32& Dij = D[i * (i + 1) / 2 + j];
+            mfma_d4 w = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k)
+                mfma_blk<false, false>(w, D[i * (i + 1) / 2 + k], D[k * (k + 1) / 2 + j], si, sj, l15, l4);
+            __syncthreads();                                   // every wave has read L_ij: its sub-block takes W
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Dij[16 * si + l4 + 4 * reg][16 * sj + l15] = w[reg];
+            __syncthreads();
+            // S_ij = -Linv_i W
+            mfma_d4 x = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+            mfma_blk<false, false>(x, D[i * (i + 1) / 2 + i], Dij, si, sj, l15, l4);
+            __syncthreads();                                   // every wave has read W: the sub-block takes S_ij
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = 16 * si + l4 + 4 * reg, c = 16 * sj + l15;
+                Dij[r][c] = -x[reg];
+                if (!fuse_rows) Sout[(NB * i + r) + (size_t)lds_ * (NB * j + c)] = -x[reg];
+            }
+            __syncthreads();
+        }
+    }
+    STAMP(21);
+    if (fuse_rows) {
+        // L[r][C0 + c] = sum_{k <= c} A[r][C0 + k] S[c][k] for the rows below the block (k_panel_rows' product): a wave takes 16 rows
+        // at a time, their kw entries in registers as the MFMA B operand, S[c][k] from the sub-blocks in LDS as the A operand
+        __syncthreads();
+        const int nf = fd.nf[t];
+        for (int row0 = C0 + kw + 16 * wv; row0 < nf; row0 += 64) {
+            const int row = row0 + l15;
+            const bool rok = row < nf;
+            double a[NBLK * 8];
+#pragma unroll
+            for (int kk = 0; kk < NBLK * 8; ++kk) {
+                const int k = 4 * kk + l4;
+                a[kk] = (rok && k < kw) ? F[row + (size_t)ldp * (C0 + k)] : 0.0;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NBLK * 2; ++cb) {
+                if (16 * cb >= kw) break;
+                const int bi = cb >> 1;
+                mfma_d4 acc = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4 * cb + 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[bi * (bi + 1) / 2 + (kk >> 3)][16 * (cb & 1) + l15][4 * (kk & 7) + l4], a[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = 16 * cb + l4 + 4 * reg;
+                    if (rok && c < kw) F[row + (size_t)ldp * (C0 + c)] = acc[reg];
+                }
+            }
+        }
+    }
+}
+
+
 // ---- k_diag_block2: the same block, the same outputs, scheduled for latency.
 // k_diag_block runs its phases one after the other on ONE workgroup: four register factorisations on wave 0 (three waves
 // idle), then the MFMA phases with wave 0 idle in between, then the inverse S -- 45 us per block, and the chain of these
