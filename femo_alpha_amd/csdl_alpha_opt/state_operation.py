@@ -82,9 +82,10 @@ class StateOperation(csdl.experimental.CustomImplicitOperation):
         if mode == "fwd":
             d_outputs[name] = self.fea.solveLinearFwd(self.fea_du, self.A, self.fea_dR, d_residuals[name], self.ksp)
         elif mode == "rev":
+            # (d_outputs[name] of shape (k, ndof): the seeds of k outputs at once -- one grouped adjoint solve, FEA.solveLinearBwd)
             d_residuals[name] = self.fea.solveLinearBwd(self.fea_dR, self.A, self.fea_du, d_outputs[name], self.ksp)
             for bc in self.fea.bc:
-                d_residuals[name][bc.dof_indices()[0]] = 0.0
+                d_residuals[name][..., bc.dof_indices()[0]] = 0.0
         else:
             raise ValueError("mode must be either 'fwd' or 'rev'.")
 

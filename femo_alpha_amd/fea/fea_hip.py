@@ -178,6 +178,13 @@ class LinearSolver:
         self.iterations, self.relres = 0, 0.0
 
     def solve(self, rhs):
+        rhs = np.asarray(rhs, dtype=np.float64)
+        if rhs.ndim == 2:
+            # several right-hand sides (rows): ONE grouped solve -- the factor is streamed once per group of up to four vectors
+            # (femo_solve_linear_multi) instead of once per vector
+            x, its, rrs = self.A.ctx.solve_linear_multi(rhs)
+            self.iterations, self.relres = int(its.max()), float(rrs.max())
+            return x
         x, self.iterations, self.relres = self.A.ctx.solve_linear(rhs)
         return x
 
@@ -331,16 +338,22 @@ class FEA:
             self.last_solve = solveNonlinear(res, func, bc, self.PDE_SOLVER, self.REPORT, self.initialize)
 
     def solveLinearFwd(self, du, A, dR, dR_array, ksp=None):
-        """du = A^-1 dR."""
-        setFuncArray(dR, dR_array)
+        """du = A^-1 dR.  ``dR_array`` of shape (k, ndof): k right-hand sides in one grouped solve (an extension of the reference's
+        one-vector call, fea_dolfinx.py:172-187: the seeds of several outputs or several tangent columns are known together)."""
         ksp = ksp or LinearSolver(A)
+        if np.ndim(dR_array) == 2:
+            return ksp.solve(dR_array)
+        setFuncArray(dR, dR_array)
         du.set(ksp.solve(dR.get()))
         return du.get()
 
     def solveLinearBwd(self, dR, A, du, du_array, ksp=None):
-        """dR = A^-T du; A is symmetric so the same solve serves (reference quirk Q3)."""
-        setFuncArray(du, du_array)
+        """dR = A^-T du; A is symmetric so the same solve serves (reference quirk Q3).  ``du_array`` of shape (k, ndof): k adjoint
+        right-hand sides -- one per registered output of the state, rm_shell_model.py:221-253 -- in one grouped solve."""
         ksp = ksp or LinearSolver(A)
+        if np.ndim(du_array) == 2:
+            return ksp.solve(du_array)
+        setFuncArray(du, du_array)
         dR.set(ksp.solve(du.get()))
         return dR.get()
 

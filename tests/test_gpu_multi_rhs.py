@@ -154,3 +154,53 @@ def test_multi_rhs_at_config3_size():
     print(f"wing1m: 4 total gradients grouped {t_multi * 1e3:.2f} ms, one at a time {t_single * 1e3:.2f} ms (host wall-clock incl. copies)")
     assert t_multi < 0.8 * t_single
     c.close()
+
+
+def test_operator_surface_takes_the_seeds_of_several_outputs():
+    """StateOperation.apply_inverse_jacobian (state_operation.py:188-220) with d_outputs[state] of shape (k, ndof): the seeds of k outputs
+    in one grouped solve, Dirichlet rows zeroed in every one -- the same vectors as k separate calls, in both modes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from femo_alpha_amd import csdl
+    from femo_alpha_amd.csdl_alpha_opt.state_operation import StateOperation
+    from femo_alpha_amd.rm_shell.rm_shell_model import RMShellModel
+    mesh = plate_mesh(2.0, 10.0, 6, 24)
+    nn = mesh.nn
+    marker = lambda x: np.less(x[0], 3e-16)
+    rng = np.random.default_rng(2)
+    recorder = csdl.Recorder(inline=True)
+    recorder.start()
+    pressure = csdl.Variable(value=np.tile([0.0, 0.0, 5.0], (nn, 1)), name="force_vector")
+    thickness = csdl.Variable(value=0.1 * (1 + 0.2 * rng.uniform(-1, 1, nn)), name="thickness")
+    E = csdl.Variable(value=1e8 * np.ones(nn), name="E")
+    nu = csdl.Variable(value=0.3 * np.ones(nn), name="nu")
+    density = csdl.Variable(value=10.0 * np.ones(nn), name="density")
+    model = RMShellModel(mesh, shell_bc_func=marker, PENALTY_BC=False, record=False)        # strong Dirichlet rows: they must come back zero
+    model.evaluate(pressure, thickness, E, nu, density, None, debug_mode=False, is_pressure=True)
+    recorder.stop()
+    fea = model.fea
+    op = StateOperation(fea=fea, args_name_list=fea.states_dict["disp_solid"]["arguments"], state_name="disp_solid")
+    inputs = {name: fea.inputs_dict[name]["function"].x.array.copy() for name in fea.states_dict["disp_solid"]["arguments"]}
+    outputs = {}
+    fea.opt_iter = 0
+    op.solve_residual_equations(inputs, outputs)
+    S = rng.uniform(-1, 1, (4, mesh.ndof))
+    bc = np.concatenate([b.dof_indices()[0] for b in fea.bc])
+    assert bc.size > 0
+    for mode, (src, dst) in (("rev", ("d_outputs", "d_residuals")), ("fwd", ("d_residuals", "d_outputs"))):
+        single = []
+        for s in S:
+            d = {"d_outputs": {}, "d_residuals": {}}
+            d[src]["disp_solid"] = s.copy()
+            op.apply_inverse_jacobian(inputs, outputs, d["d_outputs"], d["d_residuals"], mode)
+            single.append(d[dst]["disp_solid"].copy())
+        d = {"d_outputs": {}, "d_residuals": {}}
+        d[src]["disp_solid"] = S.copy()
+        op.apply_inverse_jacobian(inputs, outputs, d["d_outputs"], d["d_residuals"], mode)
+        got = d[dst]["disp_solid"]
+        assert got.shape == S.shape
+        for i in range(4):
+            assert rel(got[i], single[i]) < 1e-11, (mode, i)
+        if mode == "rev":
+            assert np.all(got[:, bc] == 0.0)
