@@ -233,6 +233,10 @@ def make_case(kind="wing"):
     if kind == "wing":
         m = wing_skin_mesh(8, 24, shuffle=True)
         marker = lambda x: np.less(x[1], 1e-12)
+    elif kind == "wing_tri_nu":    # triangles with a nodal Poisson ratio: the rule of the whole mesh is decided on the global field
+        from femo_alpha_amd.mesh import quads_to_triangles
+        m = quads_to_triangles(wing_skin_mesh(8, 24, shuffle=True))
+        marker = lambda x: np.less(x[1], 1e-12)
     elif kind == "wing_cr":        # ShellElement 'CG2CR1' (linear_shell_model.py:68-73): triangles, rotation on the edge midpoints
         from femo_alpha_amd.mesh import ShellMesh, quads_to_triangles
         t = quads_to_triangles(wing_skin_mesh(8, 24, shuffle=True))
@@ -244,6 +248,8 @@ def make_case(kind="wing"):
     rng = np.random.default_rng(7)
     fields = dict(thickness=0.02 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=np.array([7e9]), nu=np.array([0.3]),
                   density=np.array([2700.0]), F_solid=rng.uniform(-1, 1, (m.nn, 3)) * 50)
+    if kind == "wing_tri_nu":
+        fields["nu"] = 0.3 * (1 + 0.3 * rng.uniform(-1, 1, m.nn))       # a nodal Poisson ratio that varies: every rank must take degree 9
     return m, marker, fields
 
 
@@ -287,7 +293,7 @@ def run_driver(ds, fields, rtol=1e-12):
     w = ds.gather_state()
     J, M = ds.functional("compliance"), ds.functional("mass")
     g, it2, rel2 = ds.total_gradient("compliance", "thickness")
-    return dict(w=w, J=J, M=M, g=g, it=it, rel=rel, it2=it2, rel2=rel2, nghost=ds.info["nghost"], ntop=ds.info["n_top"])
+    return dict(w=w, J=J, M=M, g=g, it=it, rel=rel, it2=it2, rel2=rel2, nghost=ds.info["nghost"], ntop=ds.info["n_top"], nquad=ds.nquad)
 
 
 # ---- several ranks inside ONE process (threads): a GPU box admits at most 6 processes on its card, so the 8-partition case of

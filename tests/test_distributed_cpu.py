@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (8, "wing"), (2, "plate"), (2, "wing_cr"), (4, "wing_cr")])
+@pytest.mark.parametrize("world,kind", [(1, "wing"), (2, "wing"), (4, "wing"), (8, "wing"), (2, "plate"), (2, "wing_cr"), (4, "wing_cr"), (2, "wing_tri_nu")])
 def test_partitioned_solve_matches_single_domain(world, kind):
     m, marker, fields = H.make_case(kind)
     w0, J0, dJ0, M0 = H.reference_solution(m, marker, fields)
@@ -35,6 +35,8 @@ def test_partitioned_solve_matches_single_domain(world, kind):
     assert np.abs(r["g"] - dJ0).max() < 1e-7 * np.abs(dJ0).max()
     if world > 1:
         assert int(r["ntop"]) > 0
+    # the rule of the whole mesh: triangles with a nodal Poisson ratio that varies take UFL's degree 9 on every rank
+    assert int(r["nquad"]) == {"wing_tri_nu": 9, "wing_cr": 6}.get(kind, m.recommended_nquad())
 
 
 @pytest.mark.parametrize("kind", ["wing", "wing_cr"])

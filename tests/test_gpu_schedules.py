@@ -45,7 +45,7 @@ def test_random_schedules_give_the_same_solution(case, seed):
     for _ in range(8):
         post = dict(trailing=int(rng.integers(0, 3)), left_min=int(rng.choice([1, 8, 64, 4096])), left_max=int(rng.choice([16, 2048, 100000])),
                     super_panel=int(rng.choice([0, 200, 256, 384, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
-                    super_panel_ahead=int(rng.integers(0, 2)), diag_ahead=int(rng.integers(0, 2)), rows_preload_wg=int(rng.choice([0, 64, 100000])), rows_fine_wg=int(rng.choice([0, 64, 100000])), narrow_fine_wg=int(rng.choice([0, 16, 100000])), narrow_split=int(rng.choice([1, 3, 4, 8])), narrow_split_wg=int(rng.choice([8, 1024, 100000])), super_tiles=int(rng.integers(0, 2)), super_tiles_min=int(rng.choice([1, 3, 8])), split_cnt=int(rng.choice([0, 16, 100000])), split_groups=int(rng.choice([2, 3, 4, 8])), fuse_rows=int(rng.integers(0, 2)), sweep_graph=int(rng.integers(0, 2)), fuse_rows_cnt=int(rng.choice([1, 512])), fuse_rows_np=int(rng.choice([128, 256, 100000])), diag_v1_cnt=int(rng.choice([1, 512])), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
+                    super_panel_ahead=int(rng.integers(0, 2)), diag_ahead=int(rng.integers(0, 2)), rows_preload_wg=int(rng.choice([0, 64, 100000])), rows_fine_wg=int(rng.choice([0, 64, 100000])), narrow_fine_wg=int(rng.choice([0, 16, 100000])), narrow_split=int(rng.choice([1, 3, 4, 8])), narrow_split_wg=int(rng.choice([8, 1024, 100000])), super_tiles=int(rng.integers(0, 2)), super_tiles_min=int(rng.choice([1, 3, 8])), split_cnt=int(rng.choice([0, 16, 100000])), split_groups=int(rng.choice([2, 3, 4, 8])), fuse_rows=int(rng.integers(0, 2)), diag_t=int(rng.integers(0, 3)), sweep_graph=int(rng.integers(0, 2)), fuse_rows_cnt=int(rng.choice([1, 512])), fuse_rows_np=int(rng.choice([128, 256, 100000])), diag_v1_cnt=int(rng.choice([1, 512])), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
                     fused_schur=int(rng.integers(0, 2)), diag_v1=int(rng.integers(0, 3)), big_tiles=int(rng.integers(0, 2)), big_min_wg=int(rng.choice([1, 64, 512])), grid_chunk=int(rng.choice([3, 17, 65535])), xinv_small_cnt=int(rng.choice([0, 32, 100000])),
                     strip_cnt=int(rng.choice([0, 1, 256])), strip_kmax=int(rng.choice([64, 128, 160])), sweep_fuse=int(rng.integers(0, 2)), sweep_w=int(rng.integers(0, 2)), assemble_fc=int(rng.choice([0, 1, 2])))
         pre = dict(wide_cnt=int(rng.choice([0, 8, 512, 100000])), wide_np=int(rng.choice([64, 512])), swork_slots=int(rng.choice([2, 100, 8192])))
@@ -107,3 +107,40 @@ def test_lighter_quadrature_rule_of_the_front_assembly():
     for w, g in ((w4, g4), (w3, g3)):
         assert np.abs(w - w0).max() < 1e-9 * np.abs(w0).max()
         assert np.abs(g - g0).max() < 1e-8 * np.abs(g0).max()
+
+
+@pytest.mark.parametrize("kind", ["quad", "tri"])
+def test_node_order_of_the_fronts_gives_the_same_solution(kind):
+    """Rows of a front in ascending node id (node_order 0, rounds 1-5) or along the separators (node_order 1, the default from round 6:
+    a child's Schur block lands in long runs of consecutive parent rows): any order of the pivots inside a front is a valid elimination
+    order, so iteration counts and solutions agree; and with node_order 1 ``up_map`` is increasing along every child's boundary rows."""
+    from femo_alpha_amd.backend import ShellContext
+    from femo_alpha_amd.mesh import quads_to_triangles
+    from femo_alpha_amd.solver.symbolic import build_plan
+    m = wing_skin_mesh(32, 96, shuffle=True).renumbered()[0]
+    if kind == "tri":
+        m = quads_to_triangles(m)
+    marker = lambda x: np.less(x[1], 1e-9)
+    res = {}
+    for order in (0, 1):
+        plan = build_plan(m, 8, node_order=order)
+        if order == 1:
+            for t in range(plan.ntree):
+                up = plan.up_map[plan.dof_off[t] + plan.npiv[t]: plan.dof_off[t + 1]]
+                assert np.all(np.diff(up) > 0), t
+        c = ShellContext(m)
+        r = np.random.default_rng(1)
+        c.set_field("thickness", 0.02 * (1 + 0.3 * r.uniform(-1, 1, m.nn)))
+        for k, v in (("E", [7e10]), ("nu", [0.3]), ("density", [2700.0])):
+            c.set_field(k, v)
+        c.set_field("F_solid", r.uniform(-1, 1, (m.nn, 3)))
+        c.set_penalty_facets(m.penalty_facets(marker))
+        c.enable_frontal(plan=plan)
+        c.set_solver(preconditioner=2, rtol=1e-12, maxit=30, check_every=1)
+        it, _ = c.solve_state(True)
+        g, it2, _ = c.total_gradient("compliance", "thickness")
+        res[order] = (it, c.get_state(), g)
+        c.close()
+    assert abs(res[0][0] - res[1][0]) <= 1
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-9 * np.abs(res[1][1]).max()
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-8 * np.abs(res[1][2]).max()
