@@ -75,6 +75,13 @@ def test_multi_rhs_solves_equal_separate_solves(options):
             assert it[i] == ref[i][1], (nrhs, i, it, [r[1] for r in ref])
             assert rel(X[i], ref[i][0]) < 1e-11, (nrhs, i)
             assert rr[i] <= 1e-12
+    # the per-level timing of the grouped sweeps (femo_sweep_profile_multi): one forward and one backward time per tree level
+    for nr in (2, 4):
+        prof = c.sweep_profile_multi(nr)
+        assert prof.shape == (c.plan.nlevels, 2) and np.all(prof >= 0) and prof.sum() > 0
+    from femo_alpha_amd._lib import FemoHipError
+    with pytest.raises(FemoHipError, match="2 or 4"):
+        c.sweep_profile_multi(3)
     # option "multi_rhs" 0: one at a time through the same entry point
     c.set_option("multi_rhs", 0)
     X, it, rr = c.solve_linear_multi(B[:3])

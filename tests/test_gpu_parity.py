@@ -632,6 +632,11 @@ def test_triangle_rules_against_the_symbolic_derivation():
         c = ShellContext(m, nquad=deg)
         fill(c)
         assert c.nquad == deg and c.quadrature() == (deg, {6: 12, 9: 19, 12: 33}[deg])
+        # the tables the kernels receive (femo_quadrature_tables, host only): weights of the rule sum to the area of the unit triangle
+        import ctypes as C
+        wts, npts = np.zeros(36), C.c_int32()
+        assert c.lib.femo_quadrature_tables(3, deg, 0, 0, 0, C.byref(npts), wts.ctypes.data_as(C.POINTER(C.c_double)), *([None] * 7)) == 0
+        assert npts.value == c.quadrature()[1] and abs(wts[:npts.value].sum() - 0.5) < 1e-16
         c.enable_csr()
         Ke = c.assemble_csr().toarray()[np.ix_(d, d)]
         ref = g[f"TR_Ke_d{deg}"]
