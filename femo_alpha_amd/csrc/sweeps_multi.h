@@ -12,7 +12,7 @@ namespace femo {
 
 // forward, one workgroup per front (levels of many small fronts): y_p = L11^-1 v_p -> yv ; v_B -= L21 y_p
 template <int NR>
-__global__ void __launch_bounds__(256, NR > 2 ? 2 : 3)
+__global__ void __launch_bounds__(256, 3)
 k_front_fwd_small_m(FrontDev fd, const int* __restrict__ level_nodes, double* __restrict__ v, double* __restrict__ yv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -106,6 +106,8 @@ k_front_fwd_small_m(FrontDev fd, const int* __restrict__ level_nodes, double* __
                     const int col = min(cb + q, np - 1);
 #pragma unroll
                     for (int rr = 0; rr < NR; ++rr) s[rr] += a[q] * y[col * NR + rr];
+                    // the LDS reads of the vectors stay with their group of eight columns: hoisted all at once they cost 32 x NR doubles
+                    // of registers beside the 32 loads in flight
                 }
             }
             if (G > 1) {
@@ -130,7 +132,7 @@ k_front_fwd_small_m(FrontDev fd, const int* __restrict__ level_nodes, double* __
 
 // backward, one workgroup per front: x_p = L11^-T (y_p - L21^T x_B)
 template <int NR>
-__global__ void __launch_bounds__(256, NR > 2 ? 2 : 3)
+__global__ void __launch_bounds__(256, 3)
 k_front_bwd_small_m(FrontDev fd, const int* __restrict__ level_nodes, const double* __restrict__ sv, double* __restrict__ xv) {
     const int t = level_nodes[blockIdx.x];
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -232,7 +234,7 @@ k_front_bwd_small_m(FrontDev fd, const int* __restrict__ level_nodes, const doub
 
 // wide levels, plain products: 128 x 128 tile of X (TRI) or L21
 template <bool TRI, int NR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_sweep_gemv_n_m(FrontDev fd, const int* __restrict__ level_nodes, int first, const double* __restrict__ in, double* __restrict__ out) {
     const int t = level_nodes[first + blockIdx.y], bx = (int)blockIdx.x;
     const int np = fd.npiv[t], nf = fd.nf[t];
@@ -273,14 +275,21 @@ k_sweep_gemv_n_m(FrontDev fd, const int* __restrict__ level_nodes, int first, co
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) s[rr] = 0.0;
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) a[k] = (r < nrows && 32 * h + k < clim) ? row[(size_t)ld * (32 * h + k)] : 0.0;
+        int xoff = (hw * ch + 32 * h) * NR;
 #pragma unroll
-        for (int k = 0; k < 32; ++k)
+        for (int kb = 0; kb < 4; ++kb) {
+            // The address of this group's LDS reads is tied to the previous group's sums: left to itself the compiler issues the reads of
+            // all 32 columns x NR vectors at once (256 registers at NR = 4, beside the 32 loads in flight: 394 in all, one workgroup per CU)
+            if (NR > 1) asm volatile("" : "+v"(xoff), "+v"(s[0]));
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) s[rr] += a[k] * xs[(hw * ch + 32 * h + k) * NR + rr];
+            for (int k = 8 * kb; k < 8 * kb + 8; ++k)
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) s[rr] += a[k] * xs[xoff + k * NR + rr];
+        }
     }
     if (ch)
 #pragma unroll
