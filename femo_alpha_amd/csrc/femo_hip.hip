@@ -52,6 +52,8 @@ struct femo_ctx {
     hipStream_t stream_m = nullptr;          // diagonal look-ahead: a stream that may not use the CUs reserved for the diagonal blocks
     hipEvent_t ev_da[2] = {nullptr, nullptr};
     hipStream_t stream3 = nullptr;           // L11^-1 of a finished level is formed beside the factorisation of the next ones
+    hipStream_t stream_a = nullptr;          // option "sweep_ahead": the forward sweep of the lower levels beside the factorisation of the top
+    hipEvent_t ev_a[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_x[2] = {nullptr, nullptr};
     int nn = 0, nel = 0, nvc = 0, npc = 0, nP2 = 0, ndof_u = 0, ndof = 0, ld = 0;   // ndof = vector length = mesh DOFs + nghost
     int nghost = 0;
@@ -199,6 +201,11 @@ struct femo_ctx {
         // preconditioner and re-factorise only if the solve has not converged after this many iterations (0: always re-factorise, the
         // default and what the bench measures).  PCG iterates on the CURRENT matrix-free operator, so the answer is the same either way; the
         // reference never refreshes its derivative matrices at all (quirk Q2, csdl_alpha_opt/state_operation.py:130-131)
+        // The first preconditioner application of a cold solve starts from z = b, which is known before the factorisation: its forward
+        // sweep through the levels [0, nlevels - sweep_ahead) runs on a stream of its own as soon as those levels are factorised,
+        // beside the chain of the top levels (31 fronts, 4.4 of 11.5 ms at 1 M DOF, most of the chip idle); the solve joins it before
+        // the sweep of the top levels.  0 = off.
+        int sweep_ahead = 2;
         int diag_t = 0;           // 1 / 2: classes of fewer than four sub-blocks take k_diag_block_t (LDL / Cholesky elimination): measured slower / equal (profiles/r6_diag_ab.txt)
         int multi_rhs = 1;        // femo_solve_linear_multi / femo_total_gradients: 1 = right-hand sides share the sweeps in groups of up to 4; 0 = one at a time
         int stale_factor = 0;
@@ -222,6 +229,8 @@ struct femo_ctx {
         double* snap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // thickness, E, nu, density, uhat as they were when that factor was made
         bool snap_valid = false;
         bool w_mode = false;                  // the wide levels of the stored factor hold W = L21 X where L21 was (option "sweep_w" at the time of the factorisation)
+        double* ahead_vec = nullptr;          // option "sweep_ahead": the vector whose forward sweep the running factorisation starts (null: none)
+        int ahead_levels = 0;                 // ... through the levels [0, ahead_levels); set by the factorisation when it did
         bool x_inflight = false;              // k_xinv launches on stream3 that the main stream has not waited for yet (event ev_x[1])
         int ntree = 0, nlevels = 0;
         std::vector<int> h_nf, h_npiv, h_level_off, h_level_nodes, h_level_maxnp, h_level_maxnb;
@@ -280,6 +289,7 @@ static int fail(femo_ctx* c, const std::string& msg) {
 // whatever the operator A = aK K + aM M (+ Dirichlet treatment) depends on has changed: both preconditioners are stale
 static void operator_changed(femo_ctx* c, bool fields_only = false);
 static int snapshot_fields(femo_ctx* c);
+static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEvent_t>* marks = nullptr);
 
 // ------------------------------------------------------------------------------------------ tables
 static void gauss_legendre(int n, double* x, double* w) {
@@ -1256,6 +1266,22 @@ static int frontal_factorize_range(femo_ctx* c, int l0, int l1, bool assemble) {
             }
         }
         HIPCHK(c, hipGetLastError());
+        if (fr.ahead_vec && L + 1 == fr.nlevels - c->opt.sweep_ahead && l0 == 0 && l1 == fr.nlevels && !fr.profile) {
+            // option "sweep_ahead": levels [0, L] are factorised (main stream) and their X is on its way (stream3): the forward sweep of
+            // the waiting vector through them starts now, on its own stream, beside the chain of the levels above
+            HIPCHK(c, hipEventRecord(c->ev_a[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream_a, c->ev_a[0], 0));
+            HIPCHK(c, hipEventRecord(c->ev_a[1], c->stream3));
+            HIPCHK(c, hipStreamWaitEvent(c->stream_a, c->ev_a[1], 0));
+            hipStream_t main_stream = c->stream;
+            const bool keep_inflight = fr.x_inflight;
+            c->stream = c->stream_a; fr.x_inflight = false;            // (the sweep's own join has nothing to wait for: done above)
+            const int rc_a = frontal_fwd(c, fr.ahead_vec, 0, L + 1, nullptr);
+            c->stream = main_stream; fr.x_inflight = keep_inflight;
+            if (rc_a) return rc_a;
+            HIPCHK(c, hipEventRecord(c->ev_a[2], c->stream_a));
+            fr.ahead_levels = L + 1;
+        }
     }
     if (x_pending) {
         HIPCHK(c, hipEventRecord(c->ev_x[1], c->stream3));
@@ -1318,7 +1344,7 @@ static int frontal_factorize(femo_ctx* c) { return frontal_factorize_range(c, 0,
 // v <- (L L^T)^-1 v   (c->tmp is the scratch vector: forward v -> tmp, backward tmp -> v)
 // Wide levels: two matrix-vector products per sweep (X = L11^-1 and L21), accumulated with atomics into entries that the
 // memset at the start of the sweep zeroed; the other levels: one workgroup per front.
-static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEvent_t>* marks = nullptr) {
+static int frontal_fwd(femo_ctx* c, double* v, int l0, int l1, std::vector<hipEvent_t>* marks) {
     auto& fr = c->fr;
     const FrontDev fd = front_dev(c);
     double* y = c->tmp;
@@ -1705,7 +1731,19 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     int factor_state = stale ? 1 : 0;
     if (stale) { c->fr.t_assemble_ms = 0; c->fr.t_factor_ms = 0; }
     if (!c->fr.factored && !stale) {
-        if (int rc = frontal_factorize(c)) return rc;
+        // option "sweep_ahead": a cold solve from a zero guess applies the factor to z = b first, and b is known now -- hand it to the
+        // factorisation, which starts its forward sweep through the lower levels beside the chain of the top ones
+        const bool ahead = zero_guess && c->opt.sweep_ahead > 0 && c->fr.nlevels > c->opt.sweep_ahead + 1 && !c->opt.equilibrate &&
+                           c->opt.sweep_w == 0 && !c->opt.sweep_fuse;
+        c->fr.ahead_levels = 0;
+        if (ahead) {
+            if (mask) hipLaunchKernelGGL(k_mask_zero, dim3(vg), dim3(256), 0, c->stream, b, mask, n);
+            HIPCHK(c, hipMemcpyAsync(c->z, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            c->fr.ahead_vec = c->z;
+        }
+        const int rc = frontal_factorize(c);
+        c->fr.ahead_vec = nullptr;
+        if (rc) { c->fr.ahead_levels = 0; return rc; }
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     auto dot = [&](const double* a, const double* bb, double* out) -> int {
@@ -1737,6 +1775,10 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
     const double target = c->rtol * c->rtol * bb;
     // device scalars: [0] r.z of the previous iteration, [1] r.z, [2] p.Ap, [3] r.r -- one host synchronisation per iteration
     int k_restart = 0;                             // iteration at which the search directions start afresh
+    if (c->fr.ahead_levels > 0 && !(bb > 0 && rr > target && k < c->maxit)) {      // nothing to iterate: the started sweep must not outlive this call
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_a[2], 0));
+        c->fr.ahead_levels = 0;
+    }
     while (bb > 0 && rr > target && k < c->maxit) {
         // (never end a solve unconverged on a kept factor: a fresh one needs two iterations, so the refresh comes no later than maxit - 2)
         if (stale && k >= std::min(c->opt.stale_factor, std::max(c->maxit - 2, 0))) {
@@ -1753,8 +1795,18 @@ static int pcg_frontal(femo_ctx* c, double* b, double* x, bool zero_guess, int32
             if (!(rr > target)) break;
         }
         HIPCHK(c, hipMemsetAsync(c->scal + 1, 0, 3 * sizeof(double), c->stream));
+        if (k == 0 && c->fr.ahead_levels > 0) {
+            // z = b has been swept through the levels [0, ahead_levels) beside the factorisation of the top: join, finish the sweeps
+            const int la = c->fr.ahead_levels;
+            c->fr.ahead_levels = 0;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_a[2], 0));
+            if (frontal_fwd(c, c->z, la, c->fr.nlevels)) return 1;
+            if (frontal_bwd(c, c->z, 0, c->fr.nlevels)) return 1;
+        } else {
+        c->fr.ahead_levels = 0;
         HIPCHK(c, hipMemcpyAsync(c->z, c->r, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         if (frontal_solve_z(c)) return 1;
+        }
         hipLaunchKernelGGL(k_dot, dim3(red_grid(n)), dim3(256), 0, c->stream, c->r, c->z, n, c->scal + 1);
         hipLaunchKernelGGL(k_pcgf_direction, dim3(vg), dim3(256), 0, c->stream, c->p, c->z, c->scal, k == k_restart ? 1 : 0, n);
         hipLaunchKernelGGL(k_fill, dim3(vg), dim3(256), 0, c->stream, c->Ap, 0.0, n);
@@ -1912,6 +1964,8 @@ static int create_impl(femo_ctx* c, const double* xyz, const int32_t* cells, con
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming));
     HIPCHK(c, hipStreamCreate(&c->stream_g));
     for (int i = 0; i < 2; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_g[i], hipEventDisableTiming));
+    HIPCHK(c, hipStreamCreate(&c->stream_a));      // (a lowest-priority stream here made the factorisation 6 ms SLOWER: 13.4 -> 19.4 ms)
+    for (int i = 0; i < 3; ++i) HIPCHK(c, hipEventCreateWithFlags(&c->ev_a[i], hipEventDisableTiming));
     {
         // The diagonal look-ahead (factorize_fronts) runs the bulk of a panel's work on stream_m beside the next diagonal
         // block, whose one workgroup per front needs a whole CU's LDS: stream_m leaves 32 of the 256 CUs alone (bits whose
@@ -2135,6 +2189,9 @@ void femo_destroy(femo_ctx* c) {
     for (int i = 0; i < 2; ++i)
         if (c->ev_g[i]) hipEventDestroy(c->ev_g[i]);
     if (c->stream_g) hipStreamDestroy(c->stream_g);
+    for (int i = 0; i < 3; ++i)
+        if (c->ev_a[i]) hipEventDestroy(c->ev_a[i]);
+    if (c->stream_a) hipStreamDestroy(c->stream_a);
     for (int i = 0; i < 2; ++i)
         if (c->ev_da[i]) hipEventDestroy(c->ev_da[i]);
     if (c->stream_m) hipStreamDestroy(c->stream_m);
@@ -2489,6 +2546,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "multi_rhs") { o.multi_rhs = v != 0; }
     else if (k == "diag_t") { o.diag_t = v; }
+    else if (k == "sweep_ahead") { if (v < 0) return fail(c, "sweep_ahead: number of top levels left to the solve (0: off)"); o.sweep_ahead = v; }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }
     else if (k == "sweep_read_mode") { if (v < 0 || v > 2) return fail(c, "sweep_read_mode: 0 returning atomic, 1 agent-scope load, 2 plain load (experiment)"); o.sweep_read_mode = v; }
