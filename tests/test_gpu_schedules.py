@@ -27,6 +27,7 @@ def _solve(m, marker, strong, leaf, pre, post):
     c.enable_frontal(leaf, **pre)
     c.set_solver(preconditioner=2, rtol=1e-12, maxit=30, check_every=1)
     c.factorize(); c.factorize()                     # twice: stream order must also hold across factorisations
+    c.set_field("thickness", c.get_field("thickness"))      # ... and the solve factorises once more, from cold (the path of "sweep_ahead")
     it, _ = c.solve_state(True)
     w = c.get_state()
     g, _, _ = c.total_gradient("compliance", "thickness")
@@ -45,7 +46,7 @@ def test_random_schedules_give_the_same_solution(case, seed):
     for _ in range(8):
         post = dict(trailing=int(rng.integers(0, 3)), left_min=int(rng.choice([1, 8, 64, 4096])), left_max=int(rng.choice([16, 2048, 100000])),
                     super_panel=int(rng.choice([0, 200, 256, 384, 512])), super_panel_cnt=int(rng.choice([4, 64, 100000])),
-                    super_panel_ahead=int(rng.integers(0, 2)), diag_ahead=int(rng.integers(0, 2)), rows_preload_wg=int(rng.choice([0, 64, 100000])), rows_fine_wg=int(rng.choice([0, 64, 100000])), narrow_fine_wg=int(rng.choice([0, 16, 100000])), narrow_split=int(rng.choice([1, 3, 4, 8])), narrow_split_wg=int(rng.choice([8, 1024, 100000])), super_tiles=int(rng.integers(0, 2)), super_tiles_min=int(rng.choice([1, 3, 8])), split_cnt=int(rng.choice([0, 16, 100000])), split_groups=int(rng.choice([2, 3, 4, 8])), fuse_rows=int(rng.integers(0, 2)), diag_t=int(rng.integers(0, 3)), sweep_graph=int(rng.integers(0, 2)), fuse_rows_cnt=int(rng.choice([1, 512])), fuse_rows_np=int(rng.choice([128, 256, 100000])), diag_v1_cnt=int(rng.choice([1, 512])), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
+                    super_panel_ahead=int(rng.integers(0, 2)), diag_ahead=int(rng.integers(0, 2)), rows_preload_wg=int(rng.choice([0, 64, 100000])), rows_fine_wg=int(rng.choice([0, 64, 100000])), narrow_fine_wg=int(rng.choice([0, 16, 100000])), narrow_split=int(rng.choice([1, 3, 4, 8])), narrow_split_wg=int(rng.choice([8, 1024, 100000])), super_tiles=int(rng.integers(0, 2)), super_tiles_min=int(rng.choice([1, 3, 8])), split_cnt=int(rng.choice([0, 16, 100000])), split_groups=int(rng.choice([2, 3, 4, 8])), fuse_rows=int(rng.integers(0, 2)), diag_t=int(rng.integers(0, 3)), sweep_ahead=int(rng.integers(0, 4)), sweep_graph=int(rng.integers(0, 2)), fuse_rows_cnt=int(rng.choice([1, 512])), fuse_rows_np=int(rng.choice([128, 256, 100000])), diag_v1_cnt=int(rng.choice([1, 512])), lookahead=int(rng.integers(0, 2)), lookahead_cnt=int(rng.choice([4, 16, 1000])),
                     fused_schur=int(rng.integers(0, 2)), diag_v1=int(rng.integers(0, 3)), big_tiles=int(rng.integers(0, 2)), big_min_wg=int(rng.choice([1, 64, 512])), grid_chunk=int(rng.choice([3, 17, 65535])), xinv_small_cnt=int(rng.choice([0, 32, 100000])),
                     strip_cnt=int(rng.choice([0, 1, 256])), strip_kmax=int(rng.choice([64, 128, 160])), sweep_fuse=int(rng.integers(0, 2)), sweep_w=int(rng.integers(0, 2)), assemble_fc=int(rng.choice([0, 1, 2])))
         pre = dict(wide_cnt=int(rng.choice([0, 8, 512, 100000])), wide_np=int(rng.choice([64, 512])), swork_slots=int(rng.choice([2, 100, 8192])))
@@ -144,3 +145,39 @@ def test_node_order_of_the_fronts_gives_the_same_solution(kind):
     assert abs(res[0][0] - res[1][0]) <= 1
     assert np.abs(res[0][1] - res[1][1]).max() < 1e-9 * np.abs(res[1][1]).max()
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-8 * np.abs(res[1][2]).max()
+
+
+def test_sweep_ahead_gives_the_same_solution():
+    """Option "sweep_ahead": the forward sweep of the first preconditioner application through the lower levels, started by the
+    factorisation beside the chain of the top levels -- the same iteration count and (to the rounding of the sweeps' atomics) the same
+    solution as the plain order, for every number of top levels left to the solve, also when it exceeds the tree's height, with a
+    right-hand side of zero (nothing to iterate: the started sweep is joined all the same) and in the transient march."""
+    from femo_alpha_amd.backend import ShellContext
+    m, marker = wing_skin_mesh(32, 96, shuffle=True).renumbered()[0], (lambda x: np.less(x[1], 1e-9))
+    res = {}
+    for ahead in (0, 1, 2, 3, 50):
+        c = ShellContext(m)
+        r = np.random.default_rng(1)
+        h = 0.02 * (1 + 0.3 * r.uniform(-1, 1, m.nn))
+        c.set_field("thickness", h)
+        for k, v in (("E", [7e10]), ("nu", [0.3]), ("density", [2700.0])):
+            c.set_field(k, v)
+        c.set_field("F_solid", r.uniform(-1, 1, (m.nn, 3)))
+        c.set_penalty_facets(m.penalty_facets(marker))
+        c.set_option("sweep_ahead", ahead)
+        c.enable_frontal(8)
+        c.set_solver(preconditioner=2, rtol=1e-12, maxit=30, check_every=1)
+        out = []
+        for rep in range(3):                              # cold solves one after the other: events and streams are reused
+            c.set_field("thickness", h * (1 + 0.01 * rep))
+            it, _ = c.solve_state(True)
+            out.append((it, c.get_state()))
+        c.set_field("F_solid", np.zeros((m.nn, 3)))       # zero load: factorisation, no iteration
+        it0, _ = c.solve_state(True)
+        assert it0 == 0 and np.all(c.get_state() == 0.0)
+        res[ahead] = out
+        c.close()
+    for ahead in (1, 2, 3, 50):
+        for (it_a, w_a), (it_0, w_0) in zip(res[ahead], res[0]):
+            assert it_a == it_0
+            assert np.abs(w_a - w_0).max() < 1e-10 * np.abs(w_0).max(), ahead
