@@ -44,7 +44,9 @@ _lp = C.POINTER(C.c_int64)
 def build(force=False):
     """g++ the C++ restatement into oracle/_build/ (content-hashed like the HIP library)."""
     os.makedirs(BUILD, exist_ok=True)
-    digest = hashlib.sha256(open(SRC, "rb").read() + " ".join(FLAGS).encode()).hexdigest()
+    # every source the translation unit includes (the element core is included three times; a change there must rebuild as well)
+    srcs = [SRC] + [os.path.join(HERE, f) for f in ("cpu_core.inc", "cpu_ext.inc", "cpu_dd.h")]
+    digest = hashlib.sha256(b"".join(open(f, "rb").read() for f in srcs) + " ".join(FLAGS).encode()).hexdigest()
     stamp = LIB + ".srchash"
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB
@@ -184,6 +186,39 @@ class CpuShell:
                 assert np.array_equal(colidx[pos], d)
                 vals[pos] += blk[a].astype(np.longdouble)
         return rowptr, colidx, vals
+
+    def assemble_K_dd(self, nthreads=1):
+        """(rowptr, colidx, values (nnz, 2)) of the same operator in DOUBLE-DOUBLE arithmetic, values as (hi, lo) pairs
+        (cpu_assemble_csr_dd; cpu_dd.h): the portable twin of assemble_K_extended -- no x87 needed, ~104 bits instead of 64."""
+        m, o = self.mesh, self.o
+        if o.strong_dofs.size:
+            raise NotImplementedError("extended-precision assembly handles the penalty clamp")
+        rowptr, colidx = self.pattern()
+        vals = np.zeros((colidx.size, 2))
+        rc = self.lib.cpu_assemble_csr_dd(*self._common(), _i(self.cell_p2), m.ndof_u, self._u(), *self._tables(), *self._fields(),
+                                          _i(rowptr), _i(colidx), vals.ctypes.data_as(C.c_void_p), int(nthreads))
+        assert rc == 0, "CSR pattern does not hold an element entry"
+        for d, blk in o._penalty_blocks():                    # (float64 blocks, as in the x87 operator: added exactly)
+            for a in range(d.size):
+                row = colidx[rowptr[d[a]]:rowptr[d[a] + 1]]
+                pos = rowptr[d[a]] + np.searchsorted(row, d)
+                assert np.array_equal(colidx[pos], d)
+                hi = vals[pos, 0] + blk[a]                    # two_sum: nothing of the 1e15-sized block is lost beside the elastic entry
+                v = hi - vals[pos, 0]
+                lo = (vals[pos, 0] - (hi - v)) + (blk[a] - v) + vals[pos, 1]
+                vals[pos, 0], vals[pos, 1] = hi + lo, lo - ((hi + lo) - hi)
+        return rowptr, colidx, vals
+
+    def load_vector_dd(self):
+        """F as (ndof, 2) (hi, lo) pairs (cpu_load_vector_dd)."""
+        m, o = self.mesh, self.o
+        F = np.zeros((m.ndof, 2))
+        f = np.ascontiguousarray(o.f, dtype=np.float64)
+        N2 = np.ascontiguousarray(o.N2)
+        rc = self.lib.cpu_load_vector_dd(*self._common(), _i(self.cell_p2), self._u(), _d(self.N1), _d(self.dN1), _d(self.dN2), _d(N2),
+                                         _d(self.w), _d(f), int(o.ewp), int(m.is_quad), F.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return F
 
     def load_vector_extended(self):
         """F in numpy.longdouble (cpu_load_vector_ld)."""

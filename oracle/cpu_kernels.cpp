@@ -21,6 +21,8 @@
 
 #include <omp.h>
 
+#include "cpu_dd.h"
+
 namespace {
 
 constexpr double SHEAR_K = 0.833;          // linear_shell_model.py:146
@@ -41,6 +43,10 @@ namespace f80 {
 typedef long double REAL;
 #include "cpu_core.inc"
 }  // namespace f80
+namespace fdd {
+typedef dd REAL;
+#include "cpu_core.inc"
+}  // namespace fdd
 using namespace f64;
 
 namespace {
@@ -90,74 +96,44 @@ int cpu_assemble_csr(int nel, int nvc, int npc, int nq, const double* nodes, con
     return bad;
 }
 
-// ---- the same assembly with the element mathematics in long double (x87 extended precision) and the sums kept in long double:
-// the operator of the GOLDENS.  vals_ld / F_ld: long double arrays (numpy.longdouble on x86-64 Linux).  Element matrices are formed
-// in parallel into a scratch block, the scatter is serial (no atomics on 16-byte values).
-int cpu_assemble_csr_ld(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
-                        int ndof_u, const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* w,
-                        const double* wS, const double* h, const double* E, const double* nu, int ewm, const double* hK, int quad,
-                        const int32_t* rowptr, const int32_t* colidx, long double* vals_ld, int nthreads) {
-    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, wS};
-    const int ld = 3 * npc + 3 * nvc;
-    if (ld > MAXLD || nq > MAXQ) return 1;
-    const int chunk = 4096;
-    std::vector<long double> Ke((size_t)chunk * ld * ld);
-    int bad = 0;
-    for (int e0 = 0; e0 < nel; e0 += chunk) {
-        const int ne = std::min(chunk, nel - e0);
-#pragma omp parallel for schedule(static, 16) num_threads(nthreads)
-        for (int k = 0; k < ne; ++k) {
-            f80::ElemIn el;
-            f80::load_elem(e0 + k, nvc, nodes, cells, uhat, h, E, nu, ewm, hK, el);
-            f80::element_matrix(T, el, quad != 0, 0, Ke.data() + (size_t)k * ld * ld);
-        }
-        int dofs[MAXLD];
-        for (int k = 0; k < ne; ++k) {
-            element_dofs(e0 + k, nvc, npc, cells, cell_p2, ndof_u, dofs);
-            const long double* K = Ke.data() + (size_t)k * ld * ld;
-            for (int i = 0; i < ld; ++i) {
-                const int32_t* cb = colidx + rowptr[dofs[i]];
-                const int32_t* ce = colidx + rowptr[dofs[i] + 1];
-                for (int j = 0; j < ld; ++j) {
-                    const int32_t* p = std::lower_bound(cb, ce, dofs[j]);
-                    if (p == ce || *p != dofs[j]) { bad = 1; continue; }
-                    vals_ld[p - colidx] += K[(size_t)i * ld + j];
-                }
-            }
-        }
+// ---- the operator of the GOLDENS: the same assembly with the element mathematics and the sums in an extended arithmetic
+// (cpu_ext.inc): cpu_assemble_csr_ld / cpu_load_vector_ld in x87 long double, cpu_assemble_csr_dd / cpu_load_vector_dd in
+// double-double (cpu_dd.h), the portable twin.
+#define EXT_NS f80
+#define EXT_REAL f80::REAL
+#define EXT_NAME(x) x##_ld
+#include "cpu_ext.inc"
+#undef EXT_NS
+#undef EXT_REAL
+#undef EXT_NAME
+#define EXT_NS fdd
+#define EXT_REAL fdd::REAL
+#define EXT_NAME(x) x##_dd
+#include "cpu_ext.inc"
+#undef EXT_NS
+#undef EXT_REAL
+#undef EXT_NAME
+
+// r = b - K x with K, x, b in double-double ((n, 2) arrays of (hi, lo) pairs) and every row's sum carried in double-double: the residual
+// of the goldens' refinement without x87 arithmetic.  r is returned rounded to double (it is the right-hand side of a float64 solve).
+int cpu_csr_residual_dd(int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals2, const double* x2, const double* b2,
+                        double* r, int nthreads) {
+    const dd* K = reinterpret_cast<const dd*>(vals2);
+    const dd* x = reinterpret_cast<const dd*>(x2);
+    const dd* b = reinterpret_cast<const dd*>(b2);
+#pragma omp parallel for schedule(static, 1024) num_threads(nthreads)
+    for (int64_t i = 0; i < n; ++i) {
+        dd s = b[i];
+        for (int32_t p = rowptr[i]; p < rowptr[i + 1]; ++p) s -= K[p] * x[colidx[p]];
+        r[i] = (double)s;
     }
-    return bad;
+    return 0;
 }
 
-// F_a = int f . N2_a J det dS in long double (cpu_load_vector's twin for the goldens)
-int cpu_load_vector_ld(int nel, int nvc, int npc, int nq, const double* nodes, const int32_t* cells, const int32_t* cell_p2,
-                       const double* uhat, const double* N1, const double* dN1, const double* dN2, const double* N2, const double* w,
-                       const double* f, int ewp, int quad, long double* F_ld) {
-    const Tables T{nq, nvc, npc, N1, dN1, dN2, w, w};
-    if (3 * npc + 3 * nvc > MAXLD || nq > MAXQ) return 1;
-    for (int e = 0; e < nel; ++e) {
-        long double X[4][3], U[4][3], fe[4][3], B[9][MAXLD];
-        bool has_u = false;
-        for (int b = 0; b < nvc; ++b) {
-            const int v = cells[(size_t)e * nvc + b];
-            for (int i = 0; i < 3; ++i) {
-                X[b][i] = nodes[3 * (size_t)v + i];
-                U[b][i] = uhat ? uhat[3 * (size_t)v + i] : 0.0;
-                has_u = has_u || U[b][i] != 0.0L;
-                fe[b][i] = f[3 * (size_t)(ewp ? e : v) + i];
-            }
-        }
-        for (int q = 0; q < nq; ++q) {
-            f80::QP g;
-            f80::qp_B(T, q, X, has_u ? U : nullptr, quad != 0, B, g);
-            long double fq[3] = {0, 0, 0};
-            for (int b = 0; b < nvc; ++b)
-                for (int i = 0; i < 3; ++i) fq[i] += (ewp ? (b == 0 ? 1.0L : 0.0L) : (long double)N1[(size_t)q * nvc + b]) * fe[b][i];
-            const long double wj = (long double)w[q] * g.det * g.Ju;
-            for (int a = 0; a < npc; ++a)
-                for (int i = 0; i < 3; ++i) F_ld[3 * (size_t)cell_p2[(size_t)e * npc + a] + i] += wj * N2[(size_t)q * npc + a] * fq[i];
-        }
-    }
+// x += dx (x in double-double, dx double)
+int cpu_axpy_dd(int64_t n, double* x2, const double* dx) {
+    dd* x = reinterpret_cast<dd*>(x2);
+    for (int64_t i = 0; i < n; ++i) x[i] += dd(dx[i]);
     return 0;
 }
 

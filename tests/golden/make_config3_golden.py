@@ -13,7 +13,8 @@ kept as the secondary rule.
 
 SuperLU cannot factorise this matrix (32-bit fill indices), so the preconditioner of the refinement is the CPU restatement's own
 multifrontal Cholesky (oracle/cpu_baseline.py: C++/OpenMP element matrices, LAPACK/BLAS on dense fronts); the operator the residual
-b - K x is formed with is assembled in x87 extended precision (tests/golden/_extended.py) -- the same recipe as
+b - K x is formed with is assembled in an extended arithmetic (tests/golden/_extended.py: double-double since round 6 -- portable, and
+its refinement converges to 1e-20 where the x87 one stalls at ~5e-11 on this skin; FEMO_GOLDEN_ARITH=x87 for the old one) -- the same recipe as
 make_fullsize_goldens.py: the stored numbers are the solution of the discrete problem, not of a float64-rounded matrix.  ``w_correction`` / ``lam_correction`` record the
 size of the last correction relative to the solution.  Stored: compliance, mass, max |w|, 4096 seeded samples of the state,
 and the full d compliance / d thickness vector: the north-star triple at the north-star size.
@@ -38,12 +39,18 @@ from femo_alpha_amd.solver.symbolic import build_plan            # noqa: E402
 from oracle import cpu_baseline as cb                            # noqa: E402
 from oracle.rm_shell_oracle import ShellOracle                   # noqa: E402
 sys.path.insert(0, HERE)
-from _extended import extended_system, refine                    # noqa: E402
+from _extended import as_float64, extended_system, operator_from_float64, refine                    # noqa: E402
 
 
 def main():
     t0 = time.time()
-    m, fields, marker, desc = make_workload(WORKLOAD)
+    # the unstructured skins: the Delaunay triangulation comes from scipy / qhull and goes into the golden, so that the test runs on the
+    # golden's own mesh whatever qhull is installed there
+    tri = None
+    if WORKLOAD in ("uskin1m", "uquad1m"):
+        from femo_alpha_amd.mesh import skin_triangulation
+        tri = skin_triangulation(*{"uskin1m": (116, 580), "uquad1m": (47, 239)}[WORKLOAD])[2]
+    m, fields, marker, desc = make_workload(WORKLOAD, tri=tri)
     cores = cb.host_cores()
     nquad = m.recommended_nquad() if NQUAD is None else NQUAD
     o = ShellOracle(m, nquad=nquad, penalty_facets=m.penalty_facets(marker))
@@ -54,7 +61,7 @@ def main():
     mf.factorize()
     print(f"{desc}\nassembled (extended precision) and factorised in {time.time() - t0:.0f} s", flush=True)
     say = lambda msg: print(msg, flush=True)
-    w, cw = refine(Kx, mf.solve, bx, mf.solve(np.asarray(bx, dtype=np.float64)), log=say)
+    w, cw = refine(Kx, mf.solve, bx, mf.solve(as_float64(bx)), log=say)
     J = o.compliance(w)
     rhs = o.dcompliance_du(w)
     lam, cl = refine(Kx, mf.solve, rhs, mf.solve(rhs), log=say)
@@ -62,7 +69,7 @@ def main():
     # for the record: the solution of the FLOAT64-assembled matrix (the round 1-3 goldens) against the one above
     K64 = cs.assemble_K(cores).tocsr(); K64.sort_indices()
     b64 = cs.load_vector(cores)
-    w64, _ = refine((K64.indptr, K64.indices, K64.data.astype(np.longdouble)), mf.solve, b64, mf.solve(b64), steps=6)
+    w64, _ = refine(operator_from_float64(K64, cs, cores), mf.solve, b64, mf.solve(b64), steps=6)
     d64 = (float(np.abs(w64 - w).max() / np.abs(w).max()), float(abs(o.compliance(w64) - J) / abs(J)))
     print(f"float64-assembled matrix: solution off by {d64[0]:.1e} (displacement) {d64[1]:.1e} (compliance)", flush=True)
     sample = np.sort(np.random.default_rng(7).choice(m.ndof, size=4096, replace=False))
@@ -73,7 +80,8 @@ def main():
     np.savez_compressed(os.path.join(os.environ.get("FEMO_GOLDEN_OUT", HERE), name), ndof=m.ndof, nn=m.nn, nel=m.nel, nquad=nquad, compliance=J, mass=o.mass(),
                         w_maxabs=np.abs(w).max(), w_sample_index=sample, w_sample=w[sample],
                         dcompliance_dthickness=dJ, w_correction=cw, lam_correction=cl,
-                        float64_matrix_distance_w=d64[0], float64_matrix_distance_compliance=d64[1], mesh_sha256=mesh_sha)
+                        float64_matrix_distance_w=d64[0], float64_matrix_distance_compliance=d64[1], mesh_sha256=mesh_sha,
+                        arithmetic=Kx.__class__.__name__.strip("_").lower(), **({} if tri is None else {"triangulation": np.asarray(tri, dtype=np.int32)}))
 
 
 if __name__ == "__main__":

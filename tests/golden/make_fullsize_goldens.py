@@ -35,7 +35,7 @@ from femo_alpha_amd.mesh import plate_mesh                      # noqa: E402
 from oracle import cpu_baseline as cb                            # noqa: E402
 from oracle.rm_shell_oracle import ShellOracle                   # noqa: E402
 sys.path.insert(0, HERE)
-from _extended import extended_system, refine                    # noqa: E402
+from _extended import as_float64, extended_system, operator_from_float64, refine                    # noqa: E402
 
 CLAMP = lambda x: np.less(x[0], 3e-16)
 
@@ -49,8 +49,9 @@ def run(nx, ny, element_wise, random_thickness):
     o.set_fields(h=h, E=1e8, nu=0.3, rho=10.0, f=f)
     t0 = time.time()
     lu = o.factorize()
-    Kx, bx = extended_system(cb.CpuShell(o), cb.host_cores())
-    w, cw = refine(Kx, lu.solve, bx, lu.solve(np.asarray(bx, dtype=np.float64)))
+    cs = cb.CpuShell(o)
+    Kx, bx = extended_system(cs, cb.host_cores())
+    w, cw = refine(Kx, lu.solve, bx, lu.solve(as_float64(bx)))
     J = o.compliance(w)
     rhs = o.dcompliance_du(w)
     lam, cl = refine(Kx, lu.solve, rhs, lu.solve(rhs))
@@ -58,7 +59,7 @@ def run(nx, ny, element_wise, random_thickness):
     # for the record: how far the solution of the FLOAT64-assembled matrix (the round 1-3 goldens; what any float64 code can hope
     # to reproduce) sits from the one above
     K64 = o._K.tocsr(); K64.sort_indices()
-    w64, _ = refine((K64.indptr, K64.indices, K64.data.astype(np.longdouble)), lu.solve, o.load_vector(), lu.solve(o.load_vector()))
+    w64, _ = refine(operator_from_float64(K64, cs, cb.host_cores()), lu.solve, o.load_vector(), lu.solve(o.load_vector()))
     d64 = (float(np.abs(w64 - w).max() / np.abs(w).max()), float(abs(o.compliance(w64) - J) / abs(J)))
     sample = np.sort(np.random.default_rng(7).choice(m.ndof, size=min(4096, m.ndof), replace=False))
     print(f"{nx}x{ny} element_wise={element_wise}: ndof {m.ndof}  {time.time() - t0:.0f} s  J={J:.15e}  "

@@ -83,3 +83,50 @@ def test_level_parallel_sweeps_equal_the_sequential_ones(warped):
     mf.factorize()
     b = rng.uniform(-1, 1, m.ndof)
     assert rel(mf.solve(b, by_level=True), mf.solve(b, by_level=False)) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["quad", "tri"])
+def test_the_two_extended_arithmetics_agree(kind):
+    """The operator of the goldens in x87 long double (cpu_assemble_csr_ld) and in double-double (cpu_assemble_csr_dd, oracle/cpu_dd.h: the
+    portable twin) -- two unrelated extended arithmetics through the same element core: the operator entries agree to
+    the round-off of the coarser one (64-bit mantissa, 5e-20), both differ from the float64-assembled operator by its round-off
+    (1e-16), and the two refined solutions of a thin, clamped, warped skin agree to the last places of the float64 they are rounded to
+    -- while the float64-assembled operator's solution sits orders of magnitude away.  Skipped where numpy has no x87 type."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _extended import as_float64, extended_system, operator_from_float64, refine
+    if np.finfo(np.longdouble).nmant < 63:
+        pytest.skip("numpy longdouble is not the x87 type here: the double-double path is the only one")
+    m = wing_skin_mesh(10, 40)
+    if kind == "tri":
+        m = quads_to_triangles(m)
+    clamp = lambda x: np.less(x[1], 1e-12)
+    rng = np.random.default_rng(3)
+    o = ShellOracle(m, penalty_facets=m.penalty_facets(clamp))
+    o.set_fields(h=1.27e-3 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)), E=73.1e9, nu=0.33, rho=2780.0, f=rng.uniform(-1, 1, (m.nn, 3)),
+                 uhat=1e-3 * rng.uniform(-1, 1, (m.nn, 3)))
+    cs = cb.CpuShell(o)
+    Kx, bx = extended_system(cs, 4, kind="x87")
+    Kd, bd = extended_system(cs, 4, kind="dd")
+    # operator and load vector, entry by entry
+    vd = Kd.vals[:, 0].astype(np.longdouble) + Kd.vals[:, 1].astype(np.longdouble)
+    scale = np.abs(Kx.vals).max()
+    assert np.array_equal(Kx.colidx, Kd.colidx)
+    assert float(np.abs(vd - Kx.vals).max() / scale) < 1e-18
+    bdl = bd[:, 0].astype(np.longdouble) + bd[:, 1].astype(np.longdouble)
+    assert float(np.abs(bdl - bx).max() / np.abs(bx).max()) < 1e-18
+    K64 = cs.assemble_K(4).tocsr(); K64.sort_indices()
+    d64 = float(np.abs(K64.data.astype(np.longdouble) - Kx.vals).max() / scale)
+    assert 1e-18 < d64 < 1e-15                                       # float64 assembly: its own round-off, far above the extended ones
+    # the refined solutions
+    lu = o.factorize()
+    wx, cx = refine(Kx, lu.solve, bx, lu.solve(as_float64(bx)))
+    wd, cd = refine(Kd, lu.solve, bd, lu.solve(as_float64(bd)))
+    w64, _ = refine(operator_from_float64(K64, cs, 4, kind="dd"), lu.solve, as_float64(bd), lu.solve(as_float64(bd)))
+    e_xd = np.abs(wx - wd).max() / np.abs(wx).max()
+    e_64 = np.abs(w64 - wx).max() / np.abs(wx).max()
+    print(f"{kind}: corrections {cx:.1e} / {cd:.1e}; x87 against double-double {e_xd:.1e}; float64-assembled operator {e_64:.1e} away")
+    assert max(cx, cd) < 1e-9
+    assert e_xd < 50 * max(cx, cd, 1e-15)                            # the two goldens are one number
+    assert e_64 > 100 * e_xd                                         # ... and the float64-assembled operator's solution is another
