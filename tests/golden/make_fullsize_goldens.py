@@ -12,8 +12,8 @@ BASELINE.json is stored: displacement (max |w| and 4096 seeded samples), complia
 d compliance / d thickness vector.
 
 Accuracy of the stored numbers: they are the solution of the discrete problem itself, not of a float64 matrix.  The stiffness
-matrix and the load vector are formed in x87 extended precision (tests/golden/_extended.py, oracle/cpu_kernels.cpp
-cpu_assemble_csr_ld); SuperLU on the float64 matrix is only the preconditioner of an iterative refinement whose residual is
+matrix and the load vector are formed in double-double arithmetic (tests/golden/_extended.py, oracle/cpu_kernels.cpp
+cpu_assemble_csr_dd; x87 long double, cpu_assemble_csr_ld, until round 5 and still with FEMO_GOLDEN_ARITH=x87); SuperLU on the float64 matrix is only the preconditioner of an iterative refinement whose residual is
 accumulated in extended precision on that operator.  (Round 1-3 goldens refined against the float64-assembled matrix: the rounding
 of its entries alone moved config 2 by ~1e-8 -- swapping numpy's 4-point Gauss table for the exact one, a change of 1e-16, moved
 compliance by 8e-9.)  ``w_correction`` / ``lam_correction`` record the size of the last correction relative to the solution.

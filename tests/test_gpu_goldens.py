@@ -74,7 +74,7 @@ def test_parity_triple_against_fullsize_golden(name):
 @pytest.mark.parametrize("nquad", [None, 4])
 def test_parity_triple_against_the_one_million_dof_golden(nquad):
     """BASELINE config 3 -- the bench workload itself, 1 015 470 DOF (tests/golden/make_config3_golden.py: CPU multifrontal
-    Cholesky of the oracle's matrix, polished in extended precision to 1e-10).
+    Cholesky of the oracle's matrix, refined in double-double to 1e-18).
 
     nquad None: the rule the mesh asks for and the bench runs -- 5 x 5 Gauss points on these warped cells, within 1e-9 of the
     reference's (nearly) exact integration (linear_shell_model.py:88-103; golden config3_wing1m.npz, made with n = 5).
