@@ -206,6 +206,7 @@ struct femo_ctx {
         // beside the chain of the top levels (31 fronts, 4.4 of 11.5 ms at 1 M DOF, most of the chip idle); the solve joins it before
         // the sweep of the top levels.  0 = off.
         int sweep_ahead = 2;
+        int apply_lanes = 0;      // lanes per element of the matrix-free operator (k_apply4): 0 / 4 = a DPP quad; 5 = twelve elements on 60 lanes (25 points: 5 each instead of 7 + 6 + 6 + 6): measured SLOWER, 118.6 against 103.5 us (profiles/r6_apply_lanes.txt)
         int diag_t = 0;           // 1 / 2: classes of fewer than four sub-blocks take k_diag_block_t (LDL / Cholesky elimination): measured slower / equal (profiles/r6_diag_ab.txt)
         int multi_rhs = 1;        // femo_solve_linear_multi / femo_total_gradients: 1 = right-hand sides share the sweeps in groups of up to 4; 0 = one at a time
         int stale_factor = 0;
@@ -600,11 +601,21 @@ static int refresh_penalty(femo_ctx* c) {
 static int op_apply(femo_ctx* c, const double* x, double* y, double* dotslot, double* za, double* zb, bool with_penalty,
                     double aK = 1.0, double aM = 0.0) {
     {
-        const int nb = ((nblk(c->nel, 64) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
+        const int lanes = c->opt.apply_lanes == 5 ? 5 : 4;
+        const int nb = ((nblk(c->nel, apply_epb(lanes)) + 7) / 8) * 8;      // multiple of 8 for the XCD-aware block order
 #define COMMA_TRUE , true
 #define COMMA_FALSE , false
-        if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
-        else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+#define COMMA_TRUE_4 , true, 4
+#define COMMA_FALSE_4 , false, 4
+#define COMMA_TRUE_5 , true, 5
+#define COMMA_FALSE_5 , false, 5
+        if (lanes == 5) {
+            if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE_5, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+            else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE_5, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        } else {
+            if (aM != 0.0) ELEM_LAUNCH(c, k_apply4, COMMA_TRUE_4, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+            else ELEM_LAUNCH(c, k_apply4, COMMA_FALSE_4, nb, 256, mesh_dev(c), fields_dev(c), c->tab, c->eorder, aK, aM, x, c->ybuf, dotslot, za, zb);
+        }
         const int nthreads = c->nP2 + c->nghost;
 #define GATHER_SUM(NPC_, NVC_) hipLaunchKernelGGL((k_gather_sum<NPC_, NVC_>), dim3(nblk(nthreads, 256)), dim3(256), 0, c->stream, c->nP2, c->nn, \
                                                   c->ndof_u, c->ndof, c->n2e_off, c->n2e_ent, c->ybuf, y, c->cr ? 1 : 0, c->nrot)
@@ -2546,6 +2557,7 @@ int femo_set_option(femo_ctx* c, const char* key, double value) {
     else if (k == "sweep_w") { if ((v != 0) != (o.sweep_w != 0)) { o.sweep_w = v != 0; operator_changed(c); } }
     else if (k == "multi_rhs") { o.multi_rhs = v != 0; }
     else if (k == "diag_t") { o.diag_t = v; }
+    else if (k == "apply_lanes") { if (v != 0 && v != 4 && v != 5) return fail(c, "apply_lanes: 0 or 4 (a quad of lanes per element), or 5"); o.apply_lanes = v; }
     else if (k == "sweep_ahead") { if (v < 0) return fail(c, "sweep_ahead: number of top levels left to the solve (0: off)"); o.sweep_ahead = v; }
     else if (k == "stale_rel") { if (!(value >= 0)) return fail(c, "stale_rel: a relative change >= 0"); o.stale_rel = value; }
     else if (k == "stale_factor") { if (v < 0) return fail(c, "stale_factor: PCG iterations a kept factor is given before the factorisation is refreshed (0: never keep)"); o.stale_factor = v; }

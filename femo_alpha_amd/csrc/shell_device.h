@@ -704,12 +704,33 @@ __device__ __forceinline__ int xcd_block(int b, int nb) {
     return lb;
 }
 
-template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS>
+// LPE lanes per element.  4: the lanes of a DPP quad (16 elements per wave; the default).  5 (option apply_lanes, an experiment of
+// round 6): twelve elements on 60 lanes of a wave -- for the 25 points of the 5 x 5 rule, which four lanes share as 7 + 6 + 6 + 6 (the
+// quad waits for the lane with seven) and five as 5 each; the partial results then meet through ds_bpermute (the LDS crossbar, no LDS
+// memory) instead of DPP.  Measured slower (wing1m: 118.6 against 103.5 us per application; 4 x 4 points: 39.2 against 35.2): the kernel
+// is bound by the number of vector instructions it issues (the ALU issues ~62 % of the time at two waves per SIMD), not by the slowest
+// lane of a quad, and five lanes issue more in total -- a third more waves with the same staging, reduction and stores
+// (profiles/r6_apply_lanes.txt).
+__device__ __forceinline__ double lane_get(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// sum over the five lanes base .. base + 4 of a group (s1, s2, s4: the lanes 1, 2 and 4 places further round the group)
+__device__ __forceinline__ double group5_sum(double v, int s1, int s2, int s4) {
+    const double t = v + lane_get(v, s1);
+    const double u = t + lane_get(t, s2);
+    return u + lane_get(v, s4);
+}
+__device__ __host__ constexpr int apply_epb(int lpe) { return 4 * (64 / lpe); }      // elements per block of four waves
+
+template <int NPC, int NVC, bool QUAD, bool UHAT, bool MASS, int LPE>
 __global__ void __launch_bounds__(256, 2)
 k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __restrict__ eorder, double aK, double aM,
          const double* __restrict__ x, double* __restrict__ ybuf, double* dotslot, double* zero_a, double* zero_b) {
     constexpr int LD = 3 * NPC + 3 * NVC;
-    constexpr int EPB = 64;                     // elements per block (256 threads / 4 lanes)
+    constexpr int EPW = 64 / LPE;               // elements per wave
+    constexpr int EPB = apply_epb(LPE);         // elements per block (four waves)
     constexpr int GEO = 3 * NVC + 3 * NVC + 4 * NVC;    // per element: X, uhat, (h, E, nu, rho) at the vertices
     // (r4: SQ_LDS_BANK_CONFLICT is 70 % of this kernel's LDS-active cycles; rows of an odd number of doubles -- 16 cells on 16 different
     //  bank pairs instead of every fourth cell colliding at 40 doubles = 64 B modulo 256 B -- changed nothing: 109.7 against 108 us.
@@ -730,9 +751,11 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
         if (zero_b) *zero_b = 0.0;
     }
     const int lb = xcd_block(blockIdx.x, gridDim.x);
-    const int le = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int lane = threadIdx.x & 63;
+    const int le = LPE == 4 ? threadIdx.x >> 2 : (threadIdx.x >> 6) * EPW + min(lane / LPE, EPW - 1);
+    const int sub = LPE == 4 ? threadIdx.x & 3 : lane % LPE;
     const int pos = lb * EPB + le;
-    const bool active = lb * EPB < m.nel && pos < m.nel;
+    const bool active = lb * EPB < m.nel && pos < m.nel && (LPE == 4 || lane < EPW * LPE);
     double local = 0.0;
     const int e = active ? (eorder ? eorder[pos] : pos) : 0;
     double hK = 0.0;
@@ -765,7 +788,7 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
         }
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
-            if ((i & 3) == sub) {
+            if ((i % LPE) == sub) {
                 const int node = i / 3, c = i - 3 * node;
                 const int rb = node >= NPC ? node - NPC : 0;
                 const int rnode = (NPC == 6 && NVC == 3 && m.cr) ? pid[(NVC + rb) % NPC] - m.nn : vid[rb];     // CG2CR1: the edge midpoint
@@ -780,7 +803,7 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
 #pragma unroll
         for (int i = 0; i < LD; ++i) ye[i] = 0.0;
         const int nq = stab.nq;
-        for (int q = sub; q < nq; q += 4) {
+        for (int q = sub; q < nq; q += LPE) {
             // re-derive the LDS rows every iteration: keeps the compiler from hoisting the staged values
             // out of the loop into registers
             int row = le;
@@ -805,21 +828,28 @@ k_apply4(MeshDev m, FieldsDev f, const Tables* __restrict__ tab, const int* __re
         if (MASS) {
             // The inertia term in a loop of its own (compiled out of the static operator): inside the stiffness loop its interpolated
             // vectors pushed the kernel from 242 registers to 256 + 148 B of scratch
-            for (int q = sub; q < nq; q += 4) {
+            for (int q = sub; q < nq; q += LPE) {
                 int row = le;
                 asm volatile("" : "+v"(row));
                 mass_qp<NPC, NVC>(stab, q, scm[row][q], hK, sx[row], ye);
             }
         }
+        if (LPE == 4) {
 #pragma unroll
-        for (int i = 0; i < LD; ++i) ye[i] = quad_xor_sum(ye[i]);
-        // lane `sub` owns the outputs i == sub (mod 4); the element's 39 results go to its own slot of ybuf
+            for (int i = 0; i < LD; ++i) ye[i] = quad_xor_sum(ye[i]);
+        } else {
+            const int base = lane - sub;
+            const int s1 = base + (sub + 1) % LPE, s2 = base + (sub + 2) % LPE, s4 = base + (sub + 4) % LPE;
+#pragma unroll
+            for (int i = 0; i < LD; ++i) ye[i] = group5_sum(ye[i], s1, s2, s4);
+        }
+        // lane `sub` owns the outputs i == sub (mod LPE); the element's 39 results go to its own slot of ybuf
         // (plain stores, 320 contiguous bytes per element) -- k_gather_sum adds them up per node: no atomics,
         // and a fixed summation order
         double* out = ybuf + (size_t)pos * YSTRIDE;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
-            if ((i & 3) == sub) {
+            if ((i % LPE) == sub) {
                 out[i] = ye[i];
                 local += sx[le][i] * ye[i];
             }

@@ -60,6 +60,47 @@ def test_version_device_count_and_plain_create():
     lib.femo_destroy(h)
 
 
+@pytest.mark.parametrize("variant,uhat", [("CG2CG1", False), ("CG2CG1", True), ("CG1CG1", False)])
+def test_operator_with_four_and_five_lanes_per_element(variant, uhat):
+    """Option apply_lanes: the matrix-free operator (k_apply4) with the quadrature points of an element dealt to four lanes (a DPP quad;
+    the 25 points of the 5 x 5 rule are 7 + 6 + 6 + 6; the default) or to five (5 each, twelve elements on 60 lanes of a wave, partial
+    results through ds_bpermute; measured slower, profiles/r6_apply_lanes.txt).  Both layouts against the oracle's matrix at 1e-11, each other at 1e-13, with
+    and without mesh motion, the stiffness alone and the step operator of the transient path (aK K + aM M: the inertia loop of the kernel),
+    on an element count that leaves the last wave and the last block partly empty; other rules (here 4 x 4) accept five lanes as well."""
+    from femo_alpha_amd.backend import ShellContext
+    from femo_alpha_amd.mesh import ShellMesh
+    from femo_alpha_amd._lib import FemoHipError
+    from oracle.rm_shell_oracle import ShellOracle
+    base = wing_skin_mesh(7, 11, shuffle=True)              # 77 cells: 48 + 29 (five lanes), 64 + 13 (four)
+    m = base if variant == "CG2CG1" else ShellMesh(base.nodes, base.cells, variant)
+    rng = np.random.default_rng(11)
+    f = dict(thickness=0.05 * (1 + 0.3 * rng.uniform(-1, 1, m.nn)), E=3e7 * (1 + 0.2 * rng.uniform(-1, 1, m.nn)),
+             nu=0.3 + 0.05 * rng.uniform(-1, 1, m.nn), density=10 * (1 + 0.1 * rng.uniform(-1, 1, m.nn)), F_solid=rng.uniform(-1, 1, (m.nn, 3)))
+    if uhat:
+        f["uhat"] = 0.02 * rng.uniform(-1, 1, (m.nn, 3))
+    x = rng.uniform(-1, 1, m.ndof)
+    for nquad in (5, 4):
+        o = ShellOracle(m, nquad=nquad)
+        o.set_fields(h=f["thickness"], E=f["E"], nu=f["nu"], rho=f["density"], f=f["F_solid"], uhat=f.get("uhat"))
+        Kx, Mx = o.assemble_K() @ x, o.assemble_M() @ x
+        c = ShellContext(m, nquad=nquad)
+        for k, v in f.items():
+            c.set_field(k, v)
+        got = {}
+        for lanes in (0, 4, 5):
+            c.set_option("apply_lanes", lanes)
+            y = c.apply_K(x)
+            _put(c, "p", x)
+            c.op_apply_vec2("p", "Ap", 0.5, 200.0, with_penalty=False)
+            got[lanes] = (y, _get(c, "Ap").copy())
+            assert rel(y, Kx) < 1e-11 and rel(got[lanes][1], 0.5 * Kx + 200.0 * Mx) < 1e-11, (nquad, lanes)
+        assert rel(got[5][0], got[4][0]) < 1e-13 and rel(got[5][1], got[4][1]) < 1e-13
+        assert np.array_equal(got[0][0], got[4][0]) and np.array_equal(got[0][1], got[4][1])      # 0: the default, a quad
+        with pytest.raises(FemoHipError):
+            c.set_option("apply_lanes", 6)
+        c.close()
+
+
 def test_operator_and_solves_on_vector_ids():
     """femo_op_apply_vec / femo_solve_vec / femo_vec_mask_zero / femo_device_ptr / femo_sync against apply_K and solve_linear."""
     m = wing_skin_mesh(8, 20, shuffle=True).renumbered()[0]
