@@ -167,7 +167,11 @@ int femo_set_solver(femo_ctx* ctx, int preconditioner, double rtol, int32_t maxi
  *   "strip_cnt" (0), "strip_kmax" (160), "strip_depth" (1): rank-k updates with K <= strip_kmax on levels of at least strip_cnt fronts by
  *   one workgroup per 64-row strip of a front (k_schur_strip) -- measured slower than the tile kernel, off (profiles/r5_strip_ab.txt);
  *   "sweep_fuse" (0): all consecutive wide levels of a triangular sweep as ONE launch, tiles ordered by per-front counters -- measured
- *   slower than the level-wise launches, off (profiles/r5_sweep_fuse_ab.txt); "sweep_read_mode" (its read of other workgroups' values);
+ *   slower than the level-wise launches, off (profiles/r5_sweep_fuse_ab.txt); "sweep_read_mode" (its read of other workgroups' values).
+ *   A tile of that launch waits for tiles with smaller workgroup ids: forward progress assumes that the workgroups of a launch are
+ *   dispatched in id order (observed on gfx950, not specified); the wait is bounded and poisons its result with NaN when it runs out;
+ *   "apply_lanes" (0): 5 = the matrix-free operator with five lanes per element instead of a quad of lanes -- measured slower, off
+ *   (profiles/r6_apply_lanes.txt); "diag_t" (0), "sweep_ahead" (2), "multi_rhs" (1): DESIGN.md section 0;
  *   "assemble_fc" (1): front assembly with one workgroup per leaf front -- zero fill, element columns and their sums without float
  *   atomics, the front written once (k_front_assemble_fc).  1: where it was measured to pay (triangles and CG1CG1, or at least 20
  *   quadrature points per cell), 2: always, 0: never = one wave per element adding with atomics into zero-filled fronts
